@@ -1,0 +1,321 @@
+"""CPU ORACLE (numpy) -- a from-scratch restatement of the reference's two-tower training step.
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg as the CHECKER / reported baseline -- never by the product path
+(jodalrob-twotower_amd/), which fails loudly without its HIP library.
+
+Pinned (tests/test_oracle_golden.py) against golden vectors produced by the reference's own
+PyTorch code in the build container (oracle/gen_golden.py -> tests/golden/*).
+
+Each function cites the reference lines it follows (paths relative to /root/reference).
+Everything is written by hand from the maths (forward AND backward), so that it is independent
+both of torch.autograd and of the HIP kernels it checks.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BN_EPS = 1e-5          # nn.BatchNorm1d default (src/towers/tower/base_tower.py:91)
+BN_MOMENTUM = 0.1
+NORM_EPS = 1e-12       # F.normalize default eps (base_tower.py:145)
+
+
+# ------------------------------------------------------------------------------------------------
+# a2  id wire format  (src/towers/pairs/unified_bid_data_loader.py:827-841)
+# ------------------------------------------------------------------------------------------------
+def build_batch_kjt_values(ids_bk: np.ndarray):
+    """[B,K] int64 -> (values [B*K] sample-major, lengths ones[B*K])."""
+    ids_bk = np.asarray(ids_bk, dtype=np.int64)
+    return ids_bk.reshape(-1).copy(), np.ones(ids_bk.size, dtype=np.int64)
+
+
+# ------------------------------------------------------------------------------------------------
+# a4  id unpack + clamp  (src/towers/cat_embed.py:88-123)
+# ------------------------------------------------------------------------------------------------
+def unpack_clamp_ids(values: np.ndarray, vocab_sizes) -> np.ndarray:
+    """values i64 [B*K] sample-major; returns clamped ids [B,K] (v[b*K+k] clamped to [0,V_k-1])."""
+    K = len(vocab_sizes)
+    values = np.asarray(values, dtype=np.int64)
+    B = values.size // K                                   # cat_embed.py:98 (floor division)
+    ids = values[: B * K].reshape(B, K)
+    hi = np.asarray(vocab_sizes, dtype=np.int64)[None, :] - 1
+    return np.minimum(np.maximum(ids, 0), hi)              # torch.clamp(min=0,max=V-1): cat_embed.py:117
+
+
+# ------------------------------------------------------------------------------------------------
+# a5  per-key gather + concat  (src/towers/cat_embed.py:157-178)
+# ------------------------------------------------------------------------------------------------
+def embed_lookup(tables, ids_clamped: np.ndarray) -> np.ndarray:
+    """tables: list of K arrays [V_k,E]; returns [B, K*E] in key order (exact copy of rows)."""
+    return np.concatenate([tables[k][ids_clamped[:, k]] for k in range(len(tables))], axis=1)
+
+
+def embed_grad_dense(d_concat: np.ndarray, ids_clamped: np.ndarray, vocab_sizes, E: int):
+    """a16 embedding backward: dense [V_k,E] grads, duplicate ids summed (nn.Embedding sparse=False)."""
+    grads = []
+    for k, V in enumerate(vocab_sizes):
+        g = np.zeros((V, E), dtype=d_concat.dtype)
+        np.add.at(g, ids_clamped[:, k], d_concat[:, k * E:(k + 1) * E])
+        grads.append(g)
+    return grads
+
+
+def embed_grad_sparse(d_concat: np.ndarray, ids_clamped: np.ndarray, row_offsets, E: int):
+    """Sparse-unique form of the same gradient over the FUSED row space (row = offset_k + id):
+    returns (unique_rows sorted ascending i64 [U], grad_rows [U,E]).  Sum order = ascending sample
+    index b within each unique row (the deterministic order the HIP segment-reduce uses)."""
+    B, K = ids_clamped.shape
+    rows = (ids_clamped + np.asarray(row_offsets, dtype=np.int64)[None, :]).reshape(-1)
+    vals = d_concat.reshape(B * K, E)
+    order = np.argsort(rows, kind="stable")
+    rs, vs = rows[order], vals[order]
+    uniq, start = np.unique(rs, return_index=True)
+    out = np.add.reduceat(vs, start, axis=0) if len(rs) else np.zeros((0, E), d_concat.dtype)
+    return uniq.astype(np.int64), out.astype(d_concat.dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# a6/a7  tower  (src/towers/tower/base_tower.py:71-147)
+# ------------------------------------------------------------------------------------------------
+def tower_layout(state: dict, prefix: str, keys):
+    """Reads the layer structure off the state dict: returns (n_hidden_blocks, final_idx)."""
+    i = 0
+    while f"{prefix}mlp.{4 * i + 2}.running_mean" in state:
+        i += 1
+    return i, 4 * i
+
+
+def tower_fwd(state: dict, prefix: str, keys, vocab_sizes, dense, values, train: bool, dtype=np.float32):
+    """BaseTower.forward.  Returns (emb [B,D], cache, bn_updates).
+    x = cat[dense W0^T + b0 | embed concat]          base_tower.py:133-139
+    per hidden block: BN(ReLU(x W^T + b)) (dropout p=0 / eval: identity)   base_tower.py:88-93
+    y = h W_f^T + b_f ; y / max(||y||, 1e-12)        base_tower.py:97,145
+    """
+    f = lambda a: np.asarray(a, dtype=dtype)
+    ids = unpack_clamp_ids(values, vocab_sizes)
+    tables = [f(state[f"{prefix}categorical_embedder.embeddings.{k}.weight"]) for k in keys]
+    W0, b0 = f(state[prefix + "dense_projection.weight"]), f(state[prefix + "dense_projection.bias"])
+    dense = f(dense)
+    x = np.concatenate([dense @ W0.T + b0, embed_lookup(tables, ids)], axis=1)
+    nblk, fin = tower_layout(state, prefix, keys)
+    cache = {"ids": ids, "dense": dense, "x": x, "blocks": [], "E": tables[0].shape[1] if tables else 0,
+             "H0": W0.shape[0]}
+    bn_updates = {}
+    h = x
+    for i in range(nblk):
+        W, b = f(state[f"{prefix}mlp.{4 * i}.weight"]), f(state[f"{prefix}mlp.{4 * i}.bias"])
+        g, be = f(state[f"{prefix}mlp.{4 * i + 2}.weight"]), f(state[f"{prefix}mlp.{4 * i + 2}.bias"])
+        pre = h @ W.T + b
+        a = np.maximum(pre, 0)
+        if train:
+            mean = a.mean(axis=0)
+            var = a.var(axis=0)                                         # biased, used to normalise
+            n = a.shape[0]
+            rm, rv = f(state[f"{prefix}mlp.{4 * i + 2}.running_mean"]), f(state[f"{prefix}mlp.{4 * i + 2}.running_var"])
+            bn_updates[f"{prefix}mlp.{4 * i + 2}.running_mean"] = (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean
+            bn_updates[f"{prefix}mlp.{4 * i + 2}.running_var"] = (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * var * (n / max(n - 1, 1))
+            bn_updates[f"{prefix}mlp.{4 * i + 2}.num_batches_tracked"] = \
+                np.asarray(state[f"{prefix}mlp.{4 * i + 2}.num_batches_tracked"]) + 1
+        else:
+            mean, var = f(state[f"{prefix}mlp.{4 * i + 2}.running_mean"]), f(state[f"{prefix}mlp.{4 * i + 2}.running_var"])
+        rstd = 1.0 / np.sqrt(var + dtype(BN_EPS))
+        xhat = (a - mean) * rstd
+        out = xhat * g + be
+        cache["blocks"].append({"inp": h, "W": W, "pre": pre, "xhat": xhat, "rstd": rstd, "g": g})
+        h = out
+    Wf, bf = f(state[f"{prefix}mlp.{fin}.weight"]), f(state[f"{prefix}mlp.{fin}.bias"])
+    y = h @ Wf.T + bf
+    nrm = np.sqrt((y * y).sum(axis=1, keepdims=True))
+    den = np.maximum(nrm, dtype(NORM_EPS))
+    emb = y / den
+    cache.update({"h_last": h, "Wf": Wf, "y": y, "den": den, "nrm": nrm, "emb": emb, "train": train})
+    return emb, cache, bn_updates
+
+
+def tower_bwd(cache: dict, d_emb: np.ndarray, prefix: str, keys, vocab_sizes):
+    """Backward of tower_fwd (train-mode BN, dropout p=0).  Returns {state_dict key: grad}."""
+    grads = {}
+    emb, den, nrm = cache["emb"], cache["den"], cache["nrm"]
+    # y/max(||y||,eps): for ||y||>eps  dy = (d - emb*(emb.d))/||y|| ; else dy = d/eps
+    dot = (emb * d_emb).sum(axis=1, keepdims=True)
+    dy = np.where(nrm > NORM_EPS, (d_emb - emb * dot) / den, d_emb / den)
+    nblk = len(cache["blocks"])
+    fin = 4 * nblk
+    grads[f"{prefix}mlp.{fin}.weight"] = dy.T @ cache["h_last"]
+    grads[f"{prefix}mlp.{fin}.bias"] = dy.sum(axis=0)
+    dh = dy @ cache["Wf"]
+    for i in reversed(range(nblk)):
+        blk = cache["blocks"][i]
+        xhat, rstd, g = blk["xhat"], blk["rstd"], blk["g"]
+        grads[f"{prefix}mlp.{4 * i + 2}.weight"] = (dh * xhat).sum(axis=0)
+        grads[f"{prefix}mlp.{4 * i + 2}.bias"] = dh.sum(axis=0)
+        if cache["train"]:
+            dxh = dh * g
+            da = rstd * (dxh - dxh.mean(axis=0) - xhat * (dxh * xhat).mean(axis=0))
+        else:
+            da = dh * g * rstd
+        dpre = da * (blk["pre"] > 0)
+        grads[f"{prefix}mlp.{4 * i}.weight"] = dpre.T @ blk["inp"]
+        grads[f"{prefix}mlp.{4 * i}.bias"] = dpre.sum(axis=0)
+        dh = dpre @ blk["W"]
+    H0, E = cache["H0"], cache["E"]
+    dproj, dcat = dh[:, :H0], dh[:, H0:]
+    grads[prefix + "dense_projection.weight"] = dproj.T @ cache["dense"]
+    grads[prefix + "dense_projection.bias"] = dproj.sum(axis=0)
+    for k, g in zip(keys, embed_grad_dense(dcat, cache["ids"], vocab_sizes, E)):
+        grads[f"{prefix}categorical_embedder.embeddings.{k}.weight"] = g
+    grads["_d_concat"] = dcat
+    return grads
+
+
+# ------------------------------------------------------------------------------------------------
+# a11-a13  score matrix, loss, metrics  (src/towers/two_tower_train_task.py:99-179)
+# ------------------------------------------------------------------------------------------------
+def _logsumexp(S, axis):
+    m = S.max(axis=axis, keepdims=True)
+    return (m + np.log(np.exp(S - m).sum(axis=axis, keepdims=True))).squeeze(axis)
+
+
+def score_ce_fwd(N, C, temperature=1.0):
+    """S = N C^T (/T iff T != 1)  :99-112 ;  loss = 0.5*(CE(S,diag)+CE(S^T,diag))  :114-134 ;
+    metrics :162-179.  Returns (loss, metrics dict, S, (lse_row, lse_col))."""
+    S = N @ C.T
+    if temperature != 1.0:
+        S = S / N.dtype.type(temperature)
+    B = S.shape[0]
+    diag = np.diagonal(S)
+    lse_r, lse_c = _logsumexp(S, 1), _logsumexp(S, 0)
+    loss = 0.5 * ((lse_r - diag).mean() + (lse_c - diag).mean())
+    acc = (S.argmax(axis=1) == np.arange(B)).astype(np.float32).mean()
+    pos = diag.mean()
+    neg = (S.sum() - diag.sum()) / max(B * B - B, 1) if B > 1 else np.float32("nan")
+    return loss, {"accuracy": acc, "positive_similarity_mean": pos, "negative_similarity_mean": neg,
+                  "similarity_gap": pos - neg}, S, (lse_r, lse_c)
+
+
+def score_ce_bwd(N, C, S, lse, temperature=1.0, dloss=1.0):
+    """dS = (softmax_rows + softmax_cols - 2I)/(2B) ; dN = dS C / T ; dC = dS^T N / T."""
+    B = S.shape[0]
+    dS = (np.exp(S - lse[0][:, None]) + np.exp(S - lse[1][None, :]) - 2 * np.eye(B, dtype=S.dtype)) * (dloss / (2 * B))
+    if temperature != 1.0:
+        dS = dS / S.dtype.type(temperature)
+    return dS @ C, dS.T @ N
+
+
+# ------------------------------------------------------------------------------------------------
+# a9/a10  TwoTowerModel.forward + TwoTowerTrainTask.forward (+ a16 backward)
+# ------------------------------------------------------------------------------------------------
+NT, CT = "two_tower_model.notice_tower.", "two_tower_model.company_tower."
+
+
+def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, train=True, backward=True,
+              dtype=np.float32):
+    """One forward (+backward) of the task.  batch: dict with notice_ids/company_ids [B,K] (or flat
+    values) and notice_dense/company_dense.  Returns dict(loss, metrics, sim, notice_emb, company_emb,
+    grads{state key: array}, bn_updates)."""
+    vals_n = np.asarray(batch["notice_ids"]).reshape(-1)
+    vals_c = np.asarray(batch["company_ids"]).reshape(-1)
+    if batch["notice_dense"].shape[0] != batch["company_dense"].shape[0]:
+        raise ValueError("notice/company batch size mismatch")          # two_tower_train_task.py:64-67
+    ne, cn, bn_n = tower_fwd(state, NT, keys_n, vocab_n, batch["notice_dense"], vals_n, train, dtype)
+    ce, cc, bn_c = tower_fwd(state, CT, keys_c, vocab_c, batch["company_dense"], vals_c, train, dtype)
+    loss, metrics, S, lse = score_ce_fwd(ne, ce, temperature)
+    out = {"loss": loss, **metrics, "sim": S, "notice_emb": ne, "company_emb": ce, "bn_updates": {**bn_n, **bn_c}}
+    if backward:
+        dN, dC = score_ce_bwd(ne, ce, S, lse, temperature)
+        g = tower_bwd(cn, dN, NT, keys_n, vocab_n)
+        out["d_concat_notice"] = g.pop("_d_concat")
+        g2 = tower_bwd(cc, dC, CT, keys_c, vocab_c)
+        out["d_concat_company"] = g2.pop("_d_concat")
+        out["grads"] = {**g, **g2}
+        out["ids_notice"], out["ids_company"] = cn["ids"], cc["ids"]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# a15  predict_batch top-k  (two_tower_train_task.py:181-207) and evaluator (src/evaluation/evaluator.py:20-71)
+# ------------------------------------------------------------------------------------------------
+def topk_rows(S, k):
+    """values/indices of the k largest per row, descending; ties -> lower column index first."""
+    idx = np.argsort(-S, axis=1, kind="stable")[:, :k]
+    return np.take_along_axis(S, idx, axis=1), idx
+
+
+def diag_rank(S):
+    """0-based rank of S[i,i] in row i under a descending sort (count of strictly greater entries;
+    equals the evaluator's argsort position when there are no ties with the diagonal)."""
+    d = np.diagonal(S)[:, None]
+    return (S > d).sum(axis=1)
+
+
+def recall_at_k(S, k):
+    return (diag_rank(S) < min(k, S.shape[1])).astype(np.float32).mean()          # evaluator.py:20-43
+
+
+def mrr(S):
+    return (1.0 / (diag_rank(S) + 1.0)).astype(np.float32).mean()                 # evaluator.py:45-71
+
+
+# ------------------------------------------------------------------------------------------------
+# a17  optimiser + schedule  (scripts/train.py:231-242)
+# ------------------------------------------------------------------------------------------------
+def warmup_lr(base_lr, step, warmup_steps):
+    """LambdaLR: lr used by optimiser step number `step` (0-based); step 0 has lr 0."""
+    return base_lr * (step / warmup_steps if step < warmup_steps else 1.0)
+
+
+def adam_step(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
+    """torch.optim.Adam (coupled L2 weight decay), t = 1-based step count.  In-place on p, m, v."""
+    if wd:
+        g = g + wd * p
+    m *= b1
+    m += (1 - b1) * g
+    v *= b2
+    v += (1 - b2) * g * g
+    bc1, bc2 = 1 - b1 ** t, 1 - b2 ** t
+    p -= (lr / bc1) * m / (np.sqrt(v) / np.sqrt(bc2) + eps)
+
+
+def sparse_adam_rows(table, m, v, step_rows, rows, grad_rows, lr, b1=0.9, b2=0.999, eps=1e-8, wd=0.0):
+    """Row-wise sparse Adam of this build (NOT in the reference; DESIGN.md 'optimiser semantics'):
+    only the looked-up rows are touched; each row keeps its own step count for bias correction."""
+    for r, g in zip(rows, grad_rows):
+        step_rows[r] += 1
+        adam_step(table[r], g.astype(table.dtype), m[r], v[r], int(step_rows[r]), lr, b1, b2, eps, wd)
+
+
+# ------------------------------------------------------------------------------------------------
+# a18  FeatureProjector + projection concat  (src/torchrec_preprocess/feature_projector.py:20-28,
+#      feature_preprocessor.py:150-233 / unified_bid_data_loader.py:1380-1448)
+# ------------------------------------------------------------------------------------------------
+def mlp2(x, w0, b0, w1, b1):
+    return np.maximum(x @ w0.T + b0, 0) @ w1.T + b1
+
+
+def project_features(pstate, numeric, text_dict, text_cols=None):
+    """dense_projected = cat[ num_proj(numeric) | text_proj(text[col]) for col in text_cols ]."""
+    parts = []
+    if numeric is not None:
+        parts.append(mlp2(numeric, pstate["num_proj.0.weight"], pstate["num_proj.0.bias"],
+                          pstate["num_proj.2.weight"], pstate["num_proj.2.bias"]))
+    if numeric is None or text_dict:
+        for col in (text_cols or list(text_dict)):
+            if col in text_dict:
+                parts.append(mlp2(text_dict[col], pstate["text_proj.0.weight"], pstate["text_proj.0.bias"],
+                                  pstate["text_proj.2.weight"], pstate["text_proj.2.bias"]))
+    return np.concatenate(parts, axis=1) if parts else None
+
+
+def build_id_mappings(stores):
+    """feature_preprocessor.py:235-268."""
+    n2i, c2i = {}, {}
+    if "notice" in stores:
+        n2i = {tuple(p): i for i, p in enumerate(stores["notice"].get("ids", []))}
+    if "company" in stores:
+        cids = stores["company"].get("ids", [])
+        if len(cids):
+            if isinstance(cids[0], (tuple, list)):
+                c2i = {str(t[0]): i for i, t in enumerate(cids)}
+            else:
+                c2i = {str(c): i for i, c in enumerate(cids)}
+    return n2i, c2i

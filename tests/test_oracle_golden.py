@@ -1,0 +1,148 @@
+"""Pins the numpy oracle against vectors produced by the reference's own code (tests/golden)."""
+import json
+
+import numpy as np
+import pytest
+
+import oracle_np as O
+from conftest import GOLD, load_case, split_prefix
+from params_init import init_state_numpy
+
+CASES = ["tiny_train", "tiny_eval", "deep_temp", "wide_b40", "single_hidden"]
+RTOL, ATOL = 2e-5, 2e-6     # fp32 restatement vs fp32 torch (different summation order)
+
+
+def run(case, cfg, state=None):
+    g = load_case(case)
+    state = state or split_prefix(g, "state.")
+    batch = split_prefix(g, "in.")
+    out = O.task_step(state, batch, cfg["keys_n"], cfg["keys_c"], cfg["vocab_n"], cfg["vocab_c"],
+                      temperature=cfg["T"], train=cfg["train"], backward=cfg["train"])
+    return g, out
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_matches_reference(case, manifest):
+    cfg = manifest["cases"][case]
+    g, out = run(case, cfg)
+    np.testing.assert_allclose(out["notice_emb"], g["out.notice_emb"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out["company_emb"], g["out.company_emb"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out["sim"], g["sim"], rtol=RTOL, atol=5e-6)
+    np.testing.assert_allclose(out["loss"], g["out.loss"], rtol=RTOL)
+    assert float(out["accuracy"]) == float(g["out.accuracy"])
+    for k in ("positive_similarity_mean", "negative_similarity_mean", "similarity_gap"):
+        np.testing.assert_allclose(out[k], g["out." + k], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c != "tiny_eval"])
+def test_backward_matches_reference(case, manifest):
+    cfg = manifest["cases"][case]
+    g, out = run(case, cfg)
+    ref = split_prefix(g, "grad.")
+    assert set(ref) == set(out["grads"])
+    for k, v in ref.items():
+        np.testing.assert_allclose(out["grads"][k], v, rtol=2e-4, atol=2e-7, err_msg=k)
+    # BN running stats after the train-mode forward
+    for k, v in split_prefix(g, "state_after.").items():
+        np.testing.assert_allclose(out["bn_updates"][k], v, rtol=RTOL, atol=ATOL, err_msg=k)
+
+
+def test_clamp_pinned():
+    # ids [-5, 40000, 1000] on vocabs [12, 28993, 1000] -> [0, 28992, 999]
+    got = O.unpack_clamp_ids(np.array([-5, 40000, 1000]), [12, 28993, 1000])
+    assert got.tolist() == [[0, 28992, 999]]
+    g = load_case("tiny_train")
+    ids = O.unpack_clamp_ids(g["in.notice_ids"].reshape(-1), [12, 15, 27, 50, 1000])
+    assert ids.min() >= 0 and (ids <= np.array([11, 14, 26, 49, 999])).all()
+    assert ids[0, 0] == 0 and ids[1, -1] == 999 and ids[2, 1] == 14
+
+
+def test_kjt_wire_format():
+    z = np.load(GOLD / "kjt_wire.npz")
+    v, l = O.build_batch_kjt_values(z["ids"])
+    assert np.array_equal(v, z["values"]) and np.array_equal(l, z["lengths"])
+
+
+def test_real_schema_case(manifest, schema_real):
+    cfg = manifest["cases"]["real_schema"]
+    g = load_case("real_schema")
+    shapes = {k: tuple(v) for k, v in manifest["state_dict_keys_real"].items()}
+    state = init_state_numpy(shapes, cfg["seed"])
+    assert sum(int(np.prod(s)) for k, s in shapes.items() if "running" not in k and "num_batches" not in k) \
+        == cfg["n_params"] == 2204832
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    out = O.task_step(state, split_prefix(g, "in."), kn, kc, vn, vc, temperature=1.0, train=True)
+    np.testing.assert_allclose(out["loss"], g["out.loss"], rtol=RTOL)
+    np.testing.assert_allclose(out["sim"], g["sim"], rtol=RTOL, atol=5e-6)
+    for k, v in split_prefix(g, "grad.").items():
+        if k.endswith(".rows"):
+            base = k[:-5]
+            dense = out["grads"][base]
+            nz = np.flatnonzero(np.abs(dense).sum(axis=1))
+            assert np.array_equal(nz, v), base                      # bit-exact touched-row set
+            np.testing.assert_allclose(dense[nz], g["grad." + base + ".vals"], rtol=2e-4, atol=2e-8, err_msg=base)
+        elif not k.endswith(".vals"):
+            np.testing.assert_allclose(out["grads"][k], v, rtol=3e-4, atol=3e-8, err_msg=k)
+
+
+def test_sparse_grad_equals_dense(manifest):
+    cfg = manifest["cases"]["wide_b40"]
+    g, out = run("wide_b40", cfg)
+    E = cfg["E"]
+    for side, keys, vocab, pre in (("notice", cfg["keys_n"], cfg["vocab_n"], O.NT), ("company", cfg["keys_c"], cfg["vocab_c"], O.CT)):
+        offs = np.concatenate([[0], np.cumsum(vocab)[:-1]])
+        rows, vals = O.embed_grad_sparse(out["d_concat_" + side], out["ids_" + side], offs, E)
+        fused = np.concatenate([out["grads"][f"{pre}categorical_embedder.embeddings.{k}.weight"] for k in keys])
+        assert np.array_equal(rows, np.flatnonzero(np.abs(fused).sum(1) > 0)) or len(rows) >= np.count_nonzero(np.abs(fused).sum(1))
+        np.testing.assert_allclose(fused[rows], vals, rtol=1e-5, atol=1e-8)
+        mask = np.ones(len(fused), bool); mask[rows] = False
+        assert not fused[mask].any()
+
+
+def test_adam_trajectory(manifest):
+    cfg = {**manifest["cases"]["tiny_train"], **manifest["cases"]["adam_trajectory"]}
+    z = np.load(GOLD / "adam_trajectory.npz")
+    state = {k[6:]: z[k].copy() for k in z.files if k.startswith("state.")}
+    pkeys = [k for k in state if "running" not in k and "num_batches" not in k]
+    m = {k: np.zeros_like(state[k]) for k in pkeys}
+    v = {k: np.zeros_like(state[k]) for k in pkeys}
+    for s in range(int(z["n_steps"])):
+        batch = {k[len(f"step{s}.in."):]: z[k] for k in z.files if k.startswith(f"step{s}.in.")}
+        out = O.task_step(state, batch, cfg["keys_n"], cfg["keys_c"], cfg["vocab_n"], cfg["vocab_c"], 1.0, True)
+        np.testing.assert_allclose(out["loss"], z[f"step{s}.loss"], rtol=5e-5)
+        lr = O.warmup_lr(cfg["lr"], s, cfg["warmup_steps"])
+        np.testing.assert_allclose(lr, z[f"step{s}.lr"], rtol=1e-12)
+        for k in pkeys:
+            O.adam_step(state[k], out["grads"][k], m[k], v[k], s + 1, lr, wd=cfg["weight_decay"])
+        state.update(out["bn_updates"])
+    for k in state:
+        np.testing.assert_allclose(state[k], z["final." + k], rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_eval_metrics_and_topk():
+    for case in CASES:
+        g = load_case(case)
+        S = g["sim"]
+        np.testing.assert_allclose(O.recall_at_k(S, 5), g["eval.recall@5"], rtol=1e-6)
+        np.testing.assert_allclose(O.recall_at_k(S, 10), g["eval.recall@10"], rtol=1e-6)
+        np.testing.assert_allclose(O.mrr(S), g["eval.mrr"], rtol=1e-6)
+    g = load_case("tiny_eval")
+    vals, idx = O.topk_rows(g["sim"], 5)
+    assert np.array_equal(idx, g["predict.top_indices"])
+    np.testing.assert_allclose(vals, g["predict.top_similarities"], rtol=1e-6)
+
+
+def test_projector_and_id_mappings():
+    z = np.load(GOLD / "projector.npz")
+    ps = {k[6:]: z[k] for k in z.files if k.startswith("state.")}
+    got = O.project_features(ps, z["numeric"], {"ntitle": z["text_ntitle"]}, ["ntitle"])
+    np.testing.assert_allclose(got, z["dense_projected"], rtol=2e-5, atol=2e-6)
+    cs = {k[7:]: z[k] for k in z.files if k.startswith("cstate.")}
+    got = O.project_features(cs, z["c_numeric"], {}, [])
+    np.testing.assert_allclose(got, z["c_dense_projected"], rtol=2e-5, atol=2e-6)
+    j = json.loads((GOLD / "id_mappings.json").read_text())
+    n2i, c2i = O.build_id_mappings({"notice": {"ids": [tuple(t) for t in j["notice_ids"]]},
+                                    "company": {"ids": j["company_ids"]}})
+    assert n2i == {tuple(k): v for k, v in j["notice_id_to_idx"]}
+    assert c2i == {k: v for k, v in j["company_id_to_idx"]}
