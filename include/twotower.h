@@ -1,0 +1,255 @@
+/*
+ * twotower.h -- C ABI of the MI355X-native two-tower training step (libtwotower_hip.so).
+ *
+ * The reference (zoongahn/jodalroB-twoTower) has no FFI: its hot path sits behind plain PyTorch
+ * modules.  This header is the boundary a binding for that path would use; every entry point names
+ * the reference code it replaces (paths relative to the reference root).  See INTEGRATION.md for
+ * the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - every data pointer is a DEVICE pointer borrowed from the caller (never freed / resized here);
+ *     descriptor structs themselves live in HOST memory and are read during the call only.
+ *   - scratch comes from the caller: <op>_workspace_bytes() + (workspace, workspace_bytes).
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t); no hidden synchronisation.
+ *   - returns TT_OK (0) or a negative TT_ERR_*; never throws, never exits;
+ *     tt_last_error_string() gives the thread's last message.
+ *   - row-major everywhere; `ld*` = leading dimension in ELEMENTS.
+ */
+#ifndef TWOTOWER_H_
+#define TWOTOWER_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TT_ABI_VERSION 1
+
+#define TT_OK 0
+#define TT_ERR_INVALID_ARG (-1)
+#define TT_ERR_HIP (-2)
+#define TT_ERR_WORKSPACE (-3)
+#define TT_ERR_UNSUPPORTED (-4)
+
+#define TT_F32 0
+#define TT_BF16 1
+
+#define TT_MAX_SIDES 4   /* towers fused into one lookup / gradient launch */
+#define TT_MAX_HIDDEN 8  /* [Linear,ReLU,BatchNorm1d,Dropout] blocks per tower */
+
+typedef struct tt_ctx tt_ctx; /* opaque: device id, cached device properties */
+typedef void* tt_stream;      /* hipStream_t */
+
+int tt_abi_version(void);
+int tt_ctx_create(int device, tt_ctx** out);
+int tt_ctx_destroy(tt_ctx* ctx);
+const char* tt_last_error_string(void);
+/* number of compute units of the context's device (used by callers to size synthetic work) */
+int tt_ctx_num_cus(const tt_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Categorical embedding lookup  -- replaces CategoricalEmbedder._kjt_to_dict + .forward
+ * (src/towers/cat_embed.py:88-123 id unpack + clamp, :157-178 per-key nn.Embedding gather + cat)
+ * and the torch.cat of src/towers/tower/base_tower.py:139 (rows are written straight into the MLP
+ * input buffer at a column offset).
+ *
+ * All per-key tables of all towers live in ONE fused row space `table[table_rows, E]` (f32).
+ * For side s, sample b, key k:   id  = ids[b*K + k]                       (sample-major KJT values)
+ *                                row = key_row_offset[k] + clamp(id, 0, key_vocab[k]-1)
+ *                                out[b*ld_out + k*E .. +E) = table[row*E .. +E)
+ * rows_out (optional, may be NULL): fused row of every slot, slot = side_slot_base + b*K + k with
+ * side_slot_base = sum of B*K of the earlier sides -- the input of tt_dedup_plan.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tt_embed_side {
+  const int64_t* ids;            /* [B*K] */
+  const int64_t* key_row_offset; /* [K] first fused row of key k */
+  const int64_t* key_vocab;      /* [K] rows of key k (reference: metadata count + 10) */
+  void* out;                     /* first output element of sample 0 / key 0 */
+  int64_t ld_out;
+  int32_t K;
+  int32_t out_dtype; /* TT_F32 (bit-exact row copy) or TT_BF16 (round-to-nearest-even) */
+} tt_embed_side;
+
+int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E,
+                        const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_out,
+                        tt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Duplicate-row plan for the sparse gradient (a16): stable LSD radix sort of the M slot rows, then
+ * segment boundaries of equal rows.  Depends on ids only, so callers run it during the forward.
+ *   sorted_src[i]   slot index of the i-th smallest row (ties in ascending slot order)
+ *   unique_rows[u]  u-th distinct row, ascending;   seg_offsets[u]..seg_offsets[u+1] its span
+ *   n_unique[0]     number of distinct rows U (stays on the device; consumers read it there)
+ * ---------------------------------------------------------------------------------------------- */
+size_t tt_dedup_workspace_bytes(int64_t M);
+int tt_dedup_plan(tt_ctx* ctx, const int32_t* rows, int64_t M, int64_t table_rows,
+                  int32_t* sorted_src, int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique,
+                  void* workspace, size_t workspace_bytes, tt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embedding gradient -- replaces autograd's nn.Embedding backward (dense index_add; reference
+ * builds its tables with sparse=False, src/towers/cat_embed.py:42-45; scripts/train.py:326).
+ * Slot s of source i reads d_out_i[b*ld + k*E .. +E).  Atomic-free: one wave-group per distinct
+ * row sums its contributions in ascending slot order; rows with more than 256 contributions are
+ * summed in 256-slot chunks whose partial sums are then added in chunk order (bitwise reproducible).
+ *   TT_GRAD_SPARSE     out[u*E .. +E)               = sum   (u < U; out has room for M rows)
+ *   TT_GRAD_DENSE_SET  out[unique_rows[u]*E .. +E)  = sum   (caller zeroed the dense buffer)
+ *   TT_GRAD_DENSE_ACC  out[unique_rows[u]*E .. +E) += sum
+ * ---------------------------------------------------------------------------------------------- */
+#define TT_GRAD_SPARSE 0
+#define TT_GRAD_DENSE_SET 1
+#define TT_GRAD_DENSE_ACC 2
+
+typedef struct tt_grad_src {
+  const void* d_out; /* gradient w.r.t. the lookup output of this side */
+  int64_t ld;
+  int32_t K;
+  int32_t dtype; /* TT_F32 / TT_BF16 */
+} tt_grad_src;
+
+size_t tt_embed_grad_workspace_bytes(int64_t M, int32_t E);
+int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int64_t B, int32_t E,
+                      const int32_t* sorted_src, const int32_t* seg_offsets,
+                      const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t mode,
+                      float* out, void* workspace, size_t workspace_bytes, tt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Adam -- replaces torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay coupled)
+ * (scripts/train.py:231, :327).  `step` is the 1-based step count used for bias correction.
+ *   tt_adam_dense_step : exact dense Adam over n contiguous elements (tower weights / small tables)
+ *   tt_sparse_adam_step: the same update applied only to the U looked-up rows (rows not in the batch
+ *                        keep weight, m and v untouched -- the documented difference to the
+ *                        reference's dense update; DESIGN.md "optimiser semantics")
+ * ---------------------------------------------------------------------------------------------- */
+int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n,
+                       int64_t step, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, tt_stream stream);
+int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E,
+                        const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique,
+                        int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, tt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tower MLP -- replaces BaseTower.forward after the lookup (src/towers/tower/base_tower.py:133-145)
+ * and its autograd backward:
+ *   x[:, 0:h0]      = dense W_proj^T + b_proj                 (:133; x[:, h0:] holds the lookup rows)
+ *   per hidden i    : a = relu(in W_i^T + b_i); BatchNorm1d(a) (train: batch stats, biased var,
+ *                     eps 1e-5, running stats momentum 0.1 with unbiased var; eval: running stats);
+ *                     Dropout(p) in train mode (counter-based mask from `seed`)        (:88-93)
+ *   y = h W_out^T + b_out ;  emb = y / max(||y||_2, 1e-12)                             (:97, :145)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct tt_tower_params {
+  int32_t din, h0, kcat_e, n_hidden, d_out;
+  int32_t hidden[TT_MAX_HIDDEN]; /* output width of hidden block i */
+  const float* w_proj;           /* [h0, din] */
+  const float* b_proj;           /* [h0] */
+  const float* w[TT_MAX_HIDDEN]; /* [hidden[i], in_i], in_0 = h0 + kcat_e, in_i = hidden[i-1] */
+  const float* b[TT_MAX_HIDDEN];
+  const float* bn_w[TT_MAX_HIDDEN];
+  const float* bn_b[TT_MAX_HIDDEN];
+  float* bn_rm[TT_MAX_HIDDEN]; /* running_mean, updated by the train-mode forward */
+  float* bn_rv[TT_MAX_HIDDEN]; /* running_var */
+  const float* w_out;          /* [d_out, in_last] */
+  const float* b_out;
+} tt_tower_params;
+
+typedef struct tt_tower_acts { /* caller-allocated; kept between forward and backward */
+  const float* dense;          /* [B, din] */
+  float* x;                    /* [B, h0 + kcat_e] */
+  float* pre[TT_MAX_HIDDEN];   /* [B, hidden[i]] Linear output before ReLU */
+  float* act[TT_MAX_HIDDEN];   /* [B, hidden[i]] block output (after BN and dropout) */
+  float* mean[TT_MAX_HIDDEN];  /* [hidden[i]] statistics used by BN in this pass */
+  float* rstd[TT_MAX_HIDDEN];
+  float* y;   /* [B, d_out] before normalisation */
+  float* emb; /* [B, d_out] unit rows */
+} tt_tower_acts;
+
+typedef struct tt_tower_grads { /* every buffer is overwritten, not accumulated */
+  float* w_proj;
+  float* b_proj;
+  float* w[TT_MAX_HIDDEN];
+  float* b[TT_MAX_HIDDEN];
+  float* bn_w[TT_MAX_HIDDEN];
+  float* bn_b[TT_MAX_HIDDEN];
+  float* w_out;
+  float* b_out;
+  float* d_x;                    /* [B, h0 + kcat_e]; columns [h0, ..) feed tt_embed_grad_bwd */
+  float* scratch[TT_MAX_HIDDEN]; /* [B, hidden[i]] */
+  float* d_y;                    /* [B, d_out] */
+} tt_tower_grads;
+
+/* scratch for either pass (split-K slabs of the weight gradients, column-reduction partials) */
+size_t tt_tower_workspace_bytes(const tt_tower_params* p, int64_t B);
+int tt_tower_mlp_fwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts* a, int64_t B,
+                     int32_t train, float dropout_p, uint64_t seed, void* workspace,
+                     size_t workspace_bytes, tt_stream stream);
+int tt_tower_mlp_bwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts* a,
+                     const float* d_emb, const tt_tower_grads* g, int64_t B, int32_t train,
+                     float dropout_p, uint64_t seed, void* workspace, size_t workspace_bytes,
+                     tt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * In-batch-negative score + symmetric softmax cross-entropy, never materialising the score matrix
+ * -- replaces TwoTowerTrainTask._compute_similarity_matrix / _compute_loss / _compute_metrics
+ * (src/towers/two_tower_train_task.py:99-134, :162-179), the argmax checks of
+ * _verify_positive_pair_alignment (:253-276) and, through the diagonal ranks, the evaluator's
+ * Recall@K / MRR (src/evaluation/evaluator.py:20-71).
+ *
+ * One direction:  for every row a of A[Ra, D] against all rows of Bm[Rb, D], s = <a, b> * inv_t,
+ * positive column = a + diag_offset:
+ *   sumexp[a] = sum_b exp(s_ab - shift)        (shift >= max s; unit rows => shift = inv_t)
+ *   diag[a]   = s at the positive column
+ *   rank[a]   = #{b: s_ab > diag} + #{b < positive: s_ab == diag}   (0 <=> torch.argmax hits)
+ * The loss needs direction (N,C) and direction (C,N); tt_score_loss_finish combines them:
+ *   out[0]=loss  out[1]=accuracy  out[2]=pos mean  out[3]=neg mean  out[4]=gap
+ *   out[5]=column-direction top-1 rate  out[6]=sum of all scores
+ * ---------------------------------------------------------------------------------------------- */
+int tt_score_dir_fwd(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D,
+                     float inv_t, float shift, int64_t diag_offset, float* sumexp, float* diag,
+                     int32_t* rank, float* sumscore /* [Ra] sum_b s_ab, may be NULL */,
+                     tt_stream stream);
+int tt_score_loss_finish(tt_ctx* ctx, int64_t B, float shift, const float* rowsum,
+                         const float* colsum, const float* diag, const int32_t* row_rank,
+                         const int32_t* col_rank, const float* sumscore, float* out8,
+                         tt_stream stream);
+/* gradient of one direction's operand:
+ *   dA[a] = d_loss[0] * scale * sum_b (e_ab/sumexp_a[a] + e_ab/sumexp_b[b] - 2[b == a+diag_offset]) Bm[b]
+ * with e_ab = exp(s_ab - shift) and scale = inv_t / (2 * batch); call once for (N,C) -> dN and once
+ * for (C,N) -> dC.  D <= 256. */
+int tt_score_dir_bwd(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D,
+                     float inv_t, float shift, int64_t diag_offset, const float* sumexp_a,
+                     const float* sumexp_b, const float* d_loss, float scale, float* dA,
+                     tt_stream stream);
+/* dense score matrix S[Ra, Rb] = A Bm^T * inv_t (result["similarity_matrix"], predict_batch
+ * "all_similarities": two_tower_train_task.py:94, :206) */
+int tt_score_matrix(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D,
+                    float inv_t, float* S, int64_t lds, tt_stream stream);
+/* per-row top-k of a dense matrix, descending, ties -> lower column first (torch.topk use in
+ * predict_batch :195 and evaluator.py:35); k <= 64 */
+int tt_topk_rows(tt_ctx* ctx, const float* S, int64_t R, int64_t Ccols, int64_t lds, int32_t k,
+                 float* vals, int64_t* idx, tt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Generic Linear used by the one-off feature projection -- replaces FeatureProjector.forward
+ * (src/torchrec_preprocess/feature_projector.py:20-28):  Y = act(X W^T + b)
+ * ---------------------------------------------------------------------------------------------- */
+int tt_linear_fwd(tt_ctx* ctx, const float* X, int64_t ldx, const float* W, const float* bias,
+                  float* Y, int64_t ldy, int64_t M, int32_t N, int32_t K, int32_t relu,
+                  tt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch assembly on the device -- replaces the numpy fancy-index gather of collate_fn_gpu_optimized
+ * (src/towers/pairs/unified_bid_data_loader.py:630-684) and _build_batch_kjt (:827-841):
+ *   dense_out[b, :] = dense_store[entity[b], :] ;  ids_out[b*K + k] = cat_store[entity[b]*K + k]
+ * ---------------------------------------------------------------------------------------------- */
+int tt_batch_gather(tt_ctx* ctx, const int64_t* entity, int64_t B, const float* dense_store,
+                    int32_t dense_dim, const int64_t* cat_store, int32_t K, float* dense_out,
+                    int64_t* ids_out, tt_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TWOTOWER_H_ */

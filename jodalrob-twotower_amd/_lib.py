@@ -1,0 +1,144 @@
+"""ctypes binding of libtwotower_hip.so (include/twotower.h).  PyTorch is plumbing here: it owns
+device memory and streams; every kernel on the hot path is reached through this C ABI.
+
+There is NO CPU or eager-PyTorch fallback: if the HIP library is missing, or there is no gfx950
+device, the first call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libtwotower_hip.so"
+
+TT_F32, TT_BF16 = 0, 1
+TT_MAX_SIDES, TT_MAX_HIDDEN = 4, 8
+TT_GRAD_SPARSE, TT_GRAD_DENSE_SET, TT_GRAD_DENSE_ACC = 0, 1, 2
+
+vp = C.c_void_p
+i32, i64, f32, u64, sz = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
+
+
+class EmbedSide(C.Structure):
+    _fields_ = [("ids", vp), ("key_row_offset", vp), ("key_vocab", vp), ("out", vp), ("ld_out", i64),
+                ("K", i32), ("out_dtype", i32)]
+
+
+class GradSrc(C.Structure):
+    _fields_ = [("d_out", vp), ("ld", i64), ("K", i32), ("dtype", i32)]
+
+
+_H = vp * TT_MAX_HIDDEN
+
+
+class TowerParams(C.Structure):
+    _fields_ = [("din", i32), ("h0", i32), ("kcat_e", i32), ("n_hidden", i32), ("d_out", i32),
+                ("hidden", i32 * TT_MAX_HIDDEN),
+                ("w_proj", vp), ("b_proj", vp), ("w", _H), ("b", _H), ("bn_w", _H), ("bn_b", _H),
+                ("bn_rm", _H), ("bn_rv", _H), ("w_out", vp), ("b_out", vp)]
+
+
+class TowerActs(C.Structure):
+    _fields_ = [("dense", vp), ("x", vp), ("pre", _H), ("act", _H), ("mean", _H), ("rstd", _H), ("y", vp), ("emb", vp)]
+
+
+class TowerGrads(C.Structure):
+    _fields_ = [("w_proj", vp), ("b_proj", vp), ("w", _H), ("b", _H), ("bn_w", _H), ("bn_b", _H),
+                ("w_out", vp), ("b_out", vp), ("d_x", vp), ("scratch", _H), ("d_y", vp)]
+
+
+# name -> (restype, argtypes); every symbol include/twotower.h declares
+SIGNATURES = {
+    "tt_abi_version": (C.c_int, []),
+    "tt_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
+    "tt_ctx_destroy": (C.c_int, [vp]),
+    "tt_last_error_string": (C.c_char_p, []),
+    "tt_ctx_num_cus": (C.c_int, [vp]),
+    "tt_embed_lookup_fwd": (C.c_int, [vp, vp, i64, i32, C.POINTER(EmbedSide), i32, i64, vp, vp]),
+    "tt_dedup_workspace_bytes": (sz, [i64]),
+    "tt_dedup_plan": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
+    "tt_embed_grad_workspace_bytes": (sz, [i64, i32]),
+    "tt_embed_grad_bwd": (C.c_int, [vp, C.POINTER(GradSrc), i32, i64, i32, vp, vp, vp, vp, i64, i32, vp, vp, sz, vp]),
+    "tt_adam_dense_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp]),
+    "tt_sparse_adam_step": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp]),
+    "tt_tower_workspace_bytes": (sz, [C.POINTER(TowerParams), i64]),
+    "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, sz, vp]),
+    "tt_tower_mlp_bwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), vp, C.POINTER(TowerGrads), i64, i32,
+                                   f32, u64, vp, sz, vp]),
+    "tt_score_dir_fwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, vp, vp]),
+    "tt_score_loss_finish": (C.c_int, [vp, i64, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "tt_score_dir_bwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, f32, vp, vp]),
+    "tt_score_matrix": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, vp, i64, vp]),
+    "tt_topk_rows": (C.c_int, [vp, vp, i64, i64, i64, i32, vp, vp, vp]),
+    "tt_linear_fwd": (C.c_int, [vp, vp, i64, vp, vp, vp, i64, i64, i32, i32, i32, vp]),
+    "tt_batch_gather": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+_ctxs: dict = {}
+_workspaces: dict = {}
+
+
+class TwoTowerHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen the HIP library and declare every entry point; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise TwoTowerHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the two-tower hot path.")
+        lib = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().tt_last_error_string().decode("utf-8", "replace")
+        raise TwoTowerHipError(f"{what or 'twotower call'} failed (status {rc}): {msg}")
+
+
+def ctx(device: torch.device) -> vp:
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise TwoTowerHipError(f"the two-tower hot path runs on MI355X only; got tensors on '{device}' "
+                               "(no CPU fallback exists)")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _ctxs:
+        h = vp()
+        check(load().tt_ctx_create(idx, C.byref(h)), "tt_ctx_create")
+        _ctxs[idx] = h
+    return _ctxs[idx]
+
+
+def stream(device: torch.device) -> vp:
+    return vp(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t: Optional[torch.Tensor]) -> vp:
+    return vp(0 if t is None else t.data_ptr())
+
+
+def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Stream-ordered scratch: one growable buffer per (device, stream)."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def num_cus(device: torch.device) -> int:
+    return int(load().tt_ctx_num_cus(ctx(device)))

@@ -1,0 +1,264 @@
+"""CategoricalEmbedder on one fused HBM-resident table.
+
+Drop-in for the reference class of the same name (src/towers/cat_embed.py:11-190): same constructor,
+same vocab rule (metadata category count + 10, 1000 when unknown: :50-85), same forward contract
+(kjt -> dict of [B,E] or concatenated [B,K*E]; clamp to [0,V-1]; kjt None -> zeros of batch 1), same
+state-dict keys (`embeddings.<key>.weight`, shape [V_k, E]).
+
+Layout: all per-key tables of one store are rows of ONE [R, E] f32 tensor (key k owns rows
+[off_k, off_k+V_k)); the per-key nn.Parameters are views into it, so optimisers, state_dict and
+checkpoints see the reference's tensors while the lookup / gradient kernels see one row space.
+"""
+from __future__ import annotations
+
+import os
+from pathlib import Path
+from typing import Dict, List, Optional, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .schema import category_counts
+
+
+class EmbeddingStore:
+    """One fused row space [R, E] (+ its gradient / optimiser state), shared by >= 1 embedders."""
+
+    def __init__(self, E: int, device, grad_mode: str = "dense"):
+        if grad_mode not in ("dense", "sparse"):
+            raise ValueError(f"embedding_grad must be 'dense' or 'sparse', got {grad_mode!r}")
+        self.E = E
+        self.device = torch.device(device)
+        self.grad_mode = grad_mode
+        self.weight: Optional[torch.Tensor] = None      # [R, E] f32
+        self.grad: Optional[torch.Tensor] = None        # dense mode: [R, E]
+        self.sparse_grad = None                         # sparse mode: (DedupPlan, grad_rows [M, E])
+        self.members: List["CategoricalEmbedder"] = []
+        self.version = 0
+
+    @property
+    def rows(self) -> int:
+        return 0 if self.weight is None else self.weight.shape[0]
+
+    def append_rows(self, n: int) -> int:
+        new = torch.empty((n, self.E), dtype=torch.float32, device=self.device)
+        nn.init.normal_(new)                             # nn.Embedding default init N(0,1)
+        base = self.rows
+        self.weight = new if self.weight is None else torch.cat([self.weight, new])
+        self.grad, self.sparse_grad = None, None
+        self.version += 1
+        return base
+
+    def apply(self, fn):
+        new = fn(self.weight)
+        if new is not self.weight:
+            if new.dtype != torch.float32:
+                raise TypeError("embedding tables are kept in float32")
+            self.weight = new
+            self.device = new.device
+            self.grad = None if self.grad is None else fn(self.grad)
+            self.sparse_grad = None
+            self.version += 1
+
+    @staticmethod
+    def fuse(stores: List["EmbeddingStore"]) -> "EmbeddingStore":
+        """Concatenate several stores into one row space and rebind their embedders."""
+        uniq = []
+        for s in stores:
+            if all(s is not u for u in uniq):
+                uniq.append(s)
+        if len(uniq) == 1:
+            return uniq[0]
+        first = uniq[0]
+        if any(s.E != first.E for s in uniq):
+            raise ValueError("cannot fuse embedding stores of different embedding_dim")
+        fused = EmbeddingStore(first.E, first.device, first.grad_mode)
+        fused.weight = torch.cat([s.weight.to(first.device) for s in uniq])
+        base = 0
+        for s in uniq:
+            for m in s.members:
+                m._rebind(fused, m.row_base + base)
+            base += s.rows
+        return fused
+
+    # ---- gradient bookkeeping (called from the autograd backward) ------------------------------
+    def accumulate_grad(self, plan: ops.DedupPlan, srcs, B: int):
+        """srcs: [(d_out view [B, K*E], K)] in slot order of `plan`."""
+        if self.grad_mode == "sparse":
+            grad_rows = torch.empty((max(plan.M, 1), self.E), dtype=torch.float32, device=self.device)
+            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_SPARSE, grad_rows)
+            self.sparse_grad = (plan, grad_rows)
+            return
+        params = [p for m in self.members for p in m.table_parameters()]
+        fresh = any(p.grad is None for p in params) or self.grad is None
+        if self.grad is None:
+            self.grad = torch.empty_like(self.weight)
+        if fresh:
+            self.grad.zero_()                            # reference semantics: dense [V_k, E] grads
+            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_DENSE_SET, self.grad)
+            for m in self.members:
+                m._bind_grads()
+        else:
+            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_DENSE_ACC, self.grad)
+
+
+class _Table(nn.Module):
+    """Holds the per-key Parameter (a view into the fused store); name parity with nn.Embedding."""
+
+    def __init__(self, view: torch.Tensor):
+        super().__init__()
+        self.weight = nn.Parameter(view)
+
+    @property
+    def num_embeddings(self):
+        return self.weight.shape[0]
+
+    @property
+    def embedding_dim(self):
+        return self.weight.shape[1]
+
+
+class CategoricalEmbedder(nn.Module):
+    def __init__(self, keys: List[str], metadata_path: Union[str, Path], table_name: str, embedding_dim: int = 64,
+                 device: Optional[str] = "cuda:0", safety_margin: int = 10, embedding_grad: Optional[str] = None):
+        super().__init__()
+        self.keys = list(keys)
+        self.embedding_dim = embedding_dim
+        self.device_str = str(device or "cuda:0")
+        self.safety_margin = safety_margin
+        self.vocab_sizes = self._extract_vocab_sizes(metadata_path, table_name, self.keys)
+        print(f"[CategoricalEmbedder] Initializing with {len(self.keys)} features")
+        mode = embedding_grad or os.environ.get("TT_EMBEDDING_GRAD", "dense")
+        self.store = EmbeddingStore(embedding_dim, torch.device(self.device_str), mode)
+        self.row_base = self.store.append_rows(sum(self.vocab_sizes[k] for k in self.keys)) if self.keys else 0
+        self.store.members.append(self)
+        self.embeddings = nn.ModuleDict()
+        off = self.row_base
+        offs = []
+        for k in self.keys:
+            v = self.vocab_sizes[k]
+            self.embeddings[k] = _Table(self.store.weight[off:off + v])
+            offs.append(off)
+            off += v
+        dev = self.store.device
+        self.register_buffer("_key_row_offset", torch.tensor(offs, dtype=torch.int64, device=dev), persistent=False)
+        self.register_buffer("_key_vocab", torch.tensor([self.vocab_sizes[k] for k in self.keys], dtype=torch.int64,
+                                                        device=dev), persistent=False)
+        self._bound_version = self.store.version
+
+    # ---- vocab sizes: src/towers/cat_embed.py:50-85 -------------------------------------------
+    def _extract_vocab_sizes(self, metadata_path, table_name: str, keys: List[str]) -> Dict[str, int]:
+        try:
+            counts = category_counts(table_name, metadata_path)
+        except Exception as e:                                            # whole-file failure: :82-85
+            print(f"[ERROR] Failed to extract vocab_sizes from metadata: {e}")
+            print("[FALLBACK] Using default vocab_size=1000 for all keys")
+            return {k: 1000 for k in keys}
+        out = {}
+        for k in keys:
+            if k not in counts:
+                print(f"[WARNING] Column '{k}' not found in metadata, using default vocab_size=1000")
+                out[k] = 1000
+            elif counts[k] is None:
+                print(f"[WARNING] No category count info for '{k}', using default vocab_size=1000")
+                out[k] = 1000
+            else:
+                out[k] = int(counts[k]) + self.safety_margin
+        return out
+
+    # ---- store plumbing -------------------------------------------------------------------------
+    def table_parameters(self):
+        return [self.embeddings[k].weight for k in self.keys]
+
+    def _rebind(self, store: Optional[EmbeddingStore] = None, row_base: Optional[int] = None):
+        if store is not None and store is not self.store:
+            self.store = store
+            if self not in store.members:
+                store.members.append(self)
+        if row_base is not None:
+            self.row_base = row_base
+        off = self.row_base
+        offs = []
+        for k in self.keys:
+            v = self.vocab_sizes[k]
+            self.embeddings[k].weight.data = self.store.weight[off:off + v]
+            self.embeddings[k].weight.grad = None
+            offs.append(off)
+            off += v
+        dev = self.store.device
+        self._key_row_offset = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self._key_vocab = self._key_vocab.to(dev)
+        self._bound_version = self.store.version
+        if self.store.grad is not None:
+            self._bind_grads()
+
+    def _bind_grads(self):
+        off = self.row_base
+        for k in self.keys:
+            v = self.vocab_sizes[k]
+            self.embeddings[k].weight.grad = self.store.grad[off:off + v]
+            off += v
+
+    def _apply(self, fn, recurse=True):
+        # move the fused storage ONCE, then re-point the per-key views (keeps Parameter identity, so
+        # optimisers built before .to(device) stay valid)
+        self.store.apply(fn)
+        for s_member in self.store.members:
+            if s_member._bound_version != s_member.store.version:
+                s_member._rebind()
+        self._key_row_offset = fn(self._key_row_offset) if self._key_row_offset.is_floating_point() else \
+            self._key_row_offset.to(self.store.device)
+        self._key_vocab = self._key_vocab.to(self.store.device)
+        return self
+
+    def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
+        return super().load_state_dict(state_dict, strict=strict, assign=False)   # copy through the views
+
+    # ---- forward: src/towers/cat_embed.py:126-190 ------------------------------------------------
+    def lookup_side(self, values: torch.Tensor, out_view: torch.Tensor) -> ops.LookupSide:
+        return ops.LookupSide(values, self._key_row_offset, self._key_vocab, out_view, len(self.keys))
+
+    def forward(self, kjt, return_dict: bool = True):
+        K, E = len(self.keys), self.embedding_dim
+        if kjt is None:                                                    # :143-150
+            dev = self.store.device
+            if return_dict:
+                return {k: torch.zeros(1, E, device=dev) for k in self.keys}
+            return torch.zeros(1, K * E, device=dev)
+        values = kjt.values()
+        cat = _LookupFn.apply(self, values, *self.table_parameters())
+        if not return_dict:
+            return cat
+        return {k: cat[:, i * E:(i + 1) * E] for i, k in enumerate(self.keys)}
+
+
+class _LookupFn(torch.autograd.Function):
+    """Stand-alone differentiable lookup (used when the embedder is called outside a tower)."""
+
+    @staticmethod
+    def forward(ctx, emb: CategoricalEmbedder, values: torch.Tensor, *tables):
+        K, E = len(emb.keys), emb.embedding_dim
+        values = values.to(device=emb.store.device, dtype=torch.int64).contiguous()
+        B = values.numel() // max(K, 1)                                   # :98
+        out = torch.empty((B, K * E), dtype=torch.float32, device=emb.store.device)
+        need_grad = any(t.requires_grad for t in tables) and torch.is_grad_enabled()
+        rows = ops.embed_lookup(emb.store.weight, [emb.lookup_side(values[:B * K], out)], B, want_rows=need_grad) \
+            if K and B else None
+        ctx.emb, ctx.B = emb, B
+        ctx.plan = ops.dedup_plan(rows, emb.store.rows) if rows is not None else None
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        emb = ctx.emb
+        if ctx.plan is not None:
+            d_out = d_out.contiguous()
+            emb.store.accumulate_grad(ctx.plan, [(d_out, len(emb.keys))], ctx.B)
+        return (None, None) + (None,) * len(emb.keys)
+
+
+def create_categorical_embedder(keys: List[str], metadata_path="meta/metadata.csv", table_name: str = "notice",
+                                embedding_dim: int = 64, device: Optional[str] = "cuda:0") -> CategoricalEmbedder:
+    return CategoricalEmbedder(keys=keys, metadata_path=metadata_path, table_name=table_name,
+                               embedding_dim=embedding_dim, device=device)

@@ -1,0 +1,57 @@
+// Shared internals of libtwotower_hip.so (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "twotower.h"
+
+struct tt_ctx {
+  int device;
+  int num_cus;
+  size_t lds_per_block;
+};
+
+void tt_set_error(const char* fmt, ...);
+
+#define TT_CHECK_ARG(cond, ...)         \
+  do {                                  \
+    if (!(cond)) {                      \
+      tt_set_error(__VA_ARGS__);        \
+      return TT_ERR_INVALID_ARG;        \
+    }                                   \
+  } while (0)
+
+#define TT_HIP(expr)                                                                   \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      tt_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return TT_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+#define TT_LAUNCH_CHECK() TT_HIP(hipGetLastError())
+
+static inline int64_t tt_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool tt_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// float -> bf16 round-to-nearest-even; NaN stays NaN (a plain cast lowers to v_cvt_pk_bf16_f32).
+__device__ __forceinline__ uint16_t tt_f2bf(float x) {
+  __bf16 b = static_cast<__bf16>(x);
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float tt_bf2f(uint16_t h) {
+  return __builtin_bit_cast(float, static_cast<uint32_t>(h) << 16);
+}
+
+// counter-based uniform in [0,1): one value per (seed, element index) -- dropout masks are
+// regenerated in the backward pass instead of being stored.
+__device__ __forceinline__ float tt_uniform01(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return static_cast<float>(z >> 40) * (1.0f / 16777216.0f);
+}

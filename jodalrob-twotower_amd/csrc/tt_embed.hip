@@ -1,0 +1,802 @@
+// Embedding path on gfx950: fused multi-table lookup, duplicate-row plan (LSD radix sort +
+// segment heads), atomic-free segmented gradient reduction, Adam (dense and row-sparse), and the
+// device-side batch gather.  All kernels are HBM-bound byte movers: 64-wide waves, 16-byte lanes,
+// grids capped at 8 workgroups per CU with grid-stride loops.
+#include "tt_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ------------------------------------------------------------------------------------------------
+// slot decoding shared by lookup (forward) and gradient (backward)
+// ------------------------------------------------------------------------------------------------
+struct SideDev {
+  const int64_t* ids;
+  const int64_t* off;
+  const int64_t* vocab;
+  char* out;          // lookup output / gradient source
+  int64_t ld;
+  uint32_t slot_base; // first slot of this side
+  int32_t K;
+  int32_t dtype;
+};
+
+struct SideSet {
+  SideDev s[TT_MAX_SIDES];
+  int32_t n;
+  int32_t E;
+  uint32_t C;          // VEC-wide chunks per row
+  uint32_t total_slots;
+};
+
+__device__ __forceinline__ int side_of(const SideSet& a, uint32_t slot) {
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < TT_MAX_SIDES; ++i)
+    if (i < a.n && slot >= a.s[i].slot_base) si = i;
+  return si;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4 + a5: lookup.  Task = (slot, chunk); consecutive lanes take consecutive chunks of one row, so
+// an E=32 f32 row is one 128-B line read by 8 lanes and a wave-instruction gathers 8 rows.
+// U independent tasks per thread are issued before any store to keep >= U*16 B per lane in flight.
+// ------------------------------------------------------------------------------------------------
+template <int VEC, int U>
+__global__ __launch_bounds__(kThreads) void lookup_kernel(SideSet a, const float* __restrict__ table,
+                                                          int32_t* __restrict__ rows_out) {
+  const uint32_t total = a.total_slots * a.C;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t base = blockIdx.x * blockDim.x + threadIdx.x; base < total; base += stride * U) {
+    float v[U][VEC];
+    char* dst[U];
+    int dt[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t task = base + u * stride;
+      ok[u] = task < total;
+      if (ok[u]) {
+        const uint32_t slot = task / a.C;
+        const uint32_t chunk = task - slot * a.C;
+        const int si = side_of(a, slot);
+        const SideDev& s = a.s[si];
+        const uint32_t local = slot - s.slot_base;
+        const uint32_t b = local / (uint32_t)s.K;
+        const uint32_t k = local - b * (uint32_t)s.K;
+        int64_t id = s.ids[local];
+        const int64_t hi = s.vocab[k] - 1;
+        id = id < 0 ? 0 : (id > hi ? hi : id);                 // clamp: cat_embed.py:117
+        const int64_t row = s.off[k] + id;
+        if (chunk == 0 && rows_out) rows_out[slot] = (int32_t)row;
+        const float* src = table + row * a.E + chunk * VEC;
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(src);
+          v[u][0] = t.x; v[u][1 % VEC] = t.y; v[u][2 % VEC] = t.z; v[u][3 % VEC] = t.w;
+        } else {
+          v[u][0] = src[0];
+        }
+        dt[u] = s.dtype;
+        const int64_t col = (int64_t)b * s.ld + (int64_t)k * a.E + chunk * VEC;
+        dst[u] = s.out + col * (s.dtype == TT_BF16 ? 2 : 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!ok[u]) continue;
+      if (dt[u] == TT_F32) {
+        if (VEC == 4) {
+          *reinterpret_cast<float4*>(dst[u]) = make_float4(v[u][0], v[u][1 % VEC], v[u][2 % VEC], v[u][3 % VEC]);
+        } else {
+          *reinterpret_cast<float*>(dst[u]) = v[u][0];
+        }
+      } else {
+        if (VEC == 4) {
+          ushort4 o;
+          o.x = tt_f2bf(v[u][0]); o.y = tt_f2bf(v[u][1 % VEC]); o.z = tt_f2bf(v[u][2 % VEC]); o.w = tt_f2bf(v[u][3 % VEC]);
+          *reinterpret_cast<ushort4*>(dst[u]) = o;
+        } else {
+          *reinterpret_cast<uint16_t*>(dst[u]) = tt_f2bf(v[u][0]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dedup plan: LSD radix sort (BITS per pass) of (row, slot) pairs.
+//   hist    : per-tile digit histogram        -> hist[digit * nblk + tile]
+//   scan    : exclusive scan of that array (one workgroup)
+//   scatter : stable ranking by wave ballots (no sorting network, no atomics on the output side)
+// ------------------------------------------------------------------------------------------------
+constexpr int kSortTile = 4096;                 // elements per workgroup
+constexpr int kWaveSpan = kSortTile / 4;        // contiguous elements per wave
+
+template <int BITS>
+__global__ __launch_bounds__(kThreads) void sort_hist_kernel(const uint32_t* __restrict__ keys, uint32_t M, int shift,
+                                                            uint32_t* __restrict__ hist, uint32_t nblk) {
+  constexpr uint32_t R = 1u << BITS;
+  __shared__ uint32_t h[R];
+  for (uint32_t d = threadIdx.x; d < R; d += kThreads) h[d] = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * kSortTile;
+  for (uint32_t i = threadIdx.x; i < kSortTile; i += kThreads) {
+    const uint32_t idx = base + i;
+    if (idx < M) atomicAdd(&h[(keys[idx] >> shift) & (R - 1)], 1u);
+  }
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < R; d += kThreads) hist[d * nblk + blockIdx.x] = h[d];
+}
+
+// in-place exclusive scan of n uint32 by ONE workgroup of 1024 threads; optional total output
+__global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ data, uint32_t n, int32_t* __restrict__ total_out) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t per = (n + 1023u) / 1024u;
+  const uint32_t lo = tid * per < n ? tid * per : n;
+  const uint32_t hi = lo + per < n ? lo + per : n;
+  uint32_t s = 0;
+  for (uint32_t i = lo; i < hi; ++i) s += data[i];
+  // inclusive scan of s over the 1024 threads
+  uint32_t x = s;
+  const uint32_t lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o);
+    if (lane >= (uint32_t)o) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (uint32_t w = 0; w < wave; ++w) woff += wsum[w];
+  uint32_t run = woff + x - s;                  // exclusive prefix of this thread's range
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t t = data[i];
+    data[i] = run;
+    run += t;
+  }
+  if (total_out && tid == 1023) *total_out = (int32_t)(woff + x);
+}
+
+template <int BITS>
+__global__ __launch_bounds__(kThreads) void sort_scatter_kernel(const uint32_t* __restrict__ keys_in,
+                                                               const uint32_t* __restrict__ vals_in,
+                                                               uint32_t* __restrict__ keys_out,
+                                                               uint32_t* __restrict__ vals_out, uint32_t M, int shift,
+                                                               const uint32_t* __restrict__ hist_scanned, uint32_t nblk) {
+  constexpr uint32_t R = 1u << BITS;
+  __shared__ uint32_t woff_s[4][R];
+  volatile uint32_t(*woff)[R] = woff_s;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (uint32_t d = tid; d < 4 * R; d += kThreads) (&woff_s[0][0])[d] = 0;
+  __syncthreads();
+  const uint32_t wbase = blockIdx.x * kSortTile + wave * kWaveSpan;
+  // phase 1: per-wave digit counts
+  for (uint32_t it = 0; it < kWaveSpan / 64; ++it) {
+    const uint32_t idx = wbase + it * 64 + lane;
+    if (idx < M) atomicAdd(&woff_s[wave][(keys_in[idx] >> shift) & (R - 1)], 1u);
+  }
+  __syncthreads();
+  // phase 2: counts -> starting output offset of (wave, digit)
+  for (uint32_t d = tid; d < R; d += kThreads) {
+    uint32_t base = hist_scanned[d * nblk + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = woff_s[w][d];
+      woff_s[w][d] = base;
+      base += c;
+    }
+  }
+  __syncthreads();
+  // phase 3: stable rank inside each 64-element batch from ballots, running offsets in LDS
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (uint32_t it = 0; it < kWaveSpan / 64; ++it) {
+    const uint32_t idx = wbase + it * 64 + lane;
+    const bool valid = idx < M;
+    const uint32_t key = valid ? keys_in[idx] : 0u;
+    const uint32_t val = valid ? (vals_in ? vals_in[idx] : idx) : 0u;
+    const uint32_t d = (key >> shift) & (R - 1);
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int bit = 0; bit < BITS; ++bit) {
+      const bool one = (d >> bit) & 1u;
+      const uint64_t bm = __ballot(one);
+      peers &= one ? bm : ~bm;
+    }
+    uint32_t pos = 0;
+    const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+    if (valid) pos = woff[wave][d] + rank;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) woff[wave][d] = pos + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      keys_out[pos] = key;
+      vals_out[pos] = val;
+    }
+  }
+}
+
+// segment heads -------------------------------------------------------------------------------
+__device__ __forceinline__ bool is_head(const uint32_t* keys, uint32_t i) { return i == 0 || keys[i] != keys[i - 1]; }
+
+__global__ __launch_bounds__(kThreads) void head_count_kernel(const uint32_t* __restrict__ keys, uint32_t M,
+                                                             uint32_t* __restrict__ blockcount) {
+  __shared__ uint32_t cnt;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * kSortTile;
+  uint32_t c = 0;
+  for (uint32_t i = threadIdx.x; i < kSortTile; i += kThreads) {
+    const uint32_t idx = base + i;
+    if (idx < M && is_head(keys, idx)) ++c;
+  }
+  atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) blockcount[blockIdx.x] = cnt;
+}
+
+__global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __restrict__ keys, uint32_t M,
+                                                             const uint32_t* __restrict__ blockoff,
+                                                             const int32_t* __restrict__ n_unique,
+                                                             int32_t* __restrict__ unique_rows,
+                                                             int32_t* __restrict__ seg_offsets) {
+  __shared__ uint32_t wsum[4];
+  constexpr uint32_t PER = kSortTile / kThreads;   // 16 contiguous elements per thread
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t lo = blockIdx.x * kSortTile + tid * PER;
+  uint32_t flags = 0, c = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < PER; ++j) {
+    const uint32_t idx = lo + j;
+    if (idx < M && is_head(keys, idx)) { flags |= 1u << j; ++c; }
+  }
+  uint32_t x = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o);
+    if (lane >= (uint32_t)o) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  uint32_t u = blockoff[blockIdx.x] + x - c;
+  for (uint32_t w = 0; w < wave; ++w) u += wsum[w];
+#pragma unroll
+  for (uint32_t j = 0; j < PER; ++j) {
+    if (flags & (1u << j)) {
+      unique_rows[u] = (int32_t)keys[lo + j];
+      seg_offsets[u] = (int32_t)(lo + j);
+      ++u;
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0) seg_offsets[*n_unique] = (int32_t)M;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a16: segmented gradient reduction.  A lane-group of LG lanes owns one distinct row and walks its
+// segment in ascending slot order (4 independent loads in flight, added in order).
+// ------------------------------------------------------------------------------------------------
+constexpr int kLongSeg = 256;   // segments longer than this are split into kLongSeg-slot chunks
+
+struct GradWs {
+  int32_t* counters;     // [0] chunks allocated, [1] long rows
+  int32_t* long_row;     // [maxLong]   distinct-row index u
+  int32_t* long_base;    // [maxLong]   first chunk of that row
+  int32_t* chunk_lo;     // [maxChunks]
+  int32_t* chunk_hi;
+  float* chunk_partial;  // [maxChunks, E]
+};
+
+template <int VEC>
+struct Acc {
+  float v[VEC];
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = 0.f;
+  }
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_grad_chunk(const SideSet& a, uint32_t slot, uint32_t chunk, float* o) {
+  const int si = side_of(a, slot);
+  const SideDev& s = a.s[si];
+  const uint32_t local = slot - s.slot_base;
+  const uint32_t b = local / (uint32_t)s.K;
+  const uint32_t k = local - b * (uint32_t)s.K;
+  const int64_t col = (int64_t)b * s.ld + (int64_t)k * a.E + chunk * VEC;
+  if (s.dtype == TT_F32) {
+    const float* p = reinterpret_cast<const float*>(s.out) + col;
+    if (VEC == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p);
+      o[0] = t.x; o[1 % VEC] = t.y; o[2 % VEC] = t.z; o[3 % VEC] = t.w;
+    } else {
+      o[0] = p[0];
+    }
+  } else {
+    const uint16_t* p = reinterpret_cast<const uint16_t*>(s.out) + col;
+    if (VEC == 4) {
+      const ushort4 t = *reinterpret_cast<const ushort4*>(p);
+      o[0] = tt_bf2f(t.x); o[1 % VEC] = tt_bf2f(t.y); o[2 % VEC] = tt_bf2f(t.z); o[3 % VEC] = tt_bf2f(t.w);
+    } else {
+      o[0] = tt_bf2f(p[0]);
+    }
+  }
+}
+
+// ordered sum of slots sorted_src[lo..hi) for one chunk column
+template <int VEC>
+__device__ __forceinline__ void sum_range(const SideSet& a, const int32_t* __restrict__ sorted_src, int32_t lo, int32_t hi,
+                                          uint32_t chunk, Acc<VEC>& acc) {
+  int32_t i = lo;
+  for (; i + 4 <= hi; i += 4) {
+    float t[4][VEC];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) load_grad_chunk<VEC>(a, (uint32_t)sorted_src[i + j], chunk, t[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc.v[e] += t[j][e];
+  }
+  for (; i < hi; ++i) {
+    float t[VEC];
+    load_grad_chunk<VEC>(a, (uint32_t)sorted_src[i], chunk, t);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc.v[e] += t[e];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void write_row(float* __restrict__ out, int64_t row, int32_t E, uint32_t chunk, const Acc<VEC>& acc,
+                                          bool accumulate) {
+  float* p = out + row * E + chunk * VEC;
+  if (VEC == 4) {
+    float4 t = make_float4(acc.v[0], acc.v[1 % VEC], acc.v[2 % VEC], acc.v[3 % VEC]);
+    if (accumulate) {
+      const float4 q = *reinterpret_cast<float4*>(p);
+      t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+    }
+    *reinterpret_cast<float4*>(p) = t;
+  } else {
+    p[0] = accumulate ? p[0] + acc.v[0] : acc.v[0];
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void seg_reduce_kernel(SideSet a, const int32_t* __restrict__ sorted_src,
+                                                             const int32_t* __restrict__ seg, const int32_t* __restrict__ unique_rows,
+                                                             const int32_t* __restrict__ n_unique, int32_t mode,
+                                                             float* __restrict__ out, GradWs ws, uint32_t LG) {
+  const uint32_t U = (uint32_t)*n_unique;
+  const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lig = gthread % LG;
+  const uint32_t ngroups = gridDim.x * blockDim.x / LG;
+  for (uint32_t u = gthread / LG; u < U; u += ngroups) {
+    const int32_t s0 = seg[u], s1 = seg[u + 1];
+    if (s1 - s0 > kLongSeg) {
+      if (lig == 0) {
+        const int32_t nch = (s1 - s0 + kLongSeg - 1) / kLongSeg;
+        const int32_t base = atomicAdd(&ws.counters[0], nch);
+        const int32_t li = atomicAdd(&ws.counters[1], 1);
+        ws.long_row[li] = (int32_t)u;
+        ws.long_base[li] = base;
+        for (int32_t c = 0; c < nch; ++c) {
+          ws.chunk_lo[base + c] = s0 + c * kLongSeg;
+          ws.chunk_hi[base + c] = min(s1, s0 + (c + 1) * kLongSeg);
+        }
+      }
+      continue;
+    }
+    const int64_t orow = mode == TT_GRAD_SPARSE ? (int64_t)u : (int64_t)unique_rows[u];
+    for (uint32_t chunk = lig; chunk < a.C; chunk += LG) {
+      Acc<VEC> acc;
+      acc.zero();
+      sum_range<VEC>(a, sorted_src, s0, s1, chunk, acc);
+      write_row<VEC>(out, orow, a.E, chunk, acc, mode == TT_GRAD_DENSE_ACC);
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void seg_chunk_kernel(SideSet a, const int32_t* __restrict__ sorted_src, GradWs ws, uint32_t LG) {
+  const uint32_t nchunks = (uint32_t)ws.counters[0];
+  const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lig = gthread % LG;
+  const uint32_t ngroups = gridDim.x * blockDim.x / LG;
+  for (uint32_t c = gthread / LG; c < nchunks; c += ngroups) {
+    for (uint32_t chunk = lig; chunk < a.C; chunk += LG) {
+      Acc<VEC> acc;
+      acc.zero();
+      sum_range<VEC>(a, sorted_src, ws.chunk_lo[c], ws.chunk_hi[c], chunk, acc);
+      write_row<VEC>(ws.chunk_partial, (int64_t)c, a.E, chunk, acc, false);
+    }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void seg_long_finish_kernel(int32_t E, uint32_t C, const int32_t* __restrict__ seg,
+                                                                  const int32_t* __restrict__ unique_rows, int32_t mode,
+                                                                  float* __restrict__ out, GradWs ws, uint32_t LG) {
+  const uint32_t nlong = (uint32_t)ws.counters[1];
+  const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lig = gthread % LG;
+  const uint32_t ngroups = gridDim.x * blockDim.x / LG;
+  for (uint32_t li = gthread / LG; li < nlong; li += ngroups) {
+    const int32_t u = ws.long_row[li], base = ws.long_base[li];
+    const int32_t nch = (seg[u + 1] - seg[u] + kLongSeg - 1) / kLongSeg;
+    const int64_t orow = mode == TT_GRAD_SPARSE ? (int64_t)u : (int64_t)unique_rows[u];
+    for (uint32_t chunk = lig; chunk < C; chunk += LG) {
+      Acc<VEC> acc;
+      acc.zero();
+      for (int32_t c = 0; c < nch; ++c) {
+        const float* p = ws.chunk_partial + (int64_t)(base + c) * E + chunk * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc.v[e] += p[e];
+      }
+      write_row<VEC>(out, orow, E, chunk, acc, mode == TT_GRAD_DENSE_ACC);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a17: Adam
+// ------------------------------------------------------------------------------------------------
+struct AdamK {
+  float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, wd;
+};
+
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamK& k) {
+  g = k.wd != 0.f ? g + k.wd * p : g;
+  m = k.b1 * m + (1.f - k.b1) * g;
+  v = k.b2 * v + (1.f - k.b2) * g * g;
+  const float denom = sqrtf(v) * k.inv_sqrt_bc2 + k.eps;
+  p -= k.lr_over_bc1 * (m / denom);
+}
+
+__global__ __launch_bounds__(kThreads) void adam_dense_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                             float* __restrict__ m, float* __restrict__ v, int64_t n, AdamK k) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float pp = p[i], mm = m[i], vv = v[i];
+    adam1(pp, g[i], mm, vv, k);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void adam_dense_vec4_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                                  float4* __restrict__ m, float4* __restrict__ v, int64_t n4, AdamK k) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = p[i], mm = m[i], vv = v[i];
+    const float4 gg = g[i];
+    adam1(pp.x, gg.x, mm.x, vv.x, k); adam1(pp.y, gg.y, mm.y, vv.y, k);
+    adam1(pp.z, gg.z, mm.z, vv.z, k); adam1(pp.w, gg.w, mm.w, vv.w, k);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void adam_sparse_kernel(float* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
+                                                              int32_t E, uint32_t C, const int32_t* __restrict__ unique_rows,
+                                                              const float* __restrict__ grad_rows, const int32_t* __restrict__ n_unique,
+                                                              AdamK k, uint32_t LG) {
+  const uint32_t U = (uint32_t)*n_unique;
+  const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lig = gthread % LG;
+  const uint32_t ngroups = gridDim.x * blockDim.x / LG;
+  for (uint32_t u = gthread / LG; u < U; u += ngroups) {
+    const int64_t row = unique_rows[u];
+    for (uint32_t chunk = lig; chunk < C; chunk += LG) {
+      const int64_t o = row * E + chunk * VEC;
+      const float* gp = grad_rows + (int64_t)u * E + chunk * VEC;
+      if (VEC == 4) {
+        float4 pp = *reinterpret_cast<float4*>(table + o), mm = *reinterpret_cast<float4*>(m + o),
+               vv = *reinterpret_cast<float4*>(v + o);
+        const float4 gg = *reinterpret_cast<const float4*>(gp);
+        adam1(pp.x, gg.x, mm.x, vv.x, k); adam1(pp.y, gg.y, mm.y, vv.y, k);
+        adam1(pp.z, gg.z, mm.z, vv.z, k); adam1(pp.w, gg.w, mm.w, vv.w, k);
+        *reinterpret_cast<float4*>(table + o) = pp;
+        *reinterpret_cast<float4*>(m + o) = mm;
+        *reinterpret_cast<float4*>(v + o) = vv;
+      } else {
+        float pp = table[o], mm = m[o], vv = v[o];
+        adam1(pp, gp[0], mm, vv, k);
+        table[o] = pp; m[o] = mm; v[o] = vv;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a1/a2: device-side batch assembly
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void batch_gather_kernel(const int64_t* __restrict__ entity, uint32_t B,
+                                                               const float* __restrict__ dense_store, uint32_t dense_dim,
+                                                               const int64_t* __restrict__ cat_store, uint32_t K,
+                                                               float* __restrict__ dense_out, int64_t* __restrict__ ids_out) {
+  const uint32_t per = dense_dim + K;
+  const uint32_t total = B * per;
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+    const uint32_t b = t / per, j = t - b * per;
+    const int64_t e = entity[b];
+    if (j < dense_dim) dense_out[(int64_t)b * dense_dim + j] = dense_store[e * dense_dim + j];
+    else ids_out[(int64_t)b * K + (j - dense_dim)] = cat_store[e * K + (j - dense_dim)];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------------------
+inline uint32_t pow2_at_least(uint32_t x) {
+  uint32_t p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+inline int grid_for(const tt_ctx* ctx, int64_t threads_needed) {
+  const int64_t cap = (int64_t)ctx->num_cus * 8;
+  int64_t b = tt_cdiv(threads_needed, kThreads);
+  if (b < 1) b = 1;
+  return (int)(b < cap ? b : cap);
+}
+
+struct DedupWs {
+  uint32_t *keysA, *keysB, *valsB, *hist, *blockcount;
+  size_t bytes;
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+inline DedupWs dedup_layout(char* base, int64_t M) {
+  DedupWs w;
+  const uint32_t nblk = (uint32_t)tt_cdiv(M > 0 ? M : 1, kSortTile);
+  size_t o = 0;
+  auto take = [&](size_t n) { char* p = base ? base + o : nullptr; o += align256(n); return p; };
+  w.keysA = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)(M + 1)));
+  w.keysB = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)(M + 1)));
+  w.valsB = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)(M + 1)));
+  w.hist = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)2048 * nblk));
+  w.blockcount = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)(nblk + 1)));
+  w.bytes = o;
+  return w;
+}
+
+struct GradLayout {
+  GradWs ws;
+  size_t bytes;
+  int64_t max_long, max_chunks;
+};
+
+inline GradLayout grad_layout(char* base, int64_t M, int32_t E) {
+  GradLayout g;
+  g.max_long = M / kLongSeg + 1;
+  g.max_chunks = M / kLongSeg + g.max_long + 1;
+  size_t o = 0;
+  auto take = [&](size_t n) { char* p = base ? base + o : nullptr; o += align256(n); return p; };
+  g.ws.counters = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2));
+  g.ws.long_row = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (size_t)g.max_long));
+  g.ws.long_base = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (size_t)g.max_long));
+  g.ws.chunk_lo = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (size_t)g.max_chunks));
+  g.ws.chunk_hi = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (size_t)g.max_chunks));
+  g.ws.chunk_partial = reinterpret_cast<float*>(take(sizeof(float) * (size_t)g.max_chunks * (size_t)E));
+  g.bytes = o;
+  return g;
+}
+
+template <int BITS>
+int sort_pass(hipStream_t st, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t M, int shift,
+              uint32_t* hist, uint32_t nblk) {
+  sort_hist_kernel<BITS><<<nblk, kThreads, 0, st>>>(kin, M, shift, hist, nblk);
+  TT_LAUNCH_CHECK();
+  scan_kernel<<<1, 1024, 0, st>>>(hist, (1u << BITS) * nblk, nullptr);
+  TT_LAUNCH_CHECK();
+  sort_scatter_kernel<BITS><<<nblk, kThreads, 0, st>>>(kin, vin, kout, vout, M, shift, hist, nblk);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+AdamK make_adam(int64_t step, float lr, float b1, float b2, float eps, float wd) {
+  const double bc1 = 1.0 - pow((double)b1, (double)step);
+  const double bc2 = 1.0 - pow((double)b2, (double)step);
+  AdamK k;
+  k.lr_over_bc1 = (float)((double)lr / bc1);
+  k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  k.b1 = b1; k.b2 = b2; k.eps = eps; k.wd = wd;
+  return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const tt_embed_side* sides,
+                        int32_t n_sides, int64_t B, int32_t* rows_out, tt_stream stream) {
+  TT_CHECK_ARG(ctx && table && sides, "tt_embed_lookup_fwd: NULL argument");
+  TT_CHECK_ARG(n_sides >= 1 && n_sides <= TT_MAX_SIDES, "tt_embed_lookup_fwd: n_sides=%d not in [1,%d]", n_sides, TT_MAX_SIDES);
+  TT_CHECK_ARG(E >= 1 && B >= 0 && table_rows >= 1, "tt_embed_lookup_fwd: bad E=%d B=%lld rows=%lld", E, (long long)B, (long long)table_rows);
+  TT_CHECK_ARG(table_rows <= INT32_MAX, "tt_embed_lookup_fwd: table_rows %lld exceeds int32 row index", (long long)table_rows);
+  SideSet a{};
+  a.n = n_sides;
+  a.E = E;
+  bool vec4 = (E % 4 == 0) && tt_aligned(table, 16);
+  int64_t slots = 0;
+  for (int i = 0; i < n_sides; ++i) {
+    const tt_embed_side& s = sides[i];
+    TT_CHECK_ARG(s.K >= 0 && (s.K == 0 || (s.ids && s.key_row_offset && s.key_vocab && s.out)), "tt_embed_lookup_fwd: side %d has NULL pointers", i);
+    TT_CHECK_ARG(s.out_dtype == TT_F32 || s.out_dtype == TT_BF16, "tt_embed_lookup_fwd: side %d bad out_dtype %d", i, s.out_dtype);
+    TT_CHECK_ARG(s.ld_out >= (int64_t)s.K * E, "tt_embed_lookup_fwd: side %d ld_out %lld < K*E", i, (long long)s.ld_out);
+    a.s[i] = SideDev{s.ids, s.key_row_offset, s.key_vocab, reinterpret_cast<char*>(s.out), s.ld_out, (uint32_t)slots, s.K, s.out_dtype};
+    const size_t esz = s.out_dtype == TT_BF16 ? 2 : 4;
+    vec4 = vec4 && (s.ld_out % 4 == 0) && tt_aligned(s.out, 4 * esz);
+    slots += B * s.K;
+  }
+  const int64_t C = vec4 ? E / 4 : E;
+  TT_CHECK_ARG(slots * C < (int64_t)1 << 31, "tt_embed_lookup_fwd: %lld slots x %lld chunks exceeds 2^31 tasks", (long long)slots, (long long)C);
+  if (slots == 0) return TT_OK;
+  a.C = (uint32_t)C;
+  a.total_slots = (uint32_t)slots;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  constexpr int U = 4;
+  const int grid = grid_for(ctx, tt_cdiv(slots * C, U));
+  if (vec4) lookup_kernel<4, U><<<grid, kThreads, 0, st>>>(a, table, rows_out);
+  else lookup_kernel<1, U><<<grid, kThreads, 0, st>>>(a, table, rows_out);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+size_t tt_dedup_workspace_bytes(int64_t M) { return dedup_layout(nullptr, M).bytes; }
+
+int tt_dedup_plan(tt_ctx* ctx, const int32_t* rows, int64_t M, int64_t table_rows, int32_t* sorted_src, int32_t* unique_rows,
+                  int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes, tt_stream stream) {
+  TT_CHECK_ARG(ctx && sorted_src && unique_rows && seg_offsets && n_unique, "tt_dedup_plan: NULL output");
+  TT_CHECK_ARG(M >= 0 && M < ((int64_t)1 << 31) - kSortTile, "tt_dedup_plan: M=%lld out of range", (long long)M);
+  TT_CHECK_ARG(table_rows >= 1 && table_rows <= INT32_MAX, "tt_dedup_plan: table_rows=%lld out of range", (long long)table_rows);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (M == 0) {
+    TT_HIP(hipMemsetAsync(n_unique, 0, sizeof(int32_t), st));
+    TT_HIP(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), st));
+    return TT_OK;
+  }
+  TT_CHECK_ARG(rows && workspace, "tt_dedup_plan: NULL rows/workspace");
+  if (workspace_bytes < tt_dedup_workspace_bytes(M)) {
+    tt_set_error("tt_dedup_plan: workspace %zu < required %zu", workspace_bytes, tt_dedup_workspace_bytes(M));
+    return TT_ERR_WORKSPACE;
+  }
+  DedupWs w = dedup_layout(reinterpret_cast<char*>(workspace), M);
+  const uint32_t nblk = (uint32_t)tt_cdiv(M, kSortTile);
+  int bits = 1;
+  while (((int64_t)1 << bits) < table_rows) ++bits;
+  // digit plan: fewest passes with 8- or 11-bit digits
+  int digit = 8, passes = (bits + 7) / 8;
+  if ((bits + 10) / 11 < passes) { digit = 11; passes = (bits + 10) / 11; }
+  // ping-pong so that the LAST pass lands values in sorted_src and keys in keysA
+  const uint32_t* kin = reinterpret_cast<const uint32_t*>(rows);
+  const uint32_t* vin = nullptr;
+  for (int p = 0; p < passes; ++p) {
+    const bool last_to_A = ((passes - 1 - p) % 2) == 0;
+    uint32_t* kout = last_to_A ? w.keysA : w.keysB;
+    uint32_t* vout = last_to_A ? reinterpret_cast<uint32_t*>(sorted_src) : w.valsB;
+    int rc = digit == 8 ? sort_pass<8>(st, kin, vin, kout, vout, (uint32_t)M, p * digit, w.hist, nblk)
+                        : sort_pass<11>(st, kin, vin, kout, vout, (uint32_t)M, p * digit, w.hist, nblk);
+    if (rc != TT_OK) return rc;
+    kin = kout;
+    vin = vout;
+  }
+  head_count_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount);
+  TT_LAUNCH_CHECK();
+  scan_kernel<<<1, 1024, 0, st>>>(w.blockcount, nblk, n_unique);
+  TT_LAUNCH_CHECK();
+  head_write_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount, n_unique, unique_rows, seg_offsets);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+size_t tt_embed_grad_workspace_bytes(int64_t M, int32_t E) { return grad_layout(nullptr, M > 0 ? M : 1, E > 0 ? E : 1).bytes; }
+
+int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int64_t B, int32_t E, const int32_t* sorted_src,
+                      const int32_t* seg_offsets, const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t mode,
+                      float* out, void* workspace, size_t workspace_bytes, tt_stream stream) {
+  TT_CHECK_ARG(ctx && srcs && out, "tt_embed_grad_bwd: NULL argument");
+  TT_CHECK_ARG(n_srcs >= 1 && n_srcs <= TT_MAX_SIDES, "tt_embed_grad_bwd: n_srcs=%d", n_srcs);
+  TT_CHECK_ARG(mode >= TT_GRAD_SPARSE && mode <= TT_GRAD_DENSE_ACC, "tt_embed_grad_bwd: bad mode %d", mode);
+  TT_CHECK_ARG(E >= 1 && B >= 0, "tt_embed_grad_bwd: bad E/B");
+  if (M == 0) return TT_OK;
+  TT_CHECK_ARG(sorted_src && seg_offsets && unique_rows && n_unique && workspace, "tt_embed_grad_bwd: NULL plan/workspace");
+  if (workspace_bytes < tt_embed_grad_workspace_bytes(M, E)) {
+    tt_set_error("tt_embed_grad_bwd: workspace %zu < required %zu", workspace_bytes, tt_embed_grad_workspace_bytes(M, E));
+    return TT_ERR_WORKSPACE;
+  }
+  SideSet a{};
+  a.n = n_srcs;
+  a.E = E;
+  bool vec4 = (E % 4 == 0) && tt_aligned(out, 16);
+  int64_t slots = 0;
+  for (int i = 0; i < n_srcs; ++i) {
+    const tt_grad_src& s = srcs[i];
+    TT_CHECK_ARG(s.K == 0 || s.d_out, "tt_embed_grad_bwd: src %d NULL", i);
+    TT_CHECK_ARG(s.dtype == TT_F32 || s.dtype == TT_BF16, "tt_embed_grad_bwd: src %d bad dtype", i);
+    a.s[i] = SideDev{nullptr, nullptr, nullptr, const_cast<char*>(reinterpret_cast<const char*>(s.d_out)), s.ld, (uint32_t)slots, s.K, s.dtype};
+    const size_t esz = s.dtype == TT_BF16 ? 2 : 4;
+    vec4 = vec4 && (s.ld % 4 == 0) && tt_aligned(s.d_out, 4 * esz);
+    slots += B * s.K;
+  }
+  TT_CHECK_ARG(slots == M, "tt_embed_grad_bwd: sum(B*K)=%lld != M=%lld", (long long)slots, (long long)M);
+  a.C = (uint32_t)(vec4 ? E / 4 : E);
+  a.total_slots = (uint32_t)slots;
+  const uint32_t LG = pow2_at_least(a.C) > 64 ? 64 : pow2_at_least(a.C);
+  GradLayout gl = grad_layout(reinterpret_cast<char*>(workspace), M, E);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  TT_HIP(hipMemsetAsync(gl.ws.counters, 0, 2 * sizeof(int32_t), st));
+  const int g1 = grid_for(ctx, M * LG);
+  const int g2 = grid_for(ctx, gl.max_chunks * LG);
+  const int g3 = grid_for(ctx, gl.max_long * LG);
+  if (vec4) {
+    seg_reduce_kernel<4><<<g1, kThreads, 0, st>>>(a, sorted_src, seg_offsets, unique_rows, n_unique, mode, out, gl.ws, LG);
+    TT_LAUNCH_CHECK();
+    seg_chunk_kernel<4><<<g2, kThreads, 0, st>>>(a, sorted_src, gl.ws, LG);
+    TT_LAUNCH_CHECK();
+    seg_long_finish_kernel<4><<<g3, kThreads, 0, st>>>(E, a.C, seg_offsets, unique_rows, mode, out, gl.ws, LG);
+  } else {
+    seg_reduce_kernel<1><<<g1, kThreads, 0, st>>>(a, sorted_src, seg_offsets, unique_rows, n_unique, mode, out, gl.ws, LG);
+    TT_LAUNCH_CHECK();
+    seg_chunk_kernel<1><<<g2, kThreads, 0, st>>>(a, sorted_src, gl.ws, LG);
+    TT_LAUNCH_CHECK();
+    seg_long_finish_kernel<1><<<g3, kThreads, 0, st>>>(E, a.C, seg_offsets, unique_rows, mode, out, gl.ws, LG);
+  }
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, tt_stream stream) {
+  TT_CHECK_ARG(ctx && (n == 0 || (p && g && m && v)), "tt_adam_dense_step: NULL argument");
+  TT_CHECK_ARG(step >= 1 && n >= 0, "tt_adam_dense_step: step must be >= 1");
+  if (n == 0) return TT_OK;
+  const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n % 4 == 0 && tt_aligned(p, 16) && tt_aligned(g, 16) && tt_aligned(m, 16) && tt_aligned(v, 16)) {
+    adam_dense_vec4_kernel<<<grid_for(ctx, n / 4), kThreads, 0, st>>>(reinterpret_cast<float4*>(p), reinterpret_cast<const float4*>(g),
+                                                                      reinterpret_cast<float4*>(m), reinterpret_cast<float4*>(v), n / 4, k);
+  } else {
+    adam_dense_kernel<<<grid_for(ctx, n), kThreads, 0, st>>>(p, g, m, v, n, k);
+  }
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E, const int32_t* unique_rows, const float* grad_rows,
+                        const int32_t* n_unique, int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, tt_stream stream) {
+  TT_CHECK_ARG(ctx && table && m && v, "tt_sparse_adam_step: NULL state");
+  TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 0, "tt_sparse_adam_step: bad step/E/M");
+  if (M == 0) return TT_OK;
+  TT_CHECK_ARG(unique_rows && grad_rows && n_unique, "tt_sparse_adam_step: NULL plan");
+  const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay);
+  const bool vec4 = (E % 4 == 0) && tt_aligned(table, 16) && tt_aligned(m, 16) && tt_aligned(v, 16) && tt_aligned(grad_rows, 16);
+  const uint32_t C = vec4 ? E / 4 : E;
+  const uint32_t LG = pow2_at_least(C) > 64 ? 64 : pow2_at_least(C);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(ctx, M * LG);
+  if (vec4) adam_sparse_kernel<4><<<grid, kThreads, 0, st>>>(table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG);
+  else adam_sparse_kernel<1><<<grid, kThreads, 0, st>>>(table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_batch_gather(tt_ctx* ctx, const int64_t* entity, int64_t B, const float* dense_store, int32_t dense_dim,
+                    const int64_t* cat_store, int32_t K, float* dense_out, int64_t* ids_out, tt_stream stream) {
+  TT_CHECK_ARG(ctx && entity, "tt_batch_gather: NULL argument");
+  TT_CHECK_ARG(B >= 0 && dense_dim >= 0 && K >= 0, "tt_batch_gather: negative size");
+  TT_CHECK_ARG(dense_dim == 0 || (dense_store && dense_out), "tt_batch_gather: NULL dense buffers");
+  TT_CHECK_ARG(K == 0 || (cat_store && ids_out), "tt_batch_gather: NULL id buffers");
+  const int64_t total = B * ((int64_t)dense_dim + K);
+  TT_CHECK_ARG(total < ((int64_t)1 << 31), "tt_batch_gather: too many elements");
+  if (total == 0) return TT_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  batch_gather_kernel<<<grid_for(ctx, total), kThreads, 0, st>>>(entity, (uint32_t)B, dense_store, (uint32_t)dense_dim, cat_store,
+                                                                  (uint32_t)K, dense_out, ids_out);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+}  // extern "C"

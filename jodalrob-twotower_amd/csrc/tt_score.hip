@@ -1,0 +1,385 @@
+// In-batch-negative score + symmetric softmax cross-entropy without materialising the BxB score
+// matrix.  One "direction" = 64 rows of A per workgroup swept against every row of Bm in 128-column
+// tiles: S tile on v_mfma_f32_32x32x2_f32 (exact f32 fmaf chain), exp / row sums / diagonal rank in
+// the accumulator registers; the backward recomputes the tile, forms the softmax weights in
+// registers, passes them through LDS and contracts them with the same Bm tile on MFMA.
+// Row sums use a fixed shift (unit-norm rows => |s| <= 1/T), so no running maximum is needed and all
+// reductions have a fixed order (bitwise reproducible).
+#include "tt_gemm.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int RB = 64;        // rows of A per workgroup
+constexpr int CB = 128;       // columns (rows of Bm) per tile
+constexpr int DK = 64;        // feature chunk staged in LDS
+constexpr int LDK = DK + 1;   // odd stride: conflict-free fragment reads, 2-way (free) staging writes
+constexpr int LDW = CB + 1;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+__device__ __forceinline__ int rowmap(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// stage rows [r0, r0+ROWS) x features [d0, d0+DK) of P[R, D] into S[ROWS][LDK] (zero padded)
+template <int ROWS, bool VEC>
+__device__ __forceinline__ void stage(const float* __restrict__ P, int64_t R, int D, int64_t r0, int d0, float* __restrict__ S, int t) {
+#pragma unroll
+  for (int p = 0; p < ROWS / 16; ++p) {
+    const int row = p * 16 + (t >> 4), kq = (t & 15) * 4;
+    const int64_t gr = r0 + row;
+    const int d = d0 + kq;
+    float v[4];
+    if (VEC && gr < R && d + 3 < D) {
+      const float4 q = *reinterpret_cast<const float4*>(P + gr * D + d);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (gr < R && d + j < D) ? P[gr * D + d + j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) S[row * LDK + kq + j] = v[j];
+  }
+}
+
+// S tile: wave (wr, wc) computes rows wr*32..+32 x cols wc*64..+64 as two 32x32 accumulators
+__device__ __forceinline__ void mfma_s_chunk(const float* __restrict__ As, const float* __restrict__ Bs, int wr, int wc, int li, int lh,
+                                             f32x16& acc0, f32x16& acc1) {
+#pragma unroll 8
+  for (int k = 0; k < DK; k += 2) {
+    const float a = As[(wr * 32 + li) * LDK + k + lh];
+    const float b0 = Bs[(wc * 64 + li) * LDK + k + lh];
+    const float b1 = Bs[(wc * 64 + 32 + li) * LDK + k + lh];
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ float half_sum(float x) {   // sum over the 32 lanes sharing lane>>5
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ int half_sum_i(int x) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+
+// the diagonal score as the same k-ordered fmaf chain the MFMA evaluates
+__device__ __forceinline__ float diag_score(const float* __restrict__ A, const float* __restrict__ Bm, int64_t a, int64_t b, int D, float inv_t) {
+  float acc = 0.f;
+  for (int k = 0; k < D; ++k) acc = __builtin_fmaf(A[a * D + k], Bm[b * D + k], acc);
+  return acc * inv_t;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void score_dir_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int64_t Ra,
+                                                                int64_t Rb, int D, float inv_t, float shift, int64_t diag_off,
+                                                                float* __restrict__ sumexp, float* __restrict__ diag_out,
+                                                                int32_t* __restrict__ rank_out, float* __restrict__ sumscore) {
+  __shared__ float As[RB * LDK];
+  __shared__ float Bs[CB * LDK];
+  __shared__ float diag_s[RB];
+  __shared__ float part_e[2][RB];
+  __shared__ float part_s[2][RB];
+  __shared__ int part_r[2][RB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave & 1, wc = wave >> 1, li = lane & 31, lh = lane >> 5;
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  const int nch = (D + DK - 1) / DK;
+  if (t < RB) {
+    const int64_t a = r0 + t, b = a + diag_off;
+    diag_s[t] = (a < Ra && b >= 0 && b < Rb) ? diag_score(A, Bm, a, b, D, inv_t) : 0.f;
+  }
+  if (nch == 1) stage<RB, VEC>(A, Ra, D, r0, 0, As, t);
+  __syncthreads();
+  float dg[16], se[16], ss[16];
+  int rk[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    dg[r] = diag_s[wr * 32 + rowmap(r, lh)];
+    se[r] = 0.f; ss[r] = 0.f; rk[r] = 0;
+  }
+  for (int64_t c0 = 0; c0 < Rb; c0 += CB) {
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int ch = 0; ch < nch; ++ch) {
+      __syncthreads();                                   // previous tile's readers are done
+      if (nch > 1) stage<RB, VEC>(A, Ra, D, r0, ch * DK, As, t);
+      stage<CB, VEC>(Bm, Rb, D, c0, ch * DK, Bs, t);
+      __syncthreads();
+      mfma_s_chunk(As, Bs, wr, wc, li, lh, acc0, acc1);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t col = c0 + wc * 64 + h * 32 + li;
+      const bool cv = col < Rb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float s = (h == 0 ? acc0[r] : acc1[r]) * inv_t;
+        const int64_t pos = r0 + wr * 32 + rowmap(r, lh) + diag_off;
+        if (cv) {
+          se[r] += __expf(s - shift);
+          ss[r] += s;
+          rk[r] += (s > dg[r] || (s == dg[r] && col < pos)) ? 1 : 0;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float e = half_sum(se[r]), s = half_sum(ss[r]);
+    const int k = half_sum_i(rk[r]);
+    if (li == 0) {
+      const int row = wr * 32 + rowmap(r, lh);
+      part_e[wc][row] = e; part_s[wc][row] = s; part_r[wc][row] = k;
+    }
+  }
+  __syncthreads();
+  if (t < RB && r0 + t < Ra) {
+    sumexp[r0 + t] = part_e[0][t] + part_e[1][t];
+    diag_out[r0 + t] = diag_s[t];
+    rank_out[r0 + t] = part_r[0][t] + part_r[1][t];
+    if (sumscore) sumscore[r0 + t] = part_s[0][t] + part_s[1][t];
+  }
+}
+
+// backward of one direction; NCH = ceil(D / 64) feature chunks kept as MFMA accumulators
+template <int NCH, bool VEC>
+__global__ __launch_bounds__(kThreads) void score_dir_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Bm, int64_t Ra,
+                                                                int64_t Rb, int D, float inv_t, float shift, int64_t diag_off,
+                                                                const float* __restrict__ sumexp_a, const float* __restrict__ sumexp_b,
+                                                                const float* __restrict__ d_loss, float scale, float* __restrict__ dA) {
+  __shared__ float As[RB * LDK];
+  __shared__ float Bs[CB * LDK];
+  __shared__ float Ws[RB * LDW];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave & 1, wc = wave >> 1, li = lane & 31, lh = lane >> 5;
+  const int64_t r0 = (int64_t)blockIdx.x * RB;
+  if (NCH == 1) stage<RB, VEC>(A, Ra, D, r0, 0, As, t);
+  float ia[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t a = r0 + wr * 32 + rowmap(r, lh);
+    ia[r] = a < Ra ? 1.f / sumexp_a[a] : 0.f;
+  }
+  f32x16 dacc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dacc[c][i] = 0.f;
+  for (int64_t c0 = 0; c0 < Rb; c0 += CB) {
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      __syncthreads();
+      if (NCH > 1) stage<RB, VEC>(A, Ra, D, r0, ch * DK, As, t);
+      stage<CB, VEC>(Bm, Rb, D, c0, ch * DK, Bs, t);
+      __syncthreads();
+      mfma_s_chunk(As, Bs, wr, wc, li, lh, acc0, acc1);
+    }
+    // softmax weights of this tile -> LDS in [row][col] order
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int cl = wc * 64 + h * 32 + li;
+      const int64_t col = c0 + cl;
+      const bool cv = col < Rb;
+      const float ib = cv ? 1.f / sumexp_b[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wr * 32 + rowmap(r, lh);
+        const float s = (h == 0 ? acc0[r] : acc1[r]) * inv_t;
+        float w = 0.f;
+        if (cv) {
+          w = __expf(s - shift) * (ia[r] + ib);
+          if (col == r0 + row + diag_off) w -= 2.f;
+        }
+        Ws[row * LDW + cl] = w;
+      }
+    }
+    // dA[:, chunk] += W[64 x 128] . Bm_tile[128 x 64]; wave (wr, wc) -> rows wr*32.., features wc*32..
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      __syncthreads();                                   // Ws complete (ch == 0) / Bs readers done (ch > 0)
+      if (NCH > 1) {
+        stage<CB, VEC>(Bm, Rb, D, c0, ch * DK, Bs, t);
+        __syncthreads();
+      }
+#pragma unroll 8
+      for (int kb = 0; kb < CB; kb += 2) {
+        const float a = Ws[(wr * 32 + li) * LDW + kb + lh];
+        const float b = Bs[(kb + lh) * LDK + wc * 32 + li];
+        dacc[ch] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, dacc[ch], 0, 0, 0);
+      }
+    }
+  }
+  const float g = d_loss[0] * scale;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int d = ch * DK + wc * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int64_t a = r0 + wr * 32 + rowmap(r, lh);
+      if (a < Ra && d < D) dA[a * D + d] = dacc[ch][r] * g;
+    }
+  }
+}
+
+// loss + metrics from the per-row results of both directions (one workgroup, fixed-order sums)
+__device__ __forceinline__ float block_sum(float x, float* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void loss_finish_kernel(int64_t B, float shift, const float* __restrict__ rowsum,
+                                                           const float* __restrict__ colsum, const float* __restrict__ diag,
+                                                           const int32_t* __restrict__ row_rank, const int32_t* __restrict__ col_rank,
+                                                           const float* __restrict__ sumscore, float* __restrict__ out) {
+  __shared__ float sh[16];
+  float l = 0.f, hit = 0.f, chit = 0.f, dsum = 0.f, tot = 0.f;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
+    const float d = diag[i];
+    l += (logf(rowsum[i]) + shift - d) + (logf(colsum[i]) + shift - d);
+    hit += row_rank[i] == 0 ? 1.f : 0.f;
+    chit += col_rank[i] == 0 ? 1.f : 0.f;
+    dsum += d;
+    tot += sumscore ? sumscore[i] : 0.f;
+  }
+  l = block_sum(l, sh); hit = block_sum(hit, sh); chit = block_sum(chit, sh);
+  dsum = block_sum(dsum, sh); tot = block_sum(tot, sh);
+  if (threadIdx.x == 0) {
+    const float fb = (float)B;
+    const float pos = dsum / fb;
+    const float neg = (tot - dsum) / (fb * fb - fb);       // mean over the off-diagonal (nan for B == 1, as torch)
+    out[0] = 0.5f * l / fb;
+    out[1] = hit / fb;
+    out[2] = pos;
+    out[3] = neg;
+    out[4] = pos - neg;
+    out[5] = chit / fb;
+    out[6] = tot;
+    out[7] = 0.f;
+  }
+}
+
+// top-k per row: one wave per row, k selection passes over the row in the total order
+// (value descending, column ascending) -- no marking, no scratch
+__global__ __launch_bounds__(kThreads) void topk_rows_kernel(const float* __restrict__ S, int64_t R, int64_t C, int64_t lds, int k,
+                                                            float* __restrict__ vals, int64_t* __restrict__ idx) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float* s = S + row * lds;
+  float pv = __builtin_inff();
+  int64_t pi = -1;
+  for (int j = 0; j < k; ++j) {
+    float bv = -__builtin_inff();
+    int64_t bi = INT64_MAX;
+    for (int64_t c = lane; c < C; c += 64) {
+      const float v = s[c];
+      const bool after_prev = v < pv || (v == pv && c > pi);
+      const bool better = v > bv || (v == bv && c < bi);
+      if (after_prev && better) { bv = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(bv, o);
+      const int64_t oi = __shfl_xor(bi, o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+      vals[row * k + j] = bv;
+      idx[row * k + j] = bi == INT64_MAX ? -1 : bi;
+    }
+    pv = bv; pi = bi;
+  }
+}
+
+inline bool vec_ok(const float* p, int D) { return tt_aligned(p, 16) && (D % 4 == 0); }
+
+}  // namespace
+
+extern "C" {
+
+int tt_score_dir_fwd(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D, float inv_t, float shift,
+                     int64_t diag_offset, float* sumexp, float* diag, int32_t* rank, float* sumscore, tt_stream stream) {
+  TT_CHECK_ARG(ctx && A && Bm && sumexp && diag && rank, "tt_score_dir_fwd: NULL argument");
+  TT_CHECK_ARG(Ra >= 1 && Rb >= 1 && D >= 1, "tt_score_dir_fwd: bad shape");
+  TT_CHECK_ARG(Ra < ((int64_t)1 << 31) && Rb < ((int64_t)1 << 31), "tt_score_dir_fwd: too many rows");
+  if (2.f * fabsf(inv_t) > 80.f) {
+    tt_set_error("tt_score_dir_fwd: 1/temperature = %g: fixed-shift softmax needs 2/T <= 80", inv_t);
+    return TT_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = (unsigned)tt_cdiv(Ra, RB);
+  if (vec_ok(A, D) && vec_ok(Bm, D))
+    score_dir_fwd_kernel<true><<<grid, kThreads, 0, st>>>(A, Bm, Ra, Rb, D, inv_t, shift, diag_offset, sumexp, diag, rank, sumscore);
+  else
+    score_dir_fwd_kernel<false><<<grid, kThreads, 0, st>>>(A, Bm, Ra, Rb, D, inv_t, shift, diag_offset, sumexp, diag, rank, sumscore);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_score_loss_finish(tt_ctx* ctx, int64_t B, float shift, const float* rowsum, const float* colsum, const float* diag,
+                         const int32_t* row_rank, const int32_t* col_rank, const float* sumscore, float* out8, tt_stream stream) {
+  TT_CHECK_ARG(ctx && rowsum && colsum && diag && row_rank && col_rank && out8, "tt_score_loss_finish: NULL argument");
+  TT_CHECK_ARG(B >= 1, "tt_score_loss_finish: B < 1");
+  loss_finish_kernel<<<1, 1024, 0, reinterpret_cast<hipStream_t>(stream)>>>(B, shift, rowsum, colsum, diag, row_rank, col_rank, sumscore, out8);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_score_dir_bwd(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D, float inv_t, float shift,
+                     int64_t diag_offset, const float* sumexp_a, const float* sumexp_b, const float* d_loss, float scale, float* dA,
+                     tt_stream stream) {
+  TT_CHECK_ARG(ctx && A && Bm && sumexp_a && sumexp_b && d_loss && dA, "tt_score_dir_bwd: NULL argument");
+  TT_CHECK_ARG(Ra >= 1 && Rb >= 1 && D >= 1, "tt_score_dir_bwd: bad shape");
+  if (D > 4 * DK) {
+    tt_set_error("tt_score_dir_bwd: D=%d > %d not supported", D, 4 * DK);
+    return TT_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned grid = (unsigned)tt_cdiv(Ra, RB);
+  const bool v = vec_ok(A, D) && vec_ok(Bm, D);
+  const int nch = (D + DK - 1) / DK;
+#define TT_BWD(NCHV)                                                                                                          \
+  if (v) score_dir_bwd_kernel<NCHV, true><<<grid, kThreads, 0, st>>>(A, Bm, Ra, Rb, D, inv_t, shift, diag_offset, sumexp_a, sumexp_b, d_loss, scale, dA); \
+  else score_dir_bwd_kernel<NCHV, false><<<grid, kThreads, 0, st>>>(A, Bm, Ra, Rb, D, inv_t, shift, diag_offset, sumexp_a, sumexp_b, d_loss, scale, dA);
+  switch (nch) {
+    case 1: TT_BWD(1) break;
+    case 2: TT_BWD(2) break;
+    case 3: TT_BWD(3) break;
+    default: TT_BWD(4) break;
+  }
+#undef TT_BWD
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_score_matrix(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D, float inv_t, float* S,
+                    int64_t lds, tt_stream stream) {
+  TT_CHECK_ARG(ctx && A && Bm && S, "tt_score_matrix: NULL argument");
+  TT_CHECK_ARG(Ra >= 0 && Rb >= 0 && D >= 1 && lds >= Rb, "tt_score_matrix: bad shape");
+  TT_CHECK_ARG(Ra < ((int64_t)1 << 31) && Rb < ((int64_t)1 << 31), "tt_score_matrix: too many rows");
+  return tt_gemm_nt(reinterpret_cast<hipStream_t>(stream), A, D, Bm, D, nullptr, S, lds, Ra, Rb, D, false, inv_t);
+}
+
+int tt_topk_rows(tt_ctx* ctx, const float* S, int64_t R, int64_t Ccols, int64_t lds, int32_t k, float* vals, int64_t* idx,
+                 tt_stream stream) {
+  TT_CHECK_ARG(ctx && (R == 0 || (S && vals && idx)), "tt_topk_rows: NULL argument");
+  TT_CHECK_ARG(k >= 1 && k <= 64 && k <= Ccols, "tt_topk_rows: k=%d not in [1, min(64, %lld)]", k, (long long)Ccols);
+  if (R == 0) return TT_OK;
+  topk_rows_kernel<<<(unsigned)tt_cdiv(R, 4), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(S, R, Ccols, lds, k, vals, idx);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+}  // extern "C"

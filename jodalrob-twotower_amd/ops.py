@@ -1,0 +1,202 @@
+"""Thin Python wrappers over the C ABI (one per entry point of include/twotower.h).  They only
+translate torch tensors to pointers/sizes and allocate outputs; no arithmetic happens here."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from ._lib import TT_BF16, TT_F32, TT_GRAD_DENSE_ACC, TT_GRAD_DENSE_SET, TT_GRAD_SPARSE  # noqa: F401
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return TT_F32
+    if t.dtype == torch.bfloat16:
+        return TT_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+# ---------------------------------------------------------------------------------------------- lookup
+@dataclass
+class LookupSide:
+    ids: torch.Tensor             # int64 [B*K] sample-major
+    key_row_offset: torch.Tensor  # int64 [K] (device)
+    key_vocab: torch.Tensor       # int64 [K] (device)
+    out: torch.Tensor             # 2-D view [B, K*E] inside the destination buffer (row stride = ld)
+    K: int
+
+
+def embed_lookup(table: torch.Tensor, sides: Sequence[LookupSide], B: int, want_rows: bool) -> Optional[torch.Tensor]:
+    dev = table.device
+    E = table.shape[1]
+    arr = (L.EmbedSide * len(sides))()
+    M = 0
+    for i, s in enumerate(sides):
+        if s.ids.dtype != torch.int64 or not s.ids.is_contiguous() or s.ids.device != dev:
+            raise ValueError("ids must be a contiguous int64 tensor on the table's device")
+        if s.ids.numel() != B * s.K:
+            raise ValueError(f"side {i}: {s.ids.numel()} ids for B={B}, K={s.K}")
+        assert s.out.stride(1) == 1
+        arr[i] = L.EmbedSide(L.ptr(s.ids), L.ptr(s.key_row_offset), L.ptr(s.key_vocab), L.ptr(s.out),
+                             s.out.stride(0), s.K, _dt(s.out))
+        M += B * s.K
+    rows = torch.empty(M, dtype=torch.int32, device=dev) if want_rows else None
+    L.check(L.load().tt_embed_lookup_fwd(L.ctx(dev), L.ptr(table), table.shape[0], E, arr, len(sides), B,
+                                         L.ptr(rows), L.stream(dev)), "tt_embed_lookup_fwd")
+    return rows
+
+
+@dataclass
+class DedupPlan:
+    sorted_src: torch.Tensor
+    unique_rows: torch.Tensor
+    seg_offsets: torch.Tensor
+    n_unique: torch.Tensor        # int32 [1] on device
+    M: int
+
+
+def dedup_plan(rows: torch.Tensor, table_rows: int) -> DedupPlan:
+    dev, M = rows.device, rows.numel()
+    buf = torch.empty(3 * M + 2, dtype=torch.int32, device=dev)
+    plan = DedupPlan(buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:], M)
+    lib = L.load()
+    nb = lib.tt_dedup_workspace_bytes(M)
+    ws = L.workspace(dev, nb)
+    L.check(lib.tt_dedup_plan(L.ctx(dev), L.ptr(rows), M, table_rows, L.ptr(plan.sorted_src), L.ptr(plan.unique_rows),
+                              L.ptr(plan.seg_offsets), L.ptr(plan.n_unique), L.ptr(ws), ws.numel(), L.stream(dev)),
+            "tt_dedup_plan")
+    return plan
+
+
+def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int, out: torch.Tensor):
+    """srcs: [(d_out 2-D view [B, K*E], K)]."""
+    dev = out.device
+    arr = (L.GradSrc * len(srcs))()
+    for i, (d, K) in enumerate(srcs):
+        assert d.stride(1) == 1
+        arr[i] = L.GradSrc(L.ptr(d), d.stride(0), K, _dt(d))
+    lib = L.load()
+    nb = lib.tt_embed_grad_workspace_bytes(plan.M, E)
+    ws = L.workspace(dev, nb)
+    L.check(lib.tt_embed_grad_bwd(L.ctx(dev), arr, len(srcs), B, E, L.ptr(plan.sorted_src), L.ptr(plan.seg_offsets),
+                                  L.ptr(plan.unique_rows), L.ptr(plan.n_unique), plan.M, mode, L.ptr(out), L.ptr(ws),
+                                  ws.numel(), L.stream(dev)), "tt_embed_grad_bwd")
+
+
+# ---------------------------------------------------------------------------------------------- Adam
+def adam_dense(p, g, m, v, step, lr, b1, b2, eps, wd):
+    dev = p.device
+    L.check(L.load().tt_adam_dense_step(L.ctx(dev), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), step, lr, b1, b2,
+                                        eps, wd, L.stream(dev)), "tt_adam_dense_step")
+
+
+def adam_sparse(table, m, v, plan: DedupPlan, grad_rows, step, lr, b1, b2, eps, wd):
+    dev = table.device
+    L.check(L.load().tt_sparse_adam_step(L.ctx(dev), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[1],
+                                         L.ptr(plan.unique_rows), L.ptr(grad_rows), L.ptr(plan.n_unique), plan.M, step,
+                                         lr, b1, b2, eps, wd, L.stream(dev)), "tt_sparse_adam_step")
+
+
+# ---------------------------------------------------------------------------------------------- tower MLP
+def _fill(arr, tensors):
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else 0
+
+
+def tower_params_struct(din, h0, kcat_e, hidden, d_out, w_proj, b_proj, ws, bs, bn_w, bn_b, bn_rm, bn_rv, w_out, b_out):
+    if len(hidden) > L.TT_MAX_HIDDEN:
+        raise ValueError(f"at most {L.TT_MAX_HIDDEN} hidden blocks per tower are supported")
+    p = L.TowerParams()
+    p.din, p.h0, p.kcat_e, p.n_hidden, p.d_out = din, h0, kcat_e, len(hidden), d_out
+    for i, h in enumerate(hidden):
+        p.hidden[i] = h
+    p.w_proj, p.b_proj, p.w_out, p.b_out = w_proj.data_ptr(), b_proj.data_ptr(), w_out.data_ptr(), b_out.data_ptr()
+    _fill(p.w, ws); _fill(p.b, bs); _fill(p.bn_w, bn_w); _fill(p.bn_b, bn_b); _fill(p.bn_rm, bn_rm); _fill(p.bn_rv, bn_rv)
+    return p
+
+
+def tower_workspace(params, B, dev):
+    nb = L.load().tt_tower_workspace_bytes(C.byref(params), B)
+    return L.workspace(dev, nb)
+
+
+def tower_fwd(params, acts, B, train, p_drop, seed, dev):
+    ws = tower_workspace(params, B, dev)
+    L.check(L.load().tt_tower_mlp_fwd(L.ctx(dev), C.byref(params), C.byref(acts), B, int(train), p_drop, seed, L.ptr(ws),
+                                      ws.numel(), L.stream(dev)), "tt_tower_mlp_fwd")
+
+
+def tower_bwd(params, acts, d_emb, grads, B, train, p_drop, seed, dev):
+    ws = tower_workspace(params, B, dev)
+    L.check(L.load().tt_tower_mlp_bwd(L.ctx(dev), C.byref(params), C.byref(acts), L.ptr(d_emb), C.byref(grads), B,
+                                      int(train), p_drop, seed, L.ptr(ws), ws.numel(), L.stream(dev)), "tt_tower_mlp_bwd")
+
+
+# ---------------------------------------------------------------------------------------------- score / loss
+def score_dir_fwd(A, Bm, inv_t, shift, diag_offset=0, want_sumscore=True):
+    dev, Ra, Rb, D = A.device, A.shape[0], Bm.shape[0], A.shape[1]
+    f = torch.empty((3, Ra), dtype=torch.float32, device=dev)       # sumexp, diag, sumscore
+    rank = torch.empty(Ra, dtype=torch.int32, device=dev)
+    L.check(L.load().tt_score_dir_fwd(L.ctx(dev), L.ptr(A), L.ptr(Bm), Ra, Rb, D, inv_t, shift, diag_offset, L.ptr(f[0]),
+                                      L.ptr(f[1]), L.ptr(rank), L.ptr(f[2]) if want_sumscore else None, L.stream(dev)),
+            "tt_score_dir_fwd")
+    return f[0], f[1], rank, f[2]
+
+
+def score_loss_finish(B, shift, rowsum, colsum, diag, row_rank, col_rank, sumscore):
+    dev = rowsum.device
+    out = torch.empty(8, dtype=torch.float32, device=dev)
+    L.check(L.load().tt_score_loss_finish(L.ctx(dev), B, shift, L.ptr(rowsum), L.ptr(colsum), L.ptr(diag), L.ptr(row_rank),
+                                          L.ptr(col_rank), L.ptr(sumscore), L.ptr(out), L.stream(dev)), "tt_score_loss_finish")
+    return out
+
+
+def score_dir_bwd(A, Bm, inv_t, shift, diag_offset, sumexp_a, sumexp_b, d_loss, scale):
+    dev, Ra, Rb, D = A.device, A.shape[0], Bm.shape[0], A.shape[1]
+    dA = torch.empty_like(A)
+    L.check(L.load().tt_score_dir_bwd(L.ctx(dev), L.ptr(A), L.ptr(Bm), Ra, Rb, D, inv_t, shift, diag_offset, L.ptr(sumexp_a),
+                                      L.ptr(sumexp_b), L.ptr(d_loss), scale, L.ptr(dA), L.stream(dev)), "tt_score_dir_bwd")
+    return dA
+
+
+def score_matrix(A, Bm, inv_t):
+    dev, Ra, Rb, D = A.device, A.shape[0], Bm.shape[0], A.shape[1]
+    S = torch.empty((Ra, Rb), dtype=torch.float32, device=dev)
+    L.check(L.load().tt_score_matrix(L.ctx(dev), L.ptr(A), L.ptr(Bm), Ra, Rb, D, inv_t, L.ptr(S), Rb, L.stream(dev)),
+            "tt_score_matrix")
+    return S
+
+
+def topk_rows(S, k):
+    dev, R, Cc = S.device, S.shape[0], S.shape[1]
+    assert S.stride(1) == 1
+    vals = torch.empty((R, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((R, k), dtype=torch.int64, device=dev)
+    L.check(L.load().tt_topk_rows(L.ctx(dev), L.ptr(S), R, Cc, S.stride(0), k, L.ptr(vals), L.ptr(idx), L.stream(dev)),
+            "tt_topk_rows")
+    return vals, idx
+
+
+# ---------------------------------------------------------------------------------------------- misc
+def linear_fwd(X, W, bias, relu=False):
+    dev, M, K, N = X.device, X.shape[0], X.shape[1], W.shape[0]
+    assert X.stride(1) == 1 and W.is_contiguous()
+    Y = torch.empty((M, N), dtype=torch.float32, device=dev)
+    L.check(L.load().tt_linear_fwd(L.ctx(dev), L.ptr(X), X.stride(0), L.ptr(W), L.ptr(bias), L.ptr(Y), N, M, N, K, int(relu),
+                                   L.stream(dev)), "tt_linear_fwd")
+    return Y
+
+
+def batch_gather(entity, dense_store, cat_store):
+    dev, B = entity.device, entity.numel()
+    dd = dense_store.shape[1] if dense_store is not None else 0
+    K = cat_store.shape[1] if cat_store is not None else 0
+    dense = torch.empty((B, dd), dtype=torch.float32, device=dev)
+    ids = torch.empty(B * K, dtype=torch.int64, device=dev)
+    L.check(L.load().tt_batch_gather(L.ctx(dev), L.ptr(entity), B, L.ptr(dense_store), dd, L.ptr(cat_store), K, L.ptr(dense),
+                                     L.ptr(ids), L.stream(dev)), "tt_batch_gather")
+    return dense, ids

@@ -1,0 +1,282 @@
+"""BaseTower / NoticeTower / CompanyTower on the HIP path.
+
+Drop-in for src/towers/tower/{base_tower,notice_tower,company_tower}.py: same constructor arguments,
+same sub-module names and therefore the same state-dict keys and shapes
+(`categorical_embedder.embeddings.<key>.weight`, `dense_projection.{weight,bias}`,
+`mlp.{4i}.{weight,bias}`, `mlp.{4i+2}.{weight,bias,running_mean,running_var,num_batches_tracked}`,
+`mlp.{4n}.{weight,bias}`), same forward contract: {"dense": [B,Din] f32, "kjt": KJT} -> unit rows [B,D].
+
+The torch modules below (nn.Linear / nn.BatchNorm1d / ...) are PARAMETER CONTAINERS only -- they give
+the reference's initialisation and key names; their forward is never called.  The arithmetic runs in
+libtwotower_hip.so: tt_embed_lookup_fwd writes the embedding rows straight into the MLP input buffer
+(no torch.cat), tt_tower_mlp_fwd/_bwd run the MLP, tt_dedup_plan + tt_embed_grad_bwd produce the
+table gradients.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .cat_embed import CategoricalEmbedder, EmbeddingStore
+
+
+def _al(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class BaseTower(nn.Module):
+    def __init__(self, categorical_keys: List[str], metadata_path: str = "meta/metadata.csv", table_name: str = "notice",
+                 categorical_embedding_dim: int = 64, dense_input_dim: int = 256,
+                 tower_hidden_dims: Optional[List[int]] = None, final_embedding_dim: int = 128, dropout_rate: float = 0.2,
+                 device="cuda:0", embedding_grad: Optional[str] = None):
+        super().__init__()
+        if tower_hidden_dims is None:
+            tower_hidden_dims = [256, 128]
+        self.categorical_keys = list(categorical_keys)
+        self.device = device
+        self.tower_hidden_dims = list(tower_hidden_dims)
+        self.final_embedding_dim = final_embedding_dim
+        self.dropout_rate = float(dropout_rate)
+        self.dense_input_dim = dense_input_dim
+        dev = torch.device(device)
+        self.categorical_embedder = CategoricalEmbedder(keys=self.categorical_keys, metadata_path=metadata_path,
+                                                        table_name=table_name, embedding_dim=categorical_embedding_dim,
+                                                        device=str(dev), embedding_grad=embedding_grad)
+        self.dense_projection = nn.Linear(dense_input_dim, tower_hidden_dims[0])
+        self._build_mlp(categorical_embedding_dim, tower_hidden_dims, final_embedding_dim, dropout_rate)
+        self._struct_key = None
+        self._params_struct = None
+        self.to(dev)                    # (the reference hard-codes cuda:0 here: base_tower.py:69)
+
+    def _build_mlp(self, categorical_embedding_dim, tower_hidden_dims, final_embedding_dim, dropout_rate):
+        in_dim = tower_hidden_dims[0] + len(self.categorical_keys) * categorical_embedding_dim
+        layers = []
+        for h in tower_hidden_dims[1:]:
+            layers += [nn.Linear(in_dim, h), nn.ReLU(), nn.BatchNorm1d(h), nn.Dropout(dropout_rate)]
+            in_dim = h
+        layers.append(nn.Linear(in_dim, final_embedding_dim))
+        self.mlp = nn.Sequential(*layers)
+
+    # ---- parameter plumbing ----------------------------------------------------------------------
+    @property
+    def n_hidden(self) -> int:
+        return len(self.tower_hidden_dims) - 1
+
+    def dense_parameters(self) -> List[torch.Tensor]:
+        """Order = order of the gradients tt_tower_mlp_bwd returns."""
+        ps = [self.dense_projection.weight, self.dense_projection.bias]
+        for i in range(self.n_hidden):
+            lin, bn = self.mlp[4 * i], self.mlp[4 * i + 2]
+            ps += [lin.weight, lin.bias, bn.weight, bn.bias]
+        ps += [self.mlp[4 * self.n_hidden].weight, self.mlp[4 * self.n_hidden].bias]
+        return ps
+
+    def _params(self):
+        nh = self.n_hidden
+        lins = [self.mlp[4 * i] for i in range(nh)]
+        bns = [self.mlp[4 * i + 2] for i in range(nh)]
+        out = self.mlp[4 * nh]
+        tensors = [self.dense_projection.weight, self.dense_projection.bias, out.weight, out.bias]
+        for lin, bn in zip(lins, bns):
+            tensors += [lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
+        key = tuple(t.data_ptr() for t in tensors)
+        if key != self._struct_key:
+            for t in tensors:
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise TypeError("tower parameters must be contiguous float32")
+            E = self.categorical_embedder.embedding_dim
+            self._params_struct = ops.tower_params_struct(
+                self.dense_input_dim, self.tower_hidden_dims[0], len(self.categorical_keys) * E, self.tower_hidden_dims[1:],
+                self.final_embedding_dim, self.dense_projection.weight, self.dense_projection.bias,
+                [l.weight for l in lins], [l.bias for l in lins], [b.weight for b in bns], [b.bias for b in bns],
+                [b.running_mean for b in bns], [b.running_var for b in bns], out.weight, out.bias)
+            self._struct_key = key
+        return self._params_struct
+
+    @property
+    def x_width(self) -> int:
+        return self.tower_hidden_dims[0] + len(self.categorical_keys) * self.categorical_embedder.embedding_dim
+
+    # ---- forward: src/towers/tower/base_tower.py:101-147 ------------------------------------------
+    def forward(self, tower_input: Dict[str, torch.Tensor]) -> torch.Tensor:
+        return run_towers([self], [tower_input])[0]
+
+
+class NoticeTower(BaseTower):
+    def __init__(self, categorical_keys: List[str], metadata_path: str = "meta/metadata.csv",
+                 categorical_embedding_dim: int = 64, dense_input_dim: int = 256,
+                 tower_hidden_dims: Optional[List[int]] = None, final_embedding_dim: int = 128, dropout_rate: float = 0.2,
+                 device="cuda:0", embedding_grad: Optional[str] = None):
+        super().__init__(categorical_keys=categorical_keys, metadata_path=metadata_path, table_name="notice",
+                         categorical_embedding_dim=categorical_embedding_dim, dense_input_dim=dense_input_dim,
+                         tower_hidden_dims=tower_hidden_dims, final_embedding_dim=final_embedding_dim,
+                         dropout_rate=dropout_rate, device=device, embedding_grad=embedding_grad)
+
+
+class CompanyTower(BaseTower):
+    def __init__(self, categorical_keys: List[str], metadata_path: str = "meta/metadata.csv",
+                 categorical_embedding_dim: int = 64, dense_input_dim: int = 128,
+                 tower_hidden_dims: Optional[List[int]] = None, final_embedding_dim: int = 128, dropout_rate: float = 0.2,
+                 device="cuda:0", embedding_grad: Optional[str] = None):
+        super().__init__(categorical_keys=categorical_keys, metadata_path=metadata_path, table_name="company",
+                         categorical_embedding_dim=categorical_embedding_dim, dense_input_dim=dense_input_dim,
+                         tower_hidden_dims=tower_hidden_dims, final_embedding_dim=final_embedding_dim,
+                         dropout_rate=dropout_rate, device=device, embedding_grad=embedding_grad)
+
+
+# --------------------------------------------------------------------------------------------------
+# one autograd node for >= 1 towers (lookup and table gradient fused across towers that share a store)
+# --------------------------------------------------------------------------------------------------
+def run_towers(towers: Sequence[BaseTower], inputs: Sequence[Dict]) -> List[torch.Tensor]:
+    flat = []
+    for tw, inp in zip(towers, inputs):
+        dev = tw.categorical_embedder.store.device
+        dense = inp["dense"].to(dev)
+        kjt = inp["kjt"]
+        values = (kjt.to(dev) if hasattr(kjt, "to") else kjt).values()
+        flat += [dense, values] + tw.dense_parameters() + tw.categorical_embedder.table_parameters()
+    outs = _TowersFn.apply(tuple(towers), *flat)
+    return list(outs) if isinstance(outs, tuple) else [outs]
+
+
+class _Side:
+    __slots__ = ("tower", "B", "acts", "acts_struct", "buf", "x", "emb", "train", "seed", "p_drop")
+
+
+class _TowersFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, towers, *flat):
+        sides: List[_Side] = []
+        pos = 0
+        grad_on = torch.is_grad_enabled()
+        spans = []
+        lookups: Dict[int, list] = {}
+        for tw in towers:
+            emb = tw.categorical_embedder
+            nd, nt = len(tw.dense_parameters()), len(emb.keys)
+            dense, values = flat[pos], flat[pos + 1]
+            spans.append((pos, nd, nt))
+            pos += 2 + nd + nt
+            dev = emb.store.device
+            if dense.dim() != 2 or dense.shape[1] != tw.dense_input_dim:
+                raise ValueError(f"dense input must be [B, {tw.dense_input_dim}], got {tuple(dense.shape)}")
+            dense = dense.to(dtype=torch.float32).contiguous()
+            values = values.to(dtype=torch.int64).contiguous()
+            B, K, E = dense.shape[0], len(emb.keys), emb.embedding_dim
+            if values.numel() != B * K:
+                raise ValueError(f"kjt carries {values.numel()} ids but the batch needs B*K = {B}*{K}")
+            s = _Side()
+            s.tower, s.B, s.train = tw, B, tw.training
+            s.p_drop = tw.dropout_rate if tw.training else 0.0
+            s.seed = int(torch.empty((), dtype=torch.int64).random_().item()) if s.p_drop > 0 else 0
+            # one flat activation buffer: x | (pre_i, act_i)* | (mean_i, rstd_i)* | y
+            hid = tw.tower_hidden_dims[1:]
+            sizes = [_al(B * tw.x_width)] + [_al(B * h) for h in hid for _ in (0, 1)] + [_al(h) for h in hid for _ in (0, 1)] + \
+                    [_al(B * tw.final_embedding_dim)]
+            s.buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            offs = [0]
+            for z in sizes:
+                offs.append(offs[-1] + z)
+            s.x = s.buf[:B * tw.x_width].view(B, tw.x_width)
+            s.emb = torch.empty((B, tw.final_embedding_dim), dtype=torch.float32, device=dev)
+            a = L.TowerActs()
+            base, esz = s.buf.data_ptr(), 4
+            a.dense, a.x, a.emb = dense.data_ptr(), base, s.emb.data_ptr()
+            nh = len(hid)
+            for i in range(nh):
+                a.pre[i] = base + esz * offs[1 + 2 * i]
+                a.act[i] = base + esz * offs[2 + 2 * i]
+                a.mean[i] = base + esz * offs[1 + 2 * nh + 2 * i]
+                a.rstd[i] = base + esz * offs[2 + 2 * nh + 2 * i]
+            a.y = base + esz * offs[1 + 4 * nh]
+            s.acts, s.acts_struct = (dense,), a
+            sides.append(s)
+            if K and B:
+                lookups.setdefault(id(emb.store), []).append((s, emb.lookup_side(values, s.x[:, tw.tower_hidden_dims[0]:])))
+        # fused lookup (+ duplicate-row plan when a backward will follow) per store
+        plans = []
+        for group in lookups.values():
+            store: EmbeddingStore = group[0][0].tower.categorical_embedder.store
+            B = group[0][0].B
+            if any(g[0].B != B for g in group):
+                # different batch sizes cannot share one launch: fall back to one launch per side
+                for g in group:
+                    rows = ops.embed_lookup(store.weight, [g[1]], g[0].B, want_rows=grad_on)
+                    plans.append((store, [g[0]], ops.dedup_plan(rows, store.rows) if grad_on else None))
+                continue
+            rows = ops.embed_lookup(store.weight, [g[1] for g in group], B, want_rows=grad_on)
+            plans.append((store, [g[0] for g in group], ops.dedup_plan(rows, store.rows) if grad_on else None))
+        for s in sides:
+            tw = s.tower
+            if s.B:
+                ops.tower_fwd(tw._params(), s.acts_struct, s.B, s.train, s.p_drop, s.seed, s.emb.device)
+                if s.train:
+                    for i in range(tw.n_hidden):
+                        tw.mlp[4 * i + 2].num_batches_tracked.add_(1)
+        ctx.sides, ctx.plans, ctx.spans, ctx.n_flat = sides, plans, spans, len(flat)
+        # hand out aliases: keeping the returned objects themselves on ctx would form a reference cycle
+        outs = tuple(s.emb.view(s.emb.shape) for s in sides)
+        ctx.mark_non_differentiable(*[o for o, s in zip(outs, sides) if s.B == 0])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *d_embs):
+        grads = [None] * ctx.n_flat
+        dxs = {}
+        for s, d_emb, (pos, nd, nt) in zip(ctx.sides, d_embs, ctx.spans):
+            tw = s.tower
+            if s.B == 0 or d_emb is None:
+                continue
+            dev = s.emb.device
+            d_emb = d_emb.to(dtype=torch.float32).contiguous()
+            dps = tw.dense_parameters()
+            hid = tw.tower_hidden_dims[1:]
+            B = s.B
+            sizes = [_al(p.numel()) for p in dps] + [_al(B * tw.x_width)] + [_al(B * h) for h in hid] + \
+                    [_al(B * tw.final_embedding_dim)]
+            buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+            offs = [0]
+            for z in sizes:
+                offs.append(offs[-1] + z)
+            base = buf.data_ptr()
+            views = [buf[offs[i]:offs[i] + p.numel()].view(p.shape) for i, p in enumerate(dps)]
+            g = L.TowerGrads()
+            g.w_proj, g.b_proj = base + 4 * offs[0], base + 4 * offs[1]
+            for i in range(len(hid)):
+                g.w[i], g.b[i] = base + 4 * offs[2 + 4 * i], base + 4 * offs[3 + 4 * i]
+                g.bn_w[i], g.bn_b[i] = base + 4 * offs[4 + 4 * i], base + 4 * offs[5 + 4 * i]
+                g.scratch[i] = base + 4 * offs[len(dps) + 1 + i]
+            g.w_out, g.b_out = base + 4 * offs[len(dps) - 2], base + 4 * offs[len(dps) - 1]
+            g.d_x = base + 4 * offs[len(dps)]
+            g.d_y = base + 4 * offs[len(dps) + 1 + len(hid)]
+            ops.tower_bwd(tw._params(), s.acts_struct, d_emb, g, B, s.train, s.p_drop, s.seed, dev)
+            for i, v in enumerate(views):
+                grads[pos + 2 + i] = v
+            d_x = buf[offs[len(dps)]:offs[len(dps)] + B * tw.x_width].view(B, tw.x_width)
+            dxs[id(s)] = d_x[:, tw.tower_hidden_dims[0]:]
+        # table gradients: one fused segmented reduction per store
+        for store, plan_sides, plan in ctx.plans:
+            if plan is None:
+                continue
+            srcs = []
+            for s in plan_sides:
+                K = len(s.tower.categorical_embedder.keys)
+                d = dxs.get(id(s))
+                if d is None:       # this tower received no gradient: contribute zeros
+                    d = torch.zeros((s.B, K * store.E), dtype=torch.float32, device=store.device)
+                srcs.append((d, K))
+            store.accumulate_grad(plan, srcs, plan_sides[0].B)
+        return (None, *grads)
+
+
+def tower_dense_param_names(n_hidden: int) -> List[str]:
+    names = ["dense_projection.weight", "dense_projection.bias"]
+    for i in range(n_hidden):
+        names += [f"mlp.{4 * i}.weight", f"mlp.{4 * i}.bias", f"mlp.{4 * i + 2}.weight", f"mlp.{4 * i + 2}.bias"]
+    names += [f"mlp.{4 * n_hidden}.weight", f"mlp.{4 * n_hidden}.bias"]
+    return names

@@ -1,0 +1,178 @@
+"""TwoTowerTrainTask -- drop-in for src/towers/two_tower_train_task.py:9-293 on the HIP path.
+
+forward(batch, return_metrics) -> loss, or a dict with loss / accuracy / positive_similarity_mean /
+negative_similarity_mean / similarity_gap / similarity_matrix (same keys as :89-95).
+
+The B x B score matrix is never materialised on the training path: tt_score_dir_fwd sweeps it tile
+by tile on MFMA for both softmax directions, tt_score_loss_finish forms loss and metrics, and
+tt_score_dir_bwd recomputes the tiles for the gradients.  `similarity_matrix` is produced on demand
+(eagerly for small batches, lazily above LAZY_SIM_BATCH) by tt_score_matrix.
+"""
+from __future__ import annotations
+
+from typing import Dict, Union
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .two_tower_model import TwoTowerModel, create_two_tower_model
+
+LAZY_SIM_BATCH = 2048
+
+
+class _ScoreCEFn(torch.autograd.Function):
+    """loss = 0.5 * [CE(S, diag) + CE(S^T, diag)],  S = N C^T / T   (:99-134); out8 carries the metrics."""
+
+    @staticmethod
+    def forward(ctx, n, c, inv_t):
+        n, c = n.contiguous().float(), c.contiguous().float()
+        B = n.shape[0]
+        shift = abs(inv_t)                                   # unit rows: |s| <= 1/T
+        rowsum, diag, row_rank, sumscore = ops.score_dir_fwd(n, c, inv_t, shift, 0, True)
+        colsum, _, col_rank, _ = ops.score_dir_fwd(c, n, inv_t, shift, 0, False)
+        out8 = ops.score_loss_finish(B, shift, rowsum, colsum, diag, row_rank, col_rank, sumscore)
+        ctx.save_for_backward(n, c, rowsum, colsum)
+        ctx.inv_t, ctx.shift = inv_t, shift
+        ctx.mark_non_differentiable(out8)
+        return out8[0].clone(), out8
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_out8):
+        n, c, rowsum, colsum = ctx.saved_tensors
+        B = n.shape[0]
+        d_loss = d_loss.contiguous().float().reshape(1)
+        scale = ctx.inv_t / (2.0 * B)
+        dN = ops.score_dir_bwd(n, c, ctx.inv_t, ctx.shift, 0, rowsum, colsum, d_loss, scale)
+        dC = ops.score_dir_bwd(c, n, ctx.inv_t, ctx.shift, 0, colsum, rowsum, d_loss, scale)
+        return dN, dC, None
+
+
+class _Result(dict):
+    """Result dict whose 'similarity_matrix' entry is computed on first access (large batches)."""
+
+    def __init__(self, *a, sim_thunk=None, **k):
+        super().__init__(*a, **k)
+        self._sim_thunk = sim_thunk
+
+    def _materialise(self):
+        if self._sim_thunk is not None and not dict.__contains__(self, "similarity_matrix"):
+            dict.__setitem__(self, "similarity_matrix", self._sim_thunk())
+            self._sim_thunk = None
+
+    def __missing__(self, key):
+        if key == "similarity_matrix" and self._sim_thunk is not None:
+            self._materialise()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or (key == "similarity_matrix" and self._sim_thunk is not None)
+
+    def get(self, key, default=None):
+        if key == "similarity_matrix":
+            self._materialise()
+        return dict.get(self, key, default)
+
+    def keys(self):
+        self._materialise()
+        return dict.keys(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+
+class TwoTowerTrainTask(nn.Module):
+    def __init__(self, two_tower_model: TwoTowerModel, temperature: float = 1.0, loss_type: str = "cross_entropy",
+                 label_smoothing: float = 0.0):
+        super().__init__()
+        self.two_tower_model = two_tower_model
+        self.temperature = temperature
+        self.loss_type = loss_type
+        self.label_smoothing = label_smoothing
+        if loss_type not in ["cross_entropy", "cosine_embedding"]:
+            raise ValueError(f"Unsupported loss_type: {loss_type}")                         # :37-38
+        if loss_type != "cross_entropy":
+            raise NotImplementedError("loss_type='cosine_embedding' (reference :136-158, unused by scripts/train.py) "
+                                      "has no HIP kernel; use 'cross_entropy'")
+        if label_smoothing != 0.0:
+            raise NotImplementedError("label_smoothing != 0 is not supported (the reference factory never sets it: :243-247)")
+
+    # ---- forward: :40-97 ----------------------------------------------------------------------------
+    def forward(self, batch, return_metrics: bool = False):
+        notice_input, company_input = batch["notice"], batch["company"]
+        nb, cb = notice_input["dense"].size(0), company_input["dense"].size(0)
+        if nb != cb:                                                                         # :64-67
+            raise ValueError(f"Notice와 Company 배치 크기가 다릅니다: {nb} vs {cb}")
+        notice_embeddings, company_embeddings = self.two_tower_model(notice_input, company_input)
+        loss, out8 = _ScoreCEFn.apply(notice_embeddings, company_embeddings, 1.0 / float(self.temperature))
+        if not hasattr(self, "_pair_check_done"):                                            # :82-84
+            self._verify_positive_pair_alignment(out8)
+            self._pair_check_done = True
+        if not return_metrics:
+            return loss
+        n_det, c_det, inv_t = notice_embeddings.detach(), company_embeddings.detach(), 1.0 / float(self.temperature)
+        res = _Result({"loss": loss, "accuracy": out8[1], "positive_similarity_mean": out8[2],
+                       "negative_similarity_mean": out8[3], "similarity_gap": out8[4]},
+                      sim_thunk=lambda: ops.score_matrix(n_det, c_det, inv_t))
+        if nb <= LAZY_SIM_BATCH:
+            res._materialise()
+        return res
+
+    def _compute_similarity_matrix(self, notice_embeddings, company_embeddings):                # :99-112
+        return self.two_tower_model.compute_similarity(notice_embeddings, company_embeddings, self.temperature)
+
+    def _verify_positive_pair_alignment(self, out8: torch.Tensor):                               # :253-290
+        row_hit, col_hit = float(out8[1]), float(out8[5])
+        print("🔍 [Positive Pair Alignment Check]")
+        print(f"   📊 Notice→Company Top-1 정확도: {row_hit:.3f}")
+        print(f"   📊 Company→Notice Top-1 정확도: {col_hit:.3f}")
+        print(f"   🎯 대각선이 row-max인 비율: {row_hit:.3f}")
+        if row_hit < 0.05 and col_hit < 0.05:
+            print("   🚨 CRITICAL: Positive pair 정합성 실패!")
+            print("   → DataLoader에서 notice/company 순서가 어긋남")
+            print("   → 동일한 샘플러/인덱스로 페어를 구성하세요")
+        elif row_hit < 0.3 or col_hit < 0.3:
+            print("   ⚠️  WARNING: Positive pair 정합성 부족")
+            print("   → 배치 내 positive 비율 확인 필요")
+        else:
+            print("   ✅ Positive pair 정합성 양호")
+        print()
+
+    # ---- predict_batch: :181-207 ----------------------------------------------------------------------
+    def predict_batch(self, batch, top_k: int = 10) -> Dict[str, torch.Tensor]:
+        self.eval()
+        with torch.no_grad():
+            n, c = self.two_tower_model(batch["notice"], batch["company"])
+            sim = ops.score_matrix(n.contiguous(), c.contiguous(), 1.0 / float(self.temperature))
+            vals, idx = ops.topk_rows(sim, top_k)
+            return {"top_similarities": vals, "top_indices": idx, "all_similarities": sim}
+
+    def diagonal_ranks(self, batch):
+        """0-based rank of each positive in its row (count of strictly larger scores, ties before the
+        diagonal counted) -- the quantity Recall@K / MRR need, without the B x B matrix."""
+        with torch.no_grad():
+            n, c = self.two_tower_model(batch["notice"], batch["company"])
+            inv_t = 1.0 / float(self.temperature)
+            _, _, rank, _ = ops.score_dir_fwd(n.contiguous(), c.contiguous(), inv_t, abs(inv_t), 0, False)
+            return rank
+
+
+def create_two_tower_train_task(notice_categorical_keys, company_categorical_keys, metadata_path: str = "meta/metadata.csv",
+                                categorical_embedding_dim: int = 64, notice_dense_input_dim: int = 256,
+                                company_dense_input_dim: int = 128, tower_hidden_dims=None, final_embedding_dim: int = 128,
+                                dropout_rate: float = 0.2, temperature: float = 1.0, loss_type: str = "cross_entropy",
+                                device="cuda:0", embedding_grad=None) -> TwoTowerTrainTask:
+    model = create_two_tower_model(notice_categorical_keys=notice_categorical_keys,
+                                   company_categorical_keys=company_categorical_keys, metadata_path=metadata_path,
+                                   categorical_embedding_dim=categorical_embedding_dim,
+                                   notice_dense_input_dim=notice_dense_input_dim,
+                                   company_dense_input_dim=company_dense_input_dim, tower_hidden_dims=tower_hidden_dims,
+                                   final_embedding_dim=final_embedding_dim, dropout_rate=dropout_rate, device=device,
+                                   embedding_grad=embedding_grad)
+    return TwoTowerTrainTask(two_tower_model=model, temperature=temperature, loss_type=loss_type)

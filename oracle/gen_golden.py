@@ -235,6 +235,13 @@ def main():
     (GOLD / "schema_synthetic.json").write_text(json.dumps(syn_js, ensure_ascii=False, indent=1))
     (GOLD / "schema_real.json").write_text(json.dumps(real_js, ensure_ascii=False, indent=1))
 
+    # key names + category counts of the real schema as a metadata-format fixture (data only)
+    lines = [HEADER]
+    for t in ("notice", "company"):
+        for c, v in zip(real_js[t]["categorical"], real_js[t]["vocab_sizes"]):
+            lines.append(f"{t},{c},text,Y,,Y,{v - 10},0,,,,,")
+    (GOLD / "real_vocab_metadata.csv").write_text("\n".join(lines) + "\n", encoding="utf-8")
+
     kn, kc = syn.notice.categorical, syn.company.categorical
     vn, vc = syn_js["notice"]["vocab_sizes"], syn_js["company"]["vocab_sizes"]
 

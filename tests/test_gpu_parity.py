@@ -1,0 +1,292 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI, against
+(a) golden vectors produced by the reference's own code and (b) the numpy oracle on seeded inputs.
+
+Bars: ids / row indices / ranks / top-k indices bit-exact; looked-up rows bit-exact (f32 copy);
+fp32 results rtol 2e-5 (forward), 3e-4 (gradients: different summation order), stated per assert.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_np as O
+from conftest import GOLD, load_case, split_prefix
+from params_init import init_state_numpy, synth_batch_numpy
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def tt():
+    import jodalrob_twotower_amd as m
+    from jodalrob_twotower_amd import _lib
+    _lib.load()
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return m
+
+
+def make_task(tt, cfg, meta=None, **kw):
+    return tt.create_two_tower_train_task(
+        cfg["keys_n"], cfg["keys_c"], metadata_path=str(meta or GOLD / "synthetic_metadata.csv"),
+        categorical_embedding_dim=cfg["E"], notice_dense_input_dim=cfg["din_n"], company_dense_input_dim=cfg["din_c"],
+        tower_hidden_dims=list(cfg["hidden"]), final_embedding_dim=cfg["D"], dropout_rate=kw.pop("dropout_rate", 0.0),
+        temperature=cfg["T"], device=DEV, **kw)
+
+
+def to_batch(tt, b, keys_n, keys_c):
+    return {"notice": {"dense": torch.from_numpy(b["notice_dense"]).to(DEV),
+                       "kjt": tt.build_batch_kjt(torch.from_numpy(b["notice_ids"]), keys_n).to(DEV)},
+            "company": {"dense": torch.from_numpy(b["company_dense"]).to(DEV),
+                        "kjt": tt.build_batch_kjt(torch.from_numpy(b["company_ids"]), keys_c).to(DEV)}}
+
+
+def load_state(task, state):
+    task.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+
+
+# ------------------------------------------------------------------------------------------- golden cases
+@pytest.mark.parametrize("case", ["tiny_train", "tiny_eval", "deep_temp", "wide_b40", "single_hidden"])
+def test_task_matches_reference_golden(tt, manifest, case):
+    cfg = manifest["cases"][case]
+    g = load_case(case)
+    task = make_task(tt, cfg)
+    load_state(task, split_prefix(g, "state."))
+    task.train(cfg["train"])
+    batch = to_batch(tt, split_prefix(g, "in."), cfg["keys_n"], cfg["keys_c"])
+    res = task(batch, return_metrics=True)
+    np.testing.assert_allclose(res["similarity_matrix"].cpu().numpy(), g["sim"], rtol=2e-5, atol=5e-6)
+    np.testing.assert_allclose(res["loss"].item(), g["out.loss"], rtol=2e-5)
+    assert res["accuracy"].item() == pytest.approx(float(g["out.accuracy"]), abs=1e-7)
+    for k in ("positive_similarity_mean", "negative_similarity_mean", "similarity_gap"):
+        np.testing.assert_allclose(res[k].item(), g["out." + k], rtol=1e-4, atol=2e-6)
+    if cfg["train"]:
+        res["loss"].backward()
+        ref = split_prefix(g, "grad.")
+        got = {n: p.grad for n, p in task.named_parameters()}
+        assert set(ref) == set(got)
+        for k, v in ref.items():
+            np.testing.assert_allclose(got[k].cpu().numpy(), v, rtol=3e-4, atol=3e-7, err_msg=k)
+        sd = task.state_dict()
+        for k, v in split_prefix(g, "state_after.").items():
+            np.testing.assert_allclose(sd[k].cpu().numpy(), v, rtol=2e-5, atol=2e-6, err_msg=k)
+    # tower embeddings through the model API, unit rows
+    with torch.no_grad():
+        task2 = make_task(tt, cfg)
+        load_state(task2, split_prefix(g, "state."))
+        task2.train(cfg["train"])
+        ne, ce = task2.two_tower_model(batch["notice"], batch["company"])
+    np.testing.assert_allclose(ne.cpu().numpy(), g["out.notice_emb"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(ce.cpu().numpy(), g["out.company_emb"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(ne.norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+def test_real_schema_golden(tt, manifest, schema_real):
+    cfg = dict(manifest["cases"]["real_schema"])
+    cfg.update(keys_n=schema_real["notice"]["categorical"], keys_c=schema_real["company"]["categorical"])
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    g = load_case("real_schema")
+    meta = GOLD / "real_vocab_metadata.csv"          # real key names + category counts (fixture)
+    task = make_task(tt, cfg, meta=meta)
+    shapes = {k: tuple(v) for k, v in manifest["state_dict_keys_real"].items()}
+    assert {k: tuple(v.shape) for k, v in task.state_dict().items()} == shapes      # drop-in state-dict layout
+    assert sum(p.numel() for p in task.parameters()) == 2204832
+    load_state(task, init_state_numpy(shapes, cfg["seed"]))
+    task.train()
+    res = task(to_batch(tt, split_prefix(g, "in."), cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+    np.testing.assert_allclose(res["loss"].item(), g["out.loss"], rtol=2e-5)
+    np.testing.assert_allclose(res["similarity_matrix"].cpu().numpy(), g["sim"], rtol=2e-5, atol=5e-6)
+    res["loss"].backward()
+    got = {n: p.grad.cpu().numpy() for n, p in task.named_parameters()}
+    for k, v in split_prefix(g, "grad.").items():
+        if k.endswith(".rows"):
+            base = k[:-5]
+            nz = np.flatnonzero(np.abs(got[base]).sum(axis=1))
+            assert np.array_equal(nz, v), base                       # touched-row set bit-exact
+            np.testing.assert_allclose(got[base][nz], g["grad." + base + ".vals"], rtol=3e-4, atol=3e-8, err_msg=base)
+        elif not k.endswith(".vals"):
+            np.testing.assert_allclose(got[k], v, rtol=5e-4, atol=5e-8, err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------- kernels vs oracle
+@pytest.mark.parametrize("E,B,out_dtype", [(32, 257, "f32"), (32, 1024, "bf16"), (8, 33, "f32"), (6, 19, "f32"), (64, 5, "f32")])
+def test_lookup_bit_exact(tt, E, B, out_dtype):
+    from jodalrob_twotower_amd import ops
+    rng = np.random.default_rng(E * 1000 + B)
+    vocabs = [[12, 300, 7, 5000], [3, 64]]
+    offs, rows = [], 0
+    for v in vocabs:
+        offs.append(np.concatenate([[0], np.cumsum(v)[:-1]]) + rows)
+        rows += sum(v)
+    table = rng.standard_normal((rows, E)).astype(np.float32)
+    t_table = torch.from_numpy(table).to(DEV)
+    sides, ids_all, outs = [], [], []
+    h0 = 16
+    for v, off in zip(vocabs, offs):
+        K = len(v)
+        ids = np.stack([rng.integers(-3, vk + 3, B) for vk in v], axis=1).astype(np.int64)       # incl. out-of-range
+        ids_all.append(ids)
+        out = torch.zeros((B, h0 + K * E), dtype=torch.float32 if out_dtype == "f32" else torch.bfloat16, device=DEV)
+        outs.append(out)
+        sides.append(ops.LookupSide(torch.from_numpy(ids.reshape(-1)).to(DEV), torch.from_numpy(off.astype(np.int64)).to(DEV),
+                                    torch.tensor(v, dtype=torch.int64, device=DEV), out[:, h0:], K))
+    rows_out = ops.embed_lookup(t_table, sides, B, want_rows=True)
+    exp_rows = []
+    for v, off, ids, out in zip(vocabs, offs, ids_all, outs):
+        cl = O.unpack_clamp_ids(ids.reshape(-1), v)
+        r = cl + off[None, :]
+        exp_rows.append(r.reshape(-1))
+        exp = table[r.reshape(-1)].reshape(B, -1)
+        got = out[:, h0:]
+        if out_dtype == "f32":
+            assert np.array_equal(got.cpu().numpy(), exp)                                      # bit-exact row copy
+        else:
+            assert torch.equal(got.cpu(), torch.from_numpy(exp).to(torch.bfloat16))            # RNE rounding
+        assert not out[:, :h0].any()                                                           # projection columns untouched
+    assert np.array_equal(rows_out.cpu().numpy(), np.concatenate(exp_rows).astype(np.int32))
+
+
+@pytest.mark.parametrize("M,table_rows,dist", [(1, 10, "uniform"), (4096, 200, "uniform"), (4097, 70000, "uniform"),
+                                                (100000, 2_000_000, "uniform"), (50000, 14_000_000, "zipf"),
+                                                (30000, 3, "uniform"), (20000, 1 << 25, "zipf")])
+def test_dedup_plan_bit_exact(tt, M, table_rows, dist):
+    from jodalrob_twotower_amd import ops
+    rng = np.random.default_rng(M + table_rows)
+    if dist == "uniform":
+        rows = rng.integers(0, table_rows, M)
+    else:
+        rows = np.minimum(rng.zipf(1.2, M) - 1, table_rows - 1)
+        rows = (rows * 2654435761) % table_rows                     # scatter ranks over the row space
+    rows = rows.astype(np.int32)
+    plan = ops.dedup_plan(torch.from_numpy(rows).to(DEV), table_rows)
+    U = int(plan.n_unique.item())
+    order = np.argsort(rows, kind="stable")
+    uniq, start = np.unique(rows[order], return_index=True)
+    assert U == len(uniq)
+    assert np.array_equal(plan.sorted_src.cpu().numpy(), order.astype(np.int32))              # stable sort
+    assert np.array_equal(plan.unique_rows[:U].cpu().numpy(), uniq)
+    assert np.array_equal(plan.seg_offsets[:U + 1].cpu().numpy(), np.concatenate([start, [M]]).astype(np.int32))
+
+
+@pytest.mark.parametrize("E,B,vocabs", [(32, 2048, [[2, 2, 12, 5000], [3, 100000]]), (8, 300, [[5, 9], [4]]),
+                                         (6, 64, [[3, 1000]])])
+def test_embed_grad_sparse_and_dense(tt, E, B, vocabs):
+    from jodalrob_twotower_amd import ops
+    rng = np.random.default_rng(E + B)
+    offs, rows_total = [], 0
+    for v in vocabs:
+        offs.append(np.concatenate([[0], np.cumsum(v)[:-1]]) + rows_total)
+        rows_total += sum(v)
+    srcs, rows_all, d_all = [], [], []
+    for v, off in zip(vocabs, offs):
+        K = len(v)
+        ids = np.stack([rng.integers(0, vk, B) for vk in v], axis=1)
+        d = rng.standard_normal((B, 16 + K * E)).astype(np.float32)
+        td = torch.from_numpy(d).to(DEV)
+        srcs.append((td[:, 16:], K))
+        rows_all.append((ids + off[None, :]).reshape(-1))
+        d_all.append(d[:, 16:].reshape(B * K, E))
+    rows = np.concatenate(rows_all).astype(np.int32)
+    vals = np.concatenate(d_all)
+    plan = ops.dedup_plan(torch.from_numpy(rows).to(DEV), rows_total)
+    U = int(plan.n_unique.item())
+    dense_ref = np.zeros((rows_total, E), np.float64)
+    np.add.at(dense_ref, rows, vals.astype(np.float64))
+    out = torch.full((len(rows), E), float("nan"), device=DEV)
+    ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_SPARSE, out)
+    uniq = plan.unique_rows[:U].cpu().numpy()
+    np.testing.assert_allclose(out[:U].cpu().numpy(), dense_ref[uniq], rtol=2e-5, atol=2e-5)
+    dense = torch.zeros((rows_total, E), device=DEV)
+    ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_DENSE_SET, dense)
+    ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_DENSE_ACC, dense)
+    np.testing.assert_allclose(dense.cpu().numpy(), 2 * dense_ref, rtol=2e-5, atol=4e-5)
+    # bitwise reproducible: same inputs -> identical bits
+    out2 = torch.empty_like(out)
+    ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_SPARSE, out2)
+    assert torch.equal(out[:U], out2[:U])
+
+
+def test_score_kernels_vs_oracle(tt):
+    from jodalrob_twotower_amd import ops
+    rng = np.random.default_rng(7)
+    for B, D, T in [(300, 64, 1.0), (129, 16, 0.5), (64, 6, 0.25), (1000, 128, 1.0), (257, 200, 2.0)]:
+        n = rng.standard_normal((B, D)).astype(np.float32)
+        c = rng.standard_normal((B, D)).astype(np.float32)
+        n /= np.linalg.norm(n, axis=1, keepdims=True)
+        c /= np.linalg.norm(c, axis=1, keepdims=True)
+        c[5] = c[3]                                            # duplicated company: exact score ties
+        n[7] = n[2]
+        loss, met, S, lse = O.score_ce_fwd(n.astype(np.float64), c.astype(np.float64), T)
+        dN, dC = O.score_ce_bwd(n.astype(np.float64), c.astype(np.float64), S, lse, T)
+        tn, tc = torch.from_numpy(n).to(DEV).requires_grad_(), torch.from_numpy(c).to(DEV).requires_grad_()
+        from jodalrob_twotower_amd.two_tower_train_task import _ScoreCEFn
+        l, out8 = _ScoreCEFn.apply(tn, tc, 1.0 / T)
+        l.backward()
+        np.testing.assert_allclose(l.item(), loss, rtol=5e-6)
+        np.testing.assert_allclose(tn.grad.cpu().numpy(), dN, rtol=1e-4, atol=2e-8)
+        np.testing.assert_allclose(tc.grad.cpu().numpy(), dC, rtol=1e-4, atol=2e-8)
+        np.testing.assert_allclose(out8[2].item(), met["positive_similarity_mean"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out8[3].item(), met["negative_similarity_mean"], rtol=1e-3, atol=2e-6)
+        # ranks: against the f32 score matrix the kernel family itself produces (ties are bit-level)
+        Sg = ops.score_matrix(tn.detach(), tc.detach(), 1.0 / T).cpu().numpy()
+        _, _, rank, _ = ops.score_dir_fwd(tn.detach(), tc.detach(), 1.0 / T, 1.0 / T, 0, False)
+        d = np.diagonal(Sg)[:, None]
+        exp_rank = (Sg > d).sum(1) + ((Sg == d) & (np.arange(B)[None, :] < np.arange(B)[:, None])).sum(1)
+        assert np.array_equal(rank.cpu().numpy(), exp_rank.astype(np.int32))
+        assert out8[1].item() == pytest.approx((exp_rank == 0).mean(), abs=1e-7)
+        assert (Sg.argmax(1) == np.arange(B)).mean() == pytest.approx((exp_rank == 0).mean(), abs=1e-12)
+        vals, idx = ops.topk_rows(torch.from_numpy(Sg).to(DEV), 7)
+        ev, ei = O.topk_rows(Sg, 7)
+        assert np.array_equal(idx.cpu().numpy(), ei) and np.array_equal(vals.cpu().numpy(), ev)
+
+
+def test_adam_trajectory_golden(tt, manifest):
+    cfg = {**manifest["cases"]["tiny_train"], **manifest["cases"]["adam_trajectory"]}
+    z = np.load(GOLD / "adam_trajectory.npz")
+    task = make_task(tt, cfg)
+    load_state(task, {k[6:]: z[k] for k in z.files if k.startswith("state.")})
+    opt = torch.optim.Adam(task.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    warm = cfg["warmup_steps"]
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: s / warm if s < warm else 1.0, last_epoch=-1)
+    task.train()
+    for s in range(cfg["n_steps"]):
+        b = {k[len(f"step{s}.in."):]: z[k] for k in z.files if k.startswith(f"step{s}.in.")}
+        opt.zero_grad()
+        res = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+        res["loss"].backward()
+        opt.step()
+        sched.step()
+        np.testing.assert_allclose(res["loss"].item(), z[f"step{s}.loss"], rtol=5e-5)
+    for k, v in task.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), z["final." + k], rtol=3e-4, atol=3e-6, err_msg=k)
+
+
+def test_predict_batch_golden(tt, manifest):
+    cfg = manifest["cases"]["tiny_eval"]
+    g = load_case("tiny_eval")
+    task = make_task(tt, cfg)
+    load_state(task, split_prefix(g, "state."))
+    pr = task.predict_batch(to_batch(tt, split_prefix(g, "in."), cfg["keys_n"], cfg["keys_c"]), top_k=5)
+    assert np.array_equal(pr["top_indices"].cpu().numpy(), g["predict.top_indices"])
+    np.testing.assert_allclose(pr["top_similarities"].cpu().numpy(), g["predict.top_similarities"], rtol=2e-5, atol=2e-6)
+
+
+def test_medium_batch_vs_oracle(tt, manifest):
+    """B=1024 on the synthetic schema with hot ids: full step vs the numpy oracle (f64 truth)."""
+    cfg = dict(manifest["cases"]["wide_b40"])
+    cfg["B"] = 1024
+    task = make_task(tt, cfg)
+    shapes = {k: tuple(v.shape) for k, v in task.state_dict().items()}
+    state = init_state_numpy(shapes, 4242)
+    load_state(task, state)
+    b = synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 4343, oob=True)
+    task.train()
+    res = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+    res["loss"].backward()
+    ref = O.task_step(state, b, cfg["keys_n"], cfg["keys_c"], cfg["vocab_n"], cfg["vocab_c"], cfg["T"], True, dtype=np.float64)
+    np.testing.assert_allclose(res["loss"].item(), ref["loss"], rtol=1e-5)
+    assert res["accuracy"].item() == pytest.approx(float(ref["accuracy"]), abs=2.0 / cfg["B"])
+    for n, p in task.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref["grads"][n], rtol=2e-3, atol=2e-7, err_msg=n)
