@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""bench.py -- training pairs/sec of the two-tower step on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+Step = TwoTowerTrainTask forward (return_metrics=True) + loss.backward() + optimiser step + LR schedule
+on one synthetic batch whose ids and dense features are already resident in HBM.  Workload at N=1 is
+BASELINE.json configs[1]: real 32+6 key schema, per-key vocabularies scaled to 1 M rows per tower,
+E=32, towers [128,64], final 64, batch 8192, in-batch negatives.
+
+Prints ONE JSON line (rank 0).  `roofline` is the embedding-lookup kernel (the kernel BASELINE.json's
+metric names): algorithmic bytes per launch / mean launch duration measured with HIP events on the
+launch stream inside the timed region.  `cpu_baseline` times the numpy oracle (checker code, used here
+only as the reported baseline) on a bounded sample of the same workload on the host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3      # v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=8192, help="pairs per GPU per step")
+    ap.add_argument("--rows-notice", type=int, default=1_000_000, help="table rows per GPU, notice tower")
+    ap.add_argument("--rows-company", type=int, default=1_000_000, help="table rows per GPU, company tower")
+    ap.add_argument("--zipf", type=float, default=None, help="Zipf alpha for ids (default uniform)")
+    ap.add_argument("--optimizer", choices=["fused_sparse", "fused_dense", "torch_adam"], default="fused_sparse")
+    ap.add_argument("--pool", type=int, default=8, help="distinct pre-generated batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--breakdown", action="store_true", help="extra instrumented pass: per-kernel HIP-event times")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run); got {world}")
+    import jodalrob_twotower_amd as tt
+    from jodalrob_twotower_amd import ops, synthetic
+    from jodalrob_twotower_amd.optim import FusedAdam
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    schema = synthetic.load_real_schema(ROOT / "jodalrob-twotower_amd" / "schema_real.json")
+    keys_n, keys_c = schema["notice"]["categorical"], schema["company"]["categorical"]
+    # weak scaling: every GPU brings its own 1 M + 1 M rows and its own 8192 pairs
+    vocab_n = synthetic.scale_vocabs(schema["notice"]["vocab_sizes"], args.rows_notice * world)
+    vocab_c = synthetic.scale_vocabs(schema["company"]["vocab_sizes"], args.rows_company * world)
+    E, hidden, D, din_n, din_c = 32, [128, 64], 64, 256, 128
+    B = args.batch
+    tmp = tempfile.mkdtemp(prefix="tt_bench_")
+    meta = synthetic.write_metadata(Path(tmp) / "metadata.csv", {"notice": dict(zip(keys_n, vocab_n)),
+                                                                 "company": dict(zip(keys_c, vocab_c))})
+    torch.manual_seed(1234)
+    grad_mode = "sparse" if args.optimizer == "fused_sparse" else "dense"
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        if world > 1:
+            from jodalrob_twotower_amd.distributed import create_distributed_train_task
+            task = create_distributed_train_task(keys_n, keys_c, metadata_path=str(meta), categorical_embedding_dim=E,
+                                                 notice_dense_input_dim=din_n, company_dense_input_dim=din_c,
+                                                 tower_hidden_dims=hidden, final_embedding_dim=D, dropout_rate=0.1,
+                                                 temperature=1.0, device=dev, embedding_grad=grad_mode)
+        else:
+            task = tt.create_two_tower_train_task(keys_n, keys_c, metadata_path=str(meta), categorical_embedding_dim=E,
+                                                  notice_dense_input_dim=din_n, company_dense_input_dim=din_c,
+                                                  tower_hidden_dims=hidden, final_embedding_dim=D, dropout_rate=0.1,
+                                                  temperature=1.0, device=dev, embedding_grad=grad_mode)
+    task.train()
+    task._pair_check_done = True            # skip the first-call diagnostic printout (host sync)
+    if args.optimizer == "torch_adam":
+        opt = torch.optim.Adam(task.parameters(), lr=1e-3, weight_decay=1e-5)
+    else:
+        opt = FusedAdam.for_task(task, lr=1e-3, weight_decay=1e-5)
+    total_steps = args.steps + args.warmup
+    warm = max(1, int(total_steps * 0.05))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: s / warm if s < warm else 1.0, last_epoch=-1)
+    pool = [synthetic.make_batch(B, vocab_n, vocab_c, keys_n, keys_c, din_n, din_c, dev, seed=1234 + 7919 * (rank * args.pool + i),
+                                 zipf_alpha=args.zipf) for i in range(args.pool)]
+
+    def step(i):
+        opt.zero_grad()
+        res = task(pool[i % args.pool], return_metrics=True)
+        res["loss"].backward()
+        opt.step()
+        sched.step()
+        return res
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        res = step(i)
+    fence()
+    timer = ops.KernelTimer(names=["tt_embed_lookup_fwd"])
+    ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    ops.set_timer(None)
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss_val = float(res["loss"])
+    ksum = timer.summary()
+    n_launch, lookup_ms = ksum.get("tt_embed_lookup_fwd", (0, float("nan")))
+
+    breakdown = None
+    if args.breakdown and rank == 0:
+        t2 = ops.KernelTimer()
+        ops.set_timer(t2)
+        for i in range(min(args.steps, 20)):
+            step(total_steps + i)
+        breakdown = {k: {"launches_per_step": v[0] / min(args.steps, 20), "mean_ms": round(v[1], 5)} for k, v in t2.summary().items()}
+        ops.set_timer(None)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    K_tot = len(keys_n) + len(keys_c)
+    bytes_per_pair = K_tot * (E * 4 + 8 + E * 4)             # table row + i64 id + f32 output row
+    algo_bytes = B * bytes_per_pair                          # one launch = one batch on this GPU
+    achieved = algo_bytes / (lookup_ms * 1e-3) / 1e9 if lookup_ms == lookup_ms and lookup_ms > 0 else None
+    traffic = None
+    pmc = ROOT / "profiles" / "lookup_pmc.json"
+    if pmc.exists():
+        try:
+            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "training pairs/sec at batch 8192 (embedding-lookup HBM GB/s in roofline)",
+        "value": B * world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: 32+6 real keys, 1M-row notice + 1M-row company tables per GPU, batch 8192 per GPU, "
+                               "E=32, towers [128,64], final 64, in-batch negatives, dropout 0.1",
+                   "batch_per_gpu": B, "global_batch": B * world, "rows_notice": sum(vocab_n), "rows_company": sum(vocab_c),
+                   "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})", "optimizer": args.optimizer,
+                   "parallelism": "single GPU" if world == 1 else f"row-wise sharded tables x{world} + data parallel towers"},
+        "roofline": {"kernel": "lookup_kernel (tt_embed_lookup_fwd)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": n_launch, "mean_launch_us": lookup_ms * 1e3},
+        "final_loss": loss_val,
+    }
+    if breakdown is not None:
+        out["kernel_breakdown"] = breakdown
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(task, pool[0], keys_n, keys_c, vocab_n, vocab_c, B, args.cpu_steps)
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(task, batch, keys_n, keys_c, vocab_n, vocab_c, B, n_steps):
+    """Oracle (numpy restatement of the reference step: forward + backward + dense Adam over every
+    parameter, reference semantics) timed on the host cores on `n_steps` steps of the same batch shape."""
+    import numpy as np
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle_np as O
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    state = {k: v.detach().cpu().numpy().copy() for k, v in task.state_dict().items()}
+    b = {"notice_ids": batch["notice"]["kjt"].values().cpu().numpy().reshape(B, len(keys_n)),
+         "company_ids": batch["company"]["kjt"].values().cpu().numpy().reshape(B, len(keys_c)),
+         "notice_dense": batch["notice"]["dense"].cpu().numpy(), "company_dense": batch["company"]["dense"].cpu().numpy()}
+    pkeys = [k for k in state if "running" not in k and "num_batches" not in k]
+    m = {k: np.zeros_like(state[k]) for k in pkeys}
+    v = {k: np.zeros_like(state[k]) for k in pkeys}
+    t0 = time.perf_counter()
+    for s in range(n_steps):
+        out = O.task_step(state, b, keys_n, keys_c, vocab_n, vocab_c, 1.0, True)
+        for k in pkeys:
+            O.adam_step(state[k], out["grads"][k], m[k], v[k], s + 1, 1e-3, wd=1e-5)
+        state.update(out["bn_updates"])
+    dt = time.perf_counter() - t0
+    return {"value": B * n_steps / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{n_steps} steps of batch {B} (forward + backward + dense Adam over all {sum(state[k].size for k in pkeys)} "
+                      f"parameters), numpy oracle: BLAS-threaded matmuls on {threads} threads, single-threaded elementwise; "
+                      f"{dt:.1f} s of CPU work; host has {os.cpu_count()} logical cores"}
+
+
+if __name__ == "__main__":
+    main()

@@ -127,6 +127,17 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
 int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n,
                        int64_t step, float lr, float beta1, float beta2, float eps,
                        float weight_decay, tt_stream stream);
+/* the same dense update over n_tensors separate tensors in one launch per 32 tensors */
+typedef struct tt_adam_tensor {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} tt_adam_tensor;
+int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors /* host array */, int32_t n_tensors,
+                       int64_t step, float lr, float beta1, float beta2, float eps,
+                       float weight_decay, tt_stream stream);
 int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E,
                         const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique,
                         int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,

@@ -32,6 +32,10 @@ class GradSrc(C.Structure):
     _fields_ = [("d_out", vp), ("ld", i64), ("K", i32), ("dtype", i32)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64)]
+
+
 _H = vp * TT_MAX_HIDDEN
 
 
@@ -64,6 +68,7 @@ SIGNATURES = {
     "tt_embed_grad_workspace_bytes": (sz, [i64, i32]),
     "tt_embed_grad_bwd": (C.c_int, [vp, C.POINTER(GradSrc), i32, i64, i32, vp, vp, vp, vp, i64, i32, vp, vp, sz, vp]),
     "tt_adam_dense_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp]),
+    "tt_adam_multi_step": (C.c_int, [vp, C.POINTER(AdamTensor), i32, i64, f32, f32, f32, f32, f32, vp]),
     "tt_sparse_adam_step": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp]),
     "tt_tower_workspace_bytes": (sz, [C.POINTER(TowerParams), i64]),
     "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, sz, vp]),

@@ -207,8 +207,7 @@ class CategoricalEmbedder(nn.Module):
         for s_member in self.store.members:
             if s_member._bound_version != s_member.store.version:
                 s_member._rebind()
-        self._key_row_offset = fn(self._key_row_offset) if self._key_row_offset.is_floating_point() else \
-            self._key_row_offset.to(self.store.device)
+        self._key_row_offset = self._key_row_offset.to(self.store.device)
         self._key_vocab = self._key_vocab.to(self.store.device)
         return self
 
@@ -242,7 +241,7 @@ class _LookupFn(torch.autograd.Function):
         values = values.to(device=emb.store.device, dtype=torch.int64).contiguous()
         B = values.numel() // max(K, 1)                                   # :98
         out = torch.empty((B, K * E), dtype=torch.float32, device=emb.store.device)
-        need_grad = any(t.requires_grad for t in tables) and torch.is_grad_enabled()
+        need_grad = any(ctx.needs_input_grad)
         rows = ops.embed_lookup(emb.store.weight, [emb.lookup_side(values[:B * K], out)], B, want_rows=need_grad) \
             if K and B else None
         ctx.emb, ctx.B = emb, B

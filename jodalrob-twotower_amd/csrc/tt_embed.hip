@@ -474,6 +474,21 @@ __global__ __launch_bounds__(kThreads) void adam_dense_vec4_kernel(float4* __res
   }
 }
 
+constexpr int kAdamMulti = 32;
+struct AdamMultiArgs {
+  tt_adam_tensor t[kAdamMulti];
+};
+
+__global__ __launch_bounds__(kThreads) void adam_multi_kernel(AdamMultiArgs a, AdamK k) {
+  const tt_adam_tensor& t = a.t[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += stride) {
+    float pp = t.p[i], mm = t.m[i], vv = t.v[i];
+    adam1(pp, t.g[i], mm, vv, k);
+    t.p[i] = pp; t.m[i] = mm; t.v[i] = vv;
+  }
+}
+
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void adam_sparse_kernel(float* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
                                                               int32_t E, uint32_t C, const int32_t* __restrict__ unique_rows,
@@ -761,6 +776,30 @@ int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v
     adam_dense_kernel<<<grid_for(ctx, n), kThreads, 0, st>>>(p, g, m, v, n, k);
   }
   TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, int64_t step, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, tt_stream stream) {
+  TT_CHECK_ARG(ctx && (n_tensors == 0 || tensors), "tt_adam_multi_step: NULL argument");
+  TT_CHECK_ARG(step >= 1 && n_tensors >= 0, "tt_adam_multi_step: step must be >= 1");
+  const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  for (int base = 0; base < n_tensors; base += kAdamMulti) {
+    AdamMultiArgs a{};
+    const int cnt = n_tensors - base < kAdamMulti ? n_tensors - base : kAdamMulti;
+    int64_t nmax = 1;
+    for (int i = 0; i < cnt; ++i) {
+      const tt_adam_tensor& t = tensors[base + i];
+      TT_CHECK_ARG(t.n >= 0 && (t.n == 0 || (t.p && t.g && t.m && t.v)), "tt_adam_multi_step: tensor %d has NULL pointers", base + i);
+      a.t[i] = t;
+      nmax = t.n > nmax ? t.n : nmax;
+    }
+    int64_t gx = tt_cdiv(nmax, kThreads);
+    if (gx > 64) gx = 64;
+    adam_multi_kernel<<<dim3((unsigned)gx, (unsigned)cnt), kThreads, 0, st>>>(a, k);
+    TT_LAUNCH_CHECK();
+  }
   return TT_OK;
 }
 

@@ -12,6 +12,51 @@ from . import _lib as L
 from ._lib import TT_BF16, TT_F32, TT_GRAD_DENSE_ACC, TT_GRAD_DENSE_SET, TT_GRAD_SPARSE  # noqa: F401
 
 
+class KernelTimer:
+    """HIP-event timing of C-ABI calls on the stream they are enqueued on (bench.py: roofline legs)."""
+
+    def __init__(self, names=None):
+        self.names = set(names) if names else None
+        self.records = {}
+
+    def wants(self, name):
+        return self.names is None or name in self.names
+
+    def summary(self):
+        """name -> (launches, mean ms); synchronises."""
+        torch.cuda.synchronize()
+        return {n: (len(ev), sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)) for n, ev in self.records.items()}
+
+
+_TIMER: Optional[KernelTimer] = None
+
+
+def set_timer(t: Optional[KernelTimer]):
+    global _TIMER
+    _TIMER = t
+
+
+class _timed:
+    __slots__ = ("name", "a")
+
+    def __init__(self, name):
+        self.name = name
+        self.a = None
+
+    def __enter__(self):
+        if _TIMER is not None and _TIMER.wants(self.name):
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.a is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            _TIMER.records.setdefault(self.name, []).append((self.a, b))
+        return False
+
+
 def _dt(t: torch.Tensor) -> int:
     if t.dtype == torch.float32:
         return TT_F32
@@ -45,8 +90,9 @@ def embed_lookup(table: torch.Tensor, sides: Sequence[LookupSide], B: int, want_
                              s.out.stride(0), s.K, _dt(s.out))
         M += B * s.K
     rows = torch.empty(M, dtype=torch.int32, device=dev) if want_rows else None
-    L.check(L.load().tt_embed_lookup_fwd(L.ctx(dev), L.ptr(table), table.shape[0], E, arr, len(sides), B,
-                                         L.ptr(rows), L.stream(dev)), "tt_embed_lookup_fwd")
+    with _timed("tt_embed_lookup_fwd"):
+        L.check(L.load().tt_embed_lookup_fwd(L.ctx(dev), L.ptr(table), table.shape[0], E, arr, len(sides), B,
+                                             L.ptr(rows), L.stream(dev)), "tt_embed_lookup_fwd")
     return rows
 
 
@@ -66,9 +112,10 @@ def dedup_plan(rows: torch.Tensor, table_rows: int) -> DedupPlan:
     lib = L.load()
     nb = lib.tt_dedup_workspace_bytes(M)
     ws = L.workspace(dev, nb)
-    L.check(lib.tt_dedup_plan(L.ctx(dev), L.ptr(rows), M, table_rows, L.ptr(plan.sorted_src), L.ptr(plan.unique_rows),
-                              L.ptr(plan.seg_offsets), L.ptr(plan.n_unique), L.ptr(ws), ws.numel(), L.stream(dev)),
-            "tt_dedup_plan")
+    with _timed("tt_dedup_plan"):
+        L.check(lib.tt_dedup_plan(L.ctx(dev), L.ptr(rows), M, table_rows, L.ptr(plan.sorted_src), L.ptr(plan.unique_rows),
+                                  L.ptr(plan.seg_offsets), L.ptr(plan.n_unique), L.ptr(ws), ws.numel(), L.stream(dev)),
+                "tt_dedup_plan")
     return plan
 
 
@@ -82,23 +129,39 @@ def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int
     lib = L.load()
     nb = lib.tt_embed_grad_workspace_bytes(plan.M, E)
     ws = L.workspace(dev, nb)
-    L.check(lib.tt_embed_grad_bwd(L.ctx(dev), arr, len(srcs), B, E, L.ptr(plan.sorted_src), L.ptr(plan.seg_offsets),
-                                  L.ptr(plan.unique_rows), L.ptr(plan.n_unique), plan.M, mode, L.ptr(out), L.ptr(ws),
-                                  ws.numel(), L.stream(dev)), "tt_embed_grad_bwd")
+    with _timed("tt_embed_grad_bwd"):
+        L.check(lib.tt_embed_grad_bwd(L.ctx(dev), arr, len(srcs), B, E, L.ptr(plan.sorted_src), L.ptr(plan.seg_offsets),
+                                      L.ptr(plan.unique_rows), L.ptr(plan.n_unique), plan.M, mode, L.ptr(out), L.ptr(ws),
+                                      ws.numel(), L.stream(dev)), "tt_embed_grad_bwd")
 
 
 # ---------------------------------------------------------------------------------------------- Adam
 def adam_dense(p, g, m, v, step, lr, b1, b2, eps, wd):
     dev = p.device
-    L.check(L.load().tt_adam_dense_step(L.ctx(dev), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), step, lr, b1, b2,
-                                        eps, wd, L.stream(dev)), "tt_adam_dense_step")
+    with _timed("tt_adam_dense_step"):
+        L.check(L.load().tt_adam_dense_step(L.ctx(dev), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), step, lr, b1, b2,
+                                            eps, wd, L.stream(dev)), "tt_adam_dense_step")
+
+
+def adam_multi(items, step, lr, b1, b2, eps, wd):
+    """items: [(p, g, m, v)] float32 contiguous tensors on one device."""
+    if not items:
+        return
+    dev = items[0][0].device
+    arr = (L.AdamTensor * len(items))()
+    for i, (p, g, m, v) in enumerate(items):
+        arr[i] = L.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+    with _timed("tt_adam_multi_step"):
+        L.check(L.load().tt_adam_multi_step(L.ctx(dev), arr, len(items), step, lr, b1, b2, eps, wd, L.stream(dev)),
+                "tt_adam_multi_step")
 
 
 def adam_sparse(table, m, v, plan: DedupPlan, grad_rows, step, lr, b1, b2, eps, wd):
     dev = table.device
-    L.check(L.load().tt_sparse_adam_step(L.ctx(dev), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[1],
-                                         L.ptr(plan.unique_rows), L.ptr(grad_rows), L.ptr(plan.n_unique), plan.M, step,
-                                         lr, b1, b2, eps, wd, L.stream(dev)), "tt_sparse_adam_step")
+    with _timed("tt_sparse_adam_step"):
+        L.check(L.load().tt_sparse_adam_step(L.ctx(dev), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[1],
+                                             L.ptr(plan.unique_rows), L.ptr(grad_rows), L.ptr(plan.n_unique), plan.M, step,
+                                             lr, b1, b2, eps, wd, L.stream(dev)), "tt_sparse_adam_step")
 
 
 # ---------------------------------------------------------------------------------------------- tower MLP
@@ -126,14 +189,16 @@ def tower_workspace(params, B, dev):
 
 def tower_fwd(params, acts, B, train, p_drop, seed, dev):
     ws = tower_workspace(params, B, dev)
-    L.check(L.load().tt_tower_mlp_fwd(L.ctx(dev), C.byref(params), C.byref(acts), B, int(train), p_drop, seed, L.ptr(ws),
-                                      ws.numel(), L.stream(dev)), "tt_tower_mlp_fwd")
+    with _timed("tt_tower_mlp_fwd"):
+        L.check(L.load().tt_tower_mlp_fwd(L.ctx(dev), C.byref(params), C.byref(acts), B, int(train), p_drop, seed, L.ptr(ws),
+                                          ws.numel(), L.stream(dev)), "tt_tower_mlp_fwd")
 
 
 def tower_bwd(params, acts, d_emb, grads, B, train, p_drop, seed, dev):
     ws = tower_workspace(params, B, dev)
-    L.check(L.load().tt_tower_mlp_bwd(L.ctx(dev), C.byref(params), C.byref(acts), L.ptr(d_emb), C.byref(grads), B,
-                                      int(train), p_drop, seed, L.ptr(ws), ws.numel(), L.stream(dev)), "tt_tower_mlp_bwd")
+    with _timed("tt_tower_mlp_bwd"):
+        L.check(L.load().tt_tower_mlp_bwd(L.ctx(dev), C.byref(params), C.byref(acts), L.ptr(d_emb), C.byref(grads), B,
+                                          int(train), p_drop, seed, L.ptr(ws), ws.numel(), L.stream(dev)), "tt_tower_mlp_bwd")
 
 
 # ---------------------------------------------------------------------------------------------- score / loss
@@ -141,33 +206,37 @@ def score_dir_fwd(A, Bm, inv_t, shift, diag_offset=0, want_sumscore=True):
     dev, Ra, Rb, D = A.device, A.shape[0], Bm.shape[0], A.shape[1]
     f = torch.empty((3, Ra), dtype=torch.float32, device=dev)       # sumexp, diag, sumscore
     rank = torch.empty(Ra, dtype=torch.int32, device=dev)
-    L.check(L.load().tt_score_dir_fwd(L.ctx(dev), L.ptr(A), L.ptr(Bm), Ra, Rb, D, inv_t, shift, diag_offset, L.ptr(f[0]),
-                                      L.ptr(f[1]), L.ptr(rank), L.ptr(f[2]) if want_sumscore else None, L.stream(dev)),
-            "tt_score_dir_fwd")
+    with _timed("tt_score_dir_fwd"):
+        L.check(L.load().tt_score_dir_fwd(L.ctx(dev), L.ptr(A), L.ptr(Bm), Ra, Rb, D, inv_t, shift, diag_offset, L.ptr(f[0]),
+                                          L.ptr(f[1]), L.ptr(rank), L.ptr(f[2]) if want_sumscore else None, L.stream(dev)),
+                "tt_score_dir_fwd")
     return f[0], f[1], rank, f[2]
 
 
 def score_loss_finish(B, shift, rowsum, colsum, diag, row_rank, col_rank, sumscore):
     dev = rowsum.device
     out = torch.empty(8, dtype=torch.float32, device=dev)
-    L.check(L.load().tt_score_loss_finish(L.ctx(dev), B, shift, L.ptr(rowsum), L.ptr(colsum), L.ptr(diag), L.ptr(row_rank),
-                                          L.ptr(col_rank), L.ptr(sumscore), L.ptr(out), L.stream(dev)), "tt_score_loss_finish")
+    with _timed("tt_score_loss_finish"):
+        L.check(L.load().tt_score_loss_finish(L.ctx(dev), B, shift, L.ptr(rowsum), L.ptr(colsum), L.ptr(diag), L.ptr(row_rank),
+                                              L.ptr(col_rank), L.ptr(sumscore), L.ptr(out), L.stream(dev)), "tt_score_loss_finish")
     return out
 
 
 def score_dir_bwd(A, Bm, inv_t, shift, diag_offset, sumexp_a, sumexp_b, d_loss, scale):
     dev, Ra, Rb, D = A.device, A.shape[0], Bm.shape[0], A.shape[1]
     dA = torch.empty_like(A)
-    L.check(L.load().tt_score_dir_bwd(L.ctx(dev), L.ptr(A), L.ptr(Bm), Ra, Rb, D, inv_t, shift, diag_offset, L.ptr(sumexp_a),
-                                      L.ptr(sumexp_b), L.ptr(d_loss), scale, L.ptr(dA), L.stream(dev)), "tt_score_dir_bwd")
+    with _timed("tt_score_dir_bwd"):
+        L.check(L.load().tt_score_dir_bwd(L.ctx(dev), L.ptr(A), L.ptr(Bm), Ra, Rb, D, inv_t, shift, diag_offset, L.ptr(sumexp_a),
+                                          L.ptr(sumexp_b), L.ptr(d_loss), scale, L.ptr(dA), L.stream(dev)), "tt_score_dir_bwd")
     return dA
 
 
 def score_matrix(A, Bm, inv_t):
     dev, Ra, Rb, D = A.device, A.shape[0], Bm.shape[0], A.shape[1]
     S = torch.empty((Ra, Rb), dtype=torch.float32, device=dev)
-    L.check(L.load().tt_score_matrix(L.ctx(dev), L.ptr(A), L.ptr(Bm), Ra, Rb, D, inv_t, L.ptr(S), Rb, L.stream(dev)),
-            "tt_score_matrix")
+    with _timed("tt_score_matrix"):
+        L.check(L.load().tt_score_matrix(L.ctx(dev), L.ptr(A), L.ptr(Bm), Ra, Rb, D, inv_t, L.ptr(S), Rb, L.stream(dev)),
+                "tt_score_matrix")
     return S
 
 
@@ -176,8 +245,9 @@ def topk_rows(S, k):
     assert S.stride(1) == 1
     vals = torch.empty((R, k), dtype=torch.float32, device=dev)
     idx = torch.empty((R, k), dtype=torch.int64, device=dev)
-    L.check(L.load().tt_topk_rows(L.ctx(dev), L.ptr(S), R, Cc, S.stride(0), k, L.ptr(vals), L.ptr(idx), L.stream(dev)),
-            "tt_topk_rows")
+    with _timed("tt_topk_rows"):
+        L.check(L.load().tt_topk_rows(L.ctx(dev), L.ptr(S), R, Cc, S.stride(0), k, L.ptr(vals), L.ptr(idx), L.stream(dev)),
+                "tt_topk_rows")
     return vals, idx
 
 

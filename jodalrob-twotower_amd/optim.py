@@ -1,0 +1,156 @@
+"""FusedAdam -- torch.optim.Adam semantics (scripts/train.py:231: lr, betas=(0.9,0.999), eps=1e-8,
+coupled weight_decay) on the HIP path, usable wherever the reference builds `optim.Adam(
+train_task.parameters(), ...)` (works with LambdaLR warm-up: lr is read from param_groups each step).
+
+  * tower weights            : one tt_adam_multi_step launch per 32 tensors (exact dense Adam)
+  * embedding tables, dense  : ONE tt_adam_dense_step over the fused [R, E] store (exact: identical to
+    grad mode                  per-key Adam since the update is elementwise)
+  * embedding tables, sparse : tt_sparse_adam_step over the rows looked up in this step only.  Rows that
+    grad mode                  were not looked up keep weight / exp_avg / exp_avg_sq untouched (the
+                               reference's dense Adam would decay their moments and apply weight decay);
+                               bias correction uses the global step.  See DESIGN.md "optimiser semantics".
+
+State layout matches torch.optim.Adam ('step', 'exp_avg', 'exp_avg_sq' per parameter; for table
+parameters these are views into store-level buffers), so optimizer.state_dict() round-trips through
+the reference's checkpoint format (scripts/train.py:506-511).
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from . import ops
+from .cat_embed import EmbeddingStore
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, stores: List[EmbeddingStore] = ()):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._stores: List[EmbeddingStore] = list(stores)
+        self._store_state: Dict[int, dict] = {}
+
+    @classmethod
+    def for_task(cls, task, **kw):
+        """Collect the embedding stores of a TwoTowerTrainTask / TwoTowerModel / tower automatically."""
+        return cls(task.parameters(), stores=find_stores(task), **kw)
+
+    # ---- store-level state --------------------------------------------------------------------------
+    def _state_of(self, store: EmbeddingStore) -> dict:
+        st = self._store_state.get(id(store))
+        if st is None or st["m"].shape != store.weight.shape or st["m"].device != store.weight.device:
+            st = {"m": torch.zeros_like(store.weight), "v": torch.zeros_like(store.weight), "step": 0}
+            self._store_state[id(store)] = st
+            for emb in store.members:                        # per-parameter views, torch.optim.Adam layout
+                off = emb.row_base
+                for k in emb.keys:
+                    n = emb.vocab_sizes[k]
+                    p = emb.embeddings[k].weight
+                    self.state[p] = {"step": torch.tensor(0.0), "exp_avg": st["m"][off:off + n],
+                                     "exp_avg_sq": st["v"][off:off + n]}
+                    off += n
+        return st
+
+    def _table_param_ids(self):
+        return {id(p) for s in self._stores for m in s.members for p in m.table_parameters()}
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        table_ids = self._table_param_ids()
+        group_of = {}
+        for group in self.param_groups:
+            for p in group["params"]:
+                group_of[id(p)] = group
+        # ---- tower weights ----
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            items = []
+            step_no = None
+            for p in group["params"]:
+                if id(p) in table_ids or p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = torch.tensor(0.0)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                step_no = int(st["step"].item())
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                items.append((p, g, st["exp_avg"], st["exp_avg_sq"], step_no))
+            by_step: Dict[int, list] = {}
+            for it in items:
+                by_step.setdefault(it[4], []).append(it[:4])
+            for s_no, its in by_step.items():
+                ops.adam_multi(its, s_no, group["lr"], b1, b2, group["eps"], group["weight_decay"])
+        # ---- embedding stores ----
+        for store in self._stores:
+            members = [p for m in store.members for p in m.table_parameters()]
+            if not members:
+                continue
+            group = group_of.get(id(members[0]))
+            if group is None:
+                continue                                     # tables not handed to this optimiser
+            b1, b2 = group["betas"]
+            st = self._state_of(store)
+            if store.grad_mode == "sparse":
+                if store.sparse_grad is None:
+                    continue
+                plan, grad_rows = store.sparse_grad
+                st["step"] += 1
+                ops.adam_sparse(store.weight, st["m"], st["v"], plan, grad_rows, st["step"], group["lr"], b1, b2,
+                                group["eps"], group["weight_decay"])
+                store.sparse_grad = None
+            else:
+                if store.grad is None or any(p.grad is None for p in members):
+                    continue
+                st["step"] += 1
+                ops.adam_dense(store.weight, store.grad, st["m"], st["v"], st["step"], group["lr"], b1, b2,
+                               group["eps"], group["weight_decay"])
+            for p in members:
+                self.state[p]["step"] = torch.tensor(float(st["step"]))
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none=set_to_none)
+        for store in self._stores:
+            store.sparse_grad = None
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        # re-point the table parameters' moments at store-level buffers
+        for store in self._stores:
+            loaded = {}
+            for emb in store.members:
+                for k in emb.keys:
+                    p = emb.embeddings[k].weight
+                    if p in self.state and "exp_avg" in self.state[p]:
+                        loaded[id(p)] = dict(self.state[p])
+            self._store_state.pop(id(store), None)
+            if not loaded:
+                continue
+            st = self._state_of(store)
+            for emb in store.members:
+                for k in emb.keys:
+                    p = emb.embeddings[k].weight
+                    old = loaded.get(id(p))
+                    if old is not None:
+                        self.state[p]["exp_avg"].copy_(old["exp_avg"])
+                        self.state[p]["exp_avg_sq"].copy_(old["exp_avg_sq"])
+                        st["step"] = max(st["step"], int(float(old["step"])))
+                        self.state[p]["step"] = torch.tensor(float(st["step"]))
+
+
+def find_stores(module) -> List[EmbeddingStore]:
+    from .cat_embed import CategoricalEmbedder
+    out = []
+    for m in module.modules():
+        if isinstance(m, CategoricalEmbedder) and all(m.store is not s for s in out):
+            out.append(m.store)
+    return out

@@ -153,7 +153,7 @@ class _TowersFn(torch.autograd.Function):
     def forward(ctx, towers, *flat):
         sides: List[_Side] = []
         pos = 0
-        grad_on = torch.is_grad_enabled()
+        grad_on = any(ctx.needs_input_grad)       # (grad mode is always off inside Function.forward)
         spans = []
         lookups: Dict[int, list] = {}
         for tw in towers:
