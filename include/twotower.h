@@ -234,6 +234,34 @@ int tt_score_dir_bwd(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, i
                      float inv_t, float shift, int64_t diag_offset, const float* sumexp_a,
                      const float* sumexp_b, const float* d_loss, float scale, float* dA,
                      tt_stream stream);
+/* ---- bf16 fast path of the same three steps: operands rounded to bf16 (round-to-nearest-even), f32
+ * accumulation on v_mfma_f32_32x32x16_bf16, exp/log in f32.  tt_score_pack_bf16 writes the two bf16
+ * operand images of X[R, D] (row-major, and fragment-ordered for the gradient product) into `packed`
+ * (tt_score_pack_bytes(R, D) bytes, 16-byte aligned); the fwd / bwd calls take packed operands and
+ * process one or two directions in ONE launch (the loss needs (N,C) and (C,N)).  D <= 256. */
+typedef struct tt_score_fwd_dir {
+  const void* A_packed;
+  const void* B_packed;
+  int64_t Ra, Rb, diag_offset;
+  float* sumexp; /* [Ra] */
+  float* diag;     /* [Ra] or NULL */
+  int32_t* rank;   /* [Ra] or NULL */
+  float* sumscore; /* [Ra] sum_b s_ab, or NULL */
+} tt_score_fwd_dir;
+typedef struct tt_score_bwd_dir {
+  const void* A_packed;
+  const void* B_packed;
+  int64_t Ra, Rb, diag_offset;
+  const float* sumexp_a; /* [Ra] */
+  const float* sumexp_b; /* [Rb], 16-byte aligned */
+  float* dA;             /* [Ra, D] f32 */
+} tt_score_bwd_dir;
+size_t tt_score_pack_bytes(int64_t R, int32_t D);
+int tt_score_pack_bf16(tt_ctx* ctx, const float* X, int64_t R, int32_t D, void* packed, tt_stream stream);
+int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t,
+                      float shift, tt_stream stream);
+int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t,
+                      float shift, const float* d_loss, float scale, tt_stream stream);
 /* dense score matrix S[Ra, Rb] = A Bm^T * inv_t (result["similarity_matrix"], predict_batch
  * "all_similarities": two_tower_train_task.py:94, :206) */
 int tt_score_matrix(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D,

@@ -36,6 +36,16 @@ class AdamTensor(C.Structure):
     _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", i64)]
 
 
+class ScoreFwdDir(C.Structure):
+    _fields_ = [("A_packed", vp), ("B_packed", vp), ("Ra", i64), ("Rb", i64), ("diag_offset", i64),
+                ("sumexp", vp), ("diag", vp), ("rank", vp), ("sumscore", vp)]
+
+
+class ScoreBwdDir(C.Structure):
+    _fields_ = [("A_packed", vp), ("B_packed", vp), ("Ra", i64), ("Rb", i64), ("diag_offset", i64),
+                ("sumexp_a", vp), ("sumexp_b", vp), ("dA", vp)]
+
+
 _H = vp * TT_MAX_HIDDEN
 
 
@@ -77,6 +87,10 @@ SIGNATURES = {
     "tt_score_dir_fwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, vp, vp]),
     "tt_score_loss_finish": (C.c_int, [vp, i64, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "tt_score_dir_bwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, f32, vp, vp]),
+    "tt_score_pack_bytes": (sz, [i64, i32]),
+    "tt_score_pack_bf16": (C.c_int, [vp, vp, i64, i32, vp, vp]),
+    "tt_score_fwd_bf16": (C.c_int, [vp, C.POINTER(ScoreFwdDir), i32, i32, f32, f32, vp]),
+    "tt_score_bwd_bf16": (C.c_int, [vp, C.POINTER(ScoreBwdDir), i32, i32, f32, f32, vp, f32, vp]),
     "tt_score_matrix": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, vp, i64, vp]),
     "tt_topk_rows": (C.c_int, [vp, vp, i64, i64, i64, i32, vp, vp, vp]),
     "tt_linear_fwd": (C.c_int, [vp, vp, i64, vp, vp, vp, i64, i64, i32, i32, i32, vp]),

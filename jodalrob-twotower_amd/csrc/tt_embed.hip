@@ -126,7 +126,31 @@ __global__ __launch_bounds__(kThreads) void sort_hist_kernel(const uint32_t* __r
     if (idx < M) atomicAdd(&h[(keys[idx] >> shift) & (R - 1)], 1u);
   }
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < R; d += kThreads) hist[d * nblk + blockIdx.x] = h[d];
+  for (uint32_t d = threadIdx.x; d < R; d += kThreads) hist[blockIdx.x * R + d] = h[d];
+}
+
+// per digit: exclusive scan over the tiles (hist[tile][digit], in place) and the digit total.
+// grid = R/64 workgroups; thread = (digit, one of 4 tile segments)
+template <int BITS>
+__global__ __launch_bounds__(kThreads) void sort_colscan_kernel(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ total) {
+  constexpr uint32_t R = 1u << BITS;
+  __shared__ uint32_t sh[4][64];
+  const uint32_t d = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
+  const uint32_t per = (nblk + 3) / 4;
+  const uint32_t lo = seg * per < nblk ? seg * per : nblk;
+  const uint32_t hi = lo + per < nblk ? lo + per : nblk;
+  uint32_t s = 0;
+  for (uint32_t b = lo; b < hi; ++b) s += hist[b * R + d];
+  sh[seg][threadIdx.x & 63] = s;
+  __syncthreads();
+  uint32_t run = 0;
+  for (uint32_t g = 0; g < seg; ++g) run += sh[g][threadIdx.x & 63];
+  for (uint32_t b = lo; b < hi; ++b) {
+    const uint32_t t = hist[b * R + d];
+    hist[b * R + d] = run;
+    run += t;
+  }
+  if (seg == 3) total[d] = run;
 }
 
 // in-place exclusive scan of n uint32 by ONE workgroup of 1024 threads; optional total output
@@ -164,9 +188,13 @@ __global__ __launch_bounds__(kThreads) void sort_scatter_kernel(const uint32_t* 
                                                                const uint32_t* __restrict__ vals_in,
                                                                uint32_t* __restrict__ keys_out,
                                                                uint32_t* __restrict__ vals_out, uint32_t M, int shift,
-                                                               const uint32_t* __restrict__ hist_scanned, uint32_t nblk) {
+                                                               const uint32_t* __restrict__ hist_scanned,
+                                                               const uint32_t* __restrict__ total) {
   constexpr uint32_t R = 1u << BITS;
+  constexpr uint32_t PER = R / kThreads;              // digits per thread in the digit-base scan
   __shared__ uint32_t woff_s[4][R];
+  __shared__ uint32_t dbase[R];
+  __shared__ uint32_t wsum[4];
   volatile uint32_t(*woff)[R] = woff_s;
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (uint32_t d = tid; d < 4 * R; d += kThreads) (&woff_s[0][0])[d] = 0;
@@ -178,9 +206,28 @@ __global__ __launch_bounds__(kThreads) void sort_scatter_kernel(const uint32_t* 
     if (idx < M) atomicAdd(&woff_s[wave][(keys_in[idx] >> shift) & (R - 1)], 1u);
   }
   __syncthreads();
+  // digit bases: exclusive scan of the digit totals (R <= 2048 values) inside the workgroup
+  {
+    uint32_t loc[PER], c = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < PER; ++j) { loc[j] = total[tid * PER + j]; c += loc[j]; }
+    uint32_t x = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(x, o);
+      if (lane >= (uint32_t)o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t run = x - c;
+    for (uint32_t w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (uint32_t j = 0; j < PER; ++j) { dbase[tid * PER + j] = run; run += loc[j]; }
+  }
+  __syncthreads();
   // phase 2: counts -> starting output offset of (wave, digit)
   for (uint32_t d = tid; d < R; d += kThreads) {
-    uint32_t base = hist_scanned[d * nblk + blockIdx.x];
+    uint32_t base = dbase[d] + hist_scanned[blockIdx.x * R + d];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const uint32_t c = woff_s[w][d];
@@ -237,11 +284,11 @@ __global__ __launch_bounds__(kThreads) void head_count_kernel(const uint32_t* __
 }
 
 __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __restrict__ keys, uint32_t M,
-                                                             const uint32_t* __restrict__ blockoff,
-                                                             const int32_t* __restrict__ n_unique,
+                                                             const uint32_t* __restrict__ blockcount,
+                                                             int32_t* __restrict__ n_unique,
                                                              int32_t* __restrict__ unique_rows,
                                                              int32_t* __restrict__ seg_offsets) {
-  __shared__ uint32_t wsum[4];
+  __shared__ uint32_t wsum[4], wbefore[4], wall[4];
   constexpr uint32_t PER = kSortTile / kThreads;   // 16 contiguous elements per thread
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t lo = blockIdx.x * kSortTile + tid * PER;
@@ -258,8 +305,21 @@ __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __
     if (lane >= (uint32_t)o) x += y;
   }
   if (lane == 63) wsum[wave] = x;
+  // offset of this tile = sum of the head counts of the tiles before it (block 0 also forms the total)
+  uint32_t before = 0, all = 0;
+  const uint32_t nblk = gridDim.x;
+  for (uint32_t b = tid; b < nblk; b += kThreads) {
+    const uint32_t v = blockcount[b];
+    all += v;
+    if (b < blockIdx.x) before += v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { before += __shfl_xor(before, o); all += __shfl_xor(all, o); }
+  if (lane == 0) { wbefore[wave] = before; wall[wave] = all; }
   __syncthreads();
-  uint32_t u = blockoff[blockIdx.x] + x - c;
+  before = wbefore[0] + wbefore[1] + wbefore[2] + wbefore[3];
+  all = wall[0] + wall[1] + wall[2] + wall[3];
+  uint32_t u = before + x - c;
   for (uint32_t w = 0; w < wave; ++w) u += wsum[w];
 #pragma unroll
   for (uint32_t j = 0; j < PER; ++j) {
@@ -269,7 +329,10 @@ __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __
       ++u;
     }
   }
-  if (blockIdx.x == 0 && tid == 0) seg_offsets[*n_unique] = (int32_t)M;
+  if (blockIdx.x == 0 && tid == 0) {
+    n_unique[0] = (int32_t)all;
+    seg_offsets[all] = (int32_t)M;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -556,7 +619,7 @@ inline int grid_for(const tt_ctx* ctx, int64_t threads_needed) {
 }
 
 struct DedupWs {
-  uint32_t *keysA, *keysB, *valsB, *hist, *blockcount;
+  uint32_t *keysA, *keysB, *valsB, *hist, *total, *blockcount;
   size_t bytes;
 };
 
@@ -571,6 +634,7 @@ inline DedupWs dedup_layout(char* base, int64_t M) {
   w.keysB = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)(M + 1)));
   w.valsB = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)(M + 1)));
   w.hist = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)2048 * nblk));
+  w.total = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)2048));
   w.blockcount = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)(nblk + 1)));
   w.bytes = o;
   return w;
@@ -600,12 +664,12 @@ inline GradLayout grad_layout(char* base, int64_t M, int32_t E) {
 
 template <int BITS>
 int sort_pass(hipStream_t st, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, uint32_t M, int shift,
-              uint32_t* hist, uint32_t nblk) {
+              uint32_t* hist, uint32_t* total, uint32_t nblk) {
   sort_hist_kernel<BITS><<<nblk, kThreads, 0, st>>>(kin, M, shift, hist, nblk);
   TT_LAUNCH_CHECK();
-  scan_kernel<<<1, 1024, 0, st>>>(hist, (1u << BITS) * nblk, nullptr);
+  sort_colscan_kernel<BITS><<<(1u << BITS) / 64, kThreads, 0, st>>>(hist, nblk, total);
   TT_LAUNCH_CHECK();
-  sort_scatter_kernel<BITS><<<nblk, kThreads, 0, st>>>(kin, vin, kout, vout, M, shift, hist, nblk);
+  sort_scatter_kernel<BITS><<<nblk, kThreads, 0, st>>>(kin, vin, kout, vout, M, shift, hist, total);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }
@@ -691,15 +755,13 @@ int tt_dedup_plan(tt_ctx* ctx, const int32_t* rows, int64_t M, int64_t table_row
     const bool last_to_A = ((passes - 1 - p) % 2) == 0;
     uint32_t* kout = last_to_A ? w.keysA : w.keysB;
     uint32_t* vout = last_to_A ? reinterpret_cast<uint32_t*>(sorted_src) : w.valsB;
-    int rc = digit == 8 ? sort_pass<8>(st, kin, vin, kout, vout, (uint32_t)M, p * digit, w.hist, nblk)
-                        : sort_pass<11>(st, kin, vin, kout, vout, (uint32_t)M, p * digit, w.hist, nblk);
+    int rc = digit == 8 ? sort_pass<8>(st, kin, vin, kout, vout, (uint32_t)M, p * digit, w.hist, w.total, nblk)
+                        : sort_pass<11>(st, kin, vin, kout, vout, (uint32_t)M, p * digit, w.hist, w.total, nblk);
     if (rc != TT_OK) return rc;
     kin = kout;
     vin = vout;
   }
   head_count_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount);
-  TT_LAUNCH_CHECK();
-  scan_kernel<<<1, 1024, 0, st>>>(w.blockcount, nblk, n_unique);
   TT_LAUNCH_CHECK();
   head_write_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount, n_unique, unique_rows, seg_offsets);
   TT_LAUNCH_CHECK();

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(const float* __res
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     float s = 0.f;
+#pragma unroll 8
     for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * slab_stride + i];
     const int64_t m = i / N, n = i - m * N;
     C[m * ldc + n] = s;
@@ -116,8 +117,9 @@ inline bool vec_ok(const float* p, int64_t ld) { return tt_aligned(p, 16) && (ld
 
 inline int tn_splits(int64_t M, int64_t N, int64_t R) {
   const int64_t tiles = tt_cdiv(M, BM) * tt_cdiv(N, BN);
-  int64_t s = 512 / (tiles > 0 ? tiles : 1);
-  const int64_t maxs = tt_cdiv(R, 64);
+  int64_t s = 256 / (tiles > 0 ? tiles : 1);
+  int64_t maxs = tt_cdiv(R, 128);
+  if (maxs > 32) maxs = 32;
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
   return (int)s;

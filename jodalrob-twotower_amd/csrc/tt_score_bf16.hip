@@ -1,0 +1,437 @@
+// bf16-MFMA fast path of the in-batch-negative score + symmetric softmax-CE (same maths as
+// tt_score.hip, operands rounded to bf16, f32 accumulation on v_mfma_f32_32x32x16_bf16).
+//
+// Wave-level design (no LDS in the main loops):
+//   * a wave owns 32*AT rows `a` of A and sweeps the rows `b` of Bm in 32-row tiles; the NW waves of a
+//     workgroup share the same A rows and split the b tiles round-robin.
+//   * the tile is computed TRANSPOSED, X = Bm_tile . A_tile^T, so an accumulator register holds
+//     X[b = rowmap(reg, lane>>5)][a = lane&31]: every per-`a` quantity (1/sumexp_a, the diagonal score,
+//     the running exp-sum and rank count) is ONE value per lane, and the accumulator registers of a tile,
+//     converted pairwise to bf16, ARE the A operand of the second MFMA (X^T . Bm) -- no lane movement.
+//   * Bm is read in two images written once per step by tt_score_pack_bf16: row-major [Rp, Dp] (operand
+//     of the first product; a wave-instruction reads 32 rows x 32 B, contiguous) and a fragment-ordered
+//     image [tile][k-step][half][d][8] whose 16-B chunks are exactly the B operand of the second product
+//     in the k-permutation the accumulator registers impose.
+//   * partial results of the NW waves are combined through LDS in a fixed tree order.
+#include "tt_common.h"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kNegBig = -3.0e38f;
+
+__host__ __device__ inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+inline int padded_d(int D) { return D <= 32 ? 32 : (D <= 64 ? 64 : (D <= 128 ? 128 : 256)); }
+
+__device__ __forceinline__ int rowmap(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// ---- pack ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ X, int64_t R, int D, int64_t Rp, int Dp,
+                                                        __bf16* __restrict__ rows, __bf16* __restrict__ frag) {
+  const int64_t nchunk = Rp * Dp / 8;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < 2 * nchunk; c += stride) {
+    bf16x8 v;
+    if (c < nchunk) {                                   // row-major image
+      const int64_t row = c / (Dp / 8);
+      const int d0 = (int)(c % (Dp / 8)) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (__bf16)((row < R && d0 + j < D) ? X[row * D + d0 + j] : 0.f);
+      *reinterpret_cast<bf16x8*>(rows + c * 8) = v;
+    } else {                                            // fragment-ordered image [t][s][h][d][8]
+      const int64_t f = c - nchunk;
+      const int d = (int)(f % Dp);
+      const int64_t rest = f / Dp;
+      const int h = (int)(rest & 1), s = (int)((rest >> 1) & 1);
+      const int64_t t = rest >> 2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t row = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+        v[j] = (__bf16)((row < R && d < D) ? X[row * D + d] : 0.f);
+      }
+      *reinterpret_cast<bf16x8*>(frag + f * 8) = v;
+    }
+  }
+}
+
+struct DirFwd {
+  const __bf16* a_rows;
+  const __bf16* b_rows;
+  int64_t Ra, Rb, off;
+  float* sumexp;
+  float* diag;
+  int32_t* rank;
+  float* sumscore;
+};
+struct FwdArgs {
+  DirFwd d[2];
+  float c1, c2, inv_t;
+};
+
+struct DirBwd {
+  const __bf16* a_rows;
+  const __bf16* b_rows;
+  const __bf16* b_frag;
+  int64_t Ra, Rb, off;
+  const float* sumexp_a;
+  const float* sumexp_b;
+  float* dA;
+};
+struct BwdArgs {
+  DirBwd d[2];
+  float c1, c2, scale;
+  const float* d_loss;
+  int D;
+};
+
+template <int KS, int AT>
+__device__ __forceinline__ void gemm1(const __bf16* __restrict__ b_rows, int64_t t, int c, int h, const bf16x8 (&ares)[AT][KS],
+                                      f32x16 (&acc)[AT]) {
+  constexpr int Dp = KS * 16;
+  bf16x8 bf[KS];
+  const __bf16* p = b_rows + (32 * t + c) * Dp + 8 * h;
+#pragma unroll
+  for (int s = 0; s < KS; ++s) bf[s] = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+#pragma unroll
+  for (int i = 0; i < AT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int i = 0; i < AT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s], ares[i][s], acc[i], 0, 0, 0);
+}
+
+// ---- forward ---------------------------------------------------------------------------------------
+template <int KS, int AT, int NW>
+__global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
+  constexpr int Dp = KS * 16, ROWS = 32 * AT;
+  __shared__ float part_e[NW][ROWS];
+  __shared__ float part_s[NW][ROWS];
+  __shared__ int part_c[NW][ROWS];
+  const DirFwd dr = args.d[blockIdx.y];
+  const int64_t a0 = (int64_t)blockIdx.x * ROWS;
+  if (a0 >= dr.Ra) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  const int64_t nT = rup(dr.Rb, 32) / 32;
+  bf16x8 ares[AT][KS];
+#pragma unroll
+  for (int i = 0; i < AT; ++i)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) ares[i][s] = *reinterpret_cast<const bf16x8*>(dr.a_rows + (a0 + 32 * i + c) * Dp + 16 * s + 8 * h);
+  int64_t pos[AT];
+  float dg[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) { pos[i] = a0 + 32 * i + c + dr.off; dg[i] = kNegBig; }
+  const int64_t posmin = a0 + dr.off, posmax = a0 + ROWS - 1 + dr.off;
+  // the diagonal scores, taken from the MFMA result itself so that ties compare bit-for-bit
+  if (posmax >= 0 && posmin < dr.Rb) {
+    const int64_t td0 = posmin > 0 ? posmin / 32 : 0;
+    const int64_t td1 = (posmax / 32) < nT - 1 ? posmax / 32 : nT - 1;
+    for (int64_t t = td0; t <= td1; ++t) {
+      f32x16 acc[AT];
+      gemm1<KS, AT>(dr.b_rows, t, c, h, ares, acc);
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (32 * t + rowmap(r, h) == pos[i]) dg[i] = acc[i][r];
+    }
+#pragma unroll
+    for (int i = 0; i < AT; ++i) dg[i] = fmaxf(dg[i], __shfl_xor(dg[i], 32));
+  }
+  float se[AT], ss[AT];
+  int cnt[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) { se[i] = 0.f; ss[i] = 0.f; cnt[i] = 0; }
+  for (int64_t t = wave; t < nT; t += NW) {
+    f32x16 acc[AT];
+    gemm1<KS, AT>(dr.b_rows, t, c, h, ares, acc);
+    const int64_t b_lo = 32 * t, b_hi = 32 * t + 31;
+    if (b_hi < dr.Rb && b_hi < posmin) {              // every b of the tile lies before every positive: ties count
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float x = acc[i][r];
+          se[i] += __builtin_amdgcn_exp2f(__builtin_fmaf(x, args.c1, args.c2));
+          ss[i] += x;
+          cnt[i] += x >= dg[i] ? 1 : 0;
+        }
+    } else if (b_hi < dr.Rb && b_lo > posmax) {       // every b after every positive: strict
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float x = acc[i][r];
+          se[i] += __builtin_amdgcn_exp2f(__builtin_fmaf(x, args.c1, args.c2));
+          ss[i] += x;
+          cnt[i] += x > dg[i] ? 1 : 0;
+        }
+    } else {                                          // tiles touching the diagonal band or the ragged end
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t b = b_lo + rowmap(r, h);
+          if (b < dr.Rb) {
+            const float x = acc[i][r];
+            se[i] += __builtin_amdgcn_exp2f(__builtin_fmaf(x, args.c1, args.c2));
+            ss[i] += x;
+            cnt[i] += (b < pos[i] ? x >= dg[i] : (b > pos[i] ? x > dg[i] : false)) ? 1 : 0;
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+    se[i] += __shfl_xor(se[i], 32);
+    ss[i] += __shfl_xor(ss[i], 32);
+    cnt[i] += __shfl_xor(cnt[i], 32);
+    if (h == 0) { part_e[wave][32 * i + c] = se[i]; part_s[wave][32 * i + c] = ss[i]; part_c[wave][32 * i + c] = cnt[i]; }
+  }
+  __syncthreads();
+  if (threadIdx.x < ROWS) {
+    const int64_t a = a0 + threadIdx.x;
+    if (a < dr.Ra) {
+      float e = 0.f, sc = 0.f;
+      int k = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { e += part_e[w][threadIdx.x]; sc += part_s[w][threadIdx.x]; k += part_c[w][threadIdx.x]; }
+      dr.sumexp[a] = e;
+      if (dr.rank) dr.rank[a] = k;
+      if (dr.sumscore) dr.sumscore[a] = sc * args.inv_t;
+    }
+  }
+  if (wave == 0 && h == 0 && dr.diag) {
+#pragma unroll
+    for (int i = 0; i < AT; ++i) {
+      const int64_t a = a0 + 32 * i + c;
+      if (a < dr.Ra) dr.diag[a] = dg[i] > -1.0e38f ? dg[i] * args.inv_t : 0.f;
+    }
+  }
+}
+
+// ---- backward --------------------------------------------------------------------------------------
+template <int KS, int AT, int NW>
+__global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
+  constexpr int Dp = KS * 16, ROWS = 32 * AT, DT = KS / 2;
+  __shared__ float red[(NW / 2) * ROWS * Dp];
+  const DirBwd dr = args.d[blockIdx.y];
+  const int64_t a0 = (int64_t)blockIdx.x * ROWS;
+  if (a0 >= dr.Ra) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  const int64_t nT = rup(dr.Rb, 32) / 32;
+  bf16x8 ares[AT][KS];
+  float ia[AT];
+  int64_t pos[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) ares[i][s] = *reinterpret_cast<const bf16x8*>(dr.a_rows + (a0 + 32 * i + c) * Dp + 16 * s + 8 * h);
+    const int64_t a = a0 + 32 * i + c;
+    ia[i] = a < dr.Ra ? __builtin_amdgcn_rcpf(dr.sumexp_a[a]) : 0.f;
+    pos[i] = a + dr.off;
+  }
+  const int64_t posmin = a0 + dr.off, posmax = a0 + ROWS - 1 + dr.off;
+  f32x16 dacc[AT][DT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i)
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc[i][d][r] = 0.f;
+  for (int64_t t = wave; t < nT; t += NW) {
+    f32x16 acc[AT];
+    gemm1<KS, AT>(dr.b_rows, t, c, h, ares, acc);
+    const int64_t b_lo = 32 * t;
+    float ib[16];
+    if (b_lo + 31 < dr.Rb) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(dr.sumexp_b + b_lo + 4 * h + 8 * q);
+        ib[4 * q + 0] = __builtin_amdgcn_rcpf(v.x); ib[4 * q + 1] = __builtin_amdgcn_rcpf(v.y);
+        ib[4 * q + 2] = __builtin_amdgcn_rcpf(v.z); ib[4 * q + 3] = __builtin_amdgcn_rcpf(v.w);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t b = b_lo + rowmap(r, h);
+        ib[r] = b < dr.Rb ? __builtin_amdgcn_rcpf(dr.sumexp_b[b]) : 0.f;
+      }
+    }
+    const bool band = !(b_lo + 31 < posmin || b_lo > posmax);
+    bf16x8 wf[AT][2];
+#pragma unroll
+    for (int i = 0; i < AT; ++i) {
+      float w[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][r], args.c1, args.c2)) * (ia[i] + ib[r]);
+      if (band) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (b_lo + rowmap(r, h) == pos[i]) w[r] -= 2.f;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[i][s][j] = (__bf16)w[8 * s + j];
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(dr.b_frag + ((((t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
+#pragma unroll
+        for (int i = 0; i < AT; ++i) dacc[i][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][s], bm, dacc[i][d], 0, 0, 0);
+      }
+  }
+  // fixed-order tree over the NW waves: upper half writes, lower half adds
+#pragma unroll
+  for (int half = NW / 2; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
+      float* slab = red + (wave - half) * ROWS * Dp;
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slab[(32 * i + rowmap(r, h)) * Dp + 32 * d + c] = dacc[i][d][r];
+    }
+    __syncthreads();
+    if (wave < half) {
+      const float* slab = red + wave * ROWS * Dp;
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dacc[i][d][r] += slab[(32 * i + rowmap(r, h)) * Dp + 32 * d + c];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    const float g = args.d_loss[0] * args.scale;
+#pragma unroll
+    for (int i = 0; i < AT; ++i)
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int64_t a = a0 + 32 * i + rowmap(r, h);
+          const int dd = 32 * d + c;
+          if (a < dr.Ra && dd < args.D) dr.dA[a * args.D + dd] = dacc[i][d][r] * g;
+        }
+  }
+}
+
+struct PackedView {
+  const __bf16* rows;
+  const __bf16* frag;
+};
+inline PackedView view(const void* packed, int64_t R, int D) {
+  const int64_t Rp = rup(R, 64);
+  const int Dp = padded_d(D);
+  const __bf16* base = reinterpret_cast<const __bf16*>(packed);
+  return PackedView{base, base + Rp * Dp};
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tt_score_pack_bytes(int64_t R, int32_t D) {
+  if (R < 0 || D < 1 || D > 256) return 0;
+  return (size_t)(4 * rup(R > 0 ? R : 1, 64) * padded_d(D));
+}
+
+int tt_score_pack_bf16(tt_ctx* ctx, const float* X, int64_t R, int32_t D, void* packed, tt_stream stream) {
+  TT_CHECK_ARG(ctx && X && packed, "tt_score_pack_bf16: NULL argument");
+  TT_CHECK_ARG(R >= 1 && D >= 1, "tt_score_pack_bf16: bad shape");
+  if (D > 256) {
+    tt_set_error("tt_score_pack_bf16: D=%d > 256 not supported", D);
+    return TT_ERR_UNSUPPORTED;
+  }
+  TT_CHECK_ARG(tt_aligned(packed, 16), "tt_score_pack_bf16: packed buffer must be 16-byte aligned");
+  const int64_t Rp = rup(R, 64);          // a workgroup reads up to 64 consecutive rows of its operand
+  const int Dp = padded_d(D);
+  __bf16* base = reinterpret_cast<__bf16*>(packed);
+  const int64_t chunks = 2 * Rp * Dp / 8;
+  int64_t grid = tt_cdiv(chunks, 256);
+  const int64_t cap = (int64_t)ctx->num_cus * 8;
+  if (grid > cap) grid = cap;
+  pack_bf16_kernel<<<(unsigned)grid, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(X, R, D, Rp, Dp, base, base + Rp * Dp);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t, float shift,
+                      tt_stream stream) {
+  TT_CHECK_ARG(ctx && dirs && (n_dirs == 1 || n_dirs == 2), "tt_score_fwd_bf16: need 1 or 2 directions");
+  TT_CHECK_ARG(D >= 1 && D <= 256, "tt_score_fwd_bf16: D=%d not in [1,256]", D);
+  if (2.f * fabsf(inv_t) > 80.f) {
+    tt_set_error("tt_score_fwd_bf16: 1/temperature = %g: fixed-shift softmax needs 2/T <= 80", inv_t);
+    return TT_ERR_UNSUPPORTED;
+  }
+  FwdArgs a{};
+  int64_t maxRa = 0;
+  for (int i = 0; i < 2; ++i) {
+    const tt_score_fwd_dir& d = dirs[i < n_dirs ? i : 0];
+    TT_CHECK_ARG(d.A_packed && d.B_packed && d.sumexp && d.Ra >= 1 && d.Rb >= 1, "tt_score_fwd_bf16: bad direction %d", i);
+    a.d[i] = DirFwd{view(d.A_packed, d.Ra, D).rows, view(d.B_packed, d.Rb, D).rows, d.Ra, d.Rb, d.diag_offset, d.sumexp, d.diag, d.rank, d.sumscore};
+    maxRa = d.Ra > maxRa ? d.Ra : maxRa;
+  }
+  a.c1 = inv_t * kLog2e;
+  a.c2 = -shift * kLog2e;
+  a.inv_t = inv_t;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int Dp = padded_d(D);
+#define TT_FWD(KS, AT, NW)                                                                                     \
+  score_fwd_bf16_kernel<KS, AT, NW><<<dim3((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs), NW * 64, 0, st>>>(a)
+  if (Dp == 32) TT_FWD(2, 2, 8);
+  else if (Dp == 64) TT_FWD(4, 2, 8);
+  else if (Dp == 128) TT_FWD(8, 2, 8);
+  else TT_FWD(16, 1, 8);
+#undef TT_FWD
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t, float shift,
+                      const float* d_loss, float scale, tt_stream stream) {
+  TT_CHECK_ARG(ctx && dirs && d_loss && (n_dirs == 1 || n_dirs == 2), "tt_score_bwd_bf16: need 1 or 2 directions");
+  TT_CHECK_ARG(D >= 1 && D <= 256, "tt_score_bwd_bf16: D=%d not in [1,256]", D);
+  BwdArgs a{};
+  int64_t maxRa = 0;
+  for (int i = 0; i < 2; ++i) {
+    const tt_score_bwd_dir& d = dirs[i < n_dirs ? i : 0];
+    TT_CHECK_ARG(d.A_packed && d.B_packed && d.sumexp_a && d.sumexp_b && d.dA && d.Ra >= 1 && d.Rb >= 1,
+                 "tt_score_bwd_bf16: bad direction %d", i);
+    TT_CHECK_ARG(tt_aligned(d.sumexp_b, 16), "tt_score_bwd_bf16: sumexp_b must be 16-byte aligned");
+    const PackedView vb = view(d.B_packed, d.Rb, D);
+    a.d[i] = DirBwd{view(d.A_packed, d.Ra, D).rows, vb.rows, vb.frag, d.Ra, d.Rb, d.diag_offset, d.sumexp_a, d.sumexp_b, d.dA};
+    maxRa = d.Ra > maxRa ? d.Ra : maxRa;
+  }
+  a.c1 = inv_t * kLog2e;
+  a.c2 = -shift * kLog2e;
+  a.scale = scale;
+  a.d_loss = d_loss;
+  a.D = D;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int Dp = padded_d(D);
+#define TT_BWD(KS, AT, NW)                                                                                     \
+  score_bwd_bf16_kernel<KS, AT, NW><<<dim3((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs), NW * 64, 0, st>>>(a)
+  if (Dp == 32) TT_BWD(2, 2, 8);
+  else if (Dp == 64) TT_BWD(4, 2, 8);
+  else if (Dp == 128) TT_BWD(8, 1, 8);
+  else TT_BWD(16, 1, 4);
+#undef TT_BWD
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+}  // extern "C"

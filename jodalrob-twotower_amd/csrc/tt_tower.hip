@@ -56,15 +56,24 @@ __global__ __launch_bounds__(kThreads) void bn_stats_partial_kernel(const float*
   }
 }
 
-__global__ void bn_stats_finish_kernel(const float* __restrict__ partial, int nchunks, int H, float* __restrict__ mean,
-                                       float* __restrict__ rstd, float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= H) return;
+// finish: workgroup = 64 columns x 4 chunk-lanes; lane j combines chunks j, j+4, ... then the four
+// partial results are combined in lane order (fixed order => reproducible)
+__global__ __launch_bounds__(kThreads) void bn_stats_finish_kernel(const float* __restrict__ partial, int nchunks, int H,
+                                                                  float* __restrict__ mean, float* __restrict__ rstd,
+                                                                  float* __restrict__ running_mean, float* __restrict__ running_var) {
+  __shared__ Wf sh[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), jl = threadIdx.x >> 6;
   Wf o{0.f, 0.f, 0.f};
-  for (int k = 0; k < nchunks; ++k) {
-    const float* p = partial + (int64_t)k * 3 * H;
-    o = wf_combine(o, Wf{p[c], p[H + c], p[2 * H + c]});
+  if (c < H) {
+    for (int k = jl; k < nchunks; k += 4) {
+      const float* p = partial + (int64_t)k * 3 * H;
+      o = wf_combine(o, Wf{p[c], p[H + c], p[2 * H + c]});
+    }
   }
+  sh[jl][threadIdx.x & 63] = o;
+  __syncthreads();
+  if (jl != 0 || c >= H) return;
+  o = wf_combine(wf_combine(sh[0][threadIdx.x], sh[1][threadIdx.x]), wf_combine(sh[2][threadIdx.x], sh[3][threadIdx.x]));
   const float var = o.n > 0.f ? o.m2 / o.n : 0.f;
   mean[c] = o.mean;
   rstd[c] = 1.f / sqrtf(var + kBnEps);
@@ -135,18 +144,24 @@ __global__ __launch_bounds__(kThreads) void colsum_partial_kernel(ColArgs a, int
   }
 }
 
-__global__ void colsum_finish_kernel(const float* __restrict__ partial, int nchunks, int H, int nv, float* __restrict__ out0,
-                                     float* __restrict__ out1) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= H) return;
+__global__ __launch_bounds__(kThreads) void colsum_finish_kernel(const float* __restrict__ partial, int nchunks, int H, int nv,
+                                                                float* __restrict__ out0, float* __restrict__ out1) {
+  __shared__ float sh[2][4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), jl = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f;
-  for (int k = 0; k < nchunks; ++k) {
-    const float* p = partial + (int64_t)k * 2 * H;
-    s0 += p[c];
-    if (nv > 1) s1 += p[H + c];
+  if (c < H) {
+    for (int k = jl; k < nchunks; k += 4) {
+      const float* p = partial + (int64_t)k * 2 * H;
+      s0 += p[c];
+      if (nv > 1) s1 += p[H + c];
+    }
   }
-  out0[c] = s0;
-  if (nv > 1) out1[c] = s1;
+  sh[0][jl][threadIdx.x & 63] = s0;
+  sh[1][jl][threadIdx.x & 63] = s1;
+  __syncthreads();
+  if (jl != 0 || c >= H) return;
+  out0[c] = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
+  if (nv > 1) out1[c] = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
 }
 
 // BN backward apply, in place on the gradient buffer:  d_act -> d_pre
@@ -218,7 +233,7 @@ inline int ew_grid(const tt_ctx* ctx, int64_t n) {
 }
 
 inline int chunks_for(int64_t B, int H) {
-  int64_t n = 512 / tt_cdiv(H, 64);
+  int64_t n = 256 / tt_cdiv(H, 64);
   const int64_t mx = tt_cdiv(B, 64);
   if (n > mx) n = mx;
   return (int)(n < 1 ? 1 : n);
@@ -273,7 +288,7 @@ int colsum(const tt_ctx* ctx, hipStream_t st, int op, const ColArgs& a, int64_t 
   if (op == 0) colsum_partial_kernel<0><<<grid, kThreads, 0, st>>>(a, (int)B, H, rpc, partial);
   else colsum_partial_kernel<1><<<grid, kThreads, 0, st>>>(a, (int)B, H, rpc, partial);
   TT_LAUNCH_CHECK();
-  colsum_finish_kernel<<<(unsigned)tt_cdiv(H, 256), 256, 0, st>>>(partial, nchunks, H, op == 0 ? 1 : 2, out0, out1);
+  colsum_finish_kernel<<<(unsigned)tt_cdiv(H, 64), kThreads, 0, st>>>(partial, nchunks, H, op == 0 ? 1 : 2, out0, out1);
   TT_LAUNCH_CHECK();
   (void)ctx;
   return TT_OK;
@@ -317,7 +332,7 @@ int tt_tower_mlp_fwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts*
       const int rpc = (int)tt_cdiv(B, nchunks);
       bn_stats_partial_kernel<<<dim3((unsigned)tt_cdiv(H, 64), (unsigned)nchunks), kThreads, 0, st>>>(a->pre[i], (int)B, H, rpc, ws.col);
       TT_LAUNCH_CHECK();
-      bn_stats_finish_kernel<<<(unsigned)tt_cdiv(H, 256), 256, 0, st>>>(ws.col, nchunks, H, a->mean[i], a->rstd[i], p->bn_rm[i], p->bn_rv[i]);
+      bn_stats_finish_kernel<<<(unsigned)tt_cdiv(H, 64), kThreads, 0, st>>>(ws.col, nchunks, H, a->mean[i], a->rstd[i], p->bn_rm[i], p->bn_rv[i]);
       TT_LAUNCH_CHECK();
     } else {
       bn_eval_prepare_kernel<<<(unsigned)tt_cdiv(H, 256), 256, 0, st>>>(p->bn_rm[i], p->bn_rv[i], H, a->mean[i], a->rstd[i]);

@@ -231,6 +231,43 @@ def score_dir_bwd(A, Bm, inv_t, shift, diag_offset, sumexp_a, sumexp_b, d_loss, 
     return dA
 
 
+def score_pack_bf16(X):
+    """f32 [R, D] -> packed bf16 operand images (uint8 buffer)."""
+    dev, R, D = X.device, X.shape[0], X.shape[1]
+    lib = L.load()
+    buf = torch.empty(lib.tt_score_pack_bytes(R, D), dtype=torch.uint8, device=dev)
+    with _timed("tt_score_pack_bf16"):
+        L.check(lib.tt_score_pack_bf16(L.ctx(dev), L.ptr(X), R, D, L.ptr(buf), L.stream(dev)), "tt_score_pack_bf16")
+    return buf
+
+
+def score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank=True):
+    """Both softmax directions of the square in-batch problem in one launch."""
+    dev = Np.device
+    Bp = (B + 3) // 4 * 4                                              # keep every row 16-byte aligned
+    f = torch.empty((4, Bp), dtype=torch.float32, device=dev)         # rowsum, colsum, diag, sumscore
+    ranks = torch.empty((2, B), dtype=torch.int32, device=dev)
+    arr = (L.ScoreFwdDir * 2)()
+    arr[0] = L.ScoreFwdDir(L.ptr(Np), L.ptr(Cp), B, B, 0, L.ptr(f[0]), L.ptr(f[2]), L.ptr(ranks[0]), L.ptr(f[3]))
+    arr[1] = L.ScoreFwdDir(L.ptr(Cp), L.ptr(Np), B, B, 0, L.ptr(f[1]), None, L.ptr(ranks[1]) if want_col_rank else None, None)
+    with _timed("tt_score_fwd_bf16"):
+        L.check(L.load().tt_score_fwd_bf16(L.ctx(dev), arr, 2, D, inv_t, shift, L.stream(dev)), "tt_score_fwd_bf16")
+    return f[0][:B], f[1][:B], f[2][:B], ranks[0], ranks[1], f[3][:B]
+
+
+def score_bwd_bf16(Np, Cp, B, D, inv_t, shift, rowsum, colsum, d_loss, scale):
+    dev = Np.device
+    dN = torch.empty((B, D), dtype=torch.float32, device=dev)
+    dC = torch.empty((B, D), dtype=torch.float32, device=dev)
+    arr = (L.ScoreBwdDir * 2)()
+    arr[0] = L.ScoreBwdDir(L.ptr(Np), L.ptr(Cp), B, B, 0, L.ptr(rowsum), L.ptr(colsum), L.ptr(dN))
+    arr[1] = L.ScoreBwdDir(L.ptr(Cp), L.ptr(Np), B, B, 0, L.ptr(colsum), L.ptr(rowsum), L.ptr(dC))
+    with _timed("tt_score_bwd_bf16"):
+        L.check(L.load().tt_score_bwd_bf16(L.ctx(dev), arr, 2, D, inv_t, shift, L.ptr(d_loss), scale, L.stream(dev)),
+                "tt_score_bwd_bf16")
+    return dN, dC
+
+
 def score_matrix(A, Bm, inv_t):
     dev, Ra, Rb, D = A.device, A.shape[0], Bm.shape[0], A.shape[1]
     S = torch.empty((Ra, Rb), dtype=torch.float32, device=dev)

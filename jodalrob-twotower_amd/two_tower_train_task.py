@@ -22,30 +22,40 @@ LAZY_SIM_BATCH = 2048
 
 
 class _ScoreCEFn(torch.autograd.Function):
-    """loss = 0.5 * [CE(S, diag) + CE(S^T, diag)],  S = N C^T / T   (:99-134); out8 carries the metrics."""
+    """loss = 0.5 * [CE(S, diag) + CE(S^T, diag)],  S = N C^T / T   (:99-134); out8 carries the metrics.
+    score_dtype 'fp32': exact-f32 MFMA path (parity); 'bf16': bf16-operand MFMA fast path."""
 
     @staticmethod
-    def forward(ctx, n, c, inv_t):
+    def forward(ctx, n, c, inv_t, score_dtype):
         n, c = n.contiguous().float(), c.contiguous().float()
-        B = n.shape[0]
+        B, D = n.shape
         shift = abs(inv_t)                                   # unit rows: |s| <= 1/T
-        rowsum, diag, row_rank, sumscore = ops.score_dir_fwd(n, c, inv_t, shift, 0, True)
-        colsum, _, col_rank, _ = ops.score_dir_fwd(c, n, inv_t, shift, 0, False)
+        if score_dtype == "bf16":
+            Np, Cp = ops.score_pack_bf16(n), ops.score_pack_bf16(c)
+            rowsum, colsum, diag, row_rank, col_rank, sumscore = ops.score_fwd_bf16(Np, Cp, B, D, inv_t, shift)
+            ctx.packed = (Np, Cp)
+        else:
+            rowsum, diag, row_rank, sumscore = ops.score_dir_fwd(n, c, inv_t, shift, 0, True)
+            colsum, _, col_rank, _ = ops.score_dir_fwd(c, n, inv_t, shift, 0, False)
+            ctx.packed = None
         out8 = ops.score_loss_finish(B, shift, rowsum, colsum, diag, row_rank, col_rank, sumscore)
         ctx.save_for_backward(n, c, rowsum, colsum)
         ctx.inv_t, ctx.shift = inv_t, shift
-        ctx.mark_non_differentiable(out8)
-        return out8[0].clone(), out8
+        ctx.mark_non_differentiable(out8, row_rank)
+        return out8[0].clone(), out8, row_rank
 
     @staticmethod
-    def backward(ctx, d_loss, _d_out8):
+    def backward(ctx, d_loss, _d_out8, _d_rank):
         n, c, rowsum, colsum = ctx.saved_tensors
-        B = n.shape[0]
+        B, D = n.shape
         d_loss = d_loss.contiguous().float().reshape(1)
         scale = ctx.inv_t / (2.0 * B)
-        dN = ops.score_dir_bwd(n, c, ctx.inv_t, ctx.shift, 0, rowsum, colsum, d_loss, scale)
-        dC = ops.score_dir_bwd(c, n, ctx.inv_t, ctx.shift, 0, colsum, rowsum, d_loss, scale)
-        return dN, dC, None
+        if ctx.packed is not None:
+            dN, dC = ops.score_bwd_bf16(ctx.packed[0], ctx.packed[1], B, D, ctx.inv_t, ctx.shift, rowsum, colsum, d_loss, scale)
+        else:
+            dN = ops.score_dir_bwd(n, c, ctx.inv_t, ctx.shift, 0, rowsum, colsum, d_loss, scale)
+            dC = ops.score_dir_bwd(c, n, ctx.inv_t, ctx.shift, 0, colsum, rowsum, d_loss, scale)
+        return dN, dC, None, None
 
 
 class _Result(dict):
@@ -89,8 +99,12 @@ class _Result(dict):
 
 class TwoTowerTrainTask(nn.Module):
     def __init__(self, two_tower_model: TwoTowerModel, temperature: float = 1.0, loss_type: str = "cross_entropy",
-                 label_smoothing: float = 0.0):
+                 label_smoothing: float = 0.0, score_dtype: str = None):
         super().__init__()
+        import os
+        self.score_dtype = score_dtype or os.environ.get("TT_SCORE_DTYPE", "fp32")
+        if self.score_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"score_dtype must be 'fp32' or 'bf16', got {self.score_dtype!r}")
         self.two_tower_model = two_tower_model
         self.temperature = temperature
         self.loss_type = loss_type
@@ -110,7 +124,7 @@ class TwoTowerTrainTask(nn.Module):
         if nb != cb:                                                                         # :64-67
             raise ValueError(f"Notice와 Company 배치 크기가 다릅니다: {nb} vs {cb}")
         notice_embeddings, company_embeddings = self.two_tower_model(notice_input, company_input)
-        loss, out8 = _ScoreCEFn.apply(notice_embeddings, company_embeddings, 1.0 / float(self.temperature))
+        loss, out8, _ = _ScoreCEFn.apply(notice_embeddings, company_embeddings, 1.0 / float(self.temperature), self.score_dtype)
         if not hasattr(self, "_pair_check_done"):                                            # :82-84
             self._verify_positive_pair_alignment(out8)
             self._pair_check_done = True
@@ -167,7 +181,7 @@ def create_two_tower_train_task(notice_categorical_keys, company_categorical_key
                                 categorical_embedding_dim: int = 64, notice_dense_input_dim: int = 256,
                                 company_dense_input_dim: int = 128, tower_hidden_dims=None, final_embedding_dim: int = 128,
                                 dropout_rate: float = 0.2, temperature: float = 1.0, loss_type: str = "cross_entropy",
-                                device="cuda:0", embedding_grad=None) -> TwoTowerTrainTask:
+                                device="cuda:0", embedding_grad=None, score_dtype=None) -> TwoTowerTrainTask:
     model = create_two_tower_model(notice_categorical_keys=notice_categorical_keys,
                                    company_categorical_keys=company_categorical_keys, metadata_path=metadata_path,
                                    categorical_embedding_dim=categorical_embedding_dim,
@@ -175,4 +189,4 @@ def create_two_tower_train_task(notice_categorical_keys, company_categorical_key
                                    company_dense_input_dim=company_dense_input_dim, tower_hidden_dims=tower_hidden_dims,
                                    final_embedding_dim=final_embedding_dim, dropout_rate=dropout_rate, device=device,
                                    embedding_grad=embedding_grad)
-    return TwoTowerTrainTask(two_tower_model=model, temperature=temperature, loss_type=loss_type)
+    return TwoTowerTrainTask(two_tower_model=model, temperature=temperature, loss_type=loss_type, score_dtype=score_dtype)

@@ -222,7 +222,7 @@ def test_score_kernels_vs_oracle(tt):
         dN, dC = O.score_ce_bwd(n.astype(np.float64), c.astype(np.float64), S, lse, T)
         tn, tc = torch.from_numpy(n).to(DEV).requires_grad_(), torch.from_numpy(c).to(DEV).requires_grad_()
         from jodalrob_twotower_amd.two_tower_train_task import _ScoreCEFn
-        l, out8 = _ScoreCEFn.apply(tn, tc, 1.0 / T)
+        l, out8, _ = _ScoreCEFn.apply(tn, tc, 1.0 / T, "fp32")
         l.backward()
         np.testing.assert_allclose(l.item(), loss, rtol=5e-6)
         np.testing.assert_allclose(tn.grad.cpu().numpy(), dN, rtol=1e-4, atol=2e-8)
@@ -240,6 +240,63 @@ def test_score_kernels_vs_oracle(tt):
         vals, idx = ops.topk_rows(torch.from_numpy(Sg).to(DEV), 7)
         ev, ei = O.topk_rows(Sg, 7)
         assert np.array_equal(idx.cpu().numpy(), ei) and np.array_equal(vals.cpu().numpy(), ev)
+
+
+def test_score_bf16_path_vs_oracle(tt):
+    """bf16-operand MFMA path: exact (to f32 accumulation) against the oracle fed the SAME bf16-rounded
+    operands; gradient operands are rounded once more to bf16 (softmax weights), so grads are compared
+    norm-wise at 1e-2 (bf16 has 8 significant bits)."""
+    from jodalrob_twotower_amd import ops
+    from jodalrob_twotower_amd.two_tower_train_task import _ScoreCEFn
+    rng = np.random.default_rng(11)
+    for B, D, T in [(300, 64, 1.0), (129, 16, 0.5), (64, 6, 0.25), (1000, 128, 1.0), (257, 200, 2.0), (2048, 64, 1.0), (70, 32, 1.0)]:
+        n = rng.standard_normal((B, D)).astype(np.float32)
+        c = rng.standard_normal((B, D)).astype(np.float32)
+        n /= np.linalg.norm(n, axis=1, keepdims=True)
+        c /= np.linalg.norm(c, axis=1, keepdims=True)
+        c[5] = c[3]
+        n[7] = n[2]
+        nb = torch.from_numpy(n).bfloat16().float().numpy().astype(np.float64)
+        cb = torch.from_numpy(c).bfloat16().float().numpy().astype(np.float64)
+        loss, met, S, lse = O.score_ce_fwd(nb, cb, T)
+        dN, dC = O.score_ce_bwd(nb, cb, S, lse, T)
+        tn, tc = torch.from_numpy(n).to(DEV).requires_grad_(), torch.from_numpy(c).to(DEV).requires_grad_()
+        l, out8, rank = _ScoreCEFn.apply(tn, tc, 1.0 / T, "bf16")
+        l.backward()
+        np.testing.assert_allclose(l.item(), loss, rtol=2e-5, err_msg=f"B={B} D={D}")
+        np.testing.assert_allclose(out8[2].item(), met["positive_similarity_mean"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(out8[3].item(), met["negative_similarity_mean"], rtol=2e-3, atol=5e-6)
+        for got, ref in ((tn.grad, dN), (tc.grad, dC)):
+            g = got.cpu().numpy().astype(np.float64)
+            assert np.linalg.norm(g - ref) <= 1e-2 * np.linalg.norm(ref), (B, D, np.linalg.norm(g - ref) / np.linalg.norm(ref))
+        d = np.diagonal(S)[:, None]
+        exp_rank = (S > d).sum(1) + ((S == d) & (np.arange(B)[None, :] < np.arange(B)[:, None])).sum(1)
+        got_rank = rank.cpu().numpy()
+        assert (got_rank == exp_rank).mean() >= 0.995, (B, D)
+        assert got_rank[5] == exp_rank[5] and got_rank[3] == exp_rank[3]       # exact ties (duplicated company)
+        # against the exact-f32 path on the same inputs: loss within bf16 operand rounding
+        l32, _, _ = _ScoreCEFn.apply(tn.detach(), tc.detach(), 1.0 / T, "fp32")
+        np.testing.assert_allclose(l.item(), l32.item(), rtol=3e-3)
+
+
+def test_task_bf16_score_close_to_fp32(tt, manifest):
+    cfg = dict(manifest["cases"]["wide_b40"])
+    cfg["B"] = 512
+    shapes = None
+    outs = {}
+    for sd in ("fp32", "bf16"):
+        task = make_task(tt, cfg, score_dtype=sd)
+        shapes = {k: tuple(v.shape) for k, v in task.state_dict().items()}
+        load_state(task, init_state_numpy(shapes, 99))
+        b = synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 98, oob=False)
+        task.train()
+        res = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+        res["loss"].backward()
+        outs[sd] = (res["loss"].item(), {n: p.grad.cpu().numpy() for n, p in task.named_parameters()})
+    np.testing.assert_allclose(outs["bf16"][0], outs["fp32"][0], rtol=3e-3)
+    for k, g32 in outs["fp32"][1].items():
+        gb = outs["bf16"][1][k]
+        assert np.linalg.norm(gb - g32) <= 3e-2 * np.linalg.norm(g32) + 1e-9, k
 
 
 def test_adam_trajectory_golden(tt, manifest):
