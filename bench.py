@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--pool", type=int, default=8, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--force-dist", action="store_true", help="use the sharded-table path even on one GPU")
     ap.add_argument("--breakdown", action="store_true", help="extra instrumented pass: per-kernel HIP-event times")
     return ap.parse_args()
 
@@ -67,10 +68,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29544")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     schema = synthetic.load_real_schema(ROOT / "jodalrob-twotower_amd" / "schema_real.json")
     keys_n, keys_c = schema["notice"]["categorical"], schema["company"]["categorical"]
@@ -86,7 +88,7 @@ def main():
     grad_mode = "sparse" if args.optimizer == "fused_sparse" else "dense"
     import contextlib, io
     with contextlib.redirect_stdout(io.StringIO()):
-        if world > 1:
+        if dist is not None:
             from jodalrob_twotower_amd.distributed import create_distributed_train_task
             task = create_distributed_train_task(keys_n, keys_c, metadata_path=str(meta), categorical_embedding_dim=E,
                                                  notice_dense_input_dim=din_n, company_dense_input_dim=din_c,

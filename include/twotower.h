@@ -60,6 +60,8 @@ int tt_ctx_num_cus(const tt_ctx* ctx);
  * For side s, sample b, key k:   id  = ids[b*K + k]                       (sample-major KJT values)
  *                                row = key_row_offset[k] + clamp(id, 0, key_vocab[k]-1)
  *                                out[b*ld_out + k*E .. +E) = table[row*E .. +E)
+ * table == NULL (with rows_out set): rows-only mode -- nothing is gathered, only rows_out is written
+ * (used to route ids to the rank that owns the row when the table is sharded).
  * rows_out (optional, may be NULL): fused row of every slot, slot = side_slot_base + b*K + k with
  * side_slot_base = sum of B*K of the earlier sides -- the input of tt_dedup_plan.
  * ---------------------------------------------------------------------------------------------- */

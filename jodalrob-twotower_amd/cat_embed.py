@@ -82,6 +82,14 @@ class EmbeddingStore:
             base += s.rows
         return fused
 
+    def optim_parameters(self):
+        """The nn.Parameters an optimiser sees for this row space (per-key views)."""
+        return [p for m in self.members for p in m.table_parameters()]
+
+    def bind_grads(self):
+        for m in self.members:
+            m._bind_grads()
+
     # ---- gradient bookkeeping (called from the autograd backward) ------------------------------
     def accumulate_grad(self, plan: ops.DedupPlan, srcs, B: int):
         """srcs: [(d_out view [B, K*E], K)] in slot order of `plan`."""
@@ -90,15 +98,14 @@ class EmbeddingStore:
             ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_SPARSE, grad_rows)
             self.sparse_grad = (plan, grad_rows)
             return
-        params = [p for m in self.members for p in m.table_parameters()]
+        params = self.optim_parameters()
         fresh = any(p.grad is None for p in params) or self.grad is None
         if self.grad is None:
             self.grad = torch.empty_like(self.weight)
         if fresh:
             self.grad.zero_()                            # reference semantics: dense [V_k, E] grads
             ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_DENSE_SET, self.grad)
-            for m in self.members:
-                m._bind_grads()
+            self.bind_grads()
         else:
             ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_DENSE_ACC, self.grad)
 
@@ -121,9 +128,11 @@ class _Table(nn.Module):
 
 class CategoricalEmbedder(nn.Module):
     def __init__(self, keys: List[str], metadata_path: Union[str, Path], table_name: str, embedding_dim: int = 64,
-                 device: Optional[str] = "cuda:0", safety_margin: int = 10, embedding_grad: Optional[str] = None):
+                 device: Optional[str] = "cuda:0", safety_margin: int = 10, embedding_grad: Optional[str] = None,
+                 materialize: bool = True):
         super().__init__()
         self.keys = list(keys)
+        self.materialize = materialize
         self.embedding_dim = embedding_dim
         self.device_str = str(device or "cuda:0")
         self.safety_margin = safety_margin
@@ -131,16 +140,22 @@ class CategoricalEmbedder(nn.Module):
         print(f"[CategoricalEmbedder] Initializing with {len(self.keys)} features")
         mode = embedding_grad or os.environ.get("TT_EMBEDDING_GRAD", "dense")
         self.store = EmbeddingStore(embedding_dim, torch.device(self.device_str), mode)
-        self.row_base = self.store.append_rows(sum(self.vocab_sizes[k] for k in self.keys)) if self.keys else 0
-        self.store.members.append(self)
         self.embeddings = nn.ModuleDict()
-        off = self.row_base
         offs = []
-        for k in self.keys:
-            v = self.vocab_sizes[k]
-            self.embeddings[k] = _Table(self.store.weight[off:off + v])
-            offs.append(off)
-            off += v
+        if materialize:
+            self.row_base = self.store.append_rows(sum(self.vocab_sizes[k] for k in self.keys)) if self.keys else 0
+            self.store.members.append(self)
+            off = self.row_base
+            for k in self.keys:
+                v = self.vocab_sizes[k]
+                self.embeddings[k] = _Table(self.store.weight[off:off + v])
+                offs.append(off)
+                off += v
+        else:       # rows live in a sharded store owned by the distributed task; only the key directory is kept
+            self.row_base, off = 0, 0
+            for k in self.keys:
+                offs.append(off)
+                off += self.vocab_sizes[k]
         dev = self.store.device
         self.register_buffer("_key_row_offset", torch.tensor(offs, dtype=torch.int64, device=dev), persistent=False)
         self.register_buffer("_key_vocab", torch.tensor([self.vocab_sizes[k] for k in self.keys], dtype=torch.int64,
@@ -169,7 +184,20 @@ class CategoricalEmbedder(nn.Module):
 
     # ---- store plumbing -------------------------------------------------------------------------
     def table_parameters(self):
-        return [self.embeddings[k].weight for k in self.keys]
+        return [self.embeddings[k].weight for k in self.keys] if self.materialize else []
+
+    @property
+    def total_rows(self) -> int:
+        return sum(self.vocab_sizes[k] for k in self.keys)
+
+    def set_row_base(self, base: int):
+        """(non-materialised embedders) place this embedder's keys at `base` of a global row space."""
+        off, offs = base, []
+        for k in self.keys:
+            offs.append(off)
+            off += self.vocab_sizes[k]
+        self.row_base = base
+        self._key_row_offset = torch.tensor(offs, dtype=torch.int64, device=self._key_row_offset.device)
 
     def _rebind(self, store: Optional[EmbeddingStore] = None, row_base: Optional[int] = None):
         if store is not None and store is not self.store:
@@ -201,6 +229,11 @@ class CategoricalEmbedder(nn.Module):
             off += v
 
     def _apply(self, fn, recurse=True):
+        if not self.materialize:
+            dev = fn(torch.empty(0, device=self._key_vocab.device)).device
+            self._key_row_offset, self._key_vocab = self._key_row_offset.to(dev), self._key_vocab.to(dev)
+            self.store.device = dev
+            return self
         # move the fused storage ONCE, then re-point the per-key views (keeps Parameter identity, so
         # optimisers built before .to(device) stay valid)
         self.store.apply(fn)

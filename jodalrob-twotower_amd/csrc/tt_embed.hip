@@ -70,6 +70,7 @@ __global__ __launch_bounds__(kThreads) void lookup_kernel(SideSet a, const float
         id = id < 0 ? 0 : (id > hi ? hi : id);                 // clamp: cat_embed.py:117
         const int64_t row = s.off[k] + id;
         if (chunk == 0 && rows_out) rows_out[slot] = (int32_t)row;
+        if (table == nullptr) { ok[u] = false; continue; }      // rows-only mode (wave-uniform)
         const float* src = table + row * a.E + chunk * VEC;
         if (VEC == 4) {
           const float4 t = *reinterpret_cast<const float4*>(src);
@@ -690,7 +691,7 @@ extern "C" {
 
 int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const tt_embed_side* sides,
                         int32_t n_sides, int64_t B, int32_t* rows_out, tt_stream stream) {
-  TT_CHECK_ARG(ctx && table && sides, "tt_embed_lookup_fwd: NULL argument");
+  TT_CHECK_ARG(ctx && sides && (table || rows_out), "tt_embed_lookup_fwd: NULL argument");
   TT_CHECK_ARG(n_sides >= 1 && n_sides <= TT_MAX_SIDES, "tt_embed_lookup_fwd: n_sides=%d not in [1,%d]", n_sides, TT_MAX_SIDES);
   TT_CHECK_ARG(E >= 1 && B >= 0 && table_rows >= 1, "tt_embed_lookup_fwd: bad E=%d B=%lld rows=%lld", E, (long long)B, (long long)table_rows);
   TT_CHECK_ARG(table_rows <= INT32_MAX, "tt_embed_lookup_fwd: table_rows %lld exceeds int32 row index", (long long)table_rows);
@@ -701,7 +702,7 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
   int64_t slots = 0;
   for (int i = 0; i < n_sides; ++i) {
     const tt_embed_side& s = sides[i];
-    TT_CHECK_ARG(s.K >= 0 && (s.K == 0 || (s.ids && s.key_row_offset && s.key_vocab && s.out)), "tt_embed_lookup_fwd: side %d has NULL pointers", i);
+    TT_CHECK_ARG(s.K >= 0 && (s.K == 0 || (s.ids && s.key_row_offset && s.key_vocab && (s.out || !table))), "tt_embed_lookup_fwd: side %d has NULL pointers", i);
     TT_CHECK_ARG(s.out_dtype == TT_F32 || s.out_dtype == TT_BF16, "tt_embed_lookup_fwd: side %d bad out_dtype %d", i, s.out_dtype);
     TT_CHECK_ARG(s.ld_out >= (int64_t)s.K * E, "tt_embed_lookup_fwd: side %d ld_out %lld < K*E", i, (long long)s.ld_out);
     a.s[i] = SideDev{s.ids, s.key_row_offset, s.key_vocab, reinterpret_cast<char*>(s.out), s.ld_out, (uint32_t)slots, s.K, s.out_dtype};
@@ -709,7 +710,7 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
     vec4 = vec4 && (s.ld_out % 4 == 0) && tt_aligned(s.out, 4 * esz);
     slots += B * s.K;
   }
-  const int64_t C = vec4 ? E / 4 : E;
+  const int64_t C = table ? (vec4 ? E / 4 : E) : 1;
   TT_CHECK_ARG(slots * C < (int64_t)1 << 31, "tt_embed_lookup_fwd: %lld slots x %lld chunks exceeds 2^31 tasks", (long long)slots, (long long)C);
   if (slots == 0) return TT_OK;
   a.C = (uint32_t)C;
@@ -717,7 +718,7 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   constexpr int U = 4;
   const int grid = grid_for(ctx, tt_cdiv(slots * C, U));
-  if (vec4) lookup_kernel<4, U><<<grid, kThreads, 0, st>>>(a, table, rows_out);
+  if (vec4 && table) lookup_kernel<4, U><<<grid, kThreads, 0, st>>>(a, table, rows_out);
   else lookup_kernel<1, U><<<grid, kThreads, 0, st>>>(a, table, rows_out);
   TT_LAUNCH_CHECK();
   return TT_OK;

@@ -1,0 +1,255 @@
+"""Multi-GPU two-tower step: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference is single-GPU (no collective anywhere: SURVEY.md §2.1); this is new design.
+
+  * tables   : ONE global fused row space (notice keys then company keys), sharded ROW-WISE:
+               owner(row) = row % world, local index = row // world  -> every key, including the two
+               29 k-row (x scale) keys, is balanced over the GPUs.
+  * batch    : each rank trains on its own B_local pairs; in-batch negatives are the rank's own
+               (standard data-parallel semantics: global objective = mean over ranks of local losses).
+  * exchange : per step  (1) bucket the rank's B_local*(K_n+K_c) row ids by owner (stable LSD sort on
+               the device), (2) all-to-all of the bucket sizes, (3) all-to-all of the ids, (4) owners
+               gather their rows (tt_embed_lookup_fwd on the local shard), (5) all-to-all of the pooled
+               rows back, un-permuted straight into the towers' MLP input buffers; the backward mirrors
+               it: all-to-all of the row gradients to the owners, duplicate-row plan + segmented
+               reduction there, then the (sparse) Adam update on the local shard.
+  * towers   : dense weights replicated; gradients summed with one all-reduce per tower over the flat
+               gradient buffer tt_tower_mlp_bwd fills (0.3 MB: latency-bound, a single call).
+               BatchNorm statistics are per rank (as torch DDP without SyncBatchNorm).
+
+xGMI is point-to-point (7 links per GPU), so the pooled-row all-to-all places each peer's chunk on its
+own link; ring-shaped collectives are avoided on the data path.
+
+`RowExchange` holds the routing logic and is device-agnostic: its compute steps come from a backend
+object.  `HipBackend` (the product path) calls the C ABI; the CPU/gloo tests inject a checker backend
+(tests/test_distributed_gloo.py) -- there is no CPU fallback in the product path.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import ops
+from .cat_embed import EmbeddingStore
+from .two_tower_model import TwoTowerModel
+from .two_tower_train_task import TwoTowerTrainTask
+
+
+class ShardedStore(EmbeddingStore):
+    """Local shard of a row-wise sharded global table: global row g lives on rank g % world at g // world."""
+
+    def __init__(self, E: int, global_rows: int, rank: int, world: int, device, grad_mode: str = "sparse", seed: int = 0):
+        super().__init__(E, device, grad_mode)
+        self.global_rows, self.rank, self.world = global_rows, rank, world
+        self.local_rows = (global_rows - rank + world - 1) // world if global_rows > rank else 0
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed * 1000003 + rank)
+        w = torch.empty((max(self.local_rows, 1), E), dtype=torch.float32)
+        w.normal_(generator=g)                                   # nn.Embedding init N(0,1)
+        self.weight = w.to(self.device)
+        self.shard_param = nn.Parameter(self.weight)             # what optimisers / checkpoints see
+
+    def optim_parameters(self):
+        return [self.shard_param]
+
+    def bind_grads(self):
+        self.shard_param.grad = self.grad
+
+    def load_global(self, global_weight: torch.Tensor):
+        """global_weight [global_rows, E] (any device): keep this rank's rows."""
+        mine = global_weight[self.rank::self.world]
+        self.weight[:mine.shape[0]].copy_(mine.to(self.weight.device))
+
+    def gather_global(self, group=None) -> torch.Tensor:
+        """all-gather the shards back into the [global_rows, E] table (checkpoint / parity use)."""
+        per = (self.global_rows + self.world - 1) // self.world
+        pad = torch.zeros((per, self.E), dtype=torch.float32, device=self.weight.device)
+        pad[:self.local_rows] = self.weight[:self.local_rows]
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad, group=group)
+        out = torch.empty((per * self.world, self.E), dtype=torch.float32, device=self.weight.device)
+        for r, p in enumerate(parts):
+            out[r::self.world] = p
+        return out[:self.global_rows]
+
+
+class HipBackend:
+    """Compute steps of the exchange on the MI355X (C ABI)."""
+
+    def global_rows(self, sides: Sequence[ops.LookupSide], B: int, E: int, table_rows: int) -> torch.Tensor:
+        return ops.embed_lookup(None, [ops.LookupSide(s.ids, s.key_row_offset, s.key_vocab, None, s.K) for s in sides], B,
+                                want_rows=True, E=E, table_rows=table_rows)
+
+    def bucket_by_owner(self, rows: torch.Tensor, world: int):
+        owners = torch.remainder(rows, world)                              # int32 [M]
+        plan = ops.dedup_plan(owners, world)                               # stable sort by owner
+        counts = torch.bincount(owners.long(), minlength=world)            # int64 [world]
+        return plan.sorted_src, counts
+
+    def owner_lookup(self, weight: torch.Tensor, local_ids: torch.Tensor, want_plan: bool):
+        n, E, dev = local_ids.numel(), weight.shape[1], weight.device
+        out = torch.empty((n, E), dtype=torch.float32, device=dev)
+        if n == 0:
+            return out, None
+        off = torch.zeros(1, dtype=torch.int64, device=dev)
+        voc = torch.full((1,), weight.shape[0], dtype=torch.int64, device=dev)
+        rows = ops.embed_lookup(weight, [ops.LookupSide(local_ids, off, voc, out, 1)], n, want_rows=want_plan)
+        return out, (ops.dedup_plan(rows, weight.shape[0]) if want_plan else None)
+
+    def place_rows(self, pooled: torch.Tensor, inv: torch.Tensor, sides: Sequence[ops.LookupSide], B: int):
+        """out_side[b, k*E:(k+1)*E] = pooled[inv[slot]]  -- the lookup kernel with `pooled` as the table."""
+        M = pooled.shape[0]
+        dev = pooled.device
+        voc_cache = {}
+        lsides, base = [], 0
+        for s in sides:
+            n = B * s.K
+            off = torch.zeros(s.K, dtype=torch.int64, device=dev)
+            voc = voc_cache.setdefault(s.K, torch.full((s.K,), M, dtype=torch.int64, device=dev))
+            lsides.append(ops.LookupSide(inv[base:base + n], off, voc, s.out, s.K))
+            base += n
+        ops.embed_lookup(pooled, lsides, B, want_rows=False)
+
+    def collect_grads(self, srcs, order: torch.Tensor, B: int, E: int) -> torch.Tensor:
+        """d_bucket[i] = gradient of slot order[i]  (identity-segment plan through tt_embed_grad_bwd)."""
+        M, dev = order.numel(), order.device
+        ar = torch.arange(M + 1, dtype=torch.int32, device=dev)
+        plan = ops.DedupPlan(order, ar[:M], ar, torch.full((1,), M, dtype=torch.int32, device=dev), M)
+        out = torch.empty((max(M, 1), E), dtype=torch.float32, device=dev)
+        ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_SPARSE, out)
+        return out[:M]
+
+    def owner_accumulate(self, store: ShardedStore, plan, d_rows: torch.Tensor):
+        store.accumulate_grad(plan, [(d_rows, 1)], d_rows.shape[0])
+
+
+class RowExchange:
+    """Routing of row ids / pooled rows / row gradients between ranks (device-agnostic)."""
+
+    def __init__(self, store: ShardedStore, group=None, backend=None):
+        self.store, self.group = store, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.backend = backend or HipBackend()
+        self.E = store.E
+
+    def _a2a(self, send: torch.Tensor, send_splits: List[int], recv_splits: List[int]) -> torch.Tensor:
+        out = torch.empty((sum(recv_splits),) + tuple(send.shape[1:]), dtype=send.dtype, device=send.device)
+        dist.all_to_all_single(out, send.contiguous(), output_split_sizes=recv_splits, input_split_sizes=send_splits,
+                               group=self.group)
+        return out
+
+    def forward(self, sides: Sequence[ops.LookupSide], B: int, want_grad: bool):
+        G, be = self.world, self.backend
+        rows = be.global_rows(sides, B, self.E, self.store.global_rows)          # int32 [M], slot order
+        M = rows.numel()
+        order, counts = be.bucket_by_owner(rows, G)                              # slots grouped by owner
+        send_ids = torch.div(rows[order.long()], G, rounding_mode="floor").to(torch.int64)
+        recv_counts = torch.empty_like(counts)
+        dist.all_to_all_single(recv_counts, counts, group=self.group)            # bucket sizes
+        send_splits, recv_splits = counts.tolist(), recv_counts.tolist()         # (one host sync per step)
+        recv_ids = self._a2a(send_ids, send_splits, recv_splits)
+        pooled_local, plan = be.owner_lookup(self.store.weight, recv_ids, want_grad)
+        pooled = self._a2a(pooled_local, recv_splits, send_splits)               # [M, E] in bucket order
+        inv = torch.empty(M, dtype=torch.int64, device=rows.device)
+        inv[order.long()] = torch.arange(M, dtype=torch.int64, device=rows.device)
+        be.place_rows(pooled, inv, sides, B)
+        return {"order": order, "send": send_splits, "recv": recv_splits, "plan": plan} if want_grad else None
+
+    def backward(self, state, srcs, B: int):
+        be = self.backend
+        d_bucket = be.collect_grads(srcs, state["order"], B, self.E)
+        d_rows = self._a2a(d_bucket, state["send"], state["recv"])               # to the owners
+        if state["plan"] is not None:
+            be.owner_accumulate(self.store, state["plan"], d_rows)
+
+    def all_reduce_dense(self, flat_grads: Sequence[torch.Tensor]):
+        for g in flat_grads:                                                     # one call per tower
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+
+
+class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
+    """TwoTowerTrainTask whose tables are row-wise sharded over the process group."""
+
+    def __init__(self, two_tower_model: TwoTowerModel, store: ShardedStore, group=None, backend=None, **kw):
+        super().__init__(two_tower_model, **kw)
+        self.sharded_store = store
+        self.embedding_shard = store.shard_param                       # registered => in .parameters()
+        self.exchange = RowExchange(store, group, backend)
+        two_tower_model.notice_tower.exchange = self.exchange
+        two_tower_model.company_tower.exchange = self.exchange
+        for p in self._dense_parameters():                             # replicas start identical
+            dist.broadcast(p.data, src=0, group=group)
+        for b in self.buffers():
+            if b.is_floating_point():
+                dist.broadcast(b, src=0, group=group)
+
+    def _dense_parameters(self):
+        return [p for n, p in self.named_parameters() if n != "embedding_shard"]
+
+    def embedding_stores(self):
+        return [self.sharded_store]
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)                 # moves embedding_shard like any parameter ...
+        st = self.sharded_store                     # ... and the store keeps aliasing it
+        st.weight = self.embedding_shard.data
+        st.device = st.weight.device
+        st.grad, st.sparse_grad = None, None
+        st.version += 1
+        return self
+
+    def key_directory(self):
+        out, base = [], 0
+        for side, tower in (("notice", self.two_tower_model.notice_tower), ("company", self.two_tower_model.company_tower)):
+            emb = tower.categorical_embedder
+            for k in emb.keys:
+                out.append((f"two_tower_model.{side}_tower.categorical_embedder.embeddings.{k}.weight", base, emb.vocab_sizes[k]))
+                base += emb.vocab_sizes[k]
+        return out
+
+    def full_state_dict(self):
+        """State dict in the REFERENCE layout (per-key [V_k, E] tables gathered from all ranks)."""
+        sd = {k: v for k, v in self.state_dict().items() if k != "embedding_shard"}
+        full = self.sharded_store.gather_global(self.exchange.group)
+        for name, base, v in self.key_directory():
+            sd[name] = full[base:base + v].clone()
+        return sd
+
+    def load_full_state_dict(self, sd):
+        own = {k: v for k, v in sd.items() if "categorical_embedder.embeddings." not in k}
+        missing = self.load_state_dict(own, strict=False)
+        glob = torch.cat([torch.as_tensor(sd[name]) for name, _, _ in self.key_directory()])
+        self.sharded_store.load_global(glob)
+        return missing
+
+
+def create_distributed_train_task(notice_categorical_keys, company_categorical_keys, metadata_path: str = "meta/metadata.csv",
+                                  categorical_embedding_dim: int = 64, notice_dense_input_dim: int = 256,
+                                  company_dense_input_dim: int = 128, tower_hidden_dims=None, final_embedding_dim: int = 128,
+                                  dropout_rate: float = 0.2, temperature: float = 1.0, loss_type: str = "cross_entropy",
+                                  device="cuda:0", embedding_grad: Optional[str] = "sparse", score_dtype=None, group=None,
+                                  backend=None, seed: int = 0) -> DistributedTwoTowerTrainTask:
+    """Same arguments as create_two_tower_train_task; requires an initialised process group."""
+    if not dist.is_initialized():
+        raise RuntimeError("create_distributed_train_task needs torch.distributed.init_process_group first")
+    if tower_hidden_dims is None:
+        tower_hidden_dims = [256, 128]
+    common = dict(metadata_path=metadata_path, categorical_embedding_dim=categorical_embedding_dim,
+                  tower_hidden_dims=tower_hidden_dims, final_embedding_dim=final_embedding_dim, dropout_rate=dropout_rate,
+                  device=device, embedding_grad=embedding_grad, materialize_tables=False)
+    model = TwoTowerModel(
+        notice_tower_config=dict(categorical_keys=notice_categorical_keys, dense_input_dim=notice_dense_input_dim, **common),
+        company_tower_config=dict(categorical_keys=company_categorical_keys, dense_input_dim=company_dense_input_dim, **common),
+        final_embedding_dim=final_embedding_dim, device=device)
+    ne, ce = model.notice_tower.categorical_embedder, model.company_tower.categorical_embedder
+    ne.set_row_base(0)
+    ce.set_row_base(ne.total_rows)
+    store = ShardedStore(categorical_embedding_dim, ne.total_rows + ce.total_rows, dist.get_rank(group),
+                         dist.get_world_size(group), torch.device(device), embedding_grad or "sparse", seed)
+    return DistributedTwoTowerTrainTask(model, store, group=group, backend=backend, temperature=temperature,
+                                        loss_type=loss_type, score_dtype=score_dtype)

@@ -75,9 +75,12 @@ class LookupSide:
     K: int
 
 
-def embed_lookup(table: torch.Tensor, sides: Sequence[LookupSide], B: int, want_rows: bool) -> Optional[torch.Tensor]:
-    dev = table.device
-    E = table.shape[1]
+def embed_lookup(table: Optional[torch.Tensor], sides: Sequence[LookupSide], B: int, want_rows: bool, E: int = 0,
+                 table_rows: int = 0) -> Optional[torch.Tensor]:
+    """table None => rows-only mode (E and table_rows then describe the row space)."""
+    dev = table.device if table is not None else sides[0].ids.device
+    E = table.shape[1] if table is not None else E
+    table_rows = table.shape[0] if table is not None else table_rows
     arr = (L.EmbedSide * len(sides))()
     M = 0
     for i, s in enumerate(sides):
@@ -85,13 +88,16 @@ def embed_lookup(table: torch.Tensor, sides: Sequence[LookupSide], B: int, want_
             raise ValueError("ids must be a contiguous int64 tensor on the table's device")
         if s.ids.numel() != B * s.K:
             raise ValueError(f"side {i}: {s.ids.numel()} ids for B={B}, K={s.K}")
-        assert s.out.stride(1) == 1
-        arr[i] = L.EmbedSide(L.ptr(s.ids), L.ptr(s.key_row_offset), L.ptr(s.key_vocab), L.ptr(s.out),
-                             s.out.stride(0), s.K, _dt(s.out))
+        if s.out is not None:
+            assert s.out.stride(1) == 1
+            arr[i] = L.EmbedSide(L.ptr(s.ids), L.ptr(s.key_row_offset), L.ptr(s.key_vocab), L.ptr(s.out),
+                                 s.out.stride(0), s.K, _dt(s.out))
+        else:
+            arr[i] = L.EmbedSide(L.ptr(s.ids), L.ptr(s.key_row_offset), L.ptr(s.key_vocab), None, s.K * E, s.K, TT_F32)
         M += B * s.K
     rows = torch.empty(M, dtype=torch.int32, device=dev) if want_rows else None
     with _timed("tt_embed_lookup_fwd"):
-        L.check(L.load().tt_embed_lookup_fwd(L.ctx(dev), L.ptr(table), table.shape[0], E, arr, len(sides), B,
+        L.check(L.load().tt_embed_lookup_fwd(L.ctx(dev), L.ptr(table), table_rows, E, arr, len(sides), B,
                                              L.ptr(rows), L.stream(dev)), "tt_embed_lookup_fwd")
     return rows
 

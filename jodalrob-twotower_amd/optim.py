@@ -43,7 +43,10 @@ class FusedAdam(torch.optim.Optimizer):
         if st is None or st["m"].shape != store.weight.shape or st["m"].device != store.weight.device:
             st = {"m": torch.zeros_like(store.weight), "v": torch.zeros_like(store.weight), "step": 0}
             self._store_state[id(store)] = st
-            for emb in store.members:                        # per-parameter views, torch.optim.Adam layout
+            shard = getattr(store, "shard_param", None)
+            if shard is not None:                            # sharded store: one parameter = the local rows
+                self.state[shard] = {"step": torch.tensor(0.0), "exp_avg": st["m"], "exp_avg_sq": st["v"]}
+            for emb in ([] if shard is not None else store.members):   # per-parameter views, torch.optim.Adam layout
                 off = emb.row_base
                 for k in emb.keys:
                     n = emb.vocab_sizes[k]
@@ -54,7 +57,7 @@ class FusedAdam(torch.optim.Optimizer):
         return st
 
     def _table_param_ids(self):
-        return {id(p) for s in self._stores for m in s.members for p in m.table_parameters()}
+        return {id(p) for s in self._stores for p in s.optim_parameters()}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -91,7 +94,7 @@ class FusedAdam(torch.optim.Optimizer):
                 ops.adam_multi(its, s_no, group["lr"], b1, b2, group["eps"], group["weight_decay"])
         # ---- embedding stores ----
         for store in self._stores:
-            members = [p for m in store.members for p in m.table_parameters()]
+            members = store.optim_parameters()
             if not members:
                 continue
             group = group_of.get(id(members[0]))
@@ -151,6 +154,8 @@ def find_stores(module) -> List[EmbeddingStore]:
     from .cat_embed import CategoricalEmbedder
     out = []
     for m in module.modules():
-        if isinstance(m, CategoricalEmbedder) and all(m.store is not s for s in out):
+        if hasattr(m, "embedding_stores"):
+            out += [s for s in m.embedding_stores() if all(s is not o for o in out)]
+        if isinstance(m, CategoricalEmbedder) and m.materialize and all(m.store is not s for s in out):
             out.append(m.store)
     return out

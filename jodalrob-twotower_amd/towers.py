@@ -33,11 +33,12 @@ class BaseTower(nn.Module):
     def __init__(self, categorical_keys: List[str], metadata_path: str = "meta/metadata.csv", table_name: str = "notice",
                  categorical_embedding_dim: int = 64, dense_input_dim: int = 256,
                  tower_hidden_dims: Optional[List[int]] = None, final_embedding_dim: int = 128, dropout_rate: float = 0.2,
-                 device="cuda:0", embedding_grad: Optional[str] = None):
+                 device="cuda:0", embedding_grad: Optional[str] = None, materialize_tables: bool = True):
         super().__init__()
         if tower_hidden_dims is None:
             tower_hidden_dims = [256, 128]
         self.categorical_keys = list(categorical_keys)
+        self.exchange = None            # set by the distributed task: sharded-table row exchange
         self.device = device
         self.tower_hidden_dims = list(tower_hidden_dims)
         self.final_embedding_dim = final_embedding_dim
@@ -46,7 +47,8 @@ class BaseTower(nn.Module):
         dev = torch.device(device)
         self.categorical_embedder = CategoricalEmbedder(keys=self.categorical_keys, metadata_path=metadata_path,
                                                         table_name=table_name, embedding_dim=categorical_embedding_dim,
-                                                        device=str(dev), embedding_grad=embedding_grad)
+                                                        device=str(dev), embedding_grad=embedding_grad,
+                                                        materialize=materialize_tables)
         self.dense_projection = nn.Linear(dense_input_dim, tower_hidden_dims[0])
         self._build_mlp(categorical_embedding_dim, tower_hidden_dims, final_embedding_dim, dropout_rate)
         self._struct_key = None
@@ -111,22 +113,24 @@ class NoticeTower(BaseTower):
     def __init__(self, categorical_keys: List[str], metadata_path: str = "meta/metadata.csv",
                  categorical_embedding_dim: int = 64, dense_input_dim: int = 256,
                  tower_hidden_dims: Optional[List[int]] = None, final_embedding_dim: int = 128, dropout_rate: float = 0.2,
-                 device="cuda:0", embedding_grad: Optional[str] = None):
+                 device="cuda:0", embedding_grad: Optional[str] = None, materialize_tables: bool = True):
         super().__init__(categorical_keys=categorical_keys, metadata_path=metadata_path, table_name="notice",
                          categorical_embedding_dim=categorical_embedding_dim, dense_input_dim=dense_input_dim,
                          tower_hidden_dims=tower_hidden_dims, final_embedding_dim=final_embedding_dim,
-                         dropout_rate=dropout_rate, device=device, embedding_grad=embedding_grad)
+                         dropout_rate=dropout_rate, device=device, embedding_grad=embedding_grad,
+                         materialize_tables=materialize_tables)
 
 
 class CompanyTower(BaseTower):
     def __init__(self, categorical_keys: List[str], metadata_path: str = "meta/metadata.csv",
                  categorical_embedding_dim: int = 64, dense_input_dim: int = 128,
                  tower_hidden_dims: Optional[List[int]] = None, final_embedding_dim: int = 128, dropout_rate: float = 0.2,
-                 device="cuda:0", embedding_grad: Optional[str] = None):
+                 device="cuda:0", embedding_grad: Optional[str] = None, materialize_tables: bool = True):
         super().__init__(categorical_keys=categorical_keys, metadata_path=metadata_path, table_name="company",
                          categorical_embedding_dim=categorical_embedding_dim, dense_input_dim=dense_input_dim,
                          tower_hidden_dims=tower_hidden_dims, final_embedding_dim=final_embedding_dim,
-                         dropout_rate=dropout_rate, device=device, embedding_grad=embedding_grad)
+                         dropout_rate=dropout_rate, device=device, embedding_grad=embedding_grad,
+                         materialize_tables=materialize_tables)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -200,6 +204,14 @@ class _TowersFn(torch.autograd.Function):
                 lookups.setdefault(id(emb.store), []).append((s, emb.lookup_side(values, s.x[:, tw.tower_hidden_dims[0]:])))
         # fused lookup (+ duplicate-row plan when a backward will follow) per store
         plans = []
+        exch = towers[0].exchange
+        ctx.exch, ctx.exch_state = exch, None
+        if exch is not None:            # sharded table: ids -> owners, pooled rows <- owners (distributed.py)
+            group = [g for grp in lookups.values() for g in grp]
+            if group:
+                ctx.exch_state = exch.forward([g[1] for g in group], group[0][0].B, grad_on)
+                ctx.exch_sides = [g[0] for g in group]
+            lookups = {}
         for group in lookups.values():
             store: EmbeddingStore = group[0][0].tower.categorical_embedder.store
             B = group[0][0].B
@@ -228,6 +240,10 @@ class _TowersFn(torch.autograd.Function):
     def backward(ctx, *d_embs):
         grads = [None] * ctx.n_flat
         dxs = {}
+        exch = ctx.exch
+        if exch is not None:            # global objective = mean over ranks of the local losses
+            d_embs = [None if d is None else d * (1.0 / exch.world) for d in d_embs]
+        flat_grads = []
         for s, d_emb, (pos, nd, nt) in zip(ctx.sides, d_embs, ctx.spans):
             tw = s.tower
             if s.B == 0 or d_emb is None:
@@ -257,8 +273,20 @@ class _TowersFn(torch.autograd.Function):
             ops.tower_bwd(tw._params(), s.acts_struct, d_emb, g, B, s.train, s.p_drop, s.seed, dev)
             for i, v in enumerate(views):
                 grads[pos + 2 + i] = v
+            flat_grads.append(buf[:offs[len(dps)]])
             d_x = buf[offs[len(dps)]:offs[len(dps)] + B * tw.x_width].view(B, tw.x_width)
             dxs[id(s)] = d_x[:, tw.tower_hidden_dims[0]:]
+        if exch is not None:
+            exch.all_reduce_dense(flat_grads)
+            if ctx.exch_state is not None:
+                srcs = []
+                for s in ctx.exch_sides:
+                    K = len(s.tower.categorical_embedder.keys)
+                    d = dxs.get(id(s))
+                    if d is None:
+                        d = torch.zeros((s.B, K * exch.E), dtype=torch.float32, device=s.emb.device)
+                    srcs.append((d, K))
+                exch.backward(ctx.exch_state, srcs, ctx.exch_sides[0].B)
         # table gradients: one fused segmented reduction per store
         for store, plan_sides, plan in ctx.plans:
             if plan is None:

@@ -28,7 +28,8 @@ class TwoTowerModel(nn.Module):
         self.company_tower = CompanyTower(**company_tower_config)
         assert notice_tower_config.get("final_embedding_dim", 128) == final_embedding_dim      # :38-39
         assert company_tower_config.get("final_embedding_dim", 128) == final_embedding_dim
-        if self.notice_tower.categorical_embedder.embedding_dim == self.company_tower.categorical_embedder.embedding_dim:
+        ne, ce = self.notice_tower.categorical_embedder, self.company_tower.categorical_embedder
+        if ne.materialize and ce.materialize and ne.embedding_dim == ce.embedding_dim:
             EmbeddingStore.fuse([self.notice_tower.categorical_embedder.store, self.company_tower.categorical_embedder.store])
         self.to(torch.device(self.device))
 

@@ -347,3 +347,96 @@ def test_medium_batch_vs_oracle(tt, manifest):
     assert res["accuracy"].item() == pytest.approx(float(ref["accuracy"]), abs=2.0 / cfg["B"])
     for n, p in task.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref["grads"][n], rtol=2e-3, atol=2e-7, err_msg=n)
+
+
+def test_distributed_world1_matches_single_gpu(tt, manifest):
+    """The sharded-table / all-to-all path (RCCL backend, world_size 1 on the one GPU of this box) must
+    reproduce the single-GPU step exactly: same loss, same dense grads, shard grad == fused table grad."""
+    import os
+    import torch.distributed as dist
+    from jodalrob_twotower_amd.distributed import create_distributed_train_task
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        cfg = dict(manifest["cases"]["wide_b40"])
+        cfg["B"] = 256
+        single = make_task(tt, cfg, embedding_grad="dense")
+        shapes = {k: tuple(v.shape) for k, v in single.state_dict().items()}
+        state = init_state_numpy(shapes, 777)
+        load_state(single, state)
+        dtask = create_distributed_train_task(
+            cfg["keys_n"], cfg["keys_c"], metadata_path=str(GOLD / "synthetic_metadata.csv"), categorical_embedding_dim=cfg["E"],
+            notice_dense_input_dim=cfg["din_n"], company_dense_input_dim=cfg["din_c"], tower_hidden_dims=list(cfg["hidden"]),
+            final_embedding_dim=cfg["D"], dropout_rate=0.0, temperature=cfg["T"], device=DEV, embedding_grad="dense")
+        dtask.load_full_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+        full = dtask.full_state_dict()
+        assert set(full) == set(state)
+        for k, v in state.items():
+            assert np.array_equal(full[k].cpu().numpy(), v), k                       # sharded <-> reference layout
+        b = synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 778, oob=True)
+        single.train(); dtask.train()
+        r1 = single(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+        r2 = dtask(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+        assert r1["loss"].item() == r2["loss"].item()
+        r1["loss"].backward(); r2["loss"].backward()
+        g1 = {n: p.grad for n, p in single.named_parameters()}
+        for n, p in dtask.named_parameters():
+            if n != "embedding_shard":
+                assert torch.equal(p.grad, g1[n]), n
+        fused = torch.cat([g1[name] for name, _, _ in dtask.key_directory()])
+        assert torch.equal(dtask.embedding_shard.grad[:fused.shape[0]], fused)
+        # sparse mode + FusedAdam on the shard: one step runs and changes only looked-up rows
+        from jodalrob_twotower_amd.optim import FusedAdam
+        dsp = create_distributed_train_task(
+            cfg["keys_n"], cfg["keys_c"], metadata_path=str(GOLD / "synthetic_metadata.csv"), categorical_embedding_dim=cfg["E"],
+            notice_dense_input_dim=cfg["din_n"], company_dense_input_dim=cfg["din_c"], tower_hidden_dims=list(cfg["hidden"]),
+            final_embedding_dim=cfg["D"], dropout_rate=0.0, temperature=cfg["T"], device=DEV, embedding_grad="sparse")
+        dsp.load_full_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+        opt = FusedAdam.for_task(dsp, lr=1e-2)
+        before = dsp.embedding_shard.detach().clone()
+        dsp.train()
+        dsp(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"])).backward()
+        opt.step()
+        changed = (dsp.embedding_shard.detach() != before).any(dim=1).cpu().numpy()
+        touched = np.zeros(len(changed), bool)
+        touched[np.flatnonzero(np.abs(fused.cpu().numpy()).sum(1) > 0)] = True
+        assert np.array_equal(changed[:len(touched)], touched)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_fused_adam_matches_oracle(tt, manifest):
+    """FusedAdam (dense tower weights + dense-mode tables) == torch.optim.Adam semantics (oracle adam_step);
+    sparse mode == the same update restricted to looked-up rows."""
+    from jodalrob_twotower_amd.optim import FusedAdam
+    cfg = dict(manifest["cases"]["wide_b40"])
+    for mode in ("dense", "sparse"):
+        task = make_task(tt, cfg, embedding_grad=mode)
+        shapes = {k: tuple(v.shape) for k, v in task.state_dict().items()}
+        state = init_state_numpy(shapes, 31)
+        load_state(task, state)
+        opt = FusedAdam.for_task(task, lr=1e-2, weight_decay=1e-4)
+        pk = [k for k in state if "running" not in k and "num_batches" not in k]
+        m = {k: np.zeros_like(state[k]) for k in pk}
+        v = {k: np.zeros_like(state[k]) for k in pk}
+        st = {k: np.array(val, copy=True) for k, val in state.items()}
+        task.train()
+        for s in range(3):
+            b = synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 50 + s, oob=False)
+            opt.zero_grad()
+            task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"])).backward()
+            opt.step()
+            ref = O.task_step(st, b, cfg["keys_n"], cfg["keys_c"], cfg["vocab_n"], cfg["vocab_c"], cfg["T"], True)
+            for k in pk:
+                g = ref["grads"][k]
+                if mode == "sparse" and "embeddings" in k:
+                    rows = np.flatnonzero(np.abs(g).sum(1) > 0)
+                    for r in rows:
+                        O.adam_step(st[k][r], g[r], m[k][r], v[k][r], s + 1, 1e-2, wd=1e-4)
+                else:
+                    O.adam_step(st[k], g, m[k], v[k], s + 1, 1e-2, wd=1e-4)
+            st.update(ref["bn_updates"])
+        for k, val in task.state_dict().items():
+            np.testing.assert_allclose(val.cpu().numpy(), st[k], rtol=2e-4, atol=2e-6, err_msg=f"{mode}:{k}")
