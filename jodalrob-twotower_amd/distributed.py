@@ -82,7 +82,7 @@ class HipBackend:
 
     def global_rows(self, sides: Sequence[ops.LookupSide], B: int, E: int, table_rows: int) -> torch.Tensor:
         return ops.embed_lookup(None, [ops.LookupSide(s.ids, s.key_row_offset, s.key_vocab, None, s.K) for s in sides], B,
-                                want_rows=True, E=E, table_rows=table_rows)
+                                want_rows=True, E=E, table_rows=table_rows, tag="[route]")
 
     def bucket_by_owner(self, rows: torch.Tensor, world: int):
         owners = torch.remainder(rows, world)                              # int32 [M]
@@ -112,7 +112,7 @@ class HipBackend:
             voc = voc_cache.setdefault(s.K, torch.full((s.K,), M, dtype=torch.int64, device=dev))
             lsides.append(ops.LookupSide(inv[base:base + n], off, voc, s.out, s.K))
             base += n
-        ops.embed_lookup(pooled, lsides, B, want_rows=False)
+        ops.embed_lookup(pooled, lsides, B, want_rows=False, tag="[place]")
 
     def collect_grads(self, srcs, order: torch.Tensor, B: int, E: int) -> torch.Tensor:
         """d_bucket[i] = gradient of slot order[i]  (identity-segment plan through tt_embed_grad_bwd)."""

@@ -76,7 +76,7 @@ class LookupSide:
 
 
 def embed_lookup(table: Optional[torch.Tensor], sides: Sequence[LookupSide], B: int, want_rows: bool, E: int = 0,
-                 table_rows: int = 0) -> Optional[torch.Tensor]:
+                 table_rows: int = 0, tag: str = "") -> Optional[torch.Tensor]:
     """table None => rows-only mode (E and table_rows then describe the row space)."""
     dev = table.device if table is not None else sides[0].ids.device
     E = table.shape[1] if table is not None else E
@@ -96,7 +96,7 @@ def embed_lookup(table: Optional[torch.Tensor], sides: Sequence[LookupSide], B: 
             arr[i] = L.EmbedSide(L.ptr(s.ids), L.ptr(s.key_row_offset), L.ptr(s.key_vocab), None, s.K * E, s.K, TT_F32)
         M += B * s.K
     rows = torch.empty(M, dtype=torch.int32, device=dev) if want_rows else None
-    with _timed("tt_embed_lookup_fwd"):
+    with _timed("tt_embed_lookup_fwd" + tag):
         L.check(L.load().tt_embed_lookup_fwd(L.ctx(dev), L.ptr(table), table_rows, E, arr, len(sides), B,
                                              L.ptr(rows), L.stream(dev)), "tt_embed_lookup_fwd")
     return rows

@@ -162,7 +162,7 @@ class _TowersFn(torch.autograd.Function):
         lookups: Dict[int, list] = {}
         for tw in towers:
             emb = tw.categorical_embedder
-            nd, nt = len(tw.dense_parameters()), len(emb.keys)
+            nd, nt = len(tw.dense_parameters()), len(emb.table_parameters())
             dense, values = flat[pos], flat[pos + 1]
             spans.append((pos, nd, nt))
             pos += 2 + nd + nt
