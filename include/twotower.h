@@ -126,9 +126,15 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
  *                        keep weight, m and v untouched -- the documented difference to the
  *                        reference's dense update; DESIGN.md "optimiser semantics")
  * ---------------------------------------------------------------------------------------------- */
+/* Graph capture: when `hparams_dev` is non-NULL the kernels read the per-step scalars from DEVICE memory
+ * instead of the host arguments, so a captured launch can be replayed with a new lr / step:
+ *   hparams_dev[0] = lr / (1 - beta1^step)   hparams_dev[1] = 1 / sqrt(1 - beta2^step)
+ *   hparams_dev[2] = beta1  [3] = beta2  [4] = eps  [5] = weight_decay        (tt_adam_hparams fills them) */
+void tt_adam_hparams(int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                     float out6[6]);
 int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n,
                        int64_t step, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, tt_stream stream);
+                       float weight_decay, const float* hparams_dev, tt_stream stream);
 /* the same dense update over n_tensors separate tensors in one launch per 32 tensors */
 typedef struct tt_adam_tensor {
   float* p;
@@ -139,11 +145,11 @@ typedef struct tt_adam_tensor {
 } tt_adam_tensor;
 int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors /* host array */, int32_t n_tensors,
                        int64_t step, float lr, float beta1, float beta2, float eps,
-                       float weight_decay, tt_stream stream);
+                       float weight_decay, const float* hparams_dev, tt_stream stream);
 int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E,
                         const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique,
                         int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, tt_stream stream);
+                        float weight_decay, const float* hparams_dev, tt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tower MLP -- replaces BaseTower.forward after the lookup (src/towers/tower/base_tower.py:133-145)
@@ -196,13 +202,15 @@ typedef struct tt_tower_grads { /* every buffer is overwritten, not accumulated 
 
 /* scratch for either pass (split-K slabs of the weight gradients, column-reduction partials) */
 size_t tt_tower_workspace_bytes(const tt_tower_params* p, int64_t B);
+/* seed_dev (may be NULL): when set, the dropout seed is read from device memory (seed + *seed_dev), so a
+ * captured launch draws a new mask on every replay once the caller updates that word. */
 int tt_tower_mlp_fwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts* a, int64_t B,
-                     int32_t train, float dropout_p, uint64_t seed, void* workspace,
-                     size_t workspace_bytes, tt_stream stream);
+                     int32_t train, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                     void* workspace, size_t workspace_bytes, tt_stream stream);
 int tt_tower_mlp_bwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts* a,
                      const float* d_emb, const tt_tower_grads* g, int64_t B, int32_t train,
-                     float dropout_p, uint64_t seed, void* workspace, size_t workspace_bytes,
-                     tt_stream stream);
+                     float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* workspace,
+                     size_t workspace_bytes, tt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * In-batch-negative score + symmetric softmax cross-entropy, never materialising the score matrix

@@ -77,13 +77,14 @@ SIGNATURES = {
     "tt_dedup_plan": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_embed_grad_workspace_bytes": (sz, [i64, i32]),
     "tt_embed_grad_bwd": (C.c_int, [vp, C.POINTER(GradSrc), i32, i64, i32, vp, vp, vp, vp, i64, i32, vp, vp, sz, vp]),
-    "tt_adam_dense_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp]),
-    "tt_adam_multi_step": (C.c_int, [vp, C.POINTER(AdamTensor), i32, i64, f32, f32, f32, f32, f32, vp]),
-    "tt_sparse_adam_step": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp]),
+    "tt_adam_hparams": (None, [i64, f32, f32, f32, f32, f32, C.POINTER(f32 * 6)]),
+    "tt_adam_dense_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp, vp]),
+    "tt_adam_multi_step": (C.c_int, [vp, C.POINTER(AdamTensor), i32, i64, f32, f32, f32, f32, f32, vp, vp]),
+    "tt_sparse_adam_step": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp, vp]),
     "tt_tower_workspace_bytes": (sz, [C.POINTER(TowerParams), i64]),
-    "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, sz, vp]),
+    "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, vp, sz, vp]),
     "tt_tower_mlp_bwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), vp, C.POINTER(TowerGrads), i64, i32,
-                                   f32, u64, vp, sz, vp]),
+                                   f32, u64, vp, vp, sz, vp]),
     "tt_score_dir_fwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, vp, vp]),
     "tt_score_loss_finish": (C.c_int, [vp, i64, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "tt_score_dir_bwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, f32, vp, vp]),

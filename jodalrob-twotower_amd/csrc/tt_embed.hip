@@ -506,7 +506,16 @@ __global__ __launch_bounds__(kThreads) void seg_long_finish_kernel(int32_t E, ui
 // ------------------------------------------------------------------------------------------------
 struct AdamK {
   float lr_over_bc1, inv_sqrt_bc2, b1, b2, eps, wd;
+  const float* dev;   // optional device copy of the six scalars above (graph replay)
 };
+
+__device__ __forceinline__ AdamK adam_resolve(const AdamK& k) {
+  if (k.dev == nullptr) return k;
+  AdamK r;
+  r.lr_over_bc1 = k.dev[0]; r.inv_sqrt_bc2 = k.dev[1]; r.b1 = k.dev[2]; r.b2 = k.dev[3]; r.eps = k.dev[4]; r.wd = k.dev[5];
+  r.dev = nullptr;
+  return r;
+}
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamK& k) {
   g = k.wd != 0.f ? g + k.wd * p : g;
@@ -517,7 +526,8 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
 }
 
 __global__ __launch_bounds__(kThreads) void adam_dense_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                             float* __restrict__ m, float* __restrict__ v, int64_t n, AdamK k) {
+                                                             float* __restrict__ m, float* __restrict__ v, int64_t n, AdamK k0) {
+  const AdamK k = adam_resolve(k0);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float pp = p[i], mm = m[i], vv = v[i];
@@ -527,7 +537,8 @@ __global__ __launch_bounds__(kThreads) void adam_dense_kernel(float* __restrict_
 }
 
 __global__ __launch_bounds__(kThreads) void adam_dense_vec4_kernel(float4* __restrict__ p, const float4* __restrict__ g,
-                                                                  float4* __restrict__ m, float4* __restrict__ v, int64_t n4, AdamK k) {
+                                                                  float4* __restrict__ m, float4* __restrict__ v, int64_t n4, AdamK k0) {
+  const AdamK k = adam_resolve(k0);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     float4 pp = p[i], mm = m[i], vv = v[i];
@@ -543,7 +554,8 @@ struct AdamMultiArgs {
   tt_adam_tensor t[kAdamMulti];
 };
 
-__global__ __launch_bounds__(kThreads) void adam_multi_kernel(AdamMultiArgs a, AdamK k) {
+__global__ __launch_bounds__(kThreads) void adam_multi_kernel(AdamMultiArgs a, AdamK k0) {
+  const AdamK k = adam_resolve(k0);
   const tt_adam_tensor& t = a.t[blockIdx.y];
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < t.n; i += stride) {
@@ -557,7 +569,8 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void adam_sparse_kernel(float* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
                                                               int32_t E, uint32_t C, const int32_t* __restrict__ unique_rows,
                                                               const float* __restrict__ grad_rows, const int32_t* __restrict__ n_unique,
-                                                              AdamK k, uint32_t LG) {
+                                                              AdamK k0, uint32_t LG) {
+  const AdamK k = adam_resolve(k0);
   const uint32_t U = (uint32_t)*n_unique;
   const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lig = gthread % LG;
@@ -675,13 +688,14 @@ int sort_pass(hipStream_t st, const uint32_t* kin, const uint32_t* vin, uint32_t
   return TT_OK;
 }
 
-AdamK make_adam(int64_t step, float lr, float b1, float b2, float eps, float wd) {
+AdamK make_adam(int64_t step, float lr, float b1, float b2, float eps, float wd, const float* dev) {
   const double bc1 = 1.0 - pow((double)b1, (double)step);
   const double bc2 = 1.0 - pow((double)b2, (double)step);
   AdamK k;
   k.lr_over_bc1 = (float)((double)lr / bc1);
   k.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   k.b1 = b1; k.b2 = b2; k.eps = eps; k.wd = wd;
+  k.dev = dev;
   return k;
 }
 
@@ -825,12 +839,17 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   return TT_OK;
 }
 
+void tt_adam_hparams(int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay, float out6[6]) {
+  const AdamK k = make_adam(step < 1 ? 1 : step, lr, beta1, beta2, eps, weight_decay, nullptr);
+  out6[0] = k.lr_over_bc1; out6[1] = k.inv_sqrt_bc2; out6[2] = k.b1; out6[3] = k.b2; out6[4] = k.eps; out6[5] = k.wd;
+}
+
 int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, tt_stream stream) {
+                       float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream) {
   TT_CHECK_ARG(ctx && (n == 0 || (p && g && m && v)), "tt_adam_dense_step: NULL argument");
   TT_CHECK_ARG(step >= 1 && n >= 0, "tt_adam_dense_step: step must be >= 1");
   if (n == 0) return TT_OK;
-  const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay);
+  const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay, hparams_dev);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n % 4 == 0 && tt_aligned(p, 16) && tt_aligned(g, 16) && tt_aligned(m, 16) && tt_aligned(v, 16)) {
     adam_dense_vec4_kernel<<<grid_for(ctx, n / 4), kThreads, 0, st>>>(reinterpret_cast<float4*>(p), reinterpret_cast<const float4*>(g),
@@ -843,10 +862,10 @@ int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v
 }
 
 int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, int64_t step, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, tt_stream stream) {
+                       float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream) {
   TT_CHECK_ARG(ctx && (n_tensors == 0 || tensors), "tt_adam_multi_step: NULL argument");
   TT_CHECK_ARG(step >= 1 && n_tensors >= 0, "tt_adam_multi_step: step must be >= 1");
-  const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay);
+  const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay, hparams_dev);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   for (int base = 0; base < n_tensors; base += kAdamMulti) {
     AdamMultiArgs a{};
@@ -868,12 +887,12 @@ int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_ten
 
 int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E, const int32_t* unique_rows, const float* grad_rows,
                         const int32_t* n_unique, int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,
-                        float weight_decay, tt_stream stream) {
+                        float weight_decay, const float* hparams_dev, tt_stream stream) {
   TT_CHECK_ARG(ctx && table && m && v, "tt_sparse_adam_step: NULL state");
   TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 0, "tt_sparse_adam_step: bad step/E/M");
   if (M == 0) return TT_OK;
   TT_CHECK_ARG(unique_rows && grad_rows && n_unique, "tt_sparse_adam_step: NULL plan");
-  const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay);
+  const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay, hparams_dev);
   const bool vec4 = (E % 4 == 0) && tt_aligned(table, 16) && tt_aligned(m, 16) && tt_aligned(v, 16) && tt_aligned(grad_rows, 16);
   const uint32_t C = vec4 ? E / 4 : E;
   const uint32_t LG = pow2_at_least(C) > 64 ? 64 : pow2_at_least(C);

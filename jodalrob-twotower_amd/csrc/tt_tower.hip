@@ -12,6 +12,7 @@ __device__ __forceinline__ float dropout_scale(bool on, float p, uint64_t seed, 
   if (!on) return 1.f;
   return tt_uniform01(seed, idx) >= p ? 1.f / (1.f - p) : 0.f;
 }
+__device__ __forceinline__ uint64_t seed_of(uint64_t seed, const uint64_t* seed_dev) { return seed_dev ? seed + seed_dev[0] : seed; }
 
 // ---- column statistics of relu(pre): Welford per thread, Chan combine ------------------------
 struct Wf {
@@ -95,7 +96,9 @@ __global__ void bn_eval_prepare_kernel(const float* __restrict__ rm, const float
 __global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ pre, int64_t total, int H,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ g, const float* __restrict__ b, bool drop, float p,
-                                                           uint64_t seed, uint64_t salt, float* __restrict__ act) {
+                                                           uint64_t seed0, const uint64_t* __restrict__ seed_dev, uint64_t salt,
+                                                           float* __restrict__ act) {
+  const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int c = (int)(i % H);
@@ -112,6 +115,7 @@ struct ColArgs {
   const float* x; int64_t ldx;
   const float* pre; const float* mean; const float* rstd;
   bool drop; float p; uint64_t seed, salt;
+  const uint64_t* seed_dev;
 };
 
 template <int OP>
@@ -121,13 +125,14 @@ __global__ __launch_bounds__(kThreads) void colsum_partial_kernel(ColArgs a, int
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * rows_per_chunk, r1 = min(B, r0 + rows_per_chunk);
   float s0 = 0.f, s1 = 0.f;
+  const uint64_t seed = (OP == 1 && a.drop) ? seed_of(a.seed, a.seed_dev) : 0;
   if (c < H) {
     for (int r = r0 + rl; r < r1; r += 4) {
       if (OP == 0) {
         s0 += a.x[(int64_t)r * a.ldx + c];
       } else {
         const int64_t i = (int64_t)r * H + c;
-        const float da = a.x[(int64_t)r * a.ldx + c] * dropout_scale(a.drop, a.p, a.seed, a.salt + (uint64_t)i);
+        const float da = a.x[(int64_t)r * a.ldx + c] * dropout_scale(a.drop, a.p, seed, a.salt + (uint64_t)i);
         const float xh = (fmaxf(a.pre[i], 0.f) - a.mean[c]) * a.rstd[c];
         s0 += da;
         s1 += da * xh;
@@ -169,8 +174,9 @@ __global__ __launch_bounds__(kThreads) void colsum_finish_kernel(const float* __
 __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(float* __restrict__ d, const float* __restrict__ pre, int64_t total, int H,
                                                                float invB, const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ g, const float* __restrict__ S1,
-                                                               const float* __restrict__ S2, bool train, bool drop, float p, uint64_t seed,
-                                                               uint64_t salt) {
+                                                               const float* __restrict__ S2, bool train, bool drop, float p, uint64_t seed0,
+                                                               const uint64_t* __restrict__ seed_dev, uint64_t salt) {
+  const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const int c = (int)(i % H);
@@ -304,7 +310,7 @@ size_t tt_tower_workspace_bytes(const tt_tower_params* p, int64_t B) {
 }
 
 int tt_tower_mlp_fwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts* a, int64_t B, int32_t train, float dropout_p,
-                     uint64_t seed, void* workspace, size_t workspace_bytes, tt_stream stream) {
+                     uint64_t seed, const uint64_t* seed_dev, void* workspace, size_t workspace_bytes, tt_stream stream) {
   TT_CHECK_ARG(ctx && a, "tt_tower_mlp_fwd: NULL argument");
   if (int rc = check_params(p, "tt_tower_mlp_fwd")) return rc;
   TT_CHECK_ARG(B >= 0 && B < ((int64_t)1 << 24), "tt_tower_mlp_fwd: B=%lld out of range", (long long)B);
@@ -339,7 +345,7 @@ int tt_tower_mlp_fwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts*
       TT_LAUNCH_CHECK();
     }
     bn_apply_kernel<<<ew_grid(ctx, B * H), kThreads, 0, st>>>(a->pre[i], B * H, H, a->mean[i], a->rstd[i], p->bn_w[i], p->bn_b[i], drop,
-                                                               dropout_p, seed, (uint64_t)(i + 1) << 40, a->act[i]);
+                                                               dropout_p, seed, seed_dev, (uint64_t)(i + 1) << 40, a->act[i]);
     TT_LAUNCH_CHECK();
     in = a->act[i];
     in_w = H;
@@ -351,8 +357,8 @@ int tt_tower_mlp_fwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts*
 }
 
 int tt_tower_mlp_bwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts* a, const float* d_emb, const tt_tower_grads* g,
-                     int64_t B, int32_t train, float dropout_p, uint64_t seed, void* workspace, size_t workspace_bytes,
-                     tt_stream stream) {
+                     int64_t B, int32_t train, float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* workspace,
+                     size_t workspace_bytes, tt_stream stream) {
   TT_CHECK_ARG(ctx && a && g && d_emb, "tt_tower_mlp_bwd: NULL argument");
   if (int rc = check_params(p, "tt_tower_mlp_bwd")) return rc;
   TT_CHECK_ARG(B >= 1 && B < ((int64_t)1 << 24), "tt_tower_mlp_bwd: B=%lld out of range", (long long)B);
@@ -384,11 +390,11 @@ int tt_tower_mlp_bwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts*
     const uint64_t salt = (uint64_t)(i + 1) << 40;
     ColArgs cb{};
     cb.x = dcur; cb.ldx = H; cb.pre = a->pre[i]; cb.mean = a->mean[i]; cb.rstd = a->rstd[i];
-    cb.drop = drop; cb.p = dropout_p; cb.seed = seed; cb.salt = salt;
+    cb.drop = drop; cb.p = dropout_p; cb.seed = seed; cb.salt = salt; cb.seed_dev = seed_dev;
     // S1 = sum da -> bn bias grad ; S2 = sum da*xhat -> bn weight grad
     if (int rc = colsum(ctx, st, 1, cb, B, H, ws.col, g->bn_b[i], g->bn_w[i])) return rc;
     bn_bwd_apply_kernel<<<ew_grid(ctx, B * H), kThreads, 0, st>>>(dcur, a->pre[i], B * H, H, 1.f / (float)B, a->mean[i], a->rstd[i],
-                                                                   p->bn_w[i], g->bn_b[i], g->bn_w[i], train != 0, drop, dropout_p, seed, salt);
+                                                                   p->bn_w[i], g->bn_b[i], g->bn_w[i], train != 0, drop, dropout_p, seed, seed_dev, salt);
     TT_LAUNCH_CHECK();
     const float* in_i = i == 0 ? a->x : a->act[i - 1];
     if (int rc = tt_gemm_tn(st, dcur, H, in_i, iw, g->w[i], iw, H, iw, B, ws.gemm, ws.gemm_bytes)) return rc;

@@ -142,14 +142,14 @@ def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int
 
 
 # ---------------------------------------------------------------------------------------------- Adam
-def adam_dense(p, g, m, v, step, lr, b1, b2, eps, wd):
+def adam_dense(p, g, m, v, step, lr, b1, b2, eps, wd, hp_dev=None):
     dev = p.device
     with _timed("tt_adam_dense_step"):
         L.check(L.load().tt_adam_dense_step(L.ctx(dev), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), step, lr, b1, b2,
-                                            eps, wd, L.stream(dev)), "tt_adam_dense_step")
+                                            eps, wd, L.ptr(hp_dev), L.stream(dev)), "tt_adam_dense_step")
 
 
-def adam_multi(items, step, lr, b1, b2, eps, wd):
+def adam_multi(items, step, lr, b1, b2, eps, wd, hp_dev=None):
     """items: [(p, g, m, v)] float32 contiguous tensors on one device."""
     if not items:
         return
@@ -158,16 +158,16 @@ def adam_multi(items, step, lr, b1, b2, eps, wd):
     for i, (p, g, m, v) in enumerate(items):
         arr[i] = L.AdamTensor(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
     with _timed("tt_adam_multi_step"):
-        L.check(L.load().tt_adam_multi_step(L.ctx(dev), arr, len(items), step, lr, b1, b2, eps, wd, L.stream(dev)),
+        L.check(L.load().tt_adam_multi_step(L.ctx(dev), arr, len(items), step, lr, b1, b2, eps, wd, L.ptr(hp_dev), L.stream(dev)),
                 "tt_adam_multi_step")
 
 
-def adam_sparse(table, m, v, plan: DedupPlan, grad_rows, step, lr, b1, b2, eps, wd):
+def adam_sparse(table, m, v, plan: DedupPlan, grad_rows, step, lr, b1, b2, eps, wd, hp_dev=None):
     dev = table.device
     with _timed("tt_sparse_adam_step"):
         L.check(L.load().tt_sparse_adam_step(L.ctx(dev), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[1],
                                              L.ptr(plan.unique_rows), L.ptr(grad_rows), L.ptr(plan.n_unique), plan.M, step,
-                                             lr, b1, b2, eps, wd, L.stream(dev)), "tt_sparse_adam_step")
+                                             lr, b1, b2, eps, wd, L.ptr(hp_dev), L.stream(dev)), "tt_sparse_adam_step")
 
 
 # ---------------------------------------------------------------------------------------------- tower MLP
@@ -188,23 +188,29 @@ def tower_params_struct(din, h0, kcat_e, hidden, d_out, w_proj, b_proj, ws, bs, 
     return p
 
 
+def adam_hparams(step, lr, b1, b2, eps, wd):
+    out = (L.f32 * 6)()
+    L.load().tt_adam_hparams(step, lr, b1, b2, eps, wd, C.byref(out))
+    return list(out)
+
+
 def tower_workspace(params, B, dev):
     nb = L.load().tt_tower_workspace_bytes(C.byref(params), B)
     return L.workspace(dev, nb)
 
 
-def tower_fwd(params, acts, B, train, p_drop, seed, dev):
+def tower_fwd(params, acts, B, train, p_drop, seed, dev, seed_dev=None):
     ws = tower_workspace(params, B, dev)
     with _timed("tt_tower_mlp_fwd"):
-        L.check(L.load().tt_tower_mlp_fwd(L.ctx(dev), C.byref(params), C.byref(acts), B, int(train), p_drop, seed, L.ptr(ws),
+        L.check(L.load().tt_tower_mlp_fwd(L.ctx(dev), C.byref(params), C.byref(acts), B, int(train), p_drop, seed, L.ptr(seed_dev), L.ptr(ws),
                                           ws.numel(), L.stream(dev)), "tt_tower_mlp_fwd")
 
 
-def tower_bwd(params, acts, d_emb, grads, B, train, p_drop, seed, dev):
+def tower_bwd(params, acts, d_emb, grads, B, train, p_drop, seed, dev, seed_dev=None):
     ws = tower_workspace(params, B, dev)
     with _timed("tt_tower_mlp_bwd"):
         L.check(L.load().tt_tower_mlp_bwd(L.ctx(dev), C.byref(params), C.byref(acts), L.ptr(d_emb), C.byref(grads), B,
-                                          int(train), p_drop, seed, L.ptr(ws), ws.numel(), L.stream(dev)), "tt_tower_mlp_bwd")
+                                          int(train), p_drop, seed, L.ptr(seed_dev), L.ptr(ws), ws.numel(), L.stream(dev)), "tt_tower_mlp_bwd")
 
 
 # ---------------------------------------------------------------------------------------------- score / loss

@@ -31,6 +31,7 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._stores: List[EmbeddingStore] = list(stores)
         self._store_state: Dict[int, dict] = {}
+        self._hp_dev = None             # [n_groups, 8] device floats while a captured graph owns the step
 
     @classmethod
     def for_task(cls, task, **kw):
@@ -65,14 +66,16 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._flush_pending()
         table_ids = self._table_param_ids()
         group_of = {}
         for group in self.param_groups:
             for p in group["params"]:
                 group_of[id(p)] = group
         # ---- tower weights ----
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
+            hp = None if self._hp_dev is None else self._hp_dev[gi]
             items = []
             step_no = None
             for p in group["params"]:
@@ -91,7 +94,7 @@ class FusedAdam(torch.optim.Optimizer):
             for it in items:
                 by_step.setdefault(it[4], []).append(it[:4])
             for s_no, its in by_step.items():
-                ops.adam_multi(its, s_no, group["lr"], b1, b2, group["eps"], group["weight_decay"])
+                ops.adam_multi(its, s_no, group["lr"], b1, b2, group["eps"], group["weight_decay"], hp)
         # ---- embedding stores ----
         for store in self._stores:
             members = store.optim_parameters()
@@ -101,6 +104,7 @@ class FusedAdam(torch.optim.Optimizer):
             if group is None:
                 continue                                     # tables not handed to this optimiser
             b1, b2 = group["betas"]
+            hp = None if self._hp_dev is None else self._hp_dev[self.param_groups.index(group)]
             st = self._state_of(store)
             if store.grad_mode == "sparse":
                 if store.sparse_grad is None:
@@ -108,17 +112,41 @@ class FusedAdam(torch.optim.Optimizer):
                 plan, grad_rows = store.sparse_grad
                 st["step"] += 1
                 ops.adam_sparse(store.weight, st["m"], st["v"], plan, grad_rows, st["step"], group["lr"], b1, b2,
-                                group["eps"], group["weight_decay"])
+                                group["eps"], group["weight_decay"], hp)
                 store.sparse_grad = None
             else:
                 if store.grad is None or any(p.grad is None for p in members):
                     continue
                 st["step"] += 1
                 ops.adam_dense(store.weight, store.grad, st["m"], st["v"], st["step"], group["lr"], b1, b2,
-                               group["eps"], group["weight_decay"])
+                               group["eps"], group["weight_decay"], hp)
             for p in members:
                 self.state[p]["step"] = torch.tensor(float(st["step"]))
         return loss
+
+    def advance_steps(self, n: int):
+        """Account for `n` optimiser steps executed by graph replays (step counters live on the host;
+        folded into the per-parameter state lazily)."""
+        self._pending_steps = getattr(self, "_pending_steps", 0) + n
+
+    def _flush_pending(self):
+        n = getattr(self, "_pending_steps", 0)
+        if n:
+            self._pending_steps = 0
+            for st in self._store_state.values():
+                st["step"] += n
+            for st in self.state.values():
+                if "step" in st:
+                    st["step"] = st["step"] + float(n)
+
+    def current_step(self) -> int:
+        self._flush_pending()
+        steps = [int(float(st["step"])) for st in self.state.values() if "step" in st]
+        return max(steps) if steps else 0
+
+    def state_dict(self):
+        self._flush_pending()
+        return super().state_dict()
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=set_to_none)

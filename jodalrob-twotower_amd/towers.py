@@ -39,6 +39,7 @@ class BaseTower(nn.Module):
             tower_hidden_dims = [256, 128]
         self.categorical_keys = list(categorical_keys)
         self.exchange = None            # set by the distributed task: sharded-table row exchange
+        self._seed_dev = None           # set by GraphedTrainStep: device word added to the dropout seed
         self.device = device
         self.tower_hidden_dims = list(tower_hidden_dims)
         self.final_embedding_dim = final_embedding_dim
@@ -226,7 +227,7 @@ class _TowersFn(torch.autograd.Function):
         for s in sides:
             tw = s.tower
             if s.B:
-                ops.tower_fwd(tw._params(), s.acts_struct, s.B, s.train, s.p_drop, s.seed, s.emb.device)
+                ops.tower_fwd(tw._params(), s.acts_struct, s.B, s.train, s.p_drop, s.seed, s.emb.device, tw._seed_dev)
                 if s.train:
                     for i in range(tw.n_hidden):
                         tw.mlp[4 * i + 2].num_batches_tracked.add_(1)
@@ -270,7 +271,7 @@ class _TowersFn(torch.autograd.Function):
             g.w_out, g.b_out = base + 4 * offs[len(dps) - 2], base + 4 * offs[len(dps) - 1]
             g.d_x = base + 4 * offs[len(dps)]
             g.d_y = base + 4 * offs[len(dps) + 1 + len(hid)]
-            ops.tower_bwd(tw._params(), s.acts_struct, d_emb, g, B, s.train, s.p_drop, s.seed, dev)
+            ops.tower_bwd(tw._params(), s.acts_struct, d_emb, g, B, s.train, s.p_drop, s.seed, dev, tw._seed_dev)
             for i, v in enumerate(views):
                 grads[pos + 2 + i] = v
             flat_grads.append(buf[:offs[len(dps)]])

@@ -440,3 +440,43 @@ def test_fused_adam_matches_oracle(tt, manifest):
             st.update(ref["bn_updates"])
         for k, val in task.state_dict().items():
             np.testing.assert_allclose(val.cpu().numpy(), st[k], rtol=2e-4, atol=2e-6, err_msg=f"{mode}:{k}")
+
+
+def test_graphed_step_equals_eager(tt, manifest):
+    """HIP-graph replay of the whole step == the same steps launched eagerly (bitwise: same kernels,
+    same order), with the learning rate changing between steps (LambdaLR warm-up) and new batches."""
+    from jodalrob_twotower_amd.graph import GraphedTrainStep
+    from jodalrob_twotower_amd.optim import FusedAdam
+    cfg = dict(manifest["cases"]["wide_b40"])
+    cfg["B"] = 256
+    batches = [synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 900 + i, oob=False) for i in range(6)]
+    finals = {}
+    for mode in ("eager", "graph"):
+        task = make_task(tt, cfg, embedding_grad="sparse", score_dtype="bf16")
+        shapes = {k: tuple(v.shape) for k, v in task.state_dict().items()}
+        load_state(task, init_state_numpy(shapes, 55))
+        task.train()
+        opt = FusedAdam.for_task(task, lr=1e-2, weight_decay=1e-5)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: (s + 1) / 4 if s < 3 else 1.0)
+        tb = [to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]) for b in batches]
+        losses = []
+        if mode == "eager":
+            for i in range(3):                      # same 3 warm-up steps the graph wrapper runs eagerly
+                opt.zero_grad(); task(tb[0], return_metrics=True)["loss"].backward(); opt.step()
+            for b in tb:
+                opt.zero_grad()
+                r = task(b, return_metrics=True)
+                r["loss"].backward()
+                opt.step(); sched.step()
+                losses.append(r["loss"].item())
+        else:
+            gs = GraphedTrainStep(task, opt, tb[0], warmup=3)
+            for b in tb:
+                r = gs.step(b)
+                sched.step()
+                losses.append(r["loss"].item())
+            assert opt.current_step() == 3 + len(tb)
+        finals[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in task.state_dict().items()})
+    assert finals["eager"][0] == finals["graph"][0]
+    for k, v in finals["eager"][1].items():
+        assert np.array_equal(v, finals["graph"][1][k]), k
