@@ -4,6 +4,8 @@
 // grids capped at 8 workgroups per CU with grid-stride loops.
 #include "tt_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -102,6 +104,191 @@ __global__ __launch_bounds__(kThreads) void lookup_kernel(SideSet a, const float
         }
       }
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4 + a5, wave-chunk form (16-byte lanes, E % 4 == 0, E/4 a power of two <= 64).  A wave owns 64
+// consecutive slots: lane l decodes slot l ONCE (coalesced 512-B id read, clamp, row, destination) and
+// parks {source, destination} in a wave-private LDS table; the wave then walks the chunk 64/C rows at a
+// time (C = E/4 lanes per row), issuing ALL row loads of the chunk before the first store, so every lane
+// keeps C x 16 B in flight and a wave-instruction still reads whole 128-B lines.
+// ------------------------------------------------------------------------------------------------
+struct SlotRec {
+  const float* src;
+  char* dst;
+};
+using f32x4n = __attribute__((ext_vector_type(4))) float;
+
+template <int C, int SPW, int MODE>   // SPW slots per wave pass; MODE 0: nt stores (default); 1: loads only;
+                                      // 2: stores only (ablations); 4: plain stores; 5: nt loads + nt stores
+__global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const float* __restrict__ table,
+                                                              int32_t* __restrict__ rows_out) {
+  __shared__ SlotRec recs[kThreads / 64][SPW];
+  __shared__ int dts[kThreads / 64][SPW];
+  constexpr int RPI = 64 / C;                       // rows per wave-instruction
+  constexpr int NIT = SPW / RPI;                    // wave-instructions per pass
+  static_assert(SPW % RPI == 0 && NIT >= 1, "SPW must be a multiple of 64/C");
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t nchunks = (a.total_slots + SPW - 1) / SPW;
+  const uint32_t wstride = gridDim.x * (kThreads / 64);
+  for (uint32_t chunk = blockIdx.x * (kThreads / 64) + wave; chunk < nchunks; chunk += wstride) {
+    const uint32_t slot = chunk * SPW + lane;
+    SlotRec rec{nullptr, nullptr};
+    int dt = TT_F32;
+    if (lane < SPW && slot < a.total_slots) {
+      const int si = side_of(a, slot);
+      const SideDev& s = a.s[si];
+      const uint32_t local = slot - s.slot_base;
+      const uint32_t b = local / (uint32_t)s.K;
+      const uint32_t k = local - b * (uint32_t)s.K;
+      int64_t id = s.ids[local];
+      const int64_t hi = s.vocab[k] - 1;
+      id = id < 0 ? 0 : (id > hi ? hi : id);               // clamp: cat_embed.py:117
+      const int64_t row = s.off[k] + id;
+      if (rows_out) rows_out[slot] = (int32_t)row;
+      rec.src = table + row * a.E;
+      dt = s.dtype;
+      rec.dst = s.out + ((int64_t)b * s.ld + (int64_t)k * a.E) * (dt == TT_BF16 ? 2 : 4);
+    }
+    if (lane < SPW) {
+      recs[wave][lane] = rec;
+      dts[wave][lane] = dt;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float4 v[NIT];
+    const uint32_t sub = lane / C, part = lane % C;
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const SlotRec r = recs[wave][j * RPI + sub];
+      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r.src != nullptr && MODE != 2) {
+        if (MODE == 5) {
+          const f32x4n t = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(r.src + part * 4));
+          v[j] = make_float4(t[0], t[1], t[2], t[3]);
+        } else {
+          v[j] = *reinterpret_cast<const float4*>(r.src + part * 4);
+        }
+      }
+    }
+    if (MODE == 1) {                                      // keep the loads alive, write one word per lane
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) acc += v[j].x + v[j].y + v[j].z + v[j].w;
+      if (acc == 12345.678f && rows_out) rows_out[0] = 1;
+    } else {
+#pragma unroll
+      for (int j = 0; j < NIT; ++j) {
+        const SlotRec r = recs[wave][j * RPI + sub];
+        if (r.dst == nullptr) continue;
+        if (dts[wave][j * RPI + sub] == TT_F32) {
+          if (MODE == 0 || MODE == 5) {
+            f32x4n t;
+            t[0] = v[j].x; t[1] = v[j].y; t[2] = v[j].z; t[3] = v[j].w;
+            __builtin_nontemporal_store(t, reinterpret_cast<f32x4n*>(r.dst + part * 16));
+          } else {
+            *reinterpret_cast<float4*>(r.dst + part * 16) = v[j];
+          }
+        } else {
+          ushort4 o;
+          o.x = tt_f2bf(v[j].x); o.y = tt_f2bf(v[j].y); o.z = tt_f2bf(v[j].z); o.w = tt_f2bf(v[j].w);
+          *reinterpret_cast<ushort4*>(r.dst + part * 8) = o;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// Software-pipelined form: a wave walks several 64-slot chunks and issues the row loads of chunk i+1
+// BEFORE the stores of chunk i, so HBM reads and writes of one wave overlap (two register / LDS sets).
+template <int C>
+__device__ __forceinline__ void lk_decode(const SideSet& a, const float* __restrict__ table, int32_t* __restrict__ rows_out,
+                                          uint32_t chunk, uint32_t lane, SlotRec* recs, int* dts) {
+  const uint32_t slot = chunk * 64 + lane;
+  SlotRec rec{nullptr, nullptr};
+  int dt = TT_F32;
+  if (slot < a.total_slots) {
+    const int si = side_of(a, slot);
+    const SideDev& s = a.s[si];
+    const uint32_t local = slot - s.slot_base;
+    const uint32_t b = local / (uint32_t)s.K;
+    const uint32_t k = local - b * (uint32_t)s.K;
+    int64_t id = s.ids[local];
+    const int64_t hi = s.vocab[k] - 1;
+    id = id < 0 ? 0 : (id > hi ? hi : id);
+    const int64_t row = s.off[k] + id;
+    if (rows_out) rows_out[slot] = (int32_t)row;
+    rec.src = table + row * a.E;
+    dt = s.dtype;
+    rec.dst = s.out + ((int64_t)b * s.ld + (int64_t)k * a.E) * (dt == TT_BF16 ? 2 : 4);
+  }
+  recs[lane] = rec;
+  dts[lane] = dt;
+}
+
+template <int C>
+__device__ __forceinline__ void lk_gather(const SlotRec* recs, uint32_t sub, uint32_t part, float4 (&v)[C]) {
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    const SlotRec r = recs[j * (64 / C) + sub];
+    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r.src != nullptr) v[j] = *reinterpret_cast<const float4*>(r.src + part * 4);
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void lk_store(const SlotRec* recs, const int* dts, uint32_t sub, uint32_t part, const float4 (&v)[C]) {
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    const SlotRec r = recs[j * (64 / C) + sub];
+    if (r.dst == nullptr) continue;
+    if (dts[j * (64 / C) + sub] == TT_F32) {
+      f32x4n t;
+      t[0] = v[j].x; t[1] = v[j].y; t[2] = v[j].z; t[3] = v[j].w;
+      __builtin_nontemporal_store(t, reinterpret_cast<f32x4n*>(r.dst + part * 16));
+    } else {
+      ushort4 o;
+      o.x = tt_f2bf(v[j].x); o.y = tt_f2bf(v[j].y); o.z = tt_f2bf(v[j].z); o.w = tt_f2bf(v[j].w);
+      *reinterpret_cast<ushort4*>(r.dst + part * 8) = o;
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(kThreads) void lookup_pipe_kernel(SideSet a, const float* __restrict__ table,
+                                                              int32_t* __restrict__ rows_out) {
+  __shared__ SlotRec recs[2][kThreads / 64][64];
+  __shared__ int dts[2][kThreads / 64][64];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t sub = lane / C, part = lane % C;
+  const uint32_t nchunks = (a.total_slots + 63) / 64;
+  const uint32_t wstride = gridDim.x * (kThreads / 64);
+  uint32_t chunk = blockIdx.x * (kThreads / 64) + wave;
+  if (chunk >= nchunks) return;
+  float4 va[C], vb[C];
+  lk_decode<C>(a, table, rows_out, chunk, lane, recs[0][wave], dts[0][wave]);
+  __builtin_amdgcn_wave_barrier();
+  lk_gather<C>(recs[0][wave], sub, part, va);
+  while (true) {
+    // ---- B: next chunk's loads, then A's stores
+    uint32_t next = chunk + wstride;
+    if (next >= nchunks) { lk_store<C>(recs[0][wave], dts[0][wave], sub, part, va); return; }
+    lk_decode<C>(a, table, rows_out, next, lane, recs[1][wave], dts[1][wave]);
+    __builtin_amdgcn_wave_barrier();
+    lk_gather<C>(recs[1][wave], sub, part, vb);
+    lk_store<C>(recs[0][wave], dts[0][wave], sub, part, va);
+    __builtin_amdgcn_wave_barrier();
+    chunk = next;
+    // ---- A: next chunk's loads, then B's stores
+    next = chunk + wstride;
+    if (next >= nchunks) { lk_store<C>(recs[1][wave], dts[1][wave], sub, part, vb); return; }
+    lk_decode<C>(a, table, rows_out, next, lane, recs[0][wave], dts[0][wave]);
+    __builtin_amdgcn_wave_barrier();
+    lk_gather<C>(recs[0][wave], sub, part, va);
+    lk_store<C>(recs[1][wave], dts[1][wave], sub, part, vb);
+    __builtin_amdgcn_wave_barrier();
+    chunk = next;
   }
 }
 
@@ -731,6 +918,48 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
   a.total_slots = (uint32_t)slots;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   constexpr int U = 4;
+  static const int variant = getenv("TT_LOOKUP_VARIANT") ? atoi(getenv("TT_LOOKUP_VARIANT")) : 0;
+  const bool pow2c = vec4 && table && C <= 64 && (C & (C - 1)) == 0;
+  static const int cpw = getenv("TT_LOOKUP_CPW") ? atoi(getenv("TT_LOOKUP_CPW")) : 0;
+  if (pow2c && cpw > 0 && C == 8) {
+    const int64_t nchunks = tt_cdiv(slots, 64);
+    const int grid = (int)tt_cdiv(nchunks, (int64_t)(kThreads / 64) * cpw);
+    lookup_pipe_kernel<8><<<grid, kThreads, 0, st>>>(a, table, rows_out);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+  }
+  if (pow2c && variant != 1) {
+    static const int spw_env = getenv("TT_LOOKUP_SPW") ? atoi(getenv("TT_LOOKUP_SPW")) : 0;
+    const int rpi = 64 / (int)C;
+    int spw = spw_env > 0 ? spw_env : 64;
+    if (spw < rpi) spw = rpi;
+    int64_t wg = tt_cdiv(tt_cdiv(slots, spw), kThreads / 64);
+    const int64_t cap = (int64_t)ctx->num_cus * 16;
+    const int grid = (int)(wg < cap ? wg : cap);
+#define TT_LK2(CV, SV)                                                                                         \
+    if (variant == 2) lookup_wave_kernel<CV, SV, 1><<<grid, kThreads, 0, st>>>(a, table, rows_out);               \
+    else if (variant == 3) lookup_wave_kernel<CV, SV, 2><<<grid, kThreads, 0, st>>>(a, table, rows_out);          \
+    else if (variant == 4) lookup_wave_kernel<CV, SV, 4><<<grid, kThreads, 0, st>>>(a, table, rows_out);          \
+    else if (variant == 5) lookup_wave_kernel<CV, SV, 5><<<grid, kThreads, 0, st>>>(a, table, rows_out);          \
+    else lookup_wave_kernel<CV, SV, 0><<<grid, kThreads, 0, st>>>(a, table, rows_out);
+#define TT_LK(CV)                                                                                              \
+    if (spw >= 64 || 64 / CV > 32) { TT_LK2(CV, 64) }                                                             \
+    else if (spw >= 32 || 64 / CV > 16) { TT_LK2(CV, (64 / CV > 32 ? 64 : 32)) }                                   \
+    else { TT_LK2(CV, (64 / CV > 16 ? 32 : 16)) }
+    switch (C) {
+      case 1: TT_LK2(1, 64) break;
+      case 2: TT_LK2(2, 64) break;
+      case 4: TT_LK(4) break;
+      case 8: TT_LK(8) break;
+      case 16: TT_LK(16) break;
+      case 32: TT_LK(32) break;
+      default: TT_LK(64) break;
+    }
+#undef TT_LK
+#undef TT_LK2
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+  }
   const int grid = grid_for(ctx, tt_cdiv(slots * C, U));
   if (vec4 && table) lookup_kernel<4, U><<<grid, kThreads, 0, st>>>(a, table, rows_out);
   else lookup_kernel<1, U><<<grid, kThreads, 0, st>>>(a, table, rows_out);
