@@ -116,6 +116,7 @@ def main():
 
     use_graph = args.mode == "graph" and dist is None and args.optimizer != "torch_adam"
     gstep = None
+    profile = ops.LookupProfile(dev) if use_graph else None      # device-clock stamps: work inside a graph
     if use_graph:
         from jodalrob_twotower_amd.graph import GraphedTrainStep
         gstep = GraphedTrainStep(task, opt, pool[0], return_metrics=True, warmup=3)
@@ -146,18 +147,18 @@ def main():
     timer = ops.KernelTimer(names=["tt_embed_lookup_fwd"])
     if gstep is None:
         ops.set_timer(timer)
+    else:
+        profile.reset()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         res = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
     ops.set_timer(None)
-    if gstep is not None:
-        ops.set_timer(timer)
-        for i in range(args.steps):
-            step(args.warmup + i, eager=True)
-        fence()
-        ops.set_timer(None)
+    lookup_us = profile.durations_us() if profile is not None else []
+    if profile is not None:
+        profile.close()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -165,6 +166,8 @@ def main():
     loss_val = float(res["loss"])
     ksum = timer.summary()
     n_launch, lookup_ms = ksum.get("tt_embed_lookup_fwd", (0, float("nan")))
+    if lookup_us:
+        n_launch, lookup_ms = len(lookup_us), sum(lookup_us) / len(lookup_us) * 1e-3
 
     breakdown = None
     if args.breakdown and rank == 0:
@@ -205,7 +208,10 @@ def main():
         "roofline": {"kernel": "lookup_kernel (tt_embed_lookup_fwd)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": n_launch, "mean_launch_us": lookup_ms * 1e3,
-                     "timed_in": "timed region (HIP events)" if gstep is None else "eager pass after the graph-replay timed region (HIP events)"},
+                     "timed_in": "timed region, HIP events on the launch stream" if gstep is None else
+                                 "timed region (graph replay), every launch: device-clock (s_memrealtime, 100 MHz) stamps, min start .. "
+                                 "max end over the kernel's workgroups, ring of per-launch slots read after the region "
+                                 "(HIP events cannot bracket one kernel inside a replayed graph)"},
         "final_loss": loss_val,
     }
     if breakdown is not None:

@@ -75,6 +75,15 @@ typedef struct tt_embed_side {
   int32_t out_dtype; /* TT_F32 (bit-exact row copy) or TT_BF16 (round-to-nearest-even) */
 } tt_embed_side;
 
+/* Measurement hook: a ring of per-launch device-clock stamps for the lookup kernel, usable inside a
+ * captured graph (where HIP events cannot bracket one kernel) and without any host synchronisation.
+ * `ring_dev` = 2 + 2*n_slots + 2*4096 uint64 words of device memory, zero-initialised by the caller:
+ *   [0] launch counter, [1] reserved, then n_slots pairs {start, end} -- pair i (mod n_slots) belongs to
+ *   launch number i: start = min over the kernel's workgroups of their first instruction, end = max over
+ *   workgroups of the time all their stores have completed; the tail is per-workgroup scratch.
+ *   100 MHz clock: (end - start) * 10 ns = duration.  While the hook is on, every lookup launch is followed by
+ *   a one-workgroup reduction kernel that fills the pair.  ring_dev == NULL switches the hook off. */
+int tt_embed_lookup_set_profile(tt_ctx* ctx, uint64_t* ring_dev, int32_t n_slots);
 int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E,
                         const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_out,
                         tt_stream stream);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "tt_ctx_destroy": (C.c_int, [vp]),
     "tt_last_error_string": (C.c_char_p, []),
     "tt_ctx_num_cus": (C.c_int, [vp]),
+    "tt_embed_lookup_set_profile": (C.c_int, [vp, vp, i32]),
     "tt_embed_lookup_fwd": (C.c_int, [vp, vp, i64, i32, C.POINTER(EmbedSide), i32, i64, vp, vp]),
     "tt_dedup_workspace_bytes": (sz, [i64]),
     "tt_dedup_plan": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),

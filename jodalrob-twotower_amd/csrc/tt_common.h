@@ -11,6 +11,8 @@ struct tt_ctx {
   int device;
   int num_cus;
   size_t lds_per_block;
+  unsigned long long* lookup_stamps;   // optional device ring (tt_embed_lookup_set_profile)
+  int lookup_stamp_slots;
 };
 
 void tt_set_error(const char* fmt, ...);

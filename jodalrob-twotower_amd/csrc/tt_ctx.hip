@@ -34,6 +34,8 @@ int tt_ctx_create(int device, tt_ctx** out) {
   c->device = device;
   c->num_cus = prop.multiProcessorCount;
   c->lds_per_block = prop.sharedMemPerBlock;
+  c->lookup_stamps = nullptr;
+  c->lookup_stamp_slots = 0;
   *out = c;
   return TT_OK;
 }

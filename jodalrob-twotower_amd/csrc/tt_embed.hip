@@ -114,6 +114,7 @@ __global__ __launch_bounds__(kThreads) void lookup_kernel(SideSet a, const float
 // time (C = E/4 lanes per row), issuing ALL row loads of the chunk before the first store, so every lane
 // keeps C x 16 B in flight and a wave-instruction still reads whole 128-B lines.
 // ------------------------------------------------------------------------------------------------
+constexpr int kProfileMaxWg = 4096;
 struct SlotRec {
   const float* src;
   char* dst;
@@ -123,7 +124,11 @@ using f32x4n = __attribute__((ext_vector_type(4))) float;
 template <int C, int SPW, int MODE>   // SPW slots per wave pass; MODE 0: nt stores (default); 1: loads only;
                                       // 2: stores only (ablations); 4: plain stores; 5: nt loads + nt stores
 __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const float* __restrict__ table,
-                                                              int32_t* __restrict__ rows_out) {
+                                                              int32_t* __restrict__ rows_out,
+                                                              unsigned long long* __restrict__ ring, int ring_slots) {
+  // measurement only: per-workgroup start/end stamps (plain stores; reduced by lookup_profile_reduce_kernel)
+  unsigned long long* wg_stamps = ring ? ring + 2 + 2 * ring_slots + 2 * blockIdx.x : nullptr;
+  if (wg_stamps && blockIdx.x < kProfileMaxWg && threadIdx.x == 0) wg_stamps[0] = __builtin_amdgcn_s_memrealtime();
   __shared__ SlotRec recs[kThreads / 64][SPW];
   __shared__ int dts[kThreads / 64][SPW];
   constexpr int RPI = 64 / C;                       // rows per wave-instruction
@@ -197,6 +202,31 @@ __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const 
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (wg_stamps) {                                       // measurement only: wait for this workgroup's stores
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (blockIdx.x < kProfileMaxWg && threadIdx.x == 0) wg_stamps[1] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+// one workgroup: min start / max end over the lookup's workgroups -> slot of this launch; bump the counter
+__global__ __launch_bounds__(kThreads) void lookup_profile_reduce_kernel(unsigned long long* __restrict__ ring, int ring_slots, int nwg) {
+  __shared__ unsigned long long smin[kThreads], smax[kThreads];
+  const unsigned long long* wg = ring + 2 + 2 * ring_slots;
+  unsigned long long lo = ~0ull, hi = 0ull;
+  for (int i = threadIdx.x; i < nwg; i += kThreads) {
+    lo = wg[2 * i] < lo ? wg[2 * i] : lo;
+    hi = wg[2 * i + 1] > hi ? wg[2 * i + 1] : hi;
+  }
+  smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < kThreads; ++i) { lo = smin[i] < lo ? smin[i] : lo; hi = smax[i] > hi ? smax[i] : hi; }
+    const unsigned long long n = ring[0];
+    ring[2 + 2 * (n % (unsigned long long)ring_slots)] = lo;
+    ring[3 + 2 * (n % (unsigned long long)ring_slots)] = hi;
+    ring[0] = n + 1;
   }
 }
 
@@ -890,6 +920,14 @@ AdamK make_adam(int64_t step, float lr, float b1, float b2, float eps, float wd,
 
 extern "C" {
 
+int tt_embed_lookup_set_profile(tt_ctx* ctx, uint64_t* ring_dev, int32_t n_slots) {
+  TT_CHECK_ARG(ctx, "tt_embed_lookup_set_profile: ctx NULL");
+  TT_CHECK_ARG(ring_dev == nullptr || n_slots >= 1, "tt_embed_lookup_set_profile: n_slots must be >= 1");
+  ctx->lookup_stamps = reinterpret_cast<unsigned long long*>(ring_dev);
+  ctx->lookup_stamp_slots = ring_dev ? n_slots : 0;
+  return TT_OK;
+}
+
 int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const tt_embed_side* sides,
                         int32_t n_sides, int64_t B, int32_t* rows_out, tt_stream stream) {
   TT_CHECK_ARG(ctx && sides && (table || rows_out), "tt_embed_lookup_fwd: NULL argument");
@@ -937,11 +975,11 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
     const int64_t cap = (int64_t)ctx->num_cus * 16;
     const int grid = (int)(wg < cap ? wg : cap);
 #define TT_LK2(CV, SV)                                                                                         \
-    if (variant == 2) lookup_wave_kernel<CV, SV, 1><<<grid, kThreads, 0, st>>>(a, table, rows_out);               \
-    else if (variant == 3) lookup_wave_kernel<CV, SV, 2><<<grid, kThreads, 0, st>>>(a, table, rows_out);          \
-    else if (variant == 4) lookup_wave_kernel<CV, SV, 4><<<grid, kThreads, 0, st>>>(a, table, rows_out);          \
-    else if (variant == 5) lookup_wave_kernel<CV, SV, 5><<<grid, kThreads, 0, st>>>(a, table, rows_out);          \
-    else lookup_wave_kernel<CV, SV, 0><<<grid, kThreads, 0, st>>>(a, table, rows_out);
+    if (variant == 2) lookup_wave_kernel<CV, SV, 1><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots);               \
+    else if (variant == 3) lookup_wave_kernel<CV, SV, 2><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots);          \
+    else if (variant == 4) lookup_wave_kernel<CV, SV, 4><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots);          \
+    else if (variant == 5) lookup_wave_kernel<CV, SV, 5><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots);          \
+    else lookup_wave_kernel<CV, SV, 0><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots);
 #define TT_LK(CV)                                                                                              \
     if (spw >= 64 || 64 / CV > 32) { TT_LK2(CV, 64) }                                                             \
     else if (spw >= 32 || 64 / CV > 16) { TT_LK2(CV, (64 / CV > 32 ? 64 : 32)) }                                   \
@@ -958,6 +996,11 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
 #undef TT_LK
 #undef TT_LK2
     TT_LAUNCH_CHECK();
+    if (ctx->lookup_stamps) {
+      lookup_profile_reduce_kernel<<<1, kThreads, 0, st>>>(ctx->lookup_stamps, ctx->lookup_stamp_slots,
+                                                           grid < kProfileMaxWg ? grid : kProfileMaxWg);
+      TT_LAUNCH_CHECK();
+    }
     return TT_OK;
   }
   const int grid = grid_for(ctx, tt_cdiv(slots * C, U));

@@ -102,6 +102,30 @@ def embed_lookup(table: Optional[torch.Tensor], sides: Sequence[LookupSide], B: 
     return rows
 
 
+class LookupProfile:
+    """Ring of device-clock stamps of the lookup kernel, one slot per launch (works inside captured graphs,
+    needs no host synchronisation while measuring)."""
+
+    def __init__(self, device, n_slots: int = 4096):
+        self.device, self.n = torch.device(device), n_slots
+        self.ring = torch.zeros(2 + 2 * n_slots + 2 * 4096, dtype=torch.int64, device=self.device)
+        L.check(L.load().tt_embed_lookup_set_profile(L.ctx(self.device), L.ptr(self.ring), n_slots), "tt_embed_lookup_set_profile")
+
+    def reset(self):
+        self.ring.zero_()
+
+    def durations_us(self):
+        """Kernel durations (us) of the launches since the last reset(); synchronises."""
+        torch.cuda.synchronize(self.device)
+        r = self.ring.cpu()
+        n = min(int(r[0]), self.n)
+        s, e = r[2:2 + 2 * n:2], r[3:3 + 2 * n:2]
+        return [float(x) * 0.01 for x in (e - s).tolist() if x > 0]  # 100 MHz clock
+
+    def close(self):
+        L.check(L.load().tt_embed_lookup_set_profile(L.ctx(self.device), None, 0), "tt_embed_lookup_set_profile")
+
+
 @dataclass
 class DedupPlan:
     sorted_src: torch.Tensor
