@@ -285,6 +285,11 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
  * "all_similarities": two_tower_train_task.py:94, :206) */
 int tt_score_matrix(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D,
                     float inv_t, float* S, int64_t lds, tt_stream stream);
+/* rank of the positive column of every row of a dense matrix (evaluator MRR / Recall@K on a given
+ * similarity matrix: src/evaluation/evaluator.py:45-71):
+ *   rank[r] = #{c: S[r,c] > S[r,r+off]} + #{c < r+off: S[r,c] == S[r,r+off]} */
+int tt_diag_rank_rows(tt_ctx* ctx, const float* S, int64_t R, int64_t Ccols, int64_t lds,
+                      int64_t diag_offset, int32_t* rank, tt_stream stream);
 /* per-row top-k of a dense matrix, descending, ties -> lower column first (torch.topk use in
  * predict_batch :195 and evaluator.py:35); k <= 64 */
 int tt_topk_rows(tt_ctx* ctx, const float* S, int64_t R, int64_t Ccols, int64_t lds, int32_t k,

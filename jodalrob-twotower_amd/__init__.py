@@ -13,8 +13,13 @@ from .cat_embed import CategoricalEmbedder, EmbeddingStore, create_categorical_e
 from .towers import BaseTower, CompanyTower, NoticeTower                          # noqa: F401
 from .two_tower_model import TwoTowerModel, create_two_tower_model               # noqa: F401
 from .two_tower_train_task import TwoTowerTrainTask, create_two_tower_train_task  # noqa: F401
+from .feature_projector import FeatureProjector                                   # noqa: F401
+from .feature_preprocessor import FeaturePreprocessor                             # noqa: F401
+from .evaluator import TwoTowerEvaluator                                          # noqa: F401
+from .optim import FusedAdam                                                      # noqa: F401
 
 __all__ = ["KeyedJaggedTensor", "build_batch_kjt", "SideSchema", "PairSchema", "TorchRecSchema",
            "build_torchrec_schema_from_meta", "classify_columns", "CategoricalEmbedder", "EmbeddingStore",
            "create_categorical_embedder", "BaseTower", "NoticeTower", "CompanyTower", "TwoTowerModel",
-           "create_two_tower_model", "TwoTowerTrainTask", "create_two_tower_train_task"]
+           "create_two_tower_model", "TwoTowerTrainTask", "create_two_tower_train_task", "FeatureProjector",
+           "FeaturePreprocessor", "TwoTowerEvaluator", "FusedAdam"]

@@ -303,6 +303,26 @@ __global__ __launch_bounds__(kThreads) void topk_rows_kernel(const float* __rest
   }
 }
 
+__global__ __launch_bounds__(kThreads) void diag_rank_rows_kernel(const float* __restrict__ S, int64_t R, int64_t C, int64_t lds,
+                                                                 int64_t off, int32_t* __restrict__ rank) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const int64_t pos = row + off;
+  const float* s = S + row * lds;
+  int cnt = 0;
+  if (pos >= 0 && pos < C) {
+    const float d = s[pos];
+    for (int64_t c = lane; c < C; c += 64) {
+      const float v = s[c];
+      cnt += (v > d || (v == d && c < pos)) ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0) rank[row] = cnt;
+}
+
 inline bool vec_ok(const float* p, int D) { return tt_aligned(p, 16) && (D % 4 == 0); }
 
 }  // namespace
@@ -370,6 +390,16 @@ int tt_score_matrix(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, in
   TT_CHECK_ARG(Ra >= 0 && Rb >= 0 && D >= 1 && lds >= Rb, "tt_score_matrix: bad shape");
   TT_CHECK_ARG(Ra < ((int64_t)1 << 31) && Rb < ((int64_t)1 << 31), "tt_score_matrix: too many rows");
   return tt_gemm_nt(reinterpret_cast<hipStream_t>(stream), A, D, Bm, D, nullptr, S, lds, Ra, Rb, D, false, inv_t);
+}
+
+int tt_diag_rank_rows(tt_ctx* ctx, const float* S, int64_t R, int64_t Ccols, int64_t lds, int64_t diag_offset, int32_t* rank,
+                      tt_stream stream) {
+  TT_CHECK_ARG(ctx && (R == 0 || (S && rank)), "tt_diag_rank_rows: NULL argument");
+  TT_CHECK_ARG(R >= 0 && Ccols >= 1 && lds >= Ccols, "tt_diag_rank_rows: bad shape");
+  if (R == 0) return TT_OK;
+  diag_rank_rows_kernel<<<(unsigned)tt_cdiv(R, 4), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(S, R, Ccols, lds, diag_offset, rank);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
 }
 
 int tt_topk_rows(tt_ctx* ctx, const float* S, int64_t R, int64_t Ccols, int64_t lds, int32_t k, float* vals, int64_t* idx,

@@ -1,0 +1,3 @@
+"""Drop-in shim: same import path as the reference's src/towers/tower/base_tower.py; re-exports the MI355X implementation.
+Put this directory's parent (`.../dropin`) and the repository root first on sys.path."""
+from jodalrob_twotower_amd.towers import BaseTower  # noqa: F401

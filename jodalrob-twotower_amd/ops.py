@@ -313,6 +313,15 @@ def score_matrix(A, Bm, inv_t):
     return S
 
 
+def diag_rank_rows(S, diag_offset=0):
+    dev, R, Cc = S.device, S.shape[0], S.shape[1]
+    assert S.stride(1) == 1 and S.dtype == torch.float32
+    rank = torch.empty(R, dtype=torch.int32, device=dev)
+    L.check(L.load().tt_diag_rank_rows(L.ctx(dev), L.ptr(S), R, Cc, S.stride(0), diag_offset, L.ptr(rank), L.stream(dev)),
+            "tt_diag_rank_rows")
+    return rank
+
+
 def topk_rows(S, k):
     dev, R, Cc = S.device, S.shape[0], S.shape[1]
     assert S.stride(1) == 1

@@ -68,3 +68,41 @@ def make_batch(B: int, vocab_n: Sequence[int], vocab_c: Sequence[int], keys_n, k
 
     return {"notice": {"dense": dense(din_n), "kjt": KeyedJaggedTensor(list(keys_n), ids_for(vocab_n))},
             "company": {"dense": dense(din_c), "kjt": KeyedJaggedTensor(list(keys_c), ids_for(vocab_c))}}
+
+
+class SyntheticSource:
+    """In-memory stand-in for the PostgreSQL engine of the reference (data/database_connector.py -- out of
+    scope): produces feature stores in the layout of src/torchrec_preprocess/feature_store.py:148-153 and
+    positive (notice, company) pairs."""
+
+    def __init__(self, n_notice: int, n_company: int, n_pairs: int, vocab_notice, vocab_company, seed: int = 0,
+                 text_dim: int = 768):
+        self.n = {"notice": n_notice, "company": n_company}
+        self.vocab = {"notice": list(vocab_notice), "company": list(vocab_company)}
+        self.n_pairs, self.seed, self.text_dim = n_pairs, seed, text_dim
+
+    def build_feature_store(self, table: str, side_schema, chunksize: int = 5000, limit=None):
+        import numpy as np
+        n = self.n[table] if limit is None else min(self.n[table], limit)
+        rng = np.random.default_rng([self.seed, 1 if table == "notice" else 2])
+        vocab = self.vocab[table]
+        if len(vocab) != len(side_schema.categorical):
+            raise ValueError(f"{table}: {len(side_schema.categorical)} categorical keys but {len(vocab)} vocab sizes")
+        if table == "notice":
+            ids = [(f"N{i:09d}", "00") for i in range(n)]
+        else:
+            ids = [f"{1000000000 + i}" for i in range(n)]
+        return {
+            "ids": ids,
+            "numeric": rng.standard_normal((n, len(side_schema.numeric))).astype(np.float32) if side_schema.numeric else None,
+            "categorical": np.stack([rng.integers(0, v, n) for v in vocab], axis=1).astype(np.int64),
+            "text": {c: rng.standard_normal((n, self.text_dim)).astype(np.float32) for c in (side_schema.text or [])},
+            "categorical_keys": list(side_schema.categorical),
+        }
+
+    def load_pairs(self, pair_schema, limit=None):
+        import numpy as np
+        rng = np.random.default_rng([self.seed, 3])
+        n = self.n_pairs if limit is None else min(self.n_pairs, limit)
+        ni, ci = rng.integers(0, self.n["notice"], n), rng.integers(0, self.n["company"], n)
+        return [((f"N{a:09d}", "00"), f"{1000000000 + b}") for a, b in zip(ni, ci)]

@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""Training driver on the MI355X path -- the counterpart of the reference's scripts/train.py
+(config dict :84-134, Adam + LambdaLR warm-up :231-242, loop :313-352, validation :367-423, evaluator
+:444-452, checkpoints :497-551, results CSV :24-75).  The reference driver needs PostgreSQL
+(DatabaseConnector(), :159); this one takes the same config keys and a synthetic feature/pair source.
+
+    python scripts/train.py [--resume PATH] [--steps N] [--batch-size B]
+"""
+from __future__ import annotations
+
+import argparse
+import csv
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "jodalrob-twotower_amd" / "dropin"))
+
+from src.evaluation.evaluator import TwoTowerEvaluator                       # noqa: E402  (same imports as the reference driver)
+from src.torchrec_preprocess.schema import build_torchrec_schema_from_meta    # noqa: E402
+from src.towers.pairs.unified_bid_data_loader import create_unified_bid_dataloaders  # noqa: E402
+from src.towers.two_tower_train_task import create_two_tower_train_task       # noqa: E402
+from jodalrob_twotower_amd import synthetic                                   # noqa: E402
+from jodalrob_twotower_amd.optim import FusedAdam                             # noqa: E402
+
+RESULT_COLUMNS = ["timestamp", "batch_size", "tower_hidden_dims", "final_embedding_dim", "categorical_embedding_dim",
+                  "learning_rate", "num_epochs", "train_batches", "final_train_loss", "final_train_accuracy", "val_loss",
+                  "val_accuracy", "recall@5", "recall@10", "mrr", "similarity_gap", "total_params", "train_seconds"]
+
+
+def save_checkpoint(model, optimizer, epoch, loss, save_dir, is_best=False, is_final=False):
+    save_dir = Path(save_dir)
+    save_dir.mkdir(parents=True, exist_ok=True)
+    ckpt = {"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": optimizer.state_dict(), "loss": loss}
+    if not is_final:
+        torch.save(ckpt, save_dir / f"checkpoint_epoch_{epoch + 1}.pt")
+    if is_best:
+        torch.save(ckpt, save_dir / "best_model.pt")
+    if is_final:
+        torch.save(ckpt, save_dir / "final_model.pt")
+        torch.save(model.state_dict(), save_dir / "model_weights.pt")
+
+
+def load_checkpoint(model, optimizer, checkpoint_path):
+    ckpt = torch.load(checkpoint_path, map_location="cuda:0", weights_only=True)
+    model.load_state_dict(ckpt["model_state_dict"])
+    optimizer.load_state_dict(ckpt["optimizer_state_dict"])
+    return ckpt["epoch"] + 1, ckpt["loss"]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--resume", default=None)
+    ap.add_argument("--batch-size", type=int, default=256)
+    ap.add_argument("--entities", type=int, default=10_000)
+    ap.add_argument("--pairs", type=int, default=100_000)
+    ap.add_argument("--steps", type=int, default=None, help="stop after this many training steps")
+    ap.add_argument("--output-dir", default="output/models")
+    a = ap.parse_args()
+    config = {"batch_size": a.batch_size, "test_split": 0.2, "shuffle_seed": 42, "pair_limit": a.pairs,
+              "categorical_embedding_dim": 32, "notice_dense_input_dim": 256, "company_dense_input_dim": 128,
+              "tower_hidden_dims": [128, 64], "final_embedding_dim": 64, "dropout_rate": 0.1, "temperature": 1.0,
+              "loss_type": "cross_entropy", "learning_rate": 1e-3, "weight_decay": 1e-5, "num_epochs": 1, "warmup_ratio": 0.05,
+              "log_interval": 20, "output_dir": a.output_dir}
+    device = torch.device("cuda:0")
+    real = synthetic.load_real_schema(ROOT / "jodalrob-twotower_amd" / "schema_real.json")
+    tmp = Path(tempfile.mkdtemp(prefix="tt_train_"))
+    meta_rows = [synthetic.META_HEADER]
+    for side in ("notice", "company"):
+        for c in real[side]["pk_cols"]:
+            meta_rows.append(f"{side},{c},text,Y,,,,0,,Y,Y,,")
+        for c in real[side]["numeric"]:
+            meta_rows.append(f"{side},{c},numeric,Y,,,,0,,,,,")
+        for c, v in zip(real[side]["categorical"], real[side]["vocab_sizes"]):
+            meta_rows.append(f"{side},{c},text,Y,,Y,{v - 10},0,,,,,")
+        for c in real[side]["text"]:
+            meta_rows.append(f"{side},{c},text,Y,,N,,0,,,,,")
+    meta = tmp / "metadata.csv"
+    meta.write_text("\n".join(meta_rows) + "\n", encoding="utf-8")
+    schema = build_torchrec_schema_from_meta(notice_table="notice", company_table="company", pair_table="bid_two_tower",
+                                             pair_notice_id_cols=["bidntceno", "bidntceord"], pair_company_id_cols=["bizno"],
+                                             metadata_path=str(meta))
+    source = synthetic.SyntheticSource(a.entities, a.entities, a.pairs, real["notice"]["vocab_sizes"], real["company"]["vocab_sizes"])
+    train_loader, test_loader = create_unified_bid_dataloaders(source, schema, batch_size=config["batch_size"],
+                                                               test_split=config["test_split"], shuffle_seed=config["shuffle_seed"],
+                                                               test_mode=True, pair_limit=config["pair_limit"], device=device)
+    train_task = create_two_tower_train_task(schema.notice.categorical, schema.company.categorical, metadata_path=str(meta),
+                                             categorical_embedding_dim=config["categorical_embedding_dim"],
+                                             notice_dense_input_dim=config["notice_dense_input_dim"],
+                                             company_dense_input_dim=config["company_dense_input_dim"],
+                                             tower_hidden_dims=config["tower_hidden_dims"],
+                                             final_embedding_dim=config["final_embedding_dim"], dropout_rate=config["dropout_rate"],
+                                             temperature=config["temperature"], loss_type=config["loss_type"], device=device)
+    optimizer = FusedAdam.for_task(train_task, lr=config["learning_rate"], weight_decay=config["weight_decay"])
+    warmup_steps = max(1, int(len(train_loader) * config["warmup_ratio"]))
+    scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda s: s / warmup_steps if s < warmup_steps else 1.0, last_epoch=-1)
+    start_epoch = 0
+    if a.resume:
+        start_epoch, _ = load_checkpoint(train_task, optimizer, a.resume)
+    total_params = sum(p.numel() for p in train_task.parameters())
+    print(f"params: {total_params:,}  train batches: {len(train_loader)}  warm-up steps: {warmup_steps}")
+    evaluator = TwoTowerEvaluator(device=device)
+    t0, steps, best = time.time(), 0, float("inf")
+    train_losses, train_accs = [], []
+    for epoch in range(start_epoch, config["num_epochs"]):
+        train_task.train()
+        for batch in train_loader:
+            optimizer.zero_grad()
+            result = train_task(batch, return_metrics=True)
+            result["loss"].backward()
+            optimizer.step()
+            scheduler.step()
+            steps += 1
+            if steps % config["log_interval"] == 0:
+                train_losses.append(result["loss"].item())
+                train_accs.append(result["accuracy"].item())
+                print(f"step {steps:5d}  loss {train_losses[-1]:.4f}  acc {train_accs[-1]:.4f}  "
+                      f"pos {result['positive_similarity_mean'].item():.3f}  neg {result['negative_similarity_mean'].item():.3f}")
+            if a.steps and steps >= a.steps:
+                break
+        val = evaluator.evaluate_comprehensive(train_task, test_loader, max_batches=50, verbose=True)
+        if val.get("loss", float("inf")) < best:
+            best = val["loss"]
+            save_checkpoint(train_task, optimizer, epoch, best, config["output_dir"], is_best=True)
+        else:
+            save_checkpoint(train_task, optimizer, epoch, val.get("loss", 0.0), config["output_dir"])
+    save_checkpoint(train_task, optimizer, config["num_epochs"] - 1, best, config["output_dir"], is_final=True)
+    row = [time.strftime("%Y-%m-%d %H:%M:%S"), config["batch_size"], str(config["tower_hidden_dims"]), config["final_embedding_dim"],
+           config["categorical_embedding_dim"], config["learning_rate"], config["num_epochs"], steps,
+           train_losses[-1] if train_losses else "", train_accs[-1] if train_accs else "", val.get("loss", ""), val.get("accuracy", ""),
+           val.get("recall@5", ""), val.get("recall@10", ""), val.get("mrr", ""), val.get("similarity_gap", ""), total_params,
+           round(time.time() - t0, 2)]
+    out_csv = Path(config["output_dir"]).parent / "train_results.csv"
+    new = not out_csv.exists()
+    with open(out_csv, "a", newline="") as f:
+        w = csv.writer(f)
+        if new:
+            w.writerow(RESULT_COLUMNS)
+        w.writerow(row)
+    print(f"done: {steps} steps in {time.time() - t0:.1f}s; results appended to {out_csv}")
+
+
+if __name__ == "__main__":
+    main()
