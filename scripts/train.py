@@ -106,7 +106,9 @@ def main():
     print(f"params: {total_params:,}  train batches: {len(train_loader)}  warm-up steps: {warmup_steps}")
     evaluator = TwoTowerEvaluator(device=device)
     t0, steps, best = time.time(), 0, float("inf")
-    train_losses, train_accs = [], []
+    train_losses, train_accs, val = [], [], {}
+    if start_epoch >= config["num_epochs"]:
+        config["num_epochs"] = start_epoch + 1           # resumed after the last epoch: run one more
     for epoch in range(start_epoch, config["num_epochs"]):
         train_task.train()
         for batch in train_loader:
