@@ -133,6 +133,8 @@ class DedupPlan:
     seg_offsets: torch.Tensor
     n_unique: torch.Tensor        # int32 [1] on device
     M: int
+    keep: object = None           # tensors that must outlive the plan's kernels
+    stream: object = None         # stream the plan was built on (joined before first use)
 
 
 def dedup_plan(rows: torch.Tensor, table_rows: int) -> DedupPlan:

@@ -14,6 +14,7 @@ table gradients.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Dict, List, Optional, Sequence
 
@@ -27,6 +28,19 @@ from .cat_embed import CategoricalEmbedder, EmbeddingStore
 
 def _al(n: int) -> int:
     return (n + 63) // 64 * 64
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev: torch.device, n: int):
+    """Cached side streams: independent towers and the duplicate-row plan run beside the main stream (every
+    kernel of a tower fills at most half of the 256 CUs); a captured graph keeps them as parallel branches."""
+    key = torch.device(dev).index
+    lst = _SIDE_STREAMS.setdefault(key, [])
+    while len(lst) < n:
+        lst.append(torch.cuda.Stream(device=dev))
+    return lst[:n]
 
 
 class BaseTower(nn.Module):
@@ -223,14 +237,35 @@ class _TowersFn(torch.autograd.Function):
                     plans.append((store, [g[0]], ops.dedup_plan(rows, store.rows) if grad_on else None))
                 continue
             rows = ops.embed_lookup(store.weight, [g[1] for g in group], B, want_rows=grad_on)
-            plans.append((store, [g[0] for g in group], ops.dedup_plan(rows, store.rows) if grad_on else None))
-        for s in sides:
+            plan = None
+            if grad_on:         # the plan depends on ids only and is first needed in the backward: side stream
+                cur = torch.cuda.current_stream(store.device)
+                ds = _side_streams(store.device, len(sides) + 1)[-1]
+                ds.wait_stream(cur)
+                with torch.cuda.stream(ds):
+                    plan = ops.dedup_plan(rows, store.rows)
+                plan.keep = rows                                   # keep the sort input alive until it has run
+                plan.stream = ds
+            plans.append((store, [g[0] for g in group], plan))
+        live = [s for s in sides if s.B]
+        if exch is None and len(live) > 1:
+            dev0 = live[0].emb.device
+            cur = torch.cuda.current_stream(dev0)
+            branch = [cur] + _side_streams(dev0, len(live) - 1)
+            for st in branch[1:]:
+                st.wait_stream(cur)
+        else:
+            branch = [None] * len(live)
+        for s, st in zip(live, branch):
             tw = s.tower
-            if s.B:
+            with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
                 ops.tower_fwd(tw._params(), s.acts_struct, s.B, s.train, s.p_drop, s.seed, s.emb.device, tw._seed_dev)
                 if s.train:
                     for i in range(tw.n_hidden):
                         tw.mlp[4 * i + 2].num_batches_tracked.add_(1)
+        for st in branch[1:]:
+            if st is not None:
+                branch[0].wait_stream(st)
         ctx.sides, ctx.plans, ctx.spans, ctx.n_flat = sides, plans, spans, len(flat)
         # hand out aliases: keeping the returned objects themselves on ctx would form a reference cycle
         outs = tuple(s.emb.view(s.emb.shape) for s in sides)
@@ -245,10 +280,18 @@ class _TowersFn(torch.autograd.Function):
         if exch is not None:            # global objective = mean over ranks of the local losses
             d_embs = [None if d is None else d * (1.0 / exch.world) for d in d_embs]
         flat_grads = []
-        for s, d_emb, (pos, nd, nt) in zip(ctx.sides, d_embs, ctx.spans):
+        work = [(s, d, sp) for s, d, sp in zip(ctx.sides, d_embs, ctx.spans) if s.B and d is not None]
+        if exch is None and len(work) > 1:
+            dev0 = work[0][0].emb.device
+            cur0 = torch.cuda.current_stream(dev0)
+            branch = [cur0] + _side_streams(dev0, len(work) - 1)
+            for st in branch[1:]:
+                st.wait_stream(cur0)
+        else:
+            branch = [None] * len(work)
+        for (s, d_emb, (pos, nd, nt)), st in zip(work, branch):
+          with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
             tw = s.tower
-            if s.B == 0 or d_emb is None:
-                continue
             dev = s.emb.device
             d_emb = d_emb.to(dtype=torch.float32).contiguous()
             dps = tw.dense_parameters()
@@ -277,6 +320,9 @@ class _TowersFn(torch.autograd.Function):
             flat_grads.append(buf[:offs[len(dps)]])
             d_x = buf[offs[len(dps)]:offs[len(dps)] + B * tw.x_width].view(B, tw.x_width)
             dxs[id(s)] = d_x[:, tw.tower_hidden_dims[0]:]
+        for st in branch[1:]:
+            if st is not None:
+                branch[0].wait_stream(st)
         if exch is not None:
             exch.all_reduce_dense(flat_grads)
             if ctx.exch_state is not None:
@@ -299,6 +345,8 @@ class _TowersFn(torch.autograd.Function):
                 if d is None:       # this tower received no gradient: contribute zeros
                     d = torch.zeros((s.B, K * store.E), dtype=torch.float32, device=store.device)
                 srcs.append((d, K))
+            if plan.stream is not None:                                           # join the plan's side stream
+                torch.cuda.current_stream(store.device).wait_stream(plan.stream)
             store.accumulate_grad(plan, srcs, plan_sides[0].B)
         return (None, *grads)
 
