@@ -10,7 +10,8 @@ int tt_gemm_nt(hipStream_t st, const float* A, int64_t lda, const float* W, int6
 int tt_gemm_nn(hipStream_t st, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
                int64_t N, int64_t K);
 // C[M,N] = A[R,M]^T . B[R,N]  reduced over the R (batch) rows in `splits` deterministic slabs
-// (weight gradient: dW = dY^T . X).  workspace: tt_gemm_tn_workspace_bytes(M,N,R).
+// (weight gradient: dW = dY^T . X).  colsum_out (optional, [M]) = sum_r A[r][m] (the bias gradient) from the same pass.
+// workspace: tt_gemm_tn_workspace_bytes(M,N,R).
 size_t tt_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 int tt_gemm_tn(hipStream_t st, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
-               int64_t N, int64_t R, void* workspace, size_t workspace_bytes);
+               int64_t N, int64_t R, void* workspace, size_t workspace_bytes, float* colsum_out = nullptr);

@@ -49,12 +49,16 @@ struct TileLoader {
   }
 };
 
-template <int MODE_A, int MODE_B, bool VEC>
+// COLSUM (TN mode only): additionally accumulate sum_k A[k][m] (the bias gradient sum_batch dY) of this
+// workgroup's k-range into colsum_slab[blockIdx.z][m] -- the A tiles are in registers anyway.
+template <int MODE_A, int MODE_B, bool VEC, bool COLSUM = false>
 __global__ __launch_bounds__(THREADS) void gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                       int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t slab_stride,
-                                                      int M, int N, int K, int kchunk, const float* __restrict__ bias, int relu, float alpha) {
+                                                      int M, int N, int K, int kchunk, const float* __restrict__ bias, int relu, float alpha,
+                                                      float* __restrict__ colsum_slab = nullptr) {
   __shared__ __attribute__((aligned(16))) float As[BK][BM + PAD];
   __shared__ __attribute__((aligned(16))) float Bs[BK][BN + PAD];
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -73,6 +77,10 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const float* __restrict__
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     la.store(As, t);
     lb.store(Bs, t);
+    if (COLSUM) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cs[j] += la.r[j];
+    }
     __syncthreads();
     if (k0 + BK < kend) {
       la.load(A, lda, m0, M, k0 + BK, kend, t);
@@ -85,6 +93,17 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const float* __restrict__
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
     __syncthreads();
+  }
+  if (COLSUM && colsum_slab && blockIdx.y == 0) {          // 16 k-lanes per column quad -> fixed-order sum through LDS
+    float(*red)[BM + PAD] = As;                            // (As is free: the loop ended with a barrier)
+    *reinterpret_cast<float4*>(&red[t >> 4][(t & 15) * 4]) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    __syncthreads();
+    if (t < BM && m0 + t < M) {
+      float sum = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum += red[q][t];
+      colsum_slab[(int64_t)blockIdx.z * M + m0 + t] = sum;
+    }
   }
   float* Cz = C + (int64_t)blockIdx.z * slab_stride;
   const int n = n0 + wc * 32 + li;
@@ -101,15 +120,24 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, int splits,
-                                                             float* __restrict__ C, int64_t ldc, int M, int N) {
+                                                             float* __restrict__ C, int64_t ldc, int M, int N,
+                                                             const float* __restrict__ colsum_slab, float* __restrict__ colsum_out) {
   const int64_t total = (int64_t)M * N;
+  const int64_t all = total + (colsum_out ? M : 0);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < all; i += stride) {
     float s = 0.f;
+    if (i < total) {
 #pragma unroll 8
-    for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * slab_stride + i];
-    const int64_t m = i / N, n = i - m * N;
-    C[m * ldc + n] = s;
+      for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * slab_stride + i];
+      const int64_t m = i / N, n = i - m * N;
+      C[m * ldc + n] = s;
+    } else {
+      const int64_t m = i - total;
+#pragma unroll 8
+      for (int z = 0; z < splits; ++z) s += colsum_slab[(int64_t)z * M + m];
+      colsum_out[m] = s;
+    }
   }
 }
 
@@ -154,11 +182,11 @@ int tt_gemm_nn(hipStream_t st, const float* A, int64_t lda, const float* W, int6
 }
 
 size_t tt_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
-  return sizeof(float) * (size_t)tn_splits(M, N, R) * (size_t)M * (size_t)N + 256;
+  return sizeof(float) * (size_t)tn_splits(M, N, R) * ((size_t)M * (size_t)N + (size_t)M) + 256;
 }
 
 int tt_gemm_tn(hipStream_t st, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
-               int64_t N, int64_t R, void* workspace, size_t workspace_bytes) {
+               int64_t N, int64_t R, void* workspace, size_t workspace_bytes, float* colsum_out) {
   if (M == 0 || N == 0) return TT_OK;
   const int splits = tn_splits(M, N, R);
   if (workspace_bytes < tt_gemm_tn_workspace_bytes(M, N, R) || !workspace) {
@@ -166,18 +194,23 @@ int tt_gemm_tn(hipStream_t st, const float* A, int64_t lda, const float* B, int6
     return TT_ERR_WORKSPACE;
   }
   float* slabs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
+  float* cslab = slabs + (size_t)splits * (size_t)M * (size_t)N;
   const int kchunk = (int)(tt_cdiv(tt_cdiv(R > 0 ? R : 1, splits), BK) * BK);
   dim3 grid((unsigned)tt_cdiv(M, BM), (unsigned)tt_cdiv(N, BN), (unsigned)splits);
   const int64_t slab_stride = M * N;
-  if (vec_ok(A, lda) && vec_ok(B, ldb))
-    gemm_kernel<1, 1, true><<<grid, THREADS, 0, st>>>(A, lda, B, ldb, slabs, N, slab_stride, (int)M, (int)N, (int)R, kchunk, nullptr, 0, 1.f);
-  else
-    gemm_kernel<1, 1, false><<<grid, THREADS, 0, st>>>(A, lda, B, ldb, slabs, N, slab_stride, (int)M, (int)N, (int)R, kchunk, nullptr, 0, 1.f);
+  const bool v = vec_ok(A, lda) && vec_ok(B, ldb);
+  if (colsum_out) {
+    if (v) gemm_kernel<1, 1, true, true><<<grid, THREADS, 0, st>>>(A, lda, B, ldb, slabs, N, slab_stride, (int)M, (int)N, (int)R, kchunk, nullptr, 0, 1.f, cslab);
+    else gemm_kernel<1, 1, false, true><<<grid, THREADS, 0, st>>>(A, lda, B, ldb, slabs, N, slab_stride, (int)M, (int)N, (int)R, kchunk, nullptr, 0, 1.f, cslab);
+  } else {
+    if (v) gemm_kernel<1, 1, true><<<grid, THREADS, 0, st>>>(A, lda, B, ldb, slabs, N, slab_stride, (int)M, (int)N, (int)R, kchunk, nullptr, 0, 1.f);
+    else gemm_kernel<1, 1, false><<<grid, THREADS, 0, st>>>(A, lda, B, ldb, slabs, N, slab_stride, (int)M, (int)N, (int)R, kchunk, nullptr, 0, 1.f);
+  }
   TT_LAUNCH_CHECK();
-  const int64_t total = M * N;
+  const int64_t total = M * N + (colsum_out ? M : 0);
   int blocks = (int)tt_cdiv(total, THREADS);
   if (blocks > 2048) blocks = 2048;
-  slab_reduce_kernel<<<blocks, THREADS, 0, st>>>(slabs, slab_stride, splits, C, ldc, (int)M, (int)N);
+  slab_reduce_kernel<<<blocks, THREADS, 0, st>>>(slabs, slab_stride, splits, C, ldc, (int)M, (int)N, cslab, colsum_out);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

@@ -7,6 +7,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr float kBnEps = 1e-5f, kBnMomentum = 0.1f, kNormEps = 1e-12f;
+constexpr int kMaxChunks = 64;   // row chunks of the two-stage column reductions
 
 __device__ __forceinline__ float dropout_scale(bool on, float p, uint64_t seed, uint64_t idx) {
   if (!on) return 1.f;
@@ -66,10 +67,15 @@ __global__ __launch_bounds__(kThreads) void bn_stats_finish_kernel(const float* 
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), jl = threadIdx.x >> 6;
   Wf o{0.f, 0.f, 0.f};
   if (c < H) {
-    for (int k = jl; k < nchunks; k += 4) {
+    Wf v[kMaxChunks / 4];
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 4; ++i) {            // all loads first (latency-bound otherwise)
+      const int k = jl + 4 * i;
       const float* p = partial + (int64_t)k * 3 * H;
-      o = wf_combine(o, Wf{p[c], p[H + c], p[2 * H + c]});
+      v[i] = k < nchunks ? Wf{p[c], p[H + c], p[2 * H + c]} : Wf{0.f, 0.f, 0.f};
     }
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 4; ++i) o = wf_combine(o, v[i]);
   }
   sh[jl][threadIdx.x & 63] = o;
   __syncthreads();
@@ -127,6 +133,7 @@ __global__ __launch_bounds__(kThreads) void colsum_partial_kernel(ColArgs a, int
   float s0 = 0.f, s1 = 0.f;
   const uint64_t seed = (OP == 1 && a.drop) ? seed_of(a.seed, a.seed_dev) : 0;
   if (c < H) {
+#pragma unroll 8
     for (int r = r0 + rl; r < r1; r += 4) {
       if (OP == 0) {
         s0 += a.x[(int64_t)r * a.ldx + c];
@@ -155,11 +162,16 @@ __global__ __launch_bounds__(kThreads) void colsum_finish_kernel(const float* __
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), jl = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f;
   if (c < H) {
-    for (int k = jl; k < nchunks; k += 4) {
+    float v0[kMaxChunks / 4], v1[kMaxChunks / 4];
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 4; ++i) {
+      const int k = jl + 4 * i;
       const float* p = partial + (int64_t)k * 2 * H;
-      s0 += p[c];
-      if (nv > 1) s1 += p[H + c];
+      v0[i] = k < nchunks ? p[c] : 0.f;
+      v1[i] = (k < nchunks && nv > 1) ? p[H + c] : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 4; ++i) { s0 += v0[i]; s1 += v1[i]; }
   }
   sh[0][jl][threadIdx.x & 63] = s0;
   sh[1][jl][threadIdx.x & 63] = s1;
@@ -240,6 +252,7 @@ inline int ew_grid(const tt_ctx* ctx, int64_t n) {
 
 inline int chunks_for(int64_t B, int H) {
   int64_t n = 256 / tt_cdiv(H, 64);
+  if (n > kMaxChunks) n = kMaxChunks;
   const int64_t mx = tt_cdiv(B, 64);
   if (n > mx) n = mx;
   return (int)(n < 1 ? 1 : n);
@@ -376,10 +389,7 @@ int tt_tower_mlp_bwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts*
   TT_LAUNCH_CHECK();
   const float* in_last = nh == 0 ? a->x : a->act[nh - 1];
   const int lw = last_width(p);
-  if (int rc = tt_gemm_tn(st, g->d_y, p->d_out, in_last, lw, g->w_out, lw, p->d_out, lw, B, ws.gemm, ws.gemm_bytes)) return rc;
-  ColArgs ca{};
-  ca.x = g->d_y; ca.ldx = p->d_out;
-  if (int rc = colsum(ctx, st, 0, ca, B, p->d_out, ws.col, g->b_out, nullptr)) return rc;
+  if (int rc = tt_gemm_tn(st, g->d_y, p->d_out, in_last, lw, g->w_out, lw, p->d_out, lw, B, ws.gemm, ws.gemm_bytes, g->b_out)) return rc;
   float* dcur = nh == 0 ? g->d_x : g->scratch[nh - 1];
   TT_CHECK_ARG(dcur, "tt_tower_mlp_bwd: NULL scratch buffer");
   if (int rc = tt_gemm_nn(st, g->d_y, p->d_out, p->w_out, lw, dcur, lw, B, lw, p->d_out)) return rc;
@@ -397,20 +407,14 @@ int tt_tower_mlp_bwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts*
                                                                    p->bn_w[i], g->bn_b[i], g->bn_w[i], train != 0, drop, dropout_p, seed, seed_dev, salt);
     TT_LAUNCH_CHECK();
     const float* in_i = i == 0 ? a->x : a->act[i - 1];
-    if (int rc = tt_gemm_tn(st, dcur, H, in_i, iw, g->w[i], iw, H, iw, B, ws.gemm, ws.gemm_bytes)) return rc;
-    ColArgs cc{};
-    cc.x = dcur; cc.ldx = H;
-    if (int rc = colsum(ctx, st, 0, cc, B, H, ws.col, g->b[i], nullptr)) return rc;
+    if (int rc = tt_gemm_tn(st, dcur, H, in_i, iw, g->w[i], iw, H, iw, B, ws.gemm, ws.gemm_bytes, g->b[i])) return rc;
     float* dnext = i == 0 ? g->d_x : g->scratch[i - 1];
     TT_CHECK_ARG(dnext, "tt_tower_mlp_bwd: NULL scratch buffer");
     if (int rc = tt_gemm_nn(st, dcur, H, p->w[i], iw, dnext, iw, B, iw, H)) return rc;
     dcur = dnext;
   }
   // dense projection: d_x[:, 0:h0]
-  if (int rc = tt_gemm_tn(st, g->d_x, wx, a->dense, p->din, g->w_proj, p->din, p->h0, p->din, B, ws.gemm, ws.gemm_bytes)) return rc;
-  ColArgs cp{};
-  cp.x = g->d_x; cp.ldx = wx;
-  if (int rc = colsum(ctx, st, 0, cp, B, p->h0, ws.col, g->b_proj, nullptr)) return rc;
+  if (int rc = tt_gemm_tn(st, g->d_x, wx, a->dense, p->din, g->w_proj, p->din, p->h0, p->din, B, ws.gemm, ws.gemm_bytes, g->b_proj)) return rc;
   return TT_OK;
 }
 
