@@ -221,6 +221,18 @@ int tt_tower_mlp_bwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts*
                      float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* workspace,
                      size_t workspace_bytes, tt_stream stream);
 
+/* The same two passes for n towers (1..TT_MAX_SIDES) with ONE launch per layer step: every kernel takes the
+ * towers' argument blocks side by side and blockIdx selects the tower ("horizontal fusion" -- each tower alone
+ * fills at most half of the 256 CUs).  All towers share B and the number of hidden blocks; widths may differ.
+ * Arrays are HOST arrays of n pointers; workspaces[t] >= tt_tower_workspace_bytes(p[t], B). */
+int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* p, const tt_tower_acts* const* a,
+                      int64_t B, int32_t train, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                      void* const* workspaces, const size_t* workspace_bytes, tt_stream stream);
+int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* p, const tt_tower_acts* const* a,
+                      const float* const* d_emb, const tt_tower_grads* const* g, int64_t B, int32_t train,
+                      float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* const* workspaces,
+                      const size_t* workspace_bytes, tt_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * In-batch-negative score + symmetric softmax cross-entropy, never materialising the score matrix
  * -- replaces TwoTowerTrainTask._compute_similarity_matrix / _compute_loss / _compute_metrics
@@ -235,7 +247,7 @@ int tt_tower_mlp_bwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts*
  *   rank[a]   = #{b: s_ab > diag} + #{b < positive: s_ab == diag}   (0 <=> torch.argmax hits)
  * The loss needs direction (N,C) and direction (C,N); tt_score_loss_finish combines them:
  *   out[0]=loss  out[1]=accuracy  out[2]=pos mean  out[3]=neg mean  out[4]=gap
- *   out[5]=column-direction top-1 rate  out[6]=sum of all scores
+ *   out[5]=column-direction top-1 rate  out[6]=sum of all scores  out[7]=loss (second copy)
  * ---------------------------------------------------------------------------------------------- */
 int tt_score_dir_fwd(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D,
                      float inv_t, float shift, int64_t diag_offset, float* sumexp, float* diag,
@@ -266,6 +278,9 @@ typedef struct tt_score_fwd_dir {
   float* diag;     /* [Ra] or NULL */
   int32_t* rank;   /* [Ra] or NULL */
   float* sumscore; /* [Ra] sum_b s_ab, or NULL */
+  int32_t rank_mode; /* with rank != NULL: 0 or 2 = full rank; 1 = top-1 flag only (rank = 0 if the positive is the
+                        row's argmax, first index winning ties, else 1) -- what the training metrics need, at a
+                        quarter of the per-element work */
 } tt_score_fwd_dir;
 typedef struct tt_score_bwd_dir {
   const void* A_packed;

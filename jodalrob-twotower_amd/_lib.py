@@ -38,7 +38,7 @@ class AdamTensor(C.Structure):
 
 class ScoreFwdDir(C.Structure):
     _fields_ = [("A_packed", vp), ("B_packed", vp), ("Ra", i64), ("Rb", i64), ("diag_offset", i64),
-                ("sumexp", vp), ("diag", vp), ("rank", vp), ("sumscore", vp)]
+                ("sumexp", vp), ("diag", vp), ("rank", vp), ("sumscore", vp), ("rank_mode", i32)]
 
 
 class ScoreBwdDir(C.Structure):
@@ -86,6 +86,10 @@ SIGNATURES = {
     "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, vp, sz, vp]),
     "tt_tower_mlp_bwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), vp, C.POINTER(TowerGrads), i64, i32,
                                    f32, u64, vp, vp, sz, vp]),
+    "tt_towers_mlp_fwd": (C.c_int, [vp, i32, C.POINTER(C.POINTER(TowerParams)), C.POINTER(C.POINTER(TowerActs)), i64, i32, f32, u64,
+                                    vp, C.POINTER(vp), C.POINTER(sz), vp]),
+    "tt_towers_mlp_bwd": (C.c_int, [vp, i32, C.POINTER(C.POINTER(TowerParams)), C.POINTER(C.POINTER(TowerActs)), C.POINTER(vp),
+                                    C.POINTER(C.POINTER(TowerGrads)), i64, i32, f32, u64, vp, C.POINTER(vp), C.POINTER(sz), vp]),
     "tt_score_dir_fwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, vp, vp]),
     "tt_score_loss_finish": (C.c_int, [vp, i64, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
     "tt_score_dir_bwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, f32, vp, vp]),

@@ -219,10 +219,16 @@ __global__ __launch_bounds__(kThreads) void lookup_profile_reduce_kernel(unsigne
     lo = wg[2 * i] < lo ? wg[2 * i] : lo;
     hi = wg[2 * i + 1] > hi ? wg[2 * i + 1] : hi;
   }
-  smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < kThreads; ++i) { lo = smin[i] < lo ? smin[i] : lo; hi = smax[i] > hi ? smax[i] : hi; }
+    for (int i = 1; i < kThreads / 64; ++i) { lo = smin[i] < lo ? smin[i] : lo; hi = smax[i] > hi ? smax[i] : hi; }
     const unsigned long long n = ring[0];
     ring[2 + 2 * (n % (unsigned long long)ring_slots)] = lo;
     ring[3 + 2 * (n % (unsigned long long)ring_slots)] = hi;

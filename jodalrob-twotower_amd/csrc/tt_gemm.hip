@@ -9,6 +9,13 @@ namespace {
 constexpr int BM = 64, BN = 64, BK = 16, PAD = 4, THREADS = 256;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
+struct GemmArgs {
+  const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t slab_stride;
+  int M, N, K, kchunk, splits;
+  const float* bias; int relu; float alpha; float* colsum_slab;
+};
+struct GemmBatch { GemmArgs a[TT_MAX_SIDES]; };
+
 // MODE 0: operand is K-contiguous  : elem(x, k) = P[x*ld + k]   (x = m for A, n for B)
 // MODE 1: operand is X-contiguous  : elem(x, k) = P[k*ld + x]
 template <int MODE, bool VEC>
@@ -50,19 +57,30 @@ struct TileLoader {
 };
 
 // COLSUM (TN mode only): additionally accumulate sum_k A[k][m] (the bias gradient sum_batch dY) of this
-// workgroup's k-range into colsum_slab[blockIdx.z][m] -- the A tiles are in registers anyway.
+// workgroup's k-range into colsum_slab[split][m] -- the A tiles are in registers anyway.
+// Horizontal batching: up to TT_MAX_SIDES independent problems (the towers) share ONE launch;
+// blockIdx.z = problem * zsplits + split, workgroups outside a problem's own grid exit at once.
 template <int MODE_A, int MODE_B, bool VEC, bool COLSUM = false>
-__global__ __launch_bounds__(THREADS) void gemm_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
-                                                      int64_t ldb, float* __restrict__ C, int64_t ldc, int64_t slab_stride,
-                                                      int M, int N, int K, int kchunk, const float* __restrict__ bias, int relu, float alpha,
-                                                      float* __restrict__ colsum_slab = nullptr) {
+__global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch, int zsplits) {
+  const GemmArgs& g = batch.a[blockIdx.z / zsplits];
+  const int split = blockIdx.z % zsplits;
+  const int M = g.M, N = g.N, K = g.K, kchunk = g.kchunk;
+  if ((int)blockIdx.x * BM >= M || (int)blockIdx.y * BN >= N || split >= g.splits) return;
+  const float* __restrict__ A = g.A;
+  const float* __restrict__ B = g.B;
+  float* __restrict__ C = g.C;
+  const int64_t lda = g.lda, ldb = g.ldb, ldc = g.ldc, slab_stride = g.slab_stride;
+  const float* __restrict__ bias = g.bias;
+  const int relu = g.relu;
+  const float alpha = g.alpha;
+  float* __restrict__ colsum_slab = g.colsum_slab;
   __shared__ __attribute__((aligned(16))) float As[BK][BM + PAD];
   __shared__ __attribute__((aligned(16))) float Bs[BK][BN + PAD];
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int kbeg = blockIdx.z * kchunk;
+  const int kbeg = split * kchunk;
   const int kend = min(K, kbeg + kchunk);
   f32x16 acc;
 #pragma unroll
@@ -102,10 +120,10 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const float* __restrict__
       float sum = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) sum += red[q][t];
-      colsum_slab[(int64_t)blockIdx.z * M + m0 + t] = sum;
+      colsum_slab[(int64_t)split * M + m0 + t] = sum;
     }
   }
-  float* Cz = C + (int64_t)blockIdx.z * slab_stride;
+  float* Cz = C + (int64_t)split * slab_stride;
   const int n = n0 + wc * 32 + li;
   const float bv = (bias && n < N) ? bias[n] : 0.f;
 #pragma unroll
@@ -119,24 +137,29 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(THREADS) void slab_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, int splits,
-                                                             float* __restrict__ C, int64_t ldc, int M, int N,
-                                                             const float* __restrict__ colsum_slab, float* __restrict__ colsum_out) {
-  const int64_t total = (int64_t)M * N;
-  const int64_t all = total + (colsum_out ? M : 0);
+struct SlabArgs {
+  const float* slabs; int64_t slab_stride; int splits; float* C; int64_t ldc; int M, N;
+  const float* colsum_slab; float* colsum_out;
+};
+struct SlabBatch { SlabArgs a[TT_MAX_SIDES]; };
+
+__global__ __launch_bounds__(THREADS) void slab_reduce_kernel(SlabBatch batch) {
+  const SlabArgs& a = batch.a[blockIdx.y];
+  const int64_t total = (int64_t)a.M * a.N;
+  const int64_t all = total + (a.colsum_out ? a.M : 0);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < all; i += stride) {
     float s = 0.f;
     if (i < total) {
 #pragma unroll 8
-      for (int z = 0; z < splits; ++z) s += slabs[(int64_t)z * slab_stride + i];
-      const int64_t m = i / N, n = i - m * N;
-      C[m * ldc + n] = s;
+      for (int z = 0; z < a.splits; ++z) s += a.slabs[(int64_t)z * a.slab_stride + i];
+      const int64_t m = i / a.N, n = i - m * a.N;
+      a.C[m * a.ldc + n] = s;
     } else {
       const int64_t m = i - total;
 #pragma unroll 8
-      for (int z = 0; z < splits; ++z) s += colsum_slab[(int64_t)z * M + m];
-      colsum_out[m] = s;
+      for (int z = 0; z < a.splits; ++z) s += a.colsum_slab[(int64_t)z * a.M + m];
+      a.colsum_out[m] = s;
     }
   }
 }
@@ -155,62 +178,93 @@ inline int tn_splits(int64_t M, int64_t N, int64_t R) {
 
 }  // namespace
 
-int tt_gemm_nt(hipStream_t st, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
-               int64_t ldc, int64_t M, int64_t N, int64_t K, bool relu, float alpha) {
-  if (M == 0 || N == 0) return TT_OK;
-  dim3 grid((unsigned)tt_cdiv(M, BM), (unsigned)tt_cdiv(N, BN), 1);
-  const int kchunk = (int)(tt_cdiv(K > 0 ? K : 1, BK) * BK);
-  if (vec_ok(A, lda) && vec_ok(W, ldw))
-    gemm_kernel<0, 0, true><<<grid, THREADS, 0, st>>>(A, lda, W, ldw, C, ldc, 0, (int)M, (int)N, (int)K, kchunk, bias, relu, alpha);
-  else
-    gemm_kernel<0, 0, false><<<grid, THREADS, 0, st>>>(A, lda, W, ldw, C, ldc, 0, (int)M, (int)N, (int)K, kchunk, bias, relu, alpha);
+template <int MA, int MB>
+static int launch_gemm(hipStream_t st, const GemmBatch& b, int n, int zsplits, bool vec, bool colsum) {
+  int mt = 1, nt = 1;
+  for (int i = 0; i < n; ++i) {
+    mt = (int)tt_cdiv(b.a[i].M, BM) > mt ? (int)tt_cdiv(b.a[i].M, BM) : mt;
+    nt = (int)tt_cdiv(b.a[i].N, BN) > nt ? (int)tt_cdiv(b.a[i].N, BN) : nt;
+  }
+  dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(n * zsplits));
+  if (colsum) {
+    if (vec) gemm_kernel<MA, MB, true, true><<<grid, THREADS, 0, st>>>(b, zsplits);
+    else gemm_kernel<MA, MB, false, true><<<grid, THREADS, 0, st>>>(b, zsplits);
+  } else {
+    if (vec) gemm_kernel<MA, MB, true, false><<<grid, THREADS, 0, st>>>(b, zsplits);
+    else gemm_kernel<MA, MB, false, false><<<grid, THREADS, 0, st>>>(b, zsplits);
+  }
   TT_LAUNCH_CHECK();
   return TT_OK;
 }
 
-int tt_gemm_nn(hipStream_t st, const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, int64_t M,
-               int64_t N, int64_t K) {
-  if (M == 0 || N == 0) return TT_OK;
-  dim3 grid((unsigned)tt_cdiv(M, BM), (unsigned)tt_cdiv(N, BN), 1);
-  const int kchunk = (int)(tt_cdiv(K > 0 ? K : 1, BK) * BK);
-  if (vec_ok(A, lda) && vec_ok(W, ldw))
-    gemm_kernel<0, 1, true><<<grid, THREADS, 0, st>>>(A, lda, W, ldw, C, ldc, 0, (int)M, (int)N, (int)K, kchunk, nullptr, 0, 1.f);
-  else
-    gemm_kernel<0, 1, false><<<grid, THREADS, 0, st>>>(A, lda, W, ldw, C, ldc, 0, (int)M, (int)N, (int)K, kchunk, nullptr, 0, 1.f);
-  TT_LAUNCH_CHECK();
-  return TT_OK;
+int tt_gemm_nt_batched(hipStream_t st, const GemmNT* it, int n) {
+  GemmBatch b{};
+  bool vec = true;
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (it[i].M == 0 || it[i].N == 0) continue;
+    b.a[m++] = GemmArgs{it[i].A, it[i].lda, it[i].W, it[i].ldw, it[i].C, it[i].ldc, 0, (int)it[i].M, (int)it[i].N, (int)it[i].K,
+                        (int)(tt_cdiv(it[i].K > 0 ? it[i].K : 1, BK) * BK), 1, it[i].bias, it[i].relu ? 1 : 0, it[i].alpha, nullptr};
+    vec = vec && vec_ok(it[i].A, it[i].lda) && vec_ok(it[i].W, it[i].ldw);
+  }
+  return m ? launch_gemm<0, 0>(st, b, m, 1, vec, false) : TT_OK;
+}
+
+int tt_gemm_nn_batched(hipStream_t st, const GemmNN* it, int n) {
+  GemmBatch b{};
+  bool vec = true;
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    if (it[i].M == 0 || it[i].N == 0) continue;
+    b.a[m++] = GemmArgs{it[i].A, it[i].lda, it[i].W, it[i].ldw, it[i].C, it[i].ldc, 0, (int)it[i].M, (int)it[i].N, (int)it[i].K,
+                        (int)(tt_cdiv(it[i].K > 0 ? it[i].K : 1, BK) * BK), 1, nullptr, 0, 1.f, nullptr};
+    vec = vec && vec_ok(it[i].A, it[i].lda) && vec_ok(it[i].W, it[i].ldw);
+  }
+  return m ? launch_gemm<0, 1>(st, b, m, 1, vec, false) : TT_OK;
 }
 
 size_t tt_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
   return sizeof(float) * (size_t)tn_splits(M, N, R) * ((size_t)M * (size_t)N + (size_t)M) + 256;
 }
 
-int tt_gemm_tn(hipStream_t st, const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M,
-               int64_t N, int64_t R, void* workspace, size_t workspace_bytes, float* colsum_out) {
-  if (M == 0 || N == 0) return TT_OK;
-  const int splits = tn_splits(M, N, R);
-  if (workspace_bytes < tt_gemm_tn_workspace_bytes(M, N, R) || !workspace) {
-    tt_set_error("tt_gemm_tn: workspace %zu < required %zu", workspace_bytes, tt_gemm_tn_workspace_bytes(M, N, R));
-    return TT_ERR_WORKSPACE;
+int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n) {
+  GemmBatch b{};
+  SlabBatch sb{};
+  bool vec = true, colsum = false;
+  int m = 0, zs = 1;
+  int64_t maxtotal = 1;
+  for (int i = 0; i < n; ++i) {
+    const GemmTN& t = it[i];
+    if (t.M == 0 || t.N == 0) continue;
+    const int splits = tn_splits(t.M, t.N, t.R);
+    if (!t.workspace || t.workspace_bytes < tt_gemm_tn_workspace_bytes(t.M, t.N, t.R)) {
+      tt_set_error("tt_gemm_tn: workspace %zu < required %zu", t.workspace_bytes, tt_gemm_tn_workspace_bytes(t.M, t.N, t.R));
+      return TT_ERR_WORKSPACE;
+    }
+    float* slabs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(t.workspace) + 255) & ~uintptr_t(255));
+    float* cslab = slabs + (size_t)splits * (size_t)t.M * (size_t)t.N;
+    const int kchunk = (int)(tt_cdiv(tt_cdiv(t.R > 0 ? t.R : 1, splits), BK) * BK);
+    b.a[m] = GemmArgs{t.A, t.lda, t.B, t.ldb, slabs, t.N, t.M * t.N, (int)t.M, (int)t.N, (int)t.R, kchunk, splits, nullptr, 0, 1.f,
+                      t.colsum_out ? cslab : nullptr};
+    sb.a[m] = SlabArgs{slabs, t.M * t.N, splits, t.C, t.ldc, (int)t.M, (int)t.N, cslab, t.colsum_out};
+    vec = vec && vec_ok(t.A, t.lda) && vec_ok(t.B, t.ldb);
+    colsum = colsum || t.colsum_out != nullptr;
+    zs = splits > zs ? splits : zs;
+    const int64_t tot = t.M * t.N + (t.colsum_out ? t.M : 0);
+    maxtotal = tot > maxtotal ? tot : maxtotal;
+    ++m;
   }
-  float* slabs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
-  float* cslab = slabs + (size_t)splits * (size_t)M * (size_t)N;
-  const int kchunk = (int)(tt_cdiv(tt_cdiv(R > 0 ? R : 1, splits), BK) * BK);
-  dim3 grid((unsigned)tt_cdiv(M, BM), (unsigned)tt_cdiv(N, BN), (unsigned)splits);
-  const int64_t slab_stride = M * N;
-  const bool v = vec_ok(A, lda) && vec_ok(B, ldb);
-  if (colsum_out) {
-    if (v) gemm_kernel<1, 1, true, true><<<grid, THREADS, 0, st>>>(A, lda, B, ldb, slabs, N, slab_stride, (int)M, (int)N, (int)R, kchunk, nullptr, 0, 1.f, cslab);
-    else gemm_kernel<1, 1, false, true><<<grid, THREADS, 0, st>>>(A, lda, B, ldb, slabs, N, slab_stride, (int)M, (int)N, (int)R, kchunk, nullptr, 0, 1.f, cslab);
-  } else {
-    if (v) gemm_kernel<1, 1, true><<<grid, THREADS, 0, st>>>(A, lda, B, ldb, slabs, N, slab_stride, (int)M, (int)N, (int)R, kchunk, nullptr, 0, 1.f);
-    else gemm_kernel<1, 1, false><<<grid, THREADS, 0, st>>>(A, lda, B, ldb, slabs, N, slab_stride, (int)M, (int)N, (int)R, kchunk, nullptr, 0, 1.f);
-  }
-  TT_LAUNCH_CHECK();
-  const int64_t total = M * N + (colsum_out ? M : 0);
-  int blocks = (int)tt_cdiv(total, THREADS);
-  if (blocks > 2048) blocks = 2048;
-  slab_reduce_kernel<<<blocks, THREADS, 0, st>>>(slabs, slab_stride, splits, C, ldc, (int)M, (int)N, cslab, colsum_out);
+  if (!m) return TT_OK;
+  if (int rc = launch_gemm<1, 1>(st, b, m, zs, vec, colsum)) return rc;
+  int blocks = (int)tt_cdiv(maxtotal, THREADS);
+  if (blocks > 1024) blocks = 1024;
+  slab_reduce_kernel<<<dim3((unsigned)blocks, (unsigned)m), THREADS, 0, st>>>(sb);
   TT_LAUNCH_CHECK();
   return TT_OK;
+}
+
+int tt_gemm_nt(hipStream_t st, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
+               int64_t ldc, int64_t M, int64_t N, int64_t K, bool relu, float alpha) {
+  const GemmNT it{A, lda, W, ldw, bias, C, ldc, M, N, K, relu, alpha};
+  return tt_gemm_nt_batched(st, &it, 1);
 }

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(1024) void loss_finish_kernel(int64_t B, float shif
     out[4] = pos - neg;
     out[5] = chit / fb;
     out[6] = tot;
-    out[7] = 0.f;
+    out[7] = out[0];          // second copy of the loss (the autograd output aliases it)
   }
 }
 

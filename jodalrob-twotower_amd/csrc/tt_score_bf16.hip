@@ -15,6 +15,8 @@
 //   * partial results of the NW waves are combined through LDS in a fixed tree order.
 #include "tt_common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
@@ -28,6 +30,13 @@ __host__ __device__ inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1
 inline int padded_d(int D) { return D <= 32 ? 32 : (D <= 64 ? 64 : (D <= 128 ? 128 : 256)); }
 
 __device__ __forceinline__ int rowmap(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// single-instruction 3-input max (plain fmaxf on MFMA results makes hipcc insert canonicalising v_max first)
+__device__ __forceinline__ float max3_asm(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
 
 // ---- pack ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ X, int64_t R, int D, int64_t Rp, int Dp,
@@ -66,6 +75,7 @@ struct DirFwd {
   float* diag;
   int32_t* rank;
   float* sumscore;
+  int32_t rank_mode;   // 0 none, 1 top-1 flag (rank = 0/1), 2 full rank
 };
 struct FwdArgs {
   DirFwd d[2];
@@ -88,14 +98,16 @@ struct BwdArgs {
   int D;
 };
 
-template <int KS, int AT>
-__device__ __forceinline__ void gemm1(const __bf16* __restrict__ b_rows, int64_t t, int c, int h, const bf16x8 (&ares)[AT][KS],
-                                      f32x16 (&acc)[AT]) {
+template <int KS>
+__device__ __forceinline__ void load_bfrag(const __bf16* __restrict__ b_rows, int64_t t, int c, int h, bf16x8 (&bf)[KS]) {
   constexpr int Dp = KS * 16;
-  bf16x8 bf[KS];
   const __bf16* p = b_rows + (32 * t + c) * Dp + 8 * h;
 #pragma unroll
   for (int s = 0; s < KS; ++s) bf[s] = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+}
+
+template <int KS, int AT>
+__device__ __forceinline__ void mfma1(const bf16x8 (&bf)[KS], const bf16x8 (&ares)[AT][KS], f32x16 (&acc)[AT]) {
 #pragma unroll
   for (int i = 0; i < AT; ++i)
 #pragma unroll
@@ -104,6 +116,14 @@ __device__ __forceinline__ void gemm1(const __bf16* __restrict__ b_rows, int64_t
   for (int s = 0; s < KS; ++s)
 #pragma unroll
     for (int i = 0; i < AT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[s], ares[i][s], acc[i], 0, 0, 0);
+}
+
+template <int KS, int AT>
+__device__ __forceinline__ void gemm1(const __bf16* __restrict__ b_rows, int64_t t, int c, int h, const bf16x8 (&ares)[AT][KS],
+                                      f32x16 (&acc)[AT]) {
+  bf16x8 bf[KS];
+  load_bfrag<KS>(b_rows, t, c, h, bf);
+  mfma1<KS, AT>(bf, ares, acc);
 }
 
 // ---- forward ---------------------------------------------------------------------------------------
@@ -144,66 +164,114 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
 #pragma unroll
     for (int i = 0; i < AT; ++i) dg[i] = fmaxf(dg[i], __shfl_xor(dg[i], 32));
   }
-  float se[AT], ss[AT];
-  int cnt[AT];
+  // per-lane accumulators of this wave's share of the b tiles
+  float se[AT], ss[AT], mb[AT], ma[AT];      // exp-sum, score-sum, max before / after the positive (top-1 mode)
+  int cnt[AT];                                // full-rank mode
 #pragma unroll
-  for (int i = 0; i < AT; ++i) { se[i] = 0.f; ss[i] = 0.f; cnt[i] = 0; }
-  for (int64_t t = wave; t < nT; t += NW) {
-    f32x16 acc[AT];
-    gemm1<KS, AT>(dr.b_rows, t, c, h, ares, acc);
+  for (int i = 0; i < AT; ++i) { se[i] = 0.f; ss[i] = 0.f; cnt[i] = 0; mb[i] = kNegBig; ma[i] = kNegBig; }
+  const int mode = dr.rank ? dr.rank_mode : 0;                 // wave-uniform
+  const bool want_ss = dr.sumscore != nullptr;
+  // (a two-accumulator variant that issues tile t+NW's MFMAs before the epilogue of tile t measured SLOWER:
+  //  199 VGPRs, 72-78 us vs 63-65 us -- kept single-buffered)
+  auto epilogue = [&](const f32x16 (&acc)[AT], int64_t t) {
     const int64_t b_lo = 32 * t, b_hi = 32 * t + 31;
-    if (b_hi < dr.Rb && b_hi < posmin) {              // every b of the tile lies before every positive: ties count
+    const bool full_tile = b_hi < dr.Rb;
+    const bool before = full_tile && b_hi < posmin, after = full_tile && b_lo > posmax;
+    if (before || after) {
 #pragma unroll
       for (int i = 0; i < AT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float x = acc[i][r];
-          se[i] += __builtin_amdgcn_exp2f(__builtin_fmaf(x, args.c1, args.c2));
-          ss[i] += x;
-          cnt[i] += x >= dg[i] ? 1 : 0;
-        }
-    } else if (b_hi < dr.Rb && b_lo > posmax) {       // every b after every positive: strict
+        for (int r = 0; r < 16; ++r) se[i] += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][r], args.c1, args.c2));
+      if (want_ss) {
 #pragma unroll
-      for (int i = 0; i < AT; ++i)
+        for (int i = 0; i < AT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float x = acc[i][r];
-          se[i] += __builtin_amdgcn_exp2f(__builtin_fmaf(x, args.c1, args.c2));
-          ss[i] += x;
-          cnt[i] += x > dg[i] ? 1 : 0;
+          for (int r = 0; r < 16; ++r) ss[i] += acc[i][r];
+      }
+      if (mode == 1) {            // top-1 only: running maxima, one v_max3 per two elements
+        if (before) {
+#pragma unroll
+          for (int i = 0; i < AT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mb[i] = max3_asm(mb[i], acc[i][r], acc[i][r + 1]);
+        } else {
+#pragma unroll
+          for (int i = 0; i < AT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) ma[i] = max3_asm(ma[i], acc[i][r], acc[i][r + 1]);
         }
-    } else {                                          // tiles touching the diagonal band or the ragged end
+      } else if (mode == 2) {     // full rank: ties before the positive count, after it they do not
+        if (before) {
+#pragma unroll
+          for (int i = 0; i < AT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cnt[i] += acc[i][r] >= dg[i] ? 1 : 0;
+        } else {
+#pragma unroll
+          for (int i = 0; i < AT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cnt[i] += acc[i][r] > dg[i] ? 1 : 0;
+        }
+      }
+    } else {                      // tiles touching the diagonal band or the ragged end: per-element care
 #pragma unroll
       for (int i = 0; i < AT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t b = b_lo + rowmap(r, h);
-          if (b < dr.Rb) {
-            const float x = acc[i][r];
-            se[i] += __builtin_amdgcn_exp2f(__builtin_fmaf(x, args.c1, args.c2));
-            ss[i] += x;
-            cnt[i] += (b < pos[i] ? x >= dg[i] : (b > pos[i] ? x > dg[i] : false)) ? 1 : 0;
-          }
+          const float x = acc[i][r];
+          const bool valid = b < dr.Rb, bef = valid && b < pos[i], aft = valid && b > pos[i];
+          se[i] += valid ? __builtin_amdgcn_exp2f(__builtin_fmaf(x, args.c1, args.c2)) : 0.f;
+          ss[i] += valid ? x : 0.f;
+          mb[i] = bef ? fmaxf(mb[i], x) : mb[i];
+          ma[i] = aft ? fmaxf(ma[i], x) : ma[i];
+          cnt[i] += ((bef && x >= dg[i]) || (aft && x > dg[i])) ? 1 : 0;
         }
     }
+  };
+  bf16x8 bnext[KS];
+  if (wave < nT) load_bfrag<KS>(dr.b_rows, wave, c, h, bnext);
+  for (int64_t t = wave; t < nT; t += NW) {
+    f32x16 acc[AT];
+    bf16x8 bcur[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bcur[s] = bnext[s];
+    if (t + NW < nT) load_bfrag<KS>(dr.b_rows, t + NW, c, h, bnext);      // next tile's operand under this tile's work
+    mfma1<KS, AT>(bcur, ares, acc);
+    epilogue(acc, t);
   }
+  __shared__ float part_mb[NW][ROWS], part_ma[NW][ROWS];
 #pragma unroll
   for (int i = 0; i < AT; ++i) {
     se[i] += __shfl_xor(se[i], 32);
     ss[i] += __shfl_xor(ss[i], 32);
     cnt[i] += __shfl_xor(cnt[i], 32);
-    if (h == 0) { part_e[wave][32 * i + c] = se[i]; part_s[wave][32 * i + c] = ss[i]; part_c[wave][32 * i + c] = cnt[i]; }
+    mb[i] = fmaxf(mb[i], __shfl_xor(mb[i], 32));
+    ma[i] = fmaxf(ma[i], __shfl_xor(ma[i], 32));
+    if (h == 0) {
+      part_e[wave][32 * i + c] = se[i]; part_s[wave][32 * i + c] = ss[i]; part_c[wave][32 * i + c] = cnt[i];
+      part_mb[wave][32 * i + c] = mb[i]; part_ma[wave][32 * i + c] = ma[i];
+    }
+  }
+  __shared__ float dg_s[ROWS];
+  if (wave == 0 && h == 0) {
+#pragma unroll
+    for (int i = 0; i < AT; ++i) dg_s[32 * i + c] = dg[i];
   }
   __syncthreads();
   if (threadIdx.x < ROWS) {
     const int64_t a = a0 + threadIdx.x;
     if (a < dr.Ra) {
-      float e = 0.f, sc = 0.f;
+      float e = 0.f, sc = 0.f, xb = kNegBig, xa = kNegBig;
       int k = 0;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) { e += part_e[w][threadIdx.x]; sc += part_s[w][threadIdx.x]; k += part_c[w][threadIdx.x]; }
+      for (int w = 0; w < NW; ++w) {
+        e += part_e[w][threadIdx.x]; sc += part_s[w][threadIdx.x]; k += part_c[w][threadIdx.x];
+        xb = fmaxf(xb, part_mb[w][threadIdx.x]); xa = fmaxf(xa, part_ma[w][threadIdx.x]);
+      }
       dr.sumexp[a] = e;
-      if (dr.rank) dr.rank[a] = k;
+      if (mode == 2) dr.rank[a] = k;
+      else if (mode == 1) dr.rank[a] = (xb < dg_s[threadIdx.x] && xa <= dg_s[threadIdx.x]) ? 0 : 1;
       if (dr.sumscore) dr.sumscore[a] = sc * args.inv_t;
     }
   }
@@ -217,7 +285,7 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
 }
 
 // ---- backward --------------------------------------------------------------------------------------
-template <int KS, int AT, int NW>
+template <int KS, int AT, int NW, bool PF_B, bool EARLY_BM>
 __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
   constexpr int Dp = KS * 16, ROWS = 32 * AT, DT = KS / 2;
   __shared__ float red[(NW / 2) * ROWS * Dp];
@@ -245,9 +313,28 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dacc[i][d][r] = 0.f;
+  bf16x8 bnext[PF_B ? KS : 1];
+  if (PF_B && wave < nT) load_bfrag<KS>(dr.b_rows, wave, c, h, reinterpret_cast<bf16x8(&)[KS]>(bnext));
   for (int64_t t = wave; t < nT; t += NW) {
     f32x16 acc[AT];
-    gemm1<KS, AT>(dr.b_rows, t, c, h, ares, acc);
+    bf16x8 bcur[KS];
+    if (PF_B) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) bcur[s] = bnext[PF_B ? s : 0];
+      if (t + NW < nT) load_bfrag<KS>(dr.b_rows, t + NW, c, h, reinterpret_cast<bf16x8(&)[KS]>(bnext));
+    } else {
+      load_bfrag<KS>(dr.b_rows, t, c, h, bcur);
+    }
+    // operands of the second product: optionally issued now, consumed after the first product + softmax weights
+    bf16x8 bm[2][DT];
+    if (EARLY_BM) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+          bm[s][d] = *reinterpret_cast<const bf16x8*>(dr.b_frag + ((((t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
+    }
+    mfma1<KS, AT>(bcur, ares, acc);
     const int64_t b_lo = 32 * t;
     float ib[16];
     if (b_lo + 31 < dr.Rb) {
@@ -285,9 +372,10 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
-        const bf16x8 bm = *reinterpret_cast<const bf16x8*>(dr.b_frag + ((((t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
+        if (!EARLY_BM)
+          bm[s][d] = *reinterpret_cast<const bf16x8*>(dr.b_frag + ((((t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
 #pragma unroll
-        for (int i = 0; i < AT; ++i) dacc[i][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][s], bm, dacc[i][d], 0, 0, 0);
+        for (int i = 0; i < AT; ++i) dacc[i][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][s], bm[s][d], dacc[i][d], 0, 0, 0);
       }
   }
   // fixed-order tree over the NW waves: upper half writes, lower half adds
@@ -382,7 +470,8 @@ int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs,
   for (int i = 0; i < 2; ++i) {
     const tt_score_fwd_dir& d = dirs[i < n_dirs ? i : 0];
     TT_CHECK_ARG(d.A_packed && d.B_packed && d.sumexp && d.Ra >= 1 && d.Rb >= 1, "tt_score_fwd_bf16: bad direction %d", i);
-    a.d[i] = DirFwd{view(d.A_packed, d.Ra, D).rows, view(d.B_packed, d.Rb, D).rows, d.Ra, d.Rb, d.diag_offset, d.sumexp, d.diag, d.rank, d.sumscore};
+    a.d[i] = DirFwd{view(d.A_packed, d.Ra, D).rows, view(d.B_packed, d.Rb, D).rows, d.Ra, d.Rb, d.diag_offset, d.sumexp, d.diag, d.rank, d.sumscore,
+                      d.rank ? (d.rank_mode == 1 ? 1 : 2) : 0};
     maxRa = d.Ra > maxRa ? d.Ra : maxRa;
   }
   a.c1 = inv_t * kLog2e;
@@ -423,12 +512,22 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
   a.D = D;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int Dp = padded_d(D);
-#define TT_BWD(KS, AT, NW)                                                                                     \
-  score_bwd_bf16_kernel<KS, AT, NW><<<dim3((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs), NW * 64, 0, st>>>(a)
-  if (Dp == 32) TT_BWD(2, 2, 8);
-  else if (Dp == 64) TT_BWD(4, 2, 8);
-  else if (Dp == 128) TT_BWD(8, 1, 8);
-  else TT_BWD(16, 1, 4);
+  static const int bvar = getenv("TT_SCORE_BWD_VARIANT") ? atoi(getenv("TT_SCORE_BWD_VARIANT")) : 0;
+#define TT_BWD(KS, AT, NW, PF, EB)                                                                             \
+  score_bwd_bf16_kernel<KS, AT, NW, PF, EB><<<dim3((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs), NW * 64, 0, st>>>(a)
+  if (Dp == 32) TT_BWD(2, 2, 8, true, true);
+  else if (Dp == 64) {
+    switch (bvar) {
+      case 1: TT_BWD(4, 2, 8, false, false); break;
+      case 2: TT_BWD(4, 2, 8, false, true); break;
+      case 3: TT_BWD(4, 1, 8, true, true); break;
+      case 4: TT_BWD(4, 1, 8, false, true); break;
+      case 5: TT_BWD(4, 1, 8, false, false); break;
+      case 6: TT_BWD(4, 2, 8, true, false); break;
+      default: TT_BWD(4, 2, 8, false, true); break;
+    }
+  } else if (Dp == 128) TT_BWD(8, 1, 8, false, true);
+  else TT_BWD(16, 1, 4, false, true);
 #undef TT_BWD
   TT_LAUNCH_CHECK();
   return TT_OK;

@@ -30,20 +30,29 @@ __device__ __forceinline__ Wf wf_combine(Wf a, Wf b) {
   return o;
 }
 
-// grid (colblocks of 64, nchunks); thread = (column, row-lane of 4)
-__global__ __launch_bounds__(kThreads) void bn_stats_partial_kernel(const float* __restrict__ pre, int B, int H, int rows_per_chunk,
-                                                                   float* __restrict__ partial /*[nchunks][3][H]*/) {
+template <typename A>
+struct Batch {
+  A a[TT_MAX_SIDES];
+};
+
+// grid (colblocks of 64, nchunks, towers); thread = (column, row-lane of 4)
+struct BnStatArgs { const float* pre; int B, H, rows_per_chunk, nchunks; float* partial; float* mean; float* rstd; float* rm; float* rv; };
+
+__global__ __launch_bounds__(kThreads) void bn_stats_partial_kernel(Batch<BnStatArgs> batch) {
+  const BnStatArgs& a = batch.a[blockIdx.z];
+  const int H = a.H;
+  if ((int)blockIdx.x * 64 >= H || (int)blockIdx.y >= a.nchunks) return;
   __shared__ Wf sh[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(B, r0 + rows_per_chunk);
+  const int r0 = blockIdx.y * a.rows_per_chunk, r1 = min(a.B, r0 + a.rows_per_chunk);
   Wf w{0.f, 0.f, 0.f};
   if (c < H) {
     for (int r = r0 + rl; r < r1; r += 4) {
-      const float a = fmaxf(pre[(int64_t)r * H + c], 0.f);
+      const float x = fmaxf(a.pre[(int64_t)r * H + c], 0.f);
       w.n += 1.f;
-      const float d = a - w.mean;
+      const float d = x - w.mean;
       w.mean += d / w.n;
-      w.m2 += d * (a - w.mean);
+      w.m2 += d * (x - w.mean);
     }
   }
   sh[rl][threadIdx.x & 63] = w;
@@ -53,26 +62,27 @@ __global__ __launch_bounds__(kThreads) void bn_stats_partial_kernel(const float*
     o = wf_combine(o, sh[1][threadIdx.x]);
     o = wf_combine(o, sh[2][threadIdx.x]);
     o = wf_combine(o, sh[3][threadIdx.x]);
-    float* p = partial + (int64_t)blockIdx.y * 3 * H;
+    float* p = a.partial + (int64_t)blockIdx.y * 3 * H;
     p[c] = o.n; p[H + c] = o.mean; p[2 * H + c] = o.m2;
   }
 }
 
-// finish: workgroup = 64 columns x 4 chunk-lanes; lane j combines chunks j, j+4, ... then the four
-// partial results are combined in lane order (fixed order => reproducible)
-__global__ __launch_bounds__(kThreads) void bn_stats_finish_kernel(const float* __restrict__ partial, int nchunks, int H,
-                                                                  float* __restrict__ mean, float* __restrict__ rstd,
-                                                                  float* __restrict__ running_mean, float* __restrict__ running_var) {
+// finish: workgroup = 64 columns x 4 chunk-lanes; lane j combines chunks j, j+4, ... (all loads first), then the
+// four partial results are combined in lane order (fixed order => reproducible)
+__global__ __launch_bounds__(kThreads) void bn_stats_finish_kernel(Batch<BnStatArgs> batch) {
+  const BnStatArgs& a = batch.a[blockIdx.y];
+  const int H = a.H;
+  if ((int)blockIdx.x * 64 >= H) return;
   __shared__ Wf sh[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), jl = threadIdx.x >> 6;
   Wf o{0.f, 0.f, 0.f};
   if (c < H) {
     Wf v[kMaxChunks / 4];
 #pragma unroll
-    for (int i = 0; i < kMaxChunks / 4; ++i) {            // all loads first (latency-bound otherwise)
+    for (int i = 0; i < kMaxChunks / 4; ++i) {
       const int k = jl + 4 * i;
-      const float* p = partial + (int64_t)k * 3 * H;
-      v[i] = k < nchunks ? Wf{p[c], p[H + c], p[2 * H + c]} : Wf{0.f, 0.f, 0.f};
+      const float* p = a.partial + (int64_t)k * 3 * H;
+      v[i] = k < a.nchunks ? Wf{p[c], p[H + c], p[2 * H + c]} : Wf{0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int i = 0; i < kMaxChunks / 4; ++i) o = wf_combine(o, v[i]);
@@ -82,82 +92,86 @@ __global__ __launch_bounds__(kThreads) void bn_stats_finish_kernel(const float* 
   if (jl != 0 || c >= H) return;
   o = wf_combine(wf_combine(sh[0][threadIdx.x], sh[1][threadIdx.x]), wf_combine(sh[2][threadIdx.x], sh[3][threadIdx.x]));
   const float var = o.n > 0.f ? o.m2 / o.n : 0.f;
-  mean[c] = o.mean;
-  rstd[c] = 1.f / sqrtf(var + kBnEps);
-  if (running_mean) {   // nn.BatchNorm1d: momentum 0.1, unbiased variance in the running estimate
-    running_mean[c] = (1.f - kBnMomentum) * running_mean[c] + kBnMomentum * o.mean;
-    running_var[c] = (1.f - kBnMomentum) * running_var[c] + kBnMomentum * (o.n > 1.f ? o.m2 / (o.n - 1.f) : var);
+  a.mean[c] = o.mean;
+  a.rstd[c] = 1.f / sqrtf(var + kBnEps);
+  if (a.rm) {   // nn.BatchNorm1d: momentum 0.1, unbiased variance in the running estimate
+    a.rm[c] = (1.f - kBnMomentum) * a.rm[c] + kBnMomentum * o.mean;
+    a.rv[c] = (1.f - kBnMomentum) * a.rv[c] + kBnMomentum * (o.n > 1.f ? o.m2 / (o.n - 1.f) : var);
   }
 }
 
-__global__ void bn_eval_prepare_kernel(const float* __restrict__ rm, const float* __restrict__ rv, int H, float* __restrict__ mean,
-                                       float* __restrict__ rstd) {
+__global__ void bn_eval_prepare_kernel(Batch<BnStatArgs> batch) {
+  const BnStatArgs& a = batch.a[blockIdx.y];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < H) {
-    mean[c] = rm[c];
-    rstd[c] = 1.f / sqrtf(rv[c] + kBnEps);
+  if (c < a.H) {
+    a.mean[c] = a.rm[c];
+    a.rstd[c] = 1.f / sqrtf(a.rv[c] + kBnEps);
   }
 }
 
-__global__ __launch_bounds__(kThreads) void bn_apply_kernel(const float* __restrict__ pre, int64_t total, int H,
-                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                           const float* __restrict__ g, const float* __restrict__ b, bool drop, float p,
-                                                           uint64_t seed0, const uint64_t* __restrict__ seed_dev, uint64_t salt,
-                                                           float* __restrict__ act) {
+struct BnApplyArgs {
+  const float* pre; int64_t total; int H; const float* mean; const float* rstd; const float* g; const float* b;
+  uint64_t salt; float* act;
+};
+
+__global__ __launch_bounds__(kThreads) void bn_apply_kernel(Batch<BnApplyArgs> batch, bool drop, float p, uint64_t seed0,
+                                                           const uint64_t* __restrict__ seed_dev) {
+  const BnApplyArgs& a = batch.a[blockIdx.y];
   const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  const int H = a.H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.total; i += stride) {
     const int c = (int)(i % H);
-    const float a = fmaxf(pre[i], 0.f);
-    const float y = (a - mean[c]) * rstd[c] * g[c] + b[c];
-    act[i] = y * dropout_scale(drop, p, seed, salt + (uint64_t)i);
+    const float x = fmaxf(a.pre[i], 0.f);
+    const float y = (x - a.mean[c]) * a.rstd[c] * a.g[c] + a.b[c];
+    a.act[i] = y * dropout_scale(drop, p, seed, a.salt + (uint64_t)i);
   }
 }
 
-// ---- deterministic two-stage column sums -----------------------------------------------------
-// OP 0: v0 = x[r, c]                                   (bias gradients)
-// OP 1: da = d_act * dropscale ; xhat from pre ; v0 = da, v1 = da * xhat   (BatchNorm backward sums)
+// ---- deterministic two-stage column sums of the BatchNorm backward ------------------------------
+//   da = d_act * dropscale ; xhat from pre ; S1 = sum da, S2 = sum da * xhat
 struct ColArgs {
   const float* x; int64_t ldx;
   const float* pre; const float* mean; const float* rstd;
-  bool drop; float p; uint64_t seed, salt;
-  const uint64_t* seed_dev;
+  uint64_t salt;
+  int B, H, rows_per_chunk, nchunks;
+  float* partial; float* out0; float* out1;
 };
 
-template <int OP>
-__global__ __launch_bounds__(kThreads) void colsum_partial_kernel(ColArgs a, int B, int H, int rows_per_chunk,
-                                                                 float* __restrict__ partial /*[nchunks][2][H]*/) {
+__global__ __launch_bounds__(kThreads) void colsum_partial_kernel(Batch<ColArgs> batch, bool drop, float p, uint64_t seed0,
+                                                                 const uint64_t* __restrict__ seed_dev) {
+  const ColArgs& a = batch.a[blockIdx.z];
+  const int H = a.H;
+  if ((int)blockIdx.x * 64 >= H || (int)blockIdx.y >= a.nchunks) return;
   __shared__ float sh[2][4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
-  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(B, r0 + rows_per_chunk);
+  const int r0 = blockIdx.y * a.rows_per_chunk, r1 = min(a.B, r0 + a.rows_per_chunk);
   float s0 = 0.f, s1 = 0.f;
-  const uint64_t seed = (OP == 1 && a.drop) ? seed_of(a.seed, a.seed_dev) : 0;
+  const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
   if (c < H) {
 #pragma unroll 8
     for (int r = r0 + rl; r < r1; r += 4) {
-      if (OP == 0) {
-        s0 += a.x[(int64_t)r * a.ldx + c];
-      } else {
-        const int64_t i = (int64_t)r * H + c;
-        const float da = a.x[(int64_t)r * a.ldx + c] * dropout_scale(a.drop, a.p, seed, a.salt + (uint64_t)i);
-        const float xh = (fmaxf(a.pre[i], 0.f) - a.mean[c]) * a.rstd[c];
-        s0 += da;
-        s1 += da * xh;
-      }
+      const int64_t i = (int64_t)r * H + c;
+      const float da = a.x[(int64_t)r * a.ldx + c] * dropout_scale(drop, p, seed, a.salt + (uint64_t)i);
+      const float xh = (fmaxf(a.pre[i], 0.f) - a.mean[c]) * a.rstd[c];
+      s0 += da;
+      s1 += da * xh;
     }
   }
   sh[0][rl][threadIdx.x & 63] = s0;
   sh[1][rl][threadIdx.x & 63] = s1;
   __syncthreads();
   if (rl == 0 && c < H) {
-    float* p = partial + (int64_t)blockIdx.y * 2 * H;
-    p[c] = ((sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + sh[0][2][threadIdx.x]) + sh[0][3][threadIdx.x];
-    if (OP == 1) p[H + c] = ((sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + sh[1][2][threadIdx.x]) + sh[1][3][threadIdx.x];
+    float* q = a.partial + (int64_t)blockIdx.y * 2 * H;
+    q[c] = ((sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + sh[0][2][threadIdx.x]) + sh[0][3][threadIdx.x];
+    q[H + c] = ((sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + sh[1][2][threadIdx.x]) + sh[1][3][threadIdx.x];
   }
 }
 
-__global__ __launch_bounds__(kThreads) void colsum_finish_kernel(const float* __restrict__ partial, int nchunks, int H, int nv,
-                                                                float* __restrict__ out0, float* __restrict__ out1) {
+__global__ __launch_bounds__(kThreads) void colsum_finish_kernel(Batch<ColArgs> batch) {
+  const ColArgs& a = batch.a[blockIdx.y];
+  const int H = a.H;
+  if ((int)blockIdx.x * 64 >= H) return;
   __shared__ float sh[2][4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), jl = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f;
@@ -166,9 +180,9 @@ __global__ __launch_bounds__(kThreads) void colsum_finish_kernel(const float* __
 #pragma unroll
     for (int i = 0; i < kMaxChunks / 4; ++i) {
       const int k = jl + 4 * i;
-      const float* p = partial + (int64_t)k * 2 * H;
-      v0[i] = k < nchunks ? p[c] : 0.f;
-      v1[i] = (k < nchunks && nv > 1) ? p[H + c] : 0.f;
+      const float* q = a.partial + (int64_t)k * 2 * H;
+      v0[i] = k < a.nchunks ? q[c] : 0.f;
+      v1[i] = k < a.nchunks ? q[H + c] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < kMaxChunks / 4; ++i) { s0 += v0[i]; s1 += v1[i]; }
@@ -177,31 +191,35 @@ __global__ __launch_bounds__(kThreads) void colsum_finish_kernel(const float* __
   sh[1][jl][threadIdx.x & 63] = s1;
   __syncthreads();
   if (jl != 0 || c >= H) return;
-  out0[c] = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
-  if (nv > 1) out1[c] = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+  a.out0[c] = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
+  a.out1[c] = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
 }
 
 // BN backward apply, in place on the gradient buffer:  d_act -> d_pre
 //   train: d_a = g rstd (da - S1/B - xhat S2/B)   eval: d_a = da g rstd ;   d_pre = d_a [pre > 0]
-__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(float* __restrict__ d, const float* __restrict__ pre, int64_t total, int H,
-                                                               float invB, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                               const float* __restrict__ g, const float* __restrict__ S1,
-                                                               const float* __restrict__ S2, bool train, bool drop, float p, uint64_t seed0,
-                                                               const uint64_t* __restrict__ seed_dev, uint64_t salt) {
+struct BnBwdArgs {
+  float* d; const float* pre; int64_t total; int H; float invB;
+  const float* mean; const float* rstd; const float* g; const float* S1; const float* S2; uint64_t salt;
+};
+
+__global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(Batch<BnBwdArgs> batch, bool train, bool drop, float p, uint64_t seed0,
+                                                               const uint64_t* __restrict__ seed_dev) {
+  const BnBwdArgs& a = batch.a[blockIdx.y];
   const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+  const int H = a.H;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.total; i += stride) {
     const int c = (int)(i % H);
-    const float pr = pre[i];
-    const float da = d[i] * dropout_scale(drop, p, seed, salt + (uint64_t)i);
+    const float pr = a.pre[i];
+    const float da = a.d[i] * dropout_scale(drop, p, seed, a.salt + (uint64_t)i);
     float dv;
     if (train) {
-      const float xh = (fmaxf(pr, 0.f) - mean[c]) * rstd[c];
-      dv = g[c] * rstd[c] * (da - S1[c] * invB - xh * (S2[c] * invB));
+      const float xh = (fmaxf(pr, 0.f) - a.mean[c]) * a.rstd[c];
+      dv = a.g[c] * a.rstd[c] * (da - a.S1[c] * a.invB - xh * (a.S2[c] * a.invB));
     } else {
-      dv = da * g[c] * rstd[c];
+      dv = da * a.g[c] * a.rstd[c];
     }
-    d[i] = pr > 0.f ? dv : 0.f;
+    a.d[i] = pr > 0.f ? dv : 0.f;
   }
 }
 
@@ -212,40 +230,43 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
-__global__ __launch_bounds__(kThreads) void l2norm_fwd_kernel(const float* __restrict__ y, int B, int D, float* __restrict__ emb) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= B) return;
+struct NormArgs { const float* y; const float* emb_in; const float* d_emb; int B, D; float* out; };
+
+__global__ __launch_bounds__(kThreads) void l2norm_fwd_kernel(Batch<NormArgs> batch) {
+  const NormArgs& a = batch.a[blockIdx.y];
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, D = a.D;
+  if (row >= a.B) return;
   float ss = 0.f;
   for (int c = lane; c < D; c += 64) {
-    const float v = y[(int64_t)row * D + c];
+    const float v = a.y[(int64_t)row * D + c];
     ss += v * v;
   }
   const float den = fmaxf(sqrtf(wave_sum(ss)), kNormEps);
-  for (int c = lane; c < D; c += 64) emb[(int64_t)row * D + c] = y[(int64_t)row * D + c] / den;
+  for (int c = lane; c < D; c += 64) a.out[(int64_t)row * D + c] = a.y[(int64_t)row * D + c] / den;
 }
 
-__global__ __launch_bounds__(kThreads) void l2norm_bwd_kernel(const float* __restrict__ y, const float* __restrict__ emb,
-                                                             const float* __restrict__ d_emb, int B, int D, float* __restrict__ d_y) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= B) return;
+__global__ __launch_bounds__(kThreads) void l2norm_bwd_kernel(Batch<NormArgs> batch) {
+  const NormArgs& a = batch.a[blockIdx.y];
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63, D = a.D;
+  if (row >= a.B) return;
   float ss = 0.f, dot = 0.f;
   for (int c = lane; c < D; c += 64) {
     const int64_t i = (int64_t)row * D + c;
-    ss += y[i] * y[i];
-    dot += emb[i] * d_emb[i];
+    ss += a.y[i] * a.y[i];
+    dot += a.emb_in[i] * a.d_emb[i];
   }
   const float nrm = sqrtf(wave_sum(ss));
   dot = wave_sum(dot);
   const float den = fmaxf(nrm, kNormEps);
   for (int c = lane; c < D; c += 64) {
     const int64_t i = (int64_t)row * D + c;
-    d_y[i] = nrm > kNormEps ? (d_emb[i] - emb[i] * dot) / den : d_emb[i] / den;
+    a.out[i] = nrm > kNormEps ? (a.d_emb[i] - a.emb_in[i] * dot) / den : a.d_emb[i] / den;
   }
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-inline int ew_grid(const tt_ctx* ctx, int64_t n) {
-  const int64_t cap = (int64_t)ctx->num_cus * 8;
+inline int ew_grid(const tt_ctx* ctx, int64_t n, int towers) {
+  const int64_t cap = (int64_t)ctx->num_cus * 8 / (towers > 0 ? towers : 1);
   int64_t b = tt_cdiv(n, kThreads);
   return (int)(b < 1 ? 1 : (b < cap ? b : cap));
 }
@@ -281,7 +302,7 @@ inline WsLayout ws_layout(const tt_tower_params* p, int64_t B, char* base) {
   g = b > g ? b : g;
   WsLayout w;
   w.gemm_bytes = (g + 255) & ~size_t(255);
-  w.col_bytes = sizeof(float) * 3 * (size_t)hmax * (size_t)(tt_cdiv(B > 0 ? B : 1, 64) < 512 ? tt_cdiv(B > 0 ? B : 1, 64) : 512) + 256;
+  w.col_bytes = sizeof(float) * 3 * (size_t)hmax * (size_t)kMaxChunks + 256;
   w.gemm = base;
   w.col = reinterpret_cast<float*>(base ? base + w.gemm_bytes : nullptr);
   w.total = w.gemm_bytes + w.col_bytes;
@@ -300,16 +321,19 @@ int check_params(const tt_tower_params* p, const char* who) {
   return TT_OK;
 }
 
-int colsum(const tt_ctx* ctx, hipStream_t st, int op, const ColArgs& a, int64_t B, int H, float* partial, float* out0, float* out1) {
-  const int nchunks = chunks_for(B, H);
-  const int rpc = (int)tt_cdiv(B, nchunks);
-  dim3 grid((unsigned)tt_cdiv(H, 64), (unsigned)nchunks);
-  if (op == 0) colsum_partial_kernel<0><<<grid, kThreads, 0, st>>>(a, (int)B, H, rpc, partial);
-  else colsum_partial_kernel<1><<<grid, kThreads, 0, st>>>(a, (int)B, H, rpc, partial);
-  TT_LAUNCH_CHECK();
-  colsum_finish_kernel<<<(unsigned)tt_cdiv(H, 64), kThreads, 0, st>>>(partial, nchunks, H, op == 0 ? 1 : 2, out0, out1);
-  TT_LAUNCH_CHECK();
-  (void)ctx;
+int check_batch(int32_t n, const tt_tower_params* const* P, int64_t B, float dropout_p, void* const* ws, const size_t* wsb,
+                const char* who) {
+  TT_CHECK_ARG(n >= 1 && n <= TT_MAX_SIDES && P && ws && wsb, "%s: need 1..%d towers", who, TT_MAX_SIDES);
+  TT_CHECK_ARG(B >= 0 && B < ((int64_t)1 << 24), "%s: B=%lld out of range", who, (long long)B);
+  TT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "%s: dropout_p=%f not in [0,1)", who, dropout_p);
+  for (int t = 0; t < n; ++t) {
+    if (int rc = check_params(P[t], who)) return rc;
+    TT_CHECK_ARG(P[t]->n_hidden == P[0]->n_hidden, "%s: towers fused into one launch must have the same number of hidden blocks", who);
+    if (B > 0 && (!ws[t] || wsb[t] < tt_tower_workspace_bytes(P[t], B))) {
+      tt_set_error("%s: workspace of tower %d: %zu < required %zu", who, t, wsb[t], tt_tower_workspace_bytes(P[t], B));
+      return TT_ERR_WORKSPACE;
+    }
+  }
   return TT_OK;
 }
 
@@ -322,100 +346,171 @@ size_t tt_tower_workspace_bytes(const tt_tower_params* p, int64_t B) {
   return ws_layout(p, B, nullptr).total;
 }
 
-int tt_tower_mlp_fwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts* a, int64_t B, int32_t train, float dropout_p,
-                     uint64_t seed, const uint64_t* seed_dev, void* workspace, size_t workspace_bytes, tt_stream stream) {
-  TT_CHECK_ARG(ctx && a, "tt_tower_mlp_fwd: NULL argument");
-  if (int rc = check_params(p, "tt_tower_mlp_fwd")) return rc;
-  TT_CHECK_ARG(B >= 0 && B < ((int64_t)1 << 24), "tt_tower_mlp_fwd: B=%lld out of range", (long long)B);
-  TT_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "tt_tower_mlp_fwd: dropout_p=%f not in [0,1)", dropout_p);
+int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, const tt_tower_acts* const* A, int64_t B,
+                      int32_t train, float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* const* workspaces,
+                      const size_t* workspace_bytes, tt_stream stream) {
+  TT_CHECK_ARG(ctx && A, "tt_towers_mlp_fwd: NULL argument");
+  if (int rc = check_batch(n, P, B, dropout_p, workspaces, workspace_bytes, "tt_towers_mlp_fwd")) return rc;
   if (B == 0) return TT_OK;
-  TT_CHECK_ARG(a->dense && a->x && a->y && a->emb, "tt_tower_mlp_fwd: NULL activation buffers");
-  if (!workspace || workspace_bytes < tt_tower_workspace_bytes(p, B)) {
-    tt_set_error("tt_tower_mlp_fwd: workspace %zu < required %zu", workspace_bytes, tt_tower_workspace_bytes(p, B));
-    return TT_ERR_WORKSPACE;
-  }
-  const WsLayout ws = ws_layout(p, B, reinterpret_cast<char*>(workspace));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int wx = p->h0 + p->kcat_e;
-  // x[:, 0:h0] = dense W_proj^T + b_proj        (base_tower.py:133)
-  if (int rc = tt_gemm_nt(st, a->dense, p->din, p->w_proj, p->din, p->b_proj, a->x, wx, B, p->h0, p->din, false)) return rc;
-  const float* in = a->x;
-  int in_w = wx;
+  WsLayout ws[TT_MAX_SIDES];
+  const float* in[TT_MAX_SIDES];
+  int in_w[TT_MAX_SIDES];
+  GemmNT nt[TT_MAX_SIDES];
+  for (int t = 0; t < n; ++t) {
+    TT_CHECK_ARG(A[t] && A[t]->dense && A[t]->x && A[t]->y && A[t]->emb, "tt_towers_mlp_fwd: NULL activation buffers");
+    ws[t] = ws_layout(P[t], B, reinterpret_cast<char*>(workspaces[t]));
+    const int wx = P[t]->h0 + P[t]->kcat_e;
+    // x[:, 0:h0] = dense W_proj^T + b_proj        (base_tower.py:133)
+    nt[t] = GemmNT{A[t]->dense, P[t]->din, P[t]->w_proj, P[t]->din, P[t]->b_proj, A[t]->x, wx, B, P[t]->h0, P[t]->din, false, 1.f};
+    in[t] = A[t]->x;
+    in_w[t] = wx;
+  }
+  if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
   const bool drop = train && dropout_p > 0.f;
-  for (int i = 0; i < p->n_hidden; ++i) {
-    const int H = p->hidden[i];
-    TT_CHECK_ARG(a->pre[i] && a->act[i] && a->mean[i] && a->rstd[i], "tt_tower_mlp_fwd: NULL buffers of block %d", i);
-    if (int rc = tt_gemm_nt(st, in, in_w, p->w[i], in_w, p->b[i], a->pre[i], H, B, H, in_w, false)) return rc;
-    if (train) {
+  const int nh = P[0]->n_hidden;
+  for (int i = 0; i < nh; ++i) {
+    Batch<BnStatArgs> bs{};
+    Batch<BnApplyArgs> ba{};
+    int hmax = 1, cmax = 1;
+    int64_t tmax = 1;
+    for (int t = 0; t < n; ++t) {
+      const int H = P[t]->hidden[i];
+      TT_CHECK_ARG(A[t]->pre[i] && A[t]->act[i] && A[t]->mean[i] && A[t]->rstd[i], "tt_towers_mlp_fwd: NULL buffers of block %d", i);
+      nt[t] = GemmNT{in[t], in_w[t], P[t]->w[i], in_w[t], P[t]->b[i], A[t]->pre[i], H, B, H, in_w[t], false, 1.f};
       const int nchunks = chunks_for(B, H);
-      const int rpc = (int)tt_cdiv(B, nchunks);
-      bn_stats_partial_kernel<<<dim3((unsigned)tt_cdiv(H, 64), (unsigned)nchunks), kThreads, 0, st>>>(a->pre[i], (int)B, H, rpc, ws.col);
+      bs.a[t] = BnStatArgs{A[t]->pre[i], (int)B, H, (int)tt_cdiv(B, nchunks), nchunks, ws[t].col, A[t]->mean[i], A[t]->rstd[i],
+                           P[t]->bn_rm[i], P[t]->bn_rv[i]};
+      ba.a[t] = BnApplyArgs{A[t]->pre[i], B * H, H, A[t]->mean[i], A[t]->rstd[i], P[t]->bn_w[i], P[t]->bn_b[i],
+                            ((uint64_t)(i + 1) << 40) ^ ((uint64_t)t << 52), A[t]->act[i]};
+      hmax = H > hmax ? H : hmax;
+      cmax = nchunks > cmax ? nchunks : cmax;
+      tmax = B * H > tmax ? B * H : tmax;
+    }
+    if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
+    if (train) {
+      bn_stats_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(bs);
       TT_LAUNCH_CHECK();
-      bn_stats_finish_kernel<<<(unsigned)tt_cdiv(H, 64), kThreads, 0, st>>>(ws.col, nchunks, H, a->mean[i], a->rstd[i], p->bn_rm[i], p->bn_rv[i]);
+      bn_stats_finish_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)n), kThreads, 0, st>>>(bs);
       TT_LAUNCH_CHECK();
     } else {
-      bn_eval_prepare_kernel<<<(unsigned)tt_cdiv(H, 256), 256, 0, st>>>(p->bn_rm[i], p->bn_rv[i], H, a->mean[i], a->rstd[i]);
+      bn_eval_prepare_kernel<<<dim3((unsigned)tt_cdiv(hmax, 256), (unsigned)n), 256, 0, st>>>(bs);
       TT_LAUNCH_CHECK();
     }
-    bn_apply_kernel<<<ew_grid(ctx, B * H), kThreads, 0, st>>>(a->pre[i], B * H, H, a->mean[i], a->rstd[i], p->bn_w[i], p->bn_b[i], drop,
-                                                               dropout_p, seed, seed_dev, (uint64_t)(i + 1) << 40, a->act[i]);
+    bn_apply_kernel<<<dim3((unsigned)ew_grid(ctx, tmax, n), (unsigned)n), kThreads, 0, st>>>(ba, drop, dropout_p, seed, seed_dev);
     TT_LAUNCH_CHECK();
-    in = a->act[i];
-    in_w = H;
+    for (int t = 0; t < n; ++t) {
+      in[t] = A[t]->act[i];
+      in_w[t] = P[t]->hidden[i];
+    }
   }
-  if (int rc = tt_gemm_nt(st, in, in_w, p->w_out, in_w, p->b_out, a->y, p->d_out, B, p->d_out, in_w, false)) return rc;
-  l2norm_fwd_kernel<<<(unsigned)tt_cdiv(B, 4), kThreads, 0, st>>>(a->y, (int)B, p->d_out, a->emb);
+  Batch<NormArgs> na{};
+  int dmax = 1;
+  for (int t = 0; t < n; ++t) {
+    nt[t] = GemmNT{in[t], in_w[t], P[t]->w_out, in_w[t], P[t]->b_out, A[t]->y, P[t]->d_out, B, P[t]->d_out, in_w[t], false, 1.f};
+    na.a[t] = NormArgs{A[t]->y, nullptr, nullptr, (int)B, P[t]->d_out, A[t]->emb};
+    dmax = P[t]->d_out > dmax ? P[t]->d_out : dmax;
+  }
+  if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
+  l2norm_fwd_kernel<<<dim3((unsigned)tt_cdiv(B, 4), (unsigned)n), kThreads, 0, st>>>(na);
   TT_LAUNCH_CHECK();
+  (void)dmax;
   return TT_OK;
+}
+
+int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, const tt_tower_acts* const* A,
+                      const float* const* d_emb, const tt_tower_grads* const* G, int64_t B, int32_t train, float dropout_p,
+                      uint64_t seed, const uint64_t* seed_dev, void* const* workspaces, const size_t* workspace_bytes,
+                      tt_stream stream) {
+  TT_CHECK_ARG(ctx && A && G && d_emb, "tt_towers_mlp_bwd: NULL argument");
+  if (int rc = check_batch(n, P, B, dropout_p, workspaces, workspace_bytes, "tt_towers_mlp_bwd")) return rc;
+  TT_CHECK_ARG(B >= 1, "tt_towers_mlp_bwd: B < 1");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const bool drop = train && dropout_p > 0.f;
+  const int nh = P[0]->n_hidden;
+  WsLayout ws[TT_MAX_SIDES];
+  float* dcur[TT_MAX_SIDES];
+  Batch<NormArgs> na{};
+  GemmTN tn[TT_MAX_SIDES];
+  GemmNN nn[TT_MAX_SIDES];
+  for (int t = 0; t < n; ++t) {
+    const tt_tower_grads* g = G[t];
+    TT_CHECK_ARG(A[t] && g && d_emb[t] && g->w_proj && g->b_proj && g->w_out && g->b_out && g->d_x && g->d_y,
+                 "tt_towers_mlp_bwd: NULL gradient buffers");
+    ws[t] = ws_layout(P[t], B, reinterpret_cast<char*>(workspaces[t]));
+    na.a[t] = NormArgs{A[t]->y, A[t]->emb, d_emb[t], (int)B, P[t]->d_out, g->d_y};
+  }
+  l2norm_bwd_kernel<<<dim3((unsigned)tt_cdiv(B, 4), (unsigned)n), kThreads, 0, st>>>(na);
+  TT_LAUNCH_CHECK();
+  for (int t = 0; t < n; ++t) {
+    const tt_tower_grads* g = G[t];
+    const float* in_last = nh == 0 ? A[t]->x : A[t]->act[nh - 1];
+    const int lw = last_width(P[t]);
+    tn[t] = GemmTN{g->d_y, P[t]->d_out, in_last, lw, g->w_out, lw, P[t]->d_out, lw, B, ws[t].gemm, ws[t].gemm_bytes, g->b_out};
+    dcur[t] = nh == 0 ? g->d_x : g->scratch[nh - 1];
+    TT_CHECK_ARG(dcur[t], "tt_towers_mlp_bwd: NULL scratch buffer");
+    nn[t] = GemmNN{g->d_y, P[t]->d_out, P[t]->w_out, lw, dcur[t], lw, B, lw, P[t]->d_out};
+  }
+  if (int rc = tt_gemm_tn_batched(st, tn, n)) return rc;
+  if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
+  for (int i = nh - 1; i >= 0; --i) {
+    Batch<ColArgs> cb{};
+    Batch<BnBwdArgs> bb{};
+    int hmax = 1, cmax = 1;
+    int64_t tmax = 1;
+    const uint64_t salt = (uint64_t)(i + 1) << 40;
+    for (int t = 0; t < n; ++t) {
+      const tt_tower_grads* g = G[t];
+      const int H = P[t]->hidden[i];
+      TT_CHECK_ARG(g->w[i] && g->b[i] && g->bn_w[i] && g->bn_b[i], "tt_towers_mlp_bwd: NULL gradient buffers of block %d", i);
+      const int nchunks = chunks_for(B, H);
+      // S1 = sum da -> bn bias grad ; S2 = sum da*xhat -> bn weight grad
+      cb.a[t] = ColArgs{dcur[t], H, A[t]->pre[i], A[t]->mean[i], A[t]->rstd[i], salt ^ ((uint64_t)t << 52), (int)B, H, (int)tt_cdiv(B, nchunks), nchunks,
+                        ws[t].col, g->bn_b[i], g->bn_w[i]};
+      bb.a[t] = BnBwdArgs{dcur[t], A[t]->pre[i], B * H, H, 1.f / (float)B, A[t]->mean[i], A[t]->rstd[i], P[t]->bn_w[i], g->bn_b[i],
+                          g->bn_w[i], salt ^ ((uint64_t)t << 52)};
+      hmax = H > hmax ? H : hmax;
+      cmax = nchunks > cmax ? nchunks : cmax;
+      tmax = B * H > tmax ? B * H : tmax;
+    }
+    colsum_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(cb, drop, dropout_p, seed, seed_dev);
+    TT_LAUNCH_CHECK();
+    colsum_finish_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)n), kThreads, 0, st>>>(cb);
+    TT_LAUNCH_CHECK();
+    bn_bwd_apply_kernel<<<dim3((unsigned)ew_grid(ctx, tmax, n), (unsigned)n), kThreads, 0, st>>>(bb, train != 0, drop, dropout_p, seed, seed_dev);
+    TT_LAUNCH_CHECK();
+    for (int t = 0; t < n; ++t) {
+      const tt_tower_grads* g = G[t];
+      const int H = P[t]->hidden[i];
+      const int iw = in_width(P[t], i);
+      const float* in_i = i == 0 ? A[t]->x : A[t]->act[i - 1];
+      tn[t] = GemmTN{dcur[t], H, in_i, iw, g->w[i], iw, H, iw, B, ws[t].gemm, ws[t].gemm_bytes, g->b[i]};
+      float* dnext = i == 0 ? g->d_x : g->scratch[i - 1];
+      TT_CHECK_ARG(dnext, "tt_towers_mlp_bwd: NULL scratch buffer");
+      nn[t] = GemmNN{dcur[t], H, P[t]->w[i], iw, dnext, iw, B, iw, H};
+      dcur[t] = dnext;
+    }
+    if (int rc = tt_gemm_tn_batched(st, tn, n)) return rc;
+    if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
+  }
+  // dense projection: d_x[:, 0:h0]
+  for (int t = 0; t < n; ++t) {
+    const tt_tower_grads* g = G[t];
+    const int wx = P[t]->h0 + P[t]->kcat_e;
+    tn[t] = GemmTN{g->d_x, wx, A[t]->dense, P[t]->din, g->w_proj, P[t]->din, P[t]->h0, P[t]->din, B, ws[t].gemm, ws[t].gemm_bytes, g->b_proj};
+  }
+  return tt_gemm_tn_batched(st, tn, n);
+}
+
+int tt_tower_mlp_fwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts* a, int64_t B, int32_t train, float dropout_p,
+                     uint64_t seed, const uint64_t* seed_dev, void* workspace, size_t workspace_bytes, tt_stream stream) {
+  return tt_towers_mlp_fwd(ctx, 1, &p, &a, B, train, dropout_p, seed, seed_dev, &workspace, &workspace_bytes, stream);
 }
 
 int tt_tower_mlp_bwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts* a, const float* d_emb, const tt_tower_grads* g,
                      int64_t B, int32_t train, float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* workspace,
                      size_t workspace_bytes, tt_stream stream) {
-  TT_CHECK_ARG(ctx && a && g && d_emb, "tt_tower_mlp_bwd: NULL argument");
-  if (int rc = check_params(p, "tt_tower_mlp_bwd")) return rc;
-  TT_CHECK_ARG(B >= 1 && B < ((int64_t)1 << 24), "tt_tower_mlp_bwd: B=%lld out of range", (long long)B);
-  TT_CHECK_ARG(g->w_proj && g->b_proj && g->w_out && g->b_out && g->d_x && g->d_y, "tt_tower_mlp_bwd: NULL gradient buffers");
-  if (!workspace || workspace_bytes < tt_tower_workspace_bytes(p, B)) {
-    tt_set_error("tt_tower_mlp_bwd: workspace %zu < required %zu", workspace_bytes, tt_tower_workspace_bytes(p, B));
-    return TT_ERR_WORKSPACE;
-  }
-  const WsLayout ws = ws_layout(p, B, reinterpret_cast<char*>(workspace));
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const int wx = p->h0 + p->kcat_e;
-  const int nh = p->n_hidden;
-  const bool drop = train && dropout_p > 0.f;
-  l2norm_bwd_kernel<<<(unsigned)tt_cdiv(B, 4), kThreads, 0, st>>>(a->y, a->emb, d_emb, (int)B, p->d_out, g->d_y);
-  TT_LAUNCH_CHECK();
-  const float* in_last = nh == 0 ? a->x : a->act[nh - 1];
-  const int lw = last_width(p);
-  if (int rc = tt_gemm_tn(st, g->d_y, p->d_out, in_last, lw, g->w_out, lw, p->d_out, lw, B, ws.gemm, ws.gemm_bytes, g->b_out)) return rc;
-  float* dcur = nh == 0 ? g->d_x : g->scratch[nh - 1];
-  TT_CHECK_ARG(dcur, "tt_tower_mlp_bwd: NULL scratch buffer");
-  if (int rc = tt_gemm_nn(st, g->d_y, p->d_out, p->w_out, lw, dcur, lw, B, lw, p->d_out)) return rc;
-  for (int i = nh - 1; i >= 0; --i) {
-    const int H = p->hidden[i];
-    const int iw = in_width(p, i);
-    TT_CHECK_ARG(g->w[i] && g->b[i] && g->bn_w[i] && g->bn_b[i], "tt_tower_mlp_bwd: NULL gradient buffers of block %d", i);
-    const uint64_t salt = (uint64_t)(i + 1) << 40;
-    ColArgs cb{};
-    cb.x = dcur; cb.ldx = H; cb.pre = a->pre[i]; cb.mean = a->mean[i]; cb.rstd = a->rstd[i];
-    cb.drop = drop; cb.p = dropout_p; cb.seed = seed; cb.salt = salt; cb.seed_dev = seed_dev;
-    // S1 = sum da -> bn bias grad ; S2 = sum da*xhat -> bn weight grad
-    if (int rc = colsum(ctx, st, 1, cb, B, H, ws.col, g->bn_b[i], g->bn_w[i])) return rc;
-    bn_bwd_apply_kernel<<<ew_grid(ctx, B * H), kThreads, 0, st>>>(dcur, a->pre[i], B * H, H, 1.f / (float)B, a->mean[i], a->rstd[i],
-                                                                   p->bn_w[i], g->bn_b[i], g->bn_w[i], train != 0, drop, dropout_p, seed, seed_dev, salt);
-    TT_LAUNCH_CHECK();
-    const float* in_i = i == 0 ? a->x : a->act[i - 1];
-    if (int rc = tt_gemm_tn(st, dcur, H, in_i, iw, g->w[i], iw, H, iw, B, ws.gemm, ws.gemm_bytes, g->b[i])) return rc;
-    float* dnext = i == 0 ? g->d_x : g->scratch[i - 1];
-    TT_CHECK_ARG(dnext, "tt_tower_mlp_bwd: NULL scratch buffer");
-    if (int rc = tt_gemm_nn(st, dcur, H, p->w[i], iw, dnext, iw, B, iw, H)) return rc;
-    dcur = dnext;
-  }
-  // dense projection: d_x[:, 0:h0]
-  if (int rc = tt_gemm_tn(st, g->d_x, wx, a->dense, p->din, g->w_proj, p->din, p->h0, p->din, B, ws.gemm, ws.gemm_bytes, g->b_proj)) return rc;
-  return TT_OK;
+  return tt_towers_mlp_bwd(ctx, 1, &p, &a, &d_emb, &g, B, train, dropout_p, seed, seed_dev, &workspace, &workspace_bytes, stream);
 }
 
 int tt_linear_fwd(tt_ctx* ctx, const float* X, int64_t ldx, const float* W, const float* bias, float* Y, int64_t ldy, int64_t M,

@@ -239,6 +239,41 @@ def tower_bwd(params, acts, d_emb, grads, B, train, p_drop, seed, dev, seed_dev=
                                           int(train), p_drop, seed, L.ptr(seed_dev), L.ptr(ws), ws.numel(), L.stream(dev)), "tt_tower_mlp_bwd")
 
 
+def _tower_workspaces(params_list, B, dev):
+    """One growable buffer per (device, stream), carved into per-tower regions."""
+    lib = L.load()
+    sizes = [(lib.tt_tower_workspace_bytes(C.byref(p), B) + 255) // 256 * 256 for p in params_list]
+    buf = L.workspace(dev, sum(sizes))
+    ptrs, off = (L.vp * len(sizes))(), 0
+    for i, z in enumerate(sizes):
+        ptrs[i] = buf.data_ptr() + off
+        off += z
+    return buf, ptrs, (L.sz * len(sizes))(*sizes)
+
+
+def towers_fwd(params_list, acts_list, B, train, p_drop, seed, dev, seed_dev=None):
+    """All towers in one launch per layer step (tt_towers_mlp_fwd)."""
+    n = len(params_list)
+    _, wptrs, wsizes = _tower_workspaces(params_list, B, dev)
+    P = (C.POINTER(L.TowerParams) * n)(*[C.pointer(p) for p in params_list])
+    A = (C.POINTER(L.TowerActs) * n)(*[C.pointer(a) for a in acts_list])
+    with _timed("tt_towers_mlp_fwd"):
+        L.check(L.load().tt_towers_mlp_fwd(L.ctx(dev), n, P, A, B, int(train), p_drop, seed, L.ptr(seed_dev), wptrs, wsizes,
+                                           L.stream(dev)), "tt_towers_mlp_fwd")
+
+
+def towers_bwd(params_list, acts_list, d_embs, grads_list, B, train, p_drop, seed, dev, seed_dev=None):
+    n = len(params_list)
+    _, wptrs, wsizes = _tower_workspaces(params_list, B, dev)
+    P = (C.POINTER(L.TowerParams) * n)(*[C.pointer(p) for p in params_list])
+    A = (C.POINTER(L.TowerActs) * n)(*[C.pointer(a) for a in acts_list])
+    G = (C.POINTER(L.TowerGrads) * n)(*[C.pointer(g) for g in grads_list])
+    D = (L.vp * n)(*[d.data_ptr() for d in d_embs])
+    with _timed("tt_towers_mlp_bwd"):
+        L.check(L.load().tt_towers_mlp_bwd(L.ctx(dev), n, P, A, D, G, B, int(train), p_drop, seed, L.ptr(seed_dev), wptrs, wsizes,
+                                           L.stream(dev)), "tt_towers_mlp_bwd")
+
+
 # ---------------------------------------------------------------------------------------------- score / loss
 def score_dir_fwd(A, Bm, inv_t, shift, diag_offset=0, want_sumscore=True):
     dev, Ra, Rb, D = A.device, A.shape[0], Bm.shape[0], A.shape[1]
@@ -279,15 +314,16 @@ def score_pack_bf16(X):
     return buf
 
 
-def score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank=True):
+def score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank=True, full_rank=True):
     """Both softmax directions of the square in-batch problem in one launch."""
     dev = Np.device
     Bp = (B + 3) // 4 * 4                                              # keep every row 16-byte aligned
     f = torch.empty((4, Bp), dtype=torch.float32, device=dev)         # rowsum, colsum, diag, sumscore
     ranks = torch.empty((2, B), dtype=torch.int32, device=dev)
     arr = (L.ScoreFwdDir * 2)()
-    arr[0] = L.ScoreFwdDir(L.ptr(Np), L.ptr(Cp), B, B, 0, L.ptr(f[0]), L.ptr(f[2]), L.ptr(ranks[0]), L.ptr(f[3]))
-    arr[1] = L.ScoreFwdDir(L.ptr(Cp), L.ptr(Np), B, B, 0, L.ptr(f[1]), None, L.ptr(ranks[1]) if want_col_rank else None, None)
+    rm = 2 if full_rank else 1
+    arr[0] = L.ScoreFwdDir(L.ptr(Np), L.ptr(Cp), B, B, 0, L.ptr(f[0]), L.ptr(f[2]), L.ptr(ranks[0]), L.ptr(f[3]), rm)
+    arr[1] = L.ScoreFwdDir(L.ptr(Cp), L.ptr(Np), B, B, 0, L.ptr(f[1]), None, L.ptr(ranks[1]) if want_col_rank else None, None, rm)
     with _timed("tt_score_fwd_bf16"):
         L.check(L.load().tt_score_fwd_bf16(L.ctx(dev), arr, 2, D, inv_t, shift, L.stream(dev)), "tt_score_fwd_bf16")
     return f[0][:B], f[1][:B], f[2][:B], ranks[0], ranks[1], f[3][:B]

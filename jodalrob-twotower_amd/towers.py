@@ -234,38 +234,44 @@ class _TowersFn(torch.autograd.Function):
                 # different batch sizes cannot share one launch: fall back to one launch per side
                 for g in group:
                     rows = ops.embed_lookup(store.weight, [g[1]], g[0].B, want_rows=grad_on)
-                    plans.append((store, [g[0]], ops.dedup_plan(rows, store.rows) if grad_on else None))
+                    plans.append([store, [g[0]], ops.dedup_plan(rows, store.rows) if grad_on else None])
                 continue
             rows = ops.embed_lookup(store.weight, [g[1] for g in group], B, want_rows=grad_on)
-            plan = None
-            if grad_on:         # the plan depends on ids only and is first needed in the backward: side stream
-                cur = torch.cuda.current_stream(store.device)
-                ds = _side_streams(store.device, len(sides) + 1)[-1]
-                ds.wait_stream(cur)
-                with torch.cuda.stream(ds):
-                    plan = ops.dedup_plan(rows, store.rows)
-                plan.keep = rows                                   # keep the sort input alive until it has run
-                plan.stream = ds
-            plans.append((store, [g[0] for g in group], plan))
+            ev = None
+            if grad_on:
+                ev = torch.cuda.Event()
+                ev.record()                                        # rows are ready here
+            plans.append([store, [g[0] for g in group], None, rows, ev])
         live = [s for s in sides if s.B]
-        if exch is None and len(live) > 1:
-            dev0 = live[0].emb.device
-            cur = torch.cuda.current_stream(dev0)
-            branch = [cur] + _side_streams(dev0, len(live) - 1)
-            for st in branch[1:]:
-                st.wait_stream(cur)
+        fused = len(live) > 1 and len({s.B for s in live}) == 1 and len({s.tower.n_hidden for s in live}) == 1 and \
+            len({(s.train, s.p_drop) for s in live}) == 1
+        if fused:           # horizontal fusion: one launch per layer step covers every tower
+            s0 = live[0]
+            ops.towers_fwd([s.tower._params() for s in live], [s.acts_struct for s in live], s0.B, s0.train, s0.p_drop, s0.seed,
+                           s0.emb.device, s0.tower._seed_dev)
+            for s in live:
+                s.seed = s0.seed
         else:
-            branch = [None] * len(live)
-        for s, st in zip(live, branch):
-            tw = s.tower
-            with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+            for s in live:
+                tw = s.tower
                 ops.tower_fwd(tw._params(), s.acts_struct, s.B, s.train, s.p_drop, s.seed, s.emb.device, tw._seed_dev)
-                if s.train:
-                    for i in range(tw.n_hidden):
-                        tw.mlp[4 * i + 2].num_batches_tracked.add_(1)
-        for st in branch[1:]:
-            if st is not None:
-                branch[0].wait_stream(st)
+        for s in live:
+            if s.train:
+                for i in range(s.tower.n_hidden):
+                    s.tower.mlp[4 * i + 2].num_batches_tracked.add_(1)
+        # duplicate-row plans: depend on ids only, first needed in the backward -> side stream, enqueued AFTER the
+        # towers so that it fills idle CUs under the score kernels instead of delaying the towers
+        for pl in plans:
+            if len(pl) == 5:
+                store, psides, _, rows, ev = pl
+                plan = None
+                if ev is not None:
+                    ds = _side_streams(store.device, len(sides) + 1)[-1]
+                    ds.wait_event(ev)
+                    with torch.cuda.stream(ds):
+                        plan = ops.dedup_plan(rows, store.rows)
+                    plan.keep, plan.stream = rows, ds              # keep the sort input alive until it has run
+                pl[:] = [store, psides, plan]
         ctx.sides, ctx.plans, ctx.spans, ctx.n_flat = sides, plans, spans, len(flat)
         # hand out aliases: keeping the returned objects themselves on ctx would form a reference cycle
         outs = tuple(s.emb.view(s.emb.shape) for s in sides)
@@ -281,16 +287,8 @@ class _TowersFn(torch.autograd.Function):
             d_embs = [None if d is None else d * (1.0 / exch.world) for d in d_embs]
         flat_grads = []
         work = [(s, d, sp) for s, d, sp in zip(ctx.sides, d_embs, ctx.spans) if s.B and d is not None]
-        if exch is None and len(work) > 1:
-            dev0 = work[0][0].emb.device
-            cur0 = torch.cuda.current_stream(dev0)
-            branch = [cur0] + _side_streams(dev0, len(work) - 1)
-            for st in branch[1:]:
-                st.wait_stream(cur0)
-        else:
-            branch = [None] * len(work)
-        for (s, d_emb, (pos, nd, nt)), st in zip(work, branch):
-          with torch.cuda.stream(st) if st is not None else contextlib.nullcontext():
+        prepared = []
+        for s, d_emb, (pos, nd, nt) in work:
             tw = s.tower
             dev = s.emb.device
             d_emb = d_emb.to(dtype=torch.float32).contiguous()
@@ -314,15 +312,23 @@ class _TowersFn(torch.autograd.Function):
             g.w_out, g.b_out = base + 4 * offs[len(dps) - 2], base + 4 * offs[len(dps) - 1]
             g.d_x = base + 4 * offs[len(dps)]
             g.d_y = base + 4 * offs[len(dps) + 1 + len(hid)]
-            ops.tower_bwd(tw._params(), s.acts_struct, d_emb, g, B, s.train, s.p_drop, s.seed, dev, tw._seed_dev)
+            prepared.append((s, d_emb, g))
             for i, v in enumerate(views):
                 grads[pos + 2 + i] = v
             flat_grads.append(buf[:offs[len(dps)]])
             d_x = buf[offs[len(dps)]:offs[len(dps)] + B * tw.x_width].view(B, tw.x_width)
             dxs[id(s)] = d_x[:, tw.tower_hidden_dims[0]:]
-        for st in branch[1:]:
-            if st is not None:
-                branch[0].wait_stream(st)
+        fused = len(prepared) > 1 and len({s.B for s, _, _ in prepared}) == 1 and \
+            len({s.tower.n_hidden for s, _, _ in prepared}) == 1 and len({(s.train, s.p_drop, s.seed) for s, _, _ in prepared}) == 1
+        if fused:
+            s0 = prepared[0][0]
+            ops.towers_bwd([s.tower._params() for s, _, _ in prepared], [s.acts_struct for s, _, _ in prepared],
+                           [d for _, d, _ in prepared], [g for _, _, g in prepared], s0.B, s0.train, s0.p_drop, s0.seed,
+                           s0.emb.device, s0.tower._seed_dev)
+        else:
+            for s, d_emb, g in prepared:
+                ops.tower_bwd(s.tower._params(), s.acts_struct, d_emb, g, s.B, s.train, s.p_drop, s.seed, s.emb.device,
+                              s.tower._seed_dev)
         if exch is not None:
             exch.all_reduce_dense(flat_grads)
             if ctx.exch_state is not None:

@@ -26,13 +26,15 @@ class _ScoreCEFn(torch.autograd.Function):
     score_dtype 'fp32': exact-f32 MFMA path (parity); 'bf16': bf16-operand MFMA fast path."""
 
     @staticmethod
-    def forward(ctx, n, c, inv_t, score_dtype):
+    def forward(ctx, n, c, inv_t, score_dtype, want_col_rank=True, full_rank=True):
         n, c = n.contiguous().float(), c.contiguous().float()
         B, D = n.shape
         shift = abs(inv_t)                                   # unit rows: |s| <= 1/T
         if score_dtype == "bf16":
             Np, Cp = ops.score_pack_bf16(n), ops.score_pack_bf16(c)
-            rowsum, colsum, diag, row_rank, col_rank, sumscore = ops.score_fwd_bf16(Np, Cp, B, D, inv_t, shift)
+            rowsum, colsum, diag, row_rank, col_rank, sumscore = ops.score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank, full_rank)
+            if not want_col_rank:
+                col_rank = row_rank                      # placeholder: column top-1 rate is only a first-call diagnostic
             ctx.packed = (Np, Cp)
         else:
             rowsum, diag, row_rank, sumscore = ops.score_dir_fwd(n, c, inv_t, shift, 0, True)
@@ -42,20 +44,21 @@ class _ScoreCEFn(torch.autograd.Function):
         ctx.save_for_backward(n, c, rowsum, colsum)
         ctx.inv_t, ctx.shift = inv_t, shift
         ctx.mark_non_differentiable(out8, row_rank)
-        return out8[0].clone(), out8, row_rank
+        return out8[7:8].view(()), out8, row_rank              # out8[7] = a second copy of the loss (no clone kernel)
 
     @staticmethod
     def backward(ctx, d_loss, _d_out8, _d_rank):
         n, c, rowsum, colsum = ctx.saved_tensors
         B, D = n.shape
-        d_loss = d_loss.contiguous().float().reshape(1)
+        if d_loss.dtype != torch.float32 or not d_loss.is_contiguous():
+            d_loss = d_loss.contiguous().float()
         scale = ctx.inv_t / (2.0 * B)
         if ctx.packed is not None:
             dN, dC = ops.score_bwd_bf16(ctx.packed[0], ctx.packed[1], B, D, ctx.inv_t, ctx.shift, rowsum, colsum, d_loss, scale)
         else:
             dN = ops.score_dir_bwd(n, c, ctx.inv_t, ctx.shift, 0, rowsum, colsum, d_loss, scale)
             dC = ops.score_dir_bwd(c, n, ctx.inv_t, ctx.shift, 0, colsum, rowsum, d_loss, scale)
-        return dN, dC, None, None
+        return dN, dC, None, None, None, None
 
 
 class _Result(dict):
@@ -124,7 +127,8 @@ class TwoTowerTrainTask(nn.Module):
         if nb != cb:                                                                         # :64-67
             raise ValueError(f"Notice와 Company 배치 크기가 다릅니다: {nb} vs {cb}")
         notice_embeddings, company_embeddings = self.two_tower_model(notice_input, company_input)
-        loss, out8, _ = _ScoreCEFn.apply(notice_embeddings, company_embeddings, 1.0 / float(self.temperature), self.score_dtype)
+        loss, out8, _ = _ScoreCEFn.apply(notice_embeddings, company_embeddings, 1.0 / float(self.temperature), self.score_dtype,
+                                         not hasattr(self, "_pair_check_done"), False)
         if not hasattr(self, "_pair_check_done"):                                            # :82-84
             self._verify_positive_pair_alignment(out8)
             self._pair_check_done = True

@@ -274,6 +274,13 @@ def test_score_bf16_path_vs_oracle(tt):
         got_rank = rank.cpu().numpy()
         assert (got_rank == exp_rank).mean() >= 0.995, (B, D)
         assert got_rank[5] == exp_rank[5] and got_rank[3] == exp_rank[3]       # exact ties (duplicated company)
+        # top-1-only mode (what the training step uses) == (full rank == 0), bit for bit
+        Np, Cp = ops.score_pack_bf16(tn.detach()), ops.score_pack_bf16(tc.detach())
+        full = ops.score_fwd_bf16(Np, Cp, B, D, 1.0 / T, 1.0 / T, True, True)
+        top1 = ops.score_fwd_bf16(Np, Cp, B, D, 1.0 / T, 1.0 / T, True, False)
+        for k in (3, 4):
+            assert torch.equal(top1[k], (full[k] != 0).to(torch.int32)), (B, D, k)
+        assert torch.equal(top1[0], full[0]) and torch.equal(top1[1], full[1])
         # against the exact-f32 path on the same inputs: loss within bf16 operand rounding
         l32, _, _ = _ScoreCEFn.apply(tn.detach(), tc.detach(), 1.0 / T, "fp32")
         np.testing.assert_allclose(l.item(), l32.item(), rtol=3e-3)
