@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--zipf", type=float, default=None, help="Zipf alpha for ids (default uniform)")
     ap.add_argument("--optimizer", choices=["fused_sparse", "fused_dense", "torch_adam"], default="fused_sparse")
     ap.add_argument("--score-dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--mlp-dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--pool", type=int, default=8, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -95,13 +96,14 @@ def main():
             task = create_distributed_train_task(keys_n, keys_c, metadata_path=str(meta), categorical_embedding_dim=E,
                                                  notice_dense_input_dim=din_n, company_dense_input_dim=din_c,
                                                  tower_hidden_dims=hidden, final_embedding_dim=D, dropout_rate=0.1,
-                                                 temperature=1.0, device=dev, embedding_grad=grad_mode, score_dtype=args.score_dtype)
+                                                 temperature=1.0, device=dev, embedding_grad=grad_mode, score_dtype=args.score_dtype,
+                                                 mlp_dtype=args.mlp_dtype)
         else:
             task = tt.create_two_tower_train_task(keys_n, keys_c, metadata_path=str(meta), categorical_embedding_dim=E,
                                                   notice_dense_input_dim=din_n, company_dense_input_dim=din_c,
                                                   tower_hidden_dims=hidden, final_embedding_dim=D, dropout_rate=0.1,
                                                   temperature=1.0, device=dev, embedding_grad=grad_mode,
-                                                  score_dtype=args.score_dtype)
+                                                  score_dtype=args.score_dtype, mlp_dtype=args.mlp_dtype)
     task.train()
     task._pair_check_done = True            # skip the first-call diagnostic printout (host sync)
     if args.optimizer == "torch_adam":
@@ -197,13 +199,14 @@ def main():
         "metric": "training pairs/sec at batch 8192 (embedding-lookup HBM GB/s in roofline)",
         "value": B * world * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 score MFMA (f32 accumulate) + f32 tower MLP and tables" if args.score_dtype == "bf16" else "f32",
+        "dtype": ("bf16" if (args.score_dtype == "bf16" and args.mlp_dtype == "bf16") else
+                  f"score {args.score_dtype} / mlp {args.mlp_dtype}") + " MFMA operands, f32 accumulate; f32 tables, activations and master weights",
         "data": "synthetic",
         "config": {"workload": "configs[1]: 32+6 real keys, 1M-row notice + 1M-row company tables per GPU, batch 8192 per GPU, "
                                "E=32, towers [128,64], final 64, in-batch negatives, dropout 0.1",
                    "batch_per_gpu": B, "global_batch": B * world, "rows_notice": sum(vocab_n), "rows_company": sum(vocab_c),
                    "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})", "optimizer": args.optimizer,
-                   "score_dtype": args.score_dtype, "launch": "hip graph replay" if gstep is not None else "eager",
+                   "score_dtype": args.score_dtype, "mlp_dtype": args.mlp_dtype, "launch": "hip graph replay" if gstep is not None else "eager",
                    "parallelism": "single GPU" if world == 1 else f"row-wise sharded tables x{world} + data parallel towers"},
         "roofline": {"kernel": "lookup_kernel (tt_embed_lookup_fwd)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,

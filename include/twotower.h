@@ -180,8 +180,11 @@ typedef struct tt_tower_params {
   const float* bn_b[TT_MAX_HIDDEN];
   float* bn_rm[TT_MAX_HIDDEN]; /* running_mean, updated by the train-mode forward */
   float* bn_rv[TT_MAX_HIDDEN]; /* running_var */
+  int64_t* bn_nbt[TT_MAX_HIDDEN]; /* num_batches_tracked (+1 per train-mode forward); may be NULL */
   const float* w_out;          /* [d_out, in_last] */
   const float* b_out;
+  int32_t compute_dtype; /* TT_F32: exact-f32 MFMA (parity); TT_BF16: GEMM operands rounded to bf16 (RNE) on the way
+                            into LDS, f32 accumulate on v_mfma_f32_32x32x16_bf16; tensors in memory stay f32 */
 } tt_tower_params;
 
 typedef struct tt_tower_acts { /* caller-allocated; kept between forward and backward */
@@ -247,7 +250,7 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* p, c
  *   rank[a]   = #{b: s_ab > diag} + #{b < positive: s_ab == diag}   (0 <=> torch.argmax hits)
  * The loss needs direction (N,C) and direction (C,N); tt_score_loss_finish combines them:
  *   out[0]=loss  out[1]=accuracy  out[2]=pos mean  out[3]=neg mean  out[4]=gap
- *   out[5]=column-direction top-1 rate  out[6]=sum of all scores  out[7]=loss (second copy)
+ *   out[5]=column-direction top-1 rate  out[6]=sum of all scores;  loss_out[0] = loss (own tensor for autograd)
  * ---------------------------------------------------------------------------------------------- */
 int tt_score_dir_fwd(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D,
                      float inv_t, float shift, int64_t diag_offset, float* sumexp, float* diag,
@@ -256,7 +259,7 @@ int tt_score_dir_fwd(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, i
 int tt_score_loss_finish(tt_ctx* ctx, int64_t B, float shift, const float* rowsum,
                          const float* colsum, const float* diag, const int32_t* row_rank,
                          const int32_t* col_rank, const float* sumscore, float* out8,
-                         tt_stream stream);
+                         float* loss_out /* [1], may be NULL */, tt_stream stream);
 /* gradient of one direction's operand:
  *   dA[a] = d_loss[0] * scale * sum_b (e_ab/sumexp_a[a] + e_ab/sumexp_b[b] - 2[b == a+diag_offset]) Bm[b]
  * with e_ab = exp(s_ab - shift) and scale = inv_t / (2 * batch); call once for (N,C) -> dN and once
@@ -292,6 +295,9 @@ typedef struct tt_score_bwd_dir {
 } tt_score_bwd_dir;
 size_t tt_score_pack_bytes(int64_t R, int32_t D);
 int tt_score_pack_bf16(tt_ctx* ctx, const float* X, int64_t R, int32_t D, void* packed, tt_stream stream);
+/* two operands in one launch (the notice and company embeddings of a step) */
+int tt_score_pack2_bf16(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0, const float* X1, int64_t R1,
+                        void* packed1, int32_t D, tt_stream stream);
 int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t,
                       float shift, tt_stream stream);
 int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t,

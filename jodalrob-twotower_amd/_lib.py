@@ -53,7 +53,7 @@ class TowerParams(C.Structure):
     _fields_ = [("din", i32), ("h0", i32), ("kcat_e", i32), ("n_hidden", i32), ("d_out", i32),
                 ("hidden", i32 * TT_MAX_HIDDEN),
                 ("w_proj", vp), ("b_proj", vp), ("w", _H), ("b", _H), ("bn_w", _H), ("bn_b", _H),
-                ("bn_rm", _H), ("bn_rv", _H), ("w_out", vp), ("b_out", vp)]
+                ("bn_rm", _H), ("bn_rv", _H), ("bn_nbt", _H), ("w_out", vp), ("b_out", vp), ("compute_dtype", i32)]
 
 
 class TowerActs(C.Structure):
@@ -91,10 +91,11 @@ SIGNATURES = {
     "tt_towers_mlp_bwd": (C.c_int, [vp, i32, C.POINTER(C.POINTER(TowerParams)), C.POINTER(C.POINTER(TowerActs)), C.POINTER(vp),
                                     C.POINTER(C.POINTER(TowerGrads)), i64, i32, f32, u64, vp, C.POINTER(vp), C.POINTER(sz), vp]),
     "tt_score_dir_fwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, vp, vp]),
-    "tt_score_loss_finish": (C.c_int, [vp, i64, f32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "tt_score_loss_finish": (C.c_int, [vp, i64, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "tt_score_dir_bwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, f32, vp, vp]),
     "tt_score_pack_bytes": (sz, [i64, i32]),
     "tt_score_pack_bf16": (C.c_int, [vp, vp, i64, i32, vp, vp]),
+    "tt_score_pack2_bf16": (C.c_int, [vp, vp, i64, vp, vp, i64, vp, i32, vp]),
     "tt_score_fwd_bf16": (C.c_int, [vp, C.POINTER(ScoreFwdDir), i32, i32, f32, f32, vp]),
     "tt_score_bwd_bf16": (C.c_int, [vp, C.POINTER(ScoreBwdDir), i32, i32, f32, f32, vp, f32, vp]),
     "tt_score_matrix": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, vp, i64, vp]),

@@ -7,7 +7,7 @@
 // C[M,N] = act(alpha * A[M,K] . W[N,K]^T + bias)  (nn.Linear forward; alpha = 1/T for score matrices)
 struct GemmNT {
   const float* A; int64_t lda; const float* W; int64_t ldw; const float* bias; float* C; int64_t ldc;
-  int64_t M, N, K; bool relu; float alpha;
+  int64_t M, N, K; bool relu; float alpha; bool bf16 = false;   // bf16: operands rounded to bf16, f32 accumulate
 };
 int tt_gemm_nt_batched(hipStream_t st, const GemmNT* items, int n);
 int tt_gemm_nt(hipStream_t st, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
@@ -15,7 +15,7 @@ int tt_gemm_nt(hipStream_t st, const float* A, int64_t lda, const float* W, int6
 
 // C[M,N] = A[M,K] . W[K,N]                        (data gradient: dX = dY . W)
 struct GemmNN {
-  const float* A; int64_t lda; const float* W; int64_t ldw; float* C; int64_t ldc; int64_t M, N, K;
+  const float* A; int64_t lda; const float* W; int64_t ldw; float* C; int64_t ldc; int64_t M, N, K; bool bf16 = false;
 };
 int tt_gemm_nn_batched(hipStream_t st, const GemmNN* items, int n);
 
@@ -24,6 +24,6 @@ int tt_gemm_nn_batched(hipStream_t st, const GemmNN* items, int n);
 size_t tt_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 struct GemmTN {
   const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t M, N, R;
-  void* workspace; size_t workspace_bytes; float* colsum_out;
+  void* workspace; size_t workspace_bytes; float* colsum_out; bool bf16 = false;
 };
 int tt_gemm_tn_batched(hipStream_t st, const GemmTN* items, int n);

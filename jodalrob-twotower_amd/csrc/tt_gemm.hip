@@ -143,6 +143,103 @@ struct SlabArgs {
 };
 struct SlabBatch { SlabArgs a[TT_MAX_SIDES]; };
 
+// ---- bf16-operand variant: f32 tensors in memory, rounded to bf16 (RNE) on the way into LDS, f32 accumulate on
+// v_mfma_f32_32x32x16_bf16 (16x fewer matrix cycles than the exact-f32 form).  LDS tiles are [x][k] with k
+// contiguous (80-B rows: conflict-free ds_read_b128 fragments of 8 consecutive k).
+using bf16x8g = __attribute__((ext_vector_type(8))) __bf16;
+constexpr int BK16 = 32, LDS16 = 40;
+
+template <int MODE>
+struct TileLoader16 {
+  float r[8];
+  __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int x0, int X, int k0, int kend, int t, bool vec) {
+    if (MODE == 0) {                       // K-contiguous: 8 consecutive k of one row per thread
+      const int x = x0 + (t >> 2), k = k0 + (t & 3) * 8;
+      if (vec && x < X && k + 7 < kend) {
+        const float4 a = *reinterpret_cast<const float4*>(P + (int64_t)x * ld + k);
+        const float4 b = *reinterpret_cast<const float4*>(P + (int64_t)x * ld + k + 4);
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (x < X && k + j < kend) ? P[(int64_t)x * ld + k + j] : 0.f;
+      }
+    } else {                               // X-contiguous: one x, 8 consecutive k (coalesced dword loads across x)
+      const int x = x0 + (t & 63), k = k0 + (t >> 6) * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] = (x < X && k + j < kend) ? P[(int64_t)(k + j) * ld + x] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* __restrict__ S, int t) const {
+    bf16x8g v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)r[j];
+    const int row = MODE == 0 ? (t >> 2) : (t & 63), kq = MODE == 0 ? (t & 3) * 8 : (t >> 6) * 8;
+    *reinterpret_cast<bf16x8g*>(S + row * LDS16 + kq) = v;
+  }
+};
+
+template <int MODE_A, int MODE_B, bool COLSUM>
+__global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(GemmBatch batch, int zsplits, int vec) {
+  const GemmArgs& g = batch.a[blockIdx.z / zsplits];
+  const int split = blockIdx.z % zsplits;
+  const int M = g.M, N = g.N, K = g.K, kchunk = g.kchunk;
+  if ((int)blockIdx.x * BM >= M || (int)blockIdx.y * BN >= N || split >= g.splits) return;
+  __shared__ __attribute__((aligned(16))) __bf16 As[BM * LDS16];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[BN * LDS16];
+  __shared__ float red[4][64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kbeg = split * kchunk, kend = min(K, kbeg + kchunk);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  TileLoader16<MODE_A> la;
+  TileLoader16<MODE_B> lb;
+  float cs = 0.f;
+  if (kbeg < kend) {
+    la.load(g.A, g.lda, m0, M, kbeg, kend, t, vec);
+    lb.load(g.B, g.ldb, n0, N, kbeg, kend, t, vec);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK16) {
+    la.store(As, t);
+    lb.store(Bs, t);
+    if (COLSUM) {                          // MODE_A == 1 there: this thread holds column (t & 63), 8 batch rows
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cs += la.r[j];
+    }
+    __syncthreads();
+    if (k0 + BK16 < kend) {
+      la.load(g.A, g.lda, m0, M, k0 + BK16, kend, t, vec);
+      lb.load(g.B, g.ldb, n0, N, k0 + BK16, kend, t, vec);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const bf16x8g a = *reinterpret_cast<const bf16x8g*>(As + (wr * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
+      const bf16x8g b = *reinterpret_cast<const bf16x8g*>(Bs + (wc * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (COLSUM && g.colsum_slab && blockIdx.y == 0) {
+    red[t >> 6][t & 63] = cs;
+    __syncthreads();
+    if (t < BM && m0 + t < M) g.colsum_slab[(int64_t)split * M + m0 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  }
+  float* Cz = g.C + (int64_t)split * g.slab_stride;
+  const int n = n0 + wc * 32 + li;
+  const float bv = (g.bias && n < N) ? g.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (m < M && n < N) {
+      float v = acc[r] * g.alpha + bv;
+      if (g.relu) v = fmaxf(v, 0.f);
+      Cz[(int64_t)m * g.ldc + n] = v;
+    }
+  }
+}
+
 __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(SlabBatch batch) {
   const SlabArgs& a = batch.a[blockIdx.y];
   const int64_t total = (int64_t)a.M * a.N;
@@ -179,13 +276,19 @@ inline int tn_splits(int64_t M, int64_t N, int64_t R) {
 }  // namespace
 
 template <int MA, int MB>
-static int launch_gemm(hipStream_t st, const GemmBatch& b, int n, int zsplits, bool vec, bool colsum) {
+static int launch_gemm(hipStream_t st, const GemmBatch& b, int n, int zsplits, bool vec, bool colsum, bool bf16 = false) {
   int mt = 1, nt = 1;
   for (int i = 0; i < n; ++i) {
     mt = (int)tt_cdiv(b.a[i].M, BM) > mt ? (int)tt_cdiv(b.a[i].M, BM) : mt;
     nt = (int)tt_cdiv(b.a[i].N, BN) > nt ? (int)tt_cdiv(b.a[i].N, BN) : nt;
   }
   dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(n * zsplits));
+  if (bf16) {
+    if (colsum) gemm_bf16_kernel<MA, MB, true><<<grid, THREADS, 0, st>>>(b, zsplits, vec ? 1 : 0);
+    else gemm_bf16_kernel<MA, MB, false><<<grid, THREADS, 0, st>>>(b, zsplits, vec ? 1 : 0);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+  }
   if (colsum) {
     if (vec) gemm_kernel<MA, MB, true, true><<<grid, THREADS, 0, st>>>(b, zsplits);
     else gemm_kernel<MA, MB, false, true><<<grid, THREADS, 0, st>>>(b, zsplits);
@@ -204,10 +307,10 @@ int tt_gemm_nt_batched(hipStream_t st, const GemmNT* it, int n) {
   for (int i = 0; i < n; ++i) {
     if (it[i].M == 0 || it[i].N == 0) continue;
     b.a[m++] = GemmArgs{it[i].A, it[i].lda, it[i].W, it[i].ldw, it[i].C, it[i].ldc, 0, (int)it[i].M, (int)it[i].N, (int)it[i].K,
-                        (int)(tt_cdiv(it[i].K > 0 ? it[i].K : 1, BK) * BK), 1, it[i].bias, it[i].relu ? 1 : 0, it[i].alpha, nullptr};
+                        (int)(tt_cdiv(it[i].K > 0 ? it[i].K : 1, BK16) * BK16), 1, it[i].bias, it[i].relu ? 1 : 0, it[i].alpha, nullptr};
     vec = vec && vec_ok(it[i].A, it[i].lda) && vec_ok(it[i].W, it[i].ldw);
   }
-  return m ? launch_gemm<0, 0>(st, b, m, 1, vec, false) : TT_OK;
+  return m ? launch_gemm<0, 0>(st, b, m, 1, vec, false, n > 0 && it[0].bf16) : TT_OK;
 }
 
 int tt_gemm_nn_batched(hipStream_t st, const GemmNN* it, int n) {
@@ -217,10 +320,10 @@ int tt_gemm_nn_batched(hipStream_t st, const GemmNN* it, int n) {
   for (int i = 0; i < n; ++i) {
     if (it[i].M == 0 || it[i].N == 0) continue;
     b.a[m++] = GemmArgs{it[i].A, it[i].lda, it[i].W, it[i].ldw, it[i].C, it[i].ldc, 0, (int)it[i].M, (int)it[i].N, (int)it[i].K,
-                        (int)(tt_cdiv(it[i].K > 0 ? it[i].K : 1, BK) * BK), 1, nullptr, 0, 1.f, nullptr};
+                        (int)(tt_cdiv(it[i].K > 0 ? it[i].K : 1, BK16) * BK16), 1, nullptr, 0, 1.f, nullptr};
     vec = vec && vec_ok(it[i].A, it[i].lda) && vec_ok(it[i].W, it[i].ldw);
   }
-  return m ? launch_gemm<0, 1>(st, b, m, 1, vec, false) : TT_OK;
+  return m ? launch_gemm<0, 1>(st, b, m, 1, vec, false, n > 0 && it[0].bf16) : TT_OK;
 }
 
 size_t tt_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
@@ -243,7 +346,7 @@ int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n) {
     }
     float* slabs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(t.workspace) + 255) & ~uintptr_t(255));
     float* cslab = slabs + (size_t)splits * (size_t)t.M * (size_t)t.N;
-    const int kchunk = (int)(tt_cdiv(tt_cdiv(t.R > 0 ? t.R : 1, splits), BK) * BK);
+    const int kchunk = (int)(tt_cdiv(tt_cdiv(t.R > 0 ? t.R : 1, splits), BK16) * BK16);
     b.a[m] = GemmArgs{t.A, t.lda, t.B, t.ldb, slabs, t.N, t.M * t.N, (int)t.M, (int)t.N, (int)t.R, kchunk, splits, nullptr, 0, 1.f,
                       t.colsum_out ? cslab : nullptr};
     sb.a[m] = SlabArgs{slabs, t.M * t.N, splits, t.C, t.ldc, (int)t.M, (int)t.N, cslab, t.colsum_out};
@@ -255,7 +358,7 @@ int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n) {
     ++m;
   }
   if (!m) return TT_OK;
-  if (int rc = launch_gemm<1, 1>(st, b, m, zs, vec, colsum)) return rc;
+  if (int rc = launch_gemm<1, 1>(st, b, m, zs, vec, colsum, it[0].bf16)) return rc;
   int blocks = (int)tt_cdiv(maxtotal, THREADS);
   if (blocks > 1024) blocks = 1024;
   slab_reduce_kernel<<<dim3((unsigned)blocks, (unsigned)m), THREADS, 0, st>>>(sb);

@@ -242,7 +242,8 @@ __device__ __forceinline__ float block_sum(float x, float* sh) {
 __global__ __launch_bounds__(1024) void loss_finish_kernel(int64_t B, float shift, const float* __restrict__ rowsum,
                                                            const float* __restrict__ colsum, const float* __restrict__ diag,
                                                            const int32_t* __restrict__ row_rank, const int32_t* __restrict__ col_rank,
-                                                           const float* __restrict__ sumscore, float* __restrict__ out) {
+                                                           const float* __restrict__ sumscore, float* __restrict__ out,
+                                                           float* __restrict__ loss_out) {
   __shared__ float sh[16];
   float l = 0.f, hit = 0.f, chit = 0.f, dsum = 0.f, tot = 0.f;
   for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
@@ -266,7 +267,8 @@ __global__ __launch_bounds__(1024) void loss_finish_kernel(int64_t B, float shif
     out[4] = pos - neg;
     out[5] = chit / fb;
     out[6] = tot;
-    out[7] = out[0];          // second copy of the loss (the autograd output aliases it)
+    out[7] = 0.f;
+    if (loss_out) loss_out[0] = out[0];
   }
 }
 
@@ -349,10 +351,11 @@ int tt_score_dir_fwd(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, i
 }
 
 int tt_score_loss_finish(tt_ctx* ctx, int64_t B, float shift, const float* rowsum, const float* colsum, const float* diag,
-                         const int32_t* row_rank, const int32_t* col_rank, const float* sumscore, float* out8, tt_stream stream) {
+                         const int32_t* row_rank, const int32_t* col_rank, const float* sumscore, float* out8, float* loss_out,
+                         tt_stream stream) {
   TT_CHECK_ARG(ctx && rowsum && colsum && diag && row_rank && col_rank && out8, "tt_score_loss_finish: NULL argument");
   TT_CHECK_ARG(B >= 1, "tt_score_loss_finish: B < 1");
-  loss_finish_kernel<<<1, 1024, 0, reinterpret_cast<hipStream_t>(stream)>>>(B, shift, rowsum, colsum, diag, row_rank, col_rank, sumscore, out8);
+  loss_finish_kernel<<<1, 1024, 0, reinterpret_cast<hipStream_t>(stream)>>>(B, shift, rowsum, colsum, diag, row_rank, col_rank, sumscore, out8, loss_out);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

@@ -39,8 +39,15 @@ __device__ __forceinline__ float max3_asm(float a, float b, float c) {
 }
 
 // ---- pack ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ X, int64_t R, int D, int64_t Rp, int Dp,
-                                                        __bf16* __restrict__ rows, __bf16* __restrict__ frag) {
+struct PackArgs { const float* X; int64_t R, Rp; __bf16* rows; __bf16* frag; };
+struct PackBatch { PackArgs a[2]; };
+
+__global__ __launch_bounds__(256) void pack_bf16_kernel(PackBatch batch, int D, int Dp) {
+  const PackArgs& pa = batch.a[blockIdx.y];
+  const float* __restrict__ X = pa.X;
+  const int64_t R = pa.R, Rp = pa.Rp;
+  __bf16* __restrict__ rows = pa.rows;
+  __bf16* __restrict__ frag = pa.frag;
   const int64_t nchunk = Rp * Dp / 8;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < 2 * nchunk; c += stride) {
@@ -437,24 +444,36 @@ size_t tt_score_pack_bytes(int64_t R, int32_t D) {
   return (size_t)(4 * rup(R > 0 ? R : 1, 64) * padded_d(D));
 }
 
-int tt_score_pack_bf16(tt_ctx* ctx, const float* X, int64_t R, int32_t D, void* packed, tt_stream stream) {
-  TT_CHECK_ARG(ctx && X && packed, "tt_score_pack_bf16: NULL argument");
-  TT_CHECK_ARG(R >= 1 && D >= 1, "tt_score_pack_bf16: bad shape");
+int tt_score_pack2_bf16(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0, const float* X1, int64_t R1, void* packed1,
+                        int32_t D, tt_stream stream) {
+  TT_CHECK_ARG(ctx && X0 && packed0, "tt_score_pack_bf16: NULL argument");
+  TT_CHECK_ARG(R0 >= 1 && D >= 1 && (X1 == nullptr || (packed1 && R1 >= 1)), "tt_score_pack_bf16: bad shape");
   if (D > 256) {
     tt_set_error("tt_score_pack_bf16: D=%d > 256 not supported", D);
     return TT_ERR_UNSUPPORTED;
   }
-  TT_CHECK_ARG(tt_aligned(packed, 16), "tt_score_pack_bf16: packed buffer must be 16-byte aligned");
-  const int64_t Rp = rup(R, 64);          // a workgroup reads up to 64 consecutive rows of its operand
+  TT_CHECK_ARG(tt_aligned(packed0, 16) && tt_aligned(packed1, 16), "tt_score_pack_bf16: packed buffers must be 16-byte aligned");
   const int Dp = padded_d(D);
-  __bf16* base = reinterpret_cast<__bf16*>(packed);
-  const int64_t chunks = 2 * Rp * Dp / 8;
-  int64_t grid = tt_cdiv(chunks, 256);
-  const int64_t cap = (int64_t)ctx->num_cus * 8;
+  PackBatch b{};
+  const int n = X1 ? 2 : 1;
+  int64_t maxchunks = 1;
+  for (int i = 0; i < n; ++i) {
+    const int64_t R = i ? R1 : R0, Rp = rup(R, 64);     // a workgroup reads up to 64 consecutive rows of its operand
+    __bf16* base = reinterpret_cast<__bf16*>(i ? packed1 : packed0);
+    b.a[i] = PackArgs{i ? X1 : X0, R, Rp, base, base + Rp * Dp};
+    const int64_t chunks = 2 * Rp * Dp / 8;
+    maxchunks = chunks > maxchunks ? chunks : maxchunks;
+  }
+  int64_t grid = tt_cdiv(maxchunks, 256);
+  const int64_t cap = (int64_t)ctx->num_cus * 4;
   if (grid > cap) grid = cap;
-  pack_bf16_kernel<<<(unsigned)grid, 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(X, R, D, Rp, Dp, base, base + Rp * Dp);
+  pack_bf16_kernel<<<dim3((unsigned)grid, (unsigned)n), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(b, D, Dp);
   TT_LAUNCH_CHECK();
   return TT_OK;
+}
+
+int tt_score_pack_bf16(tt_ctx* ctx, const float* X, int64_t R, int32_t D, void* packed, tt_stream stream) {
+  return tt_score_pack2_bf16(ctx, X, R, packed, nullptr, 0, nullptr, D, stream);
 }
 
 int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t, float shift,

@@ -36,7 +36,7 @@ struct Batch {
 };
 
 // grid (colblocks of 64, nchunks, towers); thread = (column, row-lane of 4)
-struct BnStatArgs { const float* pre; int B, H, rows_per_chunk, nchunks; float* partial; float* mean; float* rstd; float* rm; float* rv; };
+struct BnStatArgs { const float* pre; int B, H, rows_per_chunk, nchunks; float* partial; float* mean; float* rstd; float* rm; float* rv; int64_t* nbt; };
 
 __global__ __launch_bounds__(kThreads) void bn_stats_partial_kernel(Batch<BnStatArgs> batch) {
   const BnStatArgs& a = batch.a[blockIdx.z];
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(kThreads) void bn_stats_finish_kernel(Batch<BnStatA
     a.rm[c] = (1.f - kBnMomentum) * a.rm[c] + kBnMomentum * o.mean;
     a.rv[c] = (1.f - kBnMomentum) * a.rv[c] + kBnMomentum * (o.n > 1.f ? o.m2 / (o.n - 1.f) : var);
   }
+  if (a.nbt && c == 0) a.nbt[0] += 1;
 }
 
 __global__ void bn_eval_prepare_kernel(Batch<BnStatArgs> batch) {
@@ -329,6 +330,7 @@ int check_batch(int32_t n, const tt_tower_params* const* P, int64_t B, float dro
   for (int t = 0; t < n; ++t) {
     if (int rc = check_params(P[t], who)) return rc;
     TT_CHECK_ARG(P[t]->n_hidden == P[0]->n_hidden, "%s: towers fused into one launch must have the same number of hidden blocks", who);
+    TT_CHECK_ARG(P[t]->compute_dtype == P[0]->compute_dtype, "%s: towers fused into one launch must share compute_dtype", who);
     if (B > 0 && (!ws[t] || wsb[t] < tt_tower_workspace_bytes(P[t], B))) {
       tt_set_error("%s: workspace of tower %d: %zu < required %zu", who, t, wsb[t], tt_tower_workspace_bytes(P[t], B));
       return TT_ERR_WORKSPACE;
@@ -366,6 +368,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     in[t] = A[t]->x;
     in_w[t] = wx;
   }
+  for (int t = 0; t < n; ++t) nt[t].bf16 = P[0]->compute_dtype == TT_BF16;
   if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
   const bool drop = train && dropout_p > 0.f;
   const int nh = P[0]->n_hidden;
@@ -380,14 +383,15 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       nt[t] = GemmNT{in[t], in_w[t], P[t]->w[i], in_w[t], P[t]->b[i], A[t]->pre[i], H, B, H, in_w[t], false, 1.f};
       const int nchunks = chunks_for(B, H);
       bs.a[t] = BnStatArgs{A[t]->pre[i], (int)B, H, (int)tt_cdiv(B, nchunks), nchunks, ws[t].col, A[t]->mean[i], A[t]->rstd[i],
-                           P[t]->bn_rm[i], P[t]->bn_rv[i]};
+                           P[t]->bn_rm[i], P[t]->bn_rv[i], P[t]->bn_nbt[i]};
       ba.a[t] = BnApplyArgs{A[t]->pre[i], B * H, H, A[t]->mean[i], A[t]->rstd[i], P[t]->bn_w[i], P[t]->bn_b[i],
                             ((uint64_t)(i + 1) << 40) ^ ((uint64_t)t << 52), A[t]->act[i]};
       hmax = H > hmax ? H : hmax;
       cmax = nchunks > cmax ? nchunks : cmax;
       tmax = B * H > tmax ? B * H : tmax;
     }
-    if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
+    for (int t = 0; t < n; ++t) nt[t].bf16 = P[0]->compute_dtype == TT_BF16;
+  if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
     if (train) {
       bn_stats_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(bs);
       TT_LAUNCH_CHECK();
@@ -411,6 +415,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     na.a[t] = NormArgs{A[t]->y, nullptr, nullptr, (int)B, P[t]->d_out, A[t]->emb};
     dmax = P[t]->d_out > dmax ? P[t]->d_out : dmax;
   }
+  for (int t = 0; t < n; ++t) nt[t].bf16 = P[0]->compute_dtype == TT_BF16;
   if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
   l2norm_fwd_kernel<<<dim3((unsigned)tt_cdiv(B, 4), (unsigned)n), kThreads, 0, st>>>(na);
   TT_LAUNCH_CHECK();
@@ -451,6 +456,7 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     TT_CHECK_ARG(dcur[t], "tt_towers_mlp_bwd: NULL scratch buffer");
     nn[t] = GemmNN{g->d_y, P[t]->d_out, P[t]->w_out, lw, dcur[t], lw, B, lw, P[t]->d_out};
   }
+  for (int t = 0; t < n; ++t) tn[t].bf16 = nn[t].bf16 = P[0]->compute_dtype == TT_BF16;
   if (int rc = tt_gemm_tn_batched(st, tn, n)) return rc;
   if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
   for (int i = nh - 1; i >= 0; --i) {
@@ -490,6 +496,7 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       nn[t] = GemmNN{dcur[t], H, P[t]->w[i], iw, dnext, iw, B, iw, H};
       dcur[t] = dnext;
     }
+    for (int t = 0; t < n; ++t) tn[t].bf16 = nn[t].bf16 = P[0]->compute_dtype == TT_BF16;
     if (int rc = tt_gemm_tn_batched(st, tn, n)) return rc;
     if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
   }
@@ -499,6 +506,7 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     const int wx = P[t]->h0 + P[t]->kcat_e;
     tn[t] = GemmTN{g->d_x, wx, A[t]->dense, P[t]->din, g->w_proj, P[t]->din, P[t]->h0, P[t]->din, B, ws[t].gemm, ws[t].gemm_bytes, g->b_proj};
   }
+  for (int t = 0; t < n; ++t) tn[t].bf16 = P[0]->compute_dtype == TT_BF16;
   return tt_gemm_tn_batched(st, tn, n);
 }
 

@@ -232,8 +232,8 @@ def create_distributed_train_task(notice_categorical_keys, company_categorical_k
                                   categorical_embedding_dim: int = 64, notice_dense_input_dim: int = 256,
                                   company_dense_input_dim: int = 128, tower_hidden_dims=None, final_embedding_dim: int = 128,
                                   dropout_rate: float = 0.2, temperature: float = 1.0, loss_type: str = "cross_entropy",
-                                  device="cuda:0", embedding_grad: Optional[str] = "sparse", score_dtype=None, group=None,
-                                  backend=None, seed: int = 0) -> DistributedTwoTowerTrainTask:
+                                  device="cuda:0", embedding_grad: Optional[str] = "sparse", score_dtype=None, mlp_dtype=None,
+                                  group=None, backend=None, seed: int = 0) -> DistributedTwoTowerTrainTask:
     """Same arguments as create_two_tower_train_task; requires an initialised process group."""
     if not dist.is_initialized():
         raise RuntimeError("create_distributed_train_task needs torch.distributed.init_process_group first")
@@ -241,7 +241,7 @@ def create_distributed_train_task(notice_categorical_keys, company_categorical_k
         tower_hidden_dims = [256, 128]
     common = dict(metadata_path=metadata_path, categorical_embedding_dim=categorical_embedding_dim,
                   tower_hidden_dims=tower_hidden_dims, final_embedding_dim=final_embedding_dim, dropout_rate=dropout_rate,
-                  device=device, embedding_grad=embedding_grad, materialize_tables=False)
+                  device=device, embedding_grad=embedding_grad, materialize_tables=False, mlp_dtype=mlp_dtype)
     model = TwoTowerModel(
         notice_tower_config=dict(categorical_keys=notice_categorical_keys, dense_input_dim=notice_dense_input_dim, **common),
         company_tower_config=dict(categorical_keys=company_categorical_keys, dense_input_dim=company_dense_input_dim, **common),

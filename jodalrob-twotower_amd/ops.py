@@ -202,7 +202,8 @@ def _fill(arr, tensors):
         arr[i] = t.data_ptr() if t is not None else 0
 
 
-def tower_params_struct(din, h0, kcat_e, hidden, d_out, w_proj, b_proj, ws, bs, bn_w, bn_b, bn_rm, bn_rv, w_out, b_out):
+def tower_params_struct(din, h0, kcat_e, hidden, d_out, w_proj, b_proj, ws, bs, bn_w, bn_b, bn_rm, bn_rv, w_out, b_out,
+                        bn_nbt=(), compute_dtype=TT_F32):
     if len(hidden) > L.TT_MAX_HIDDEN:
         raise ValueError(f"at most {L.TT_MAX_HIDDEN} hidden blocks per tower are supported")
     p = L.TowerParams()
@@ -211,6 +212,8 @@ def tower_params_struct(din, h0, kcat_e, hidden, d_out, w_proj, b_proj, ws, bs, 
         p.hidden[i] = h
     p.w_proj, p.b_proj, p.w_out, p.b_out = w_proj.data_ptr(), b_proj.data_ptr(), w_out.data_ptr(), b_out.data_ptr()
     _fill(p.w, ws); _fill(p.b, bs); _fill(p.bn_w, bn_w); _fill(p.bn_b, bn_b); _fill(p.bn_rm, bn_rm); _fill(p.bn_rv, bn_rv)
+    _fill(p.bn_nbt, bn_nbt)
+    p.compute_dtype = compute_dtype
     return p
 
 
@@ -287,12 +290,15 @@ def score_dir_fwd(A, Bm, inv_t, shift, diag_offset=0, want_sumscore=True):
 
 
 def score_loss_finish(B, shift, rowsum, colsum, diag, row_rank, col_rank, sumscore):
+    """Returns (out8, loss): the loss is its own 0-dim tensor so that autograd sees a plain output."""
     dev = rowsum.device
     out = torch.empty(8, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
     with _timed("tt_score_loss_finish"):
         L.check(L.load().tt_score_loss_finish(L.ctx(dev), B, shift, L.ptr(rowsum), L.ptr(colsum), L.ptr(diag), L.ptr(row_rank),
-                                              L.ptr(col_rank), L.ptr(sumscore), L.ptr(out), L.stream(dev)), "tt_score_loss_finish")
-    return out
+                                              L.ptr(col_rank), L.ptr(sumscore), L.ptr(out), L.ptr(loss), L.stream(dev)),
+                "tt_score_loss_finish")
+    return out, loss
 
 
 def score_dir_bwd(A, Bm, inv_t, shift, diag_offset, sumexp_a, sumexp_b, d_loss, scale):
@@ -312,6 +318,18 @@ def score_pack_bf16(X):
     with _timed("tt_score_pack_bf16"):
         L.check(lib.tt_score_pack_bf16(L.ctx(dev), L.ptr(X), R, D, L.ptr(buf), L.stream(dev)), "tt_score_pack_bf16")
     return buf
+
+
+def score_pack2_bf16(X0, X1):
+    """Both operands of a step in one launch."""
+    dev, D = X0.device, X0.shape[1]
+    lib = L.load()
+    b0 = torch.empty(lib.tt_score_pack_bytes(X0.shape[0], D), dtype=torch.uint8, device=dev)
+    b1 = torch.empty(lib.tt_score_pack_bytes(X1.shape[0], D), dtype=torch.uint8, device=dev)
+    with _timed("tt_score_pack_bf16"):
+        L.check(lib.tt_score_pack2_bf16(L.ctx(dev), L.ptr(X0), X0.shape[0], L.ptr(b0), L.ptr(X1), X1.shape[0], L.ptr(b1), D,
+                                        L.stream(dev)), "tt_score_pack2_bf16")
+    return b0, b1
 
 
 def score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank=True, full_rank=True):

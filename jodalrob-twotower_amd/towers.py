@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -47,10 +48,14 @@ class BaseTower(nn.Module):
     def __init__(self, categorical_keys: List[str], metadata_path: str = "meta/metadata.csv", table_name: str = "notice",
                  categorical_embedding_dim: int = 64, dense_input_dim: int = 256,
                  tower_hidden_dims: Optional[List[int]] = None, final_embedding_dim: int = 128, dropout_rate: float = 0.2,
-                 device="cuda:0", embedding_grad: Optional[str] = None, materialize_tables: bool = True):
+                 device="cuda:0", embedding_grad: Optional[str] = None, materialize_tables: bool = True,
+                 mlp_dtype: Optional[str] = None):
         super().__init__()
         if tower_hidden_dims is None:
             tower_hidden_dims = [256, 128]
+        self.mlp_dtype = mlp_dtype or os.environ.get("TT_MLP_DTYPE", "fp32")
+        if self.mlp_dtype not in ("fp32", "bf16"):
+            raise ValueError(f"mlp_dtype must be 'fp32' or 'bf16', got {self.mlp_dtype!r}")
         self.categorical_keys = list(categorical_keys)
         self.exchange = None            # set by the distributed task: sharded-table row exchange
         self._seed_dev = None           # set by GraphedTrainStep: device word added to the dropout seed
@@ -101,7 +106,7 @@ class BaseTower(nn.Module):
         tensors = [self.dense_projection.weight, self.dense_projection.bias, out.weight, out.bias]
         for lin, bn in zip(lins, bns):
             tensors += [lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        key = tuple(t.data_ptr() for t in tensors)
+        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype,)
         if key != self._struct_key:
             for t in tensors:
                 if t.dtype != torch.float32 or not t.is_contiguous():
@@ -111,7 +116,9 @@ class BaseTower(nn.Module):
                 self.dense_input_dim, self.tower_hidden_dims[0], len(self.categorical_keys) * E, self.tower_hidden_dims[1:],
                 self.final_embedding_dim, self.dense_projection.weight, self.dense_projection.bias,
                 [l.weight for l in lins], [l.bias for l in lins], [b.weight for b in bns], [b.bias for b in bns],
-                [b.running_mean for b in bns], [b.running_var for b in bns], out.weight, out.bias)
+                [b.running_mean for b in bns], [b.running_var for b in bns], out.weight, out.bias,
+                bn_nbt=[b.num_batches_tracked for b in bns],
+                compute_dtype=ops.TT_BF16 if self.mlp_dtype == "bf16" else ops.TT_F32)
             self._struct_key = key
         return self._params_struct
 
@@ -128,24 +135,26 @@ class NoticeTower(BaseTower):
     def __init__(self, categorical_keys: List[str], metadata_path: str = "meta/metadata.csv",
                  categorical_embedding_dim: int = 64, dense_input_dim: int = 256,
                  tower_hidden_dims: Optional[List[int]] = None, final_embedding_dim: int = 128, dropout_rate: float = 0.2,
-                 device="cuda:0", embedding_grad: Optional[str] = None, materialize_tables: bool = True):
+                 device="cuda:0", embedding_grad: Optional[str] = None, materialize_tables: bool = True,
+                 mlp_dtype: Optional[str] = None):
         super().__init__(categorical_keys=categorical_keys, metadata_path=metadata_path, table_name="notice",
                          categorical_embedding_dim=categorical_embedding_dim, dense_input_dim=dense_input_dim,
                          tower_hidden_dims=tower_hidden_dims, final_embedding_dim=final_embedding_dim,
                          dropout_rate=dropout_rate, device=device, embedding_grad=embedding_grad,
-                         materialize_tables=materialize_tables)
+                         materialize_tables=materialize_tables, mlp_dtype=mlp_dtype)
 
 
 class CompanyTower(BaseTower):
     def __init__(self, categorical_keys: List[str], metadata_path: str = "meta/metadata.csv",
                  categorical_embedding_dim: int = 64, dense_input_dim: int = 128,
                  tower_hidden_dims: Optional[List[int]] = None, final_embedding_dim: int = 128, dropout_rate: float = 0.2,
-                 device="cuda:0", embedding_grad: Optional[str] = None, materialize_tables: bool = True):
+                 device="cuda:0", embedding_grad: Optional[str] = None, materialize_tables: bool = True,
+                 mlp_dtype: Optional[str] = None):
         super().__init__(categorical_keys=categorical_keys, metadata_path=metadata_path, table_name="company",
                          categorical_embedding_dim=categorical_embedding_dim, dense_input_dim=dense_input_dim,
                          tower_hidden_dims=tower_hidden_dims, final_embedding_dim=final_embedding_dim,
                          dropout_rate=dropout_rate, device=device, embedding_grad=embedding_grad,
-                         materialize_tables=materialize_tables)
+                         materialize_tables=materialize_tables, mlp_dtype=mlp_dtype)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -255,10 +264,6 @@ class _TowersFn(torch.autograd.Function):
             for s in live:
                 tw = s.tower
                 ops.tower_fwd(tw._params(), s.acts_struct, s.B, s.train, s.p_drop, s.seed, s.emb.device, tw._seed_dev)
-        for s in live:
-            if s.train:
-                for i in range(s.tower.n_hidden):
-                    s.tower.mlp[4 * i + 2].num_batches_tracked.add_(1)
         # duplicate-row plans: depend on ids only, first needed in the backward -> side stream, enqueued AFTER the
         # towers so that it fills idle CUs under the score kernels instead of delaying the towers
         for pl in plans:

@@ -86,12 +86,13 @@ def create_two_tower_model(notice_categorical_keys: List[str], company_categoric
                            metadata_path: str = "meta/metadata.csv", categorical_embedding_dim: int = 64,
                            notice_dense_input_dim: int = 256, company_dense_input_dim: int = 128,
                            tower_hidden_dims: Optional[List[int]] = None, final_embedding_dim: int = 128,
-                           dropout_rate: float = 0.2, device="cuda:0", embedding_grad: Optional[str] = None) -> TwoTowerModel:
+                           dropout_rate: float = 0.2, device="cuda:0", embedding_grad: Optional[str] = None,
+                           mlp_dtype: Optional[str] = None) -> TwoTowerModel:
     if tower_hidden_dims is None:
         tower_hidden_dims = [256, 128]
     common = dict(metadata_path=metadata_path, categorical_embedding_dim=categorical_embedding_dim,
                   tower_hidden_dims=tower_hidden_dims, final_embedding_dim=final_embedding_dim, dropout_rate=dropout_rate,
-                  device=device, embedding_grad=embedding_grad)
+                  device=device, embedding_grad=embedding_grad, mlp_dtype=mlp_dtype)
     return TwoTowerModel(
         notice_tower_config=dict(categorical_keys=notice_categorical_keys, dense_input_dim=notice_dense_input_dim, **common),
         company_tower_config=dict(categorical_keys=company_categorical_keys, dense_input_dim=company_dense_input_dim, **common),

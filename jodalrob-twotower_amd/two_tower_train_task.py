@@ -31,7 +31,7 @@ class _ScoreCEFn(torch.autograd.Function):
         B, D = n.shape
         shift = abs(inv_t)                                   # unit rows: |s| <= 1/T
         if score_dtype == "bf16":
-            Np, Cp = ops.score_pack_bf16(n), ops.score_pack_bf16(c)
+            Np, Cp = ops.score_pack2_bf16(n, c)
             rowsum, colsum, diag, row_rank, col_rank, sumscore = ops.score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank, full_rank)
             if not want_col_rank:
                 col_rank = row_rank                      # placeholder: column top-1 rate is only a first-call diagnostic
@@ -40,11 +40,11 @@ class _ScoreCEFn(torch.autograd.Function):
             rowsum, diag, row_rank, sumscore = ops.score_dir_fwd(n, c, inv_t, shift, 0, True)
             colsum, _, col_rank, _ = ops.score_dir_fwd(c, n, inv_t, shift, 0, False)
             ctx.packed = None
-        out8 = ops.score_loss_finish(B, shift, rowsum, colsum, diag, row_rank, col_rank, sumscore)
+        out8, loss = ops.score_loss_finish(B, shift, rowsum, colsum, diag, row_rank, col_rank, sumscore)
         ctx.save_for_backward(n, c, rowsum, colsum)
         ctx.inv_t, ctx.shift = inv_t, shift
         ctx.mark_non_differentiable(out8, row_rank)
-        return out8[7:8].view(()), out8, row_rank              # out8[7] = a second copy of the loss (no clone kernel)
+        return loss, out8, row_rank
 
     @staticmethod
     def backward(ctx, d_loss, _d_out8, _d_rank):
@@ -185,12 +185,12 @@ def create_two_tower_train_task(notice_categorical_keys, company_categorical_key
                                 categorical_embedding_dim: int = 64, notice_dense_input_dim: int = 256,
                                 company_dense_input_dim: int = 128, tower_hidden_dims=None, final_embedding_dim: int = 128,
                                 dropout_rate: float = 0.2, temperature: float = 1.0, loss_type: str = "cross_entropy",
-                                device="cuda:0", embedding_grad=None, score_dtype=None) -> TwoTowerTrainTask:
+                                device="cuda:0", embedding_grad=None, score_dtype=None, mlp_dtype=None) -> TwoTowerTrainTask:
     model = create_two_tower_model(notice_categorical_keys=notice_categorical_keys,
                                    company_categorical_keys=company_categorical_keys, metadata_path=metadata_path,
                                    categorical_embedding_dim=categorical_embedding_dim,
                                    notice_dense_input_dim=notice_dense_input_dim,
                                    company_dense_input_dim=company_dense_input_dim, tower_hidden_dims=tower_hidden_dims,
                                    final_embedding_dim=final_embedding_dim, dropout_rate=dropout_rate, device=device,
-                                   embedding_grad=embedding_grad)
+                                   embedding_grad=embedding_grad, mlp_dtype=mlp_dtype)
     return TwoTowerTrainTask(two_tower_model=model, temperature=temperature, loss_type=loss_type, score_dtype=score_dtype)
