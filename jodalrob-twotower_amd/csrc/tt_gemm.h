@@ -8,7 +8,9 @@
 struct GemmNT {
   const float* A; int64_t lda; const float* W; int64_t ldw; const float* bias; float* C; int64_t ldc;
   int64_t M, N, K; bool relu; float alpha; bool bf16 = false;   // bf16: operands rounded to bf16, f32 accumulate
+  void* workspace = nullptr; size_t workspace_bytes = 0;         // optional: enables split-K (tt_gemm_nt_workspace_bytes)
 };
+size_t tt_gemm_nt_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int tt_gemm_nt_batched(hipStream_t st, const GemmNT* items, int n);
 int tt_gemm_nt(hipStream_t st, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
                int64_t ldc, int64_t M, int64_t N, int64_t K, bool relu, float alpha = 1.f);

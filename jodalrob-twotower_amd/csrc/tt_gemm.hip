@@ -140,6 +140,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch, int zspl
 struct SlabArgs {
   const float* slabs; int64_t slab_stride; int splits; float* C; int64_t ldc; int M, N;
   const float* colsum_slab; float* colsum_out;
+  const float* bias; int relu;          // split-K forward GEMMs finish bias / ReLU here
 };
 struct SlabBatch { SlabArgs a[TT_MAX_SIDES]; };
 
@@ -251,6 +252,8 @@ __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(SlabBatch batch) {
 #pragma unroll 8
       for (int z = 0; z < a.splits; ++z) s += a.slabs[(int64_t)z * a.slab_stride + i];
       const int64_t m = i / a.N, n = i - m * a.N;
+      if (a.bias) s += a.bias[n];
+      if (a.relu) s = fmaxf(s, 0.f);
       a.C[m * a.ldc + n] = s;
     } else {
       const int64_t m = i - total;
@@ -265,9 +268,9 @@ inline bool vec_ok(const float* p, int64_t ld) { return tt_aligned(p, 16) && (ld
 
 inline int tn_splits(int64_t M, int64_t N, int64_t R) {
   const int64_t tiles = tt_cdiv(M, BM) * tt_cdiv(N, BN);
-  int64_t s = 256 / (tiles > 0 ? tiles : 1);
+  int64_t s = 1024 / (tiles > 0 ? tiles : 1);       // ~4 workgroups per CU: the loops are load-latency bound
   int64_t maxs = tt_cdiv(R, 128);
-  if (maxs > 32) maxs = 32;
+  if (maxs > 64) maxs = 64;
   if (s > maxs) s = maxs;
   if (s < 1) s = 1;
   return (int)s;
@@ -300,17 +303,67 @@ static int launch_gemm(hipStream_t st, const GemmBatch& b, int n, int zsplits, b
   return TT_OK;
 }
 
+static int nt_splits(int64_t tiles_all, int64_t K) {
+  int64_t sp = 1024 / (tiles_all > 0 ? tiles_all : 1);
+  const int64_t maxs = K / 128;                       // at least 128 of K per split
+  if (sp > maxs) sp = maxs;
+  if (sp > 16) sp = 16;
+  return (int)(sp < 1 ? 1 : sp);
+}
+
+size_t tt_gemm_nt_workspace_bytes(int64_t M, int64_t N, int64_t K) {
+  return sizeof(float) * 16 * (size_t)M * (size_t)N + 256;     // worst case: 16 slabs
+}
+
 int tt_gemm_nt_batched(hipStream_t st, const GemmNT* it, int n) {
   GemmBatch b{};
-  bool vec = true;
+  SlabBatch sb{};
+  bool vec = true, can_split = true;
   int m = 0;
+  int64_t tiles_all = 0, kmin = INT64_MAX, maxtotal = 1;
   for (int i = 0; i < n; ++i) {
     if (it[i].M == 0 || it[i].N == 0) continue;
-    b.a[m++] = GemmArgs{it[i].A, it[i].lda, it[i].W, it[i].ldw, it[i].C, it[i].ldc, 0, (int)it[i].M, (int)it[i].N, (int)it[i].K,
-                        (int)(tt_cdiv(it[i].K > 0 ? it[i].K : 1, BK16) * BK16), 1, it[i].bias, it[i].relu ? 1 : 0, it[i].alpha, nullptr};
-    vec = vec && vec_ok(it[i].A, it[i].lda) && vec_ok(it[i].W, it[i].ldw);
+    tiles_all += tt_cdiv(it[i].M, BM) * tt_cdiv(it[i].N, BN);
+    kmin = it[i].K < kmin ? it[i].K : kmin;
+    can_split = can_split && it[i].workspace && it[i].workspace_bytes >= tt_gemm_nt_workspace_bytes(it[i].M, it[i].N, it[i].K);
   }
-  return m ? launch_gemm<0, 0>(st, b, m, 1, vec, false, n > 0 && it[0].bf16) : TT_OK;
+  int zsplits = 1;
+  bool any_split = false;
+  for (int i = 0; i < n; ++i) {
+    if (it[i].M == 0 || it[i].N == 0) continue;
+    const int sp = (can_split && it[0].bf16) ? nt_splits(tiles_all, it[i].K) : 1;
+    zsplits = sp > zsplits ? sp : zsplits;
+    any_split = any_split || sp > 1;
+  }
+  (void)kmin;
+  for (int i = 0; i < n; ++i) {
+    if (it[i].M == 0 || it[i].N == 0) continue;
+    // every problem of a split launch goes through slabs (a problem whose K is too short simply uses one slab)
+    const int splits = any_split ? nt_splits(tiles_all, it[i].K) : 1;
+    const int kchunk = (int)(tt_cdiv(tt_cdiv(it[i].K > 0 ? it[i].K : 1, splits), BK16) * BK16);
+    if (any_split) {
+      float* slabs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(it[i].workspace) + 255) & ~uintptr_t(255));
+      b.a[m] = GemmArgs{it[i].A, it[i].lda, it[i].W, it[i].ldw, slabs, it[i].N, it[i].M * it[i].N, (int)it[i].M, (int)it[i].N,
+                        (int)it[i].K, kchunk, splits, nullptr, 0, it[i].alpha, nullptr};
+      sb.a[m] = SlabArgs{slabs, it[i].M * it[i].N, splits, it[i].C, it[i].ldc, (int)it[i].M, (int)it[i].N, nullptr, nullptr,
+                         it[i].bias, it[i].relu ? 1 : 0};
+      maxtotal = it[i].M * it[i].N > maxtotal ? it[i].M * it[i].N : maxtotal;
+    } else {
+      b.a[m] = GemmArgs{it[i].A, it[i].lda, it[i].W, it[i].ldw, it[i].C, it[i].ldc, 0, (int)it[i].M, (int)it[i].N, (int)it[i].K,
+                        kchunk, 1, it[i].bias, it[i].relu ? 1 : 0, it[i].alpha, nullptr};
+    }
+    vec = vec && vec_ok(it[i].A, it[i].lda) && vec_ok(it[i].W, it[i].ldw);
+    ++m;
+  }
+  if (!m) return TT_OK;
+  if (int rc = launch_gemm<0, 0>(st, b, m, zsplits, vec, false, it[0].bf16)) return rc;
+  if (any_split) {
+    int blocks = (int)tt_cdiv(maxtotal, THREADS);
+    if (blocks > 1024) blocks = 1024;
+    slab_reduce_kernel<<<dim3((unsigned)blocks, (unsigned)m), THREADS, 0, st>>>(sb);
+    TT_LAUNCH_CHECK();
+  }
+  return TT_OK;
 }
 
 int tt_gemm_nn_batched(hipStream_t st, const GemmNN* it, int n) {
@@ -349,7 +402,7 @@ int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n) {
     const int kchunk = (int)(tt_cdiv(tt_cdiv(t.R > 0 ? t.R : 1, splits), BK16) * BK16);
     b.a[m] = GemmArgs{t.A, t.lda, t.B, t.ldb, slabs, t.N, t.M * t.N, (int)t.M, (int)t.N, (int)t.R, kchunk, splits, nullptr, 0, 1.f,
                       t.colsum_out ? cslab : nullptr};
-    sb.a[m] = SlabArgs{slabs, t.M * t.N, splits, t.C, t.ldc, (int)t.M, (int)t.N, cslab, t.colsum_out};
+    sb.a[m] = SlabArgs{slabs, t.M * t.N, splits, t.C, t.ldc, (int)t.M, (int)t.N, cslab, t.colsum_out, nullptr, 0};
     vec = vec && vec_ok(t.A, t.lda) && vec_ok(t.B, t.ldb);
     colsum = colsum || t.colsum_out != nullptr;
     zs = splits > zs ? splits : zs;
@@ -368,6 +421,6 @@ int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n) {
 
 int tt_gemm_nt(hipStream_t st, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
                int64_t ldc, int64_t M, int64_t N, int64_t K, bool relu, float alpha) {
-  const GemmNT it{A, lda, W, ldw, bias, C, ldc, M, N, K, relu, alpha};
+  GemmNT it{A, lda, W, ldw, bias, C, ldc, M, N, K, relu, alpha};
   return tt_gemm_nt_batched(st, &it, 1);
 }

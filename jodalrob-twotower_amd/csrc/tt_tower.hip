@@ -301,6 +301,12 @@ inline WsLayout ws_layout(const tt_tower_params* p, int64_t B, char* base) {
   }
   const size_t b = tt_gemm_tn_workspace_bytes(p->d_out, last_width(p), B);
   g = b > g ? b : g;
+  {                                                    // split-K slabs of the forward GEMMs (largest output)
+    int nmax = p->h0 > p->d_out ? p->h0 : p->d_out;
+    for (int i = 0; i < p->n_hidden; ++i) nmax = p->hidden[i] > nmax ? p->hidden[i] : nmax;
+    const size_t f = tt_gemm_nt_workspace_bytes(B, nmax, 0);
+    g = f > g ? f : g;
+  }
   WsLayout w;
   w.gemm_bytes = (g + 255) & ~size_t(255);
   w.col_bytes = sizeof(float) * 3 * (size_t)hmax * (size_t)kMaxChunks + 256;
@@ -368,7 +374,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     in[t] = A[t]->x;
     in_w[t] = wx;
   }
-  for (int t = 0; t < n; ++t) nt[t].bf16 = P[0]->compute_dtype == TT_BF16;
+  for (int t = 0; t < n; ++t) { nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes; }
   if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
   const bool drop = train && dropout_p > 0.f;
   const int nh = P[0]->n_hidden;
@@ -390,7 +396,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       cmax = nchunks > cmax ? nchunks : cmax;
       tmax = B * H > tmax ? B * H : tmax;
     }
-    for (int t = 0; t < n; ++t) nt[t].bf16 = P[0]->compute_dtype == TT_BF16;
+    for (int t = 0; t < n; ++t) { nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes; }
   if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
     if (train) {
       bn_stats_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(bs);
@@ -415,7 +421,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     na.a[t] = NormArgs{A[t]->y, nullptr, nullptr, (int)B, P[t]->d_out, A[t]->emb};
     dmax = P[t]->d_out > dmax ? P[t]->d_out : dmax;
   }
-  for (int t = 0; t < n; ++t) nt[t].bf16 = P[0]->compute_dtype == TT_BF16;
+  for (int t = 0; t < n; ++t) { nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes; }
   if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
   l2norm_fwd_kernel<<<dim3((unsigned)tt_cdiv(B, 4), (unsigned)n), kThreads, 0, st>>>(na);
   TT_LAUNCH_CHECK();
