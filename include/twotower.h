@@ -100,6 +100,17 @@ int tt_dedup_plan(tt_ctx* ctx, const int32_t* rows, int64_t M, int64_t table_row
                   int32_t* sorted_src, int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique,
                   void* workspace, size_t workspace_bytes, tt_stream stream);
 
+/* Same plan for slot rows that come straight from tt_embed_lookup_fwd (slot = side_base + b*K + k): key k's
+ * rows lie in key k's own row range, so the sort decomposes into sum(K) independent sorts of B ids.  One
+ * workgroup per key sorts its B ids entirely in LDS (stable LSD radix, ballot ranking) and a second small
+ * launch compacts the per-key unique lists: 2 launches instead of 3 per radix pass + 2.  Needs B <= 8192 and
+ * key row ranges ascending in (side, k) order (true for the fused store); same outputs as tt_dedup_plan. */
+size_t tt_dedup_keyed_workspace_bytes(int64_t M, int32_t n_keys);
+int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K /* host [n_sides] */,
+                        int32_t n_sides, int64_t B, int32_t* sorted_src, int32_t* unique_rows,
+                        int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
+                        tt_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Embedding gradient -- replaces autograd's nn.Embedding backward (dense index_add; reference
  * builds its tables with sparse=False, src/towers/cat_embed.py:42-45; scripts/train.py:326).

@@ -76,6 +76,8 @@ SIGNATURES = {
     "tt_embed_lookup_fwd": (C.c_int, [vp, vp, i64, i32, C.POINTER(EmbedSide), i32, i64, vp, vp]),
     "tt_dedup_workspace_bytes": (sz, [i64]),
     "tt_dedup_plan": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
+    "tt_dedup_keyed_workspace_bytes": (sz, [i64, i32]),
+    "tt_dedup_plan_keyed": (C.c_int, [vp, vp, C.POINTER(i32), i32, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_embed_grad_workspace_bytes": (sz, [i64, i32]),
     "tt_embed_grad_bwd": (C.c_int, [vp, C.POINTER(GradSrc), i32, i64, i32, vp, vp, vp, vp, i64, i32, vp, vp, sz, vp]),
     "tt_adam_hparams": (None, [i64, f32, f32, f32, f32, f32, C.POINTER(f32 * 6)]),

@@ -560,6 +560,180 @@ __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// Keyed dedup plan: one 1024-thread workgroup per (side, key) sorts that key's B slot rows in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int kKeyedB = 8192;          // max ids per key (LDS: 2 x 32 KB keys + 2 x 16 KB values + 16 KB histograms)
+constexpr int kKeyedThreads = 1024;
+
+struct KeyedArgs {
+  int32_t side_base[TT_MAX_SIDES + 1];   // first slot of side i
+  int32_t key_base[TT_MAX_SIDES + 1];    // first key instance of side i
+  int32_t K[TT_MAX_SIDES];
+  int32_t n_sides;
+  int32_t B;
+};
+
+__global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, const int32_t* __restrict__ rows,
+                                                                  int32_t* __restrict__ sorted_src, int32_t* __restrict__ uniq_stage,
+                                                                  int32_t* __restrict__ seg_stage, int32_t* __restrict__ ucount) {
+  __shared__ uint32_t keys[2][kKeyedB];
+  __shared__ uint16_t vals[2][kKeyedB];
+  __shared__ uint32_t whist[16][256];
+  __shared__ uint32_t red[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ki = blockIdx.x, B = a.B;
+  int side = 0;
+#pragma unroll
+  for (int i = 1; i < TT_MAX_SIDES; ++i)
+    if (i < a.n_sides && ki >= a.key_base[i]) side = i;
+  const int K = a.K[side], k = ki - a.key_base[side], sbase = a.side_base[side];
+  // load this key's ids (stride K in the slot-major array) and find the row range
+  uint32_t lo = 0xFFFFFFFFu, hi = 0;
+  for (int b = tid; b < B; b += kKeyedThreads) {
+    const uint32_t r = (uint32_t)rows[sbase + b * K + k];
+    keys[0][b] = r;
+    vals[0][b] = (uint16_t)b;
+    lo = r < lo ? r : lo;
+    hi = r > hi ? r : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if (lane == 0) { red[wave] = lo; red[16 + wave] = hi; }
+  __syncthreads();
+  lo = red[0]; hi = red[16];
+  for (int w = 1; w < 16; ++w) { lo = red[w] < lo ? red[w] : lo; hi = red[16 + w] > hi ? red[16 + w] : hi; }
+  int bits = 0;
+  while (bits < 32 && ((hi - lo) >> bits) != 0) ++bits;
+  const int passes = (bits + 7) / 8;
+  // every wave owns a contiguous span of the array: stable LSD passes with per-wave digit histograms
+  const int span = (B + 15) / 16;
+  const int wlo = wave * span < B ? wave * span : B, whi = wlo + span < B ? wlo + span : B;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  int cur = 0;
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    for (int d = tid; d < 16 * 256; d += kKeyedThreads) (&whist[0][0])[d] = 0;
+    __syncthreads();
+    for (int i = wlo + lane; i < whi; i += 64) atomicAdd(&whist[wave][((keys[cur][i] - lo) >> shift) & 255u], 1u);
+    __syncthreads();
+    if (wave == 0) {                                  // exclusive prefix over (digit, wave), digit-major: one wave, 4 digits per lane
+      uint32_t own[4], tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) sum += whist[w][lane * 4 + j];
+        own[j] = sum;
+        tot += sum;
+      }
+      uint32_t x = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if (lane >= o) x += y;
+      }
+      uint32_t run = x - tot;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint32_t base = run;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+          const uint32_t c = whist[w][lane * 4 + j];
+          whist[w][lane * 4 + j] = base;
+          base += c;
+        }
+        run += own[j];
+      }
+    }
+    __syncthreads();
+    volatile uint32_t(*wh)[256] = whist;
+    for (int i0 = wlo; i0 < whi; i0 += 64) {
+      const int i = i0 + lane;
+      const bool valid = i < whi;
+      const uint32_t key = valid ? keys[cur][i] : 0u;
+      const uint16_t val = valid ? vals[cur][i] : (uint16_t)0;
+      const uint32_t d = ((key - lo) >> shift) & 255u;
+      uint64_t peers = __ballot(valid);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const bool one = (d >> bit) & 1u;
+        const uint64_t bm = __ballot(one);
+        peers &= one ? bm : ~bm;
+      }
+      const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+      uint32_t pos = 0;
+      if (valid) pos = wh[wave][d] + rank;
+      __builtin_amdgcn_wave_barrier();
+      if (valid && rank == 0) wh[wave][d] = pos + (uint32_t)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+      if (valid) { keys[cur ^ 1][pos] = key; vals[cur ^ 1][pos] = val; }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  // outputs: sorted slots, then the heads of this key (staged; compacted across keys by the second kernel)
+  const int64_t gbase = (int64_t)ki * B;
+  constexpr int PER = kKeyedB / kKeyedThreads;        // 8 contiguous elements per thread
+  const int i_lo = tid * PER;
+  uint32_t flags = 0, c = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = i_lo + j;
+    if (i < B) {
+      sorted_src[gbase + i] = sbase + (int)vals[cur][i] * K + k;
+      if (i == 0 || keys[cur][i] != keys[cur][i - 1]) { flags |= 1u << j; ++c; }
+    }
+  }
+  uint32_t x = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  __syncthreads();
+  if (lane == 63) red[wave] = x;
+  __syncthreads();
+  uint32_t u = x - c;
+  for (int w = 0; w < wave; ++w) u += red[w];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if (flags & (1u << j)) {
+      uniq_stage[gbase + u] = (int32_t)keys[cur][i_lo + j];
+      seg_stage[gbase + u] = (int32_t)(gbase + i_lo + j);
+      ++u;
+    }
+  }
+  if (tid == kKeyedThreads - 1) ucount[ki] = (int32_t)u;
+}
+
+__global__ __launch_bounds__(kThreads) void keyed_compact_kernel(const int32_t* __restrict__ uniq_stage, const int32_t* __restrict__ seg_stage,
+                                                                const int32_t* __restrict__ ucount, int n_keys, int B, int64_t M,
+                                                                int32_t* __restrict__ unique_rows, int32_t* __restrict__ seg_offsets,
+                                                                int32_t* __restrict__ n_unique) {
+  const int ki = blockIdx.x;
+  int before = 0, all = 0;
+  for (int q = 0; q < n_keys; ++q) {                   // n_keys is a few dozen
+    const int v = ucount[q];
+    all += v;
+    if (q < ki) before += v;
+  }
+  const int U = ucount[ki];
+  const int64_t gbase = (int64_t)ki * B;
+  for (int u = threadIdx.x; u < U; u += kThreads) {
+    unique_rows[before + u] = uniq_stage[gbase + u];
+    seg_offsets[before + u] = seg_stage[gbase + u];
+  }
+  if (ki == 0 && threadIdx.x == 0) {
+    n_unique[0] = all;
+    seg_offsets[all] = (int32_t)M;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a16: segmented gradient reduction.  A lane-group of LG lanes owns one distinct row and walks its
 // segment in ascending slot order (4 independent loads in flight, added in order).
 // ------------------------------------------------------------------------------------------------
@@ -1057,6 +1231,56 @@ int tt_dedup_plan(tt_ctx* ctx, const int32_t* rows, int64_t M, int64_t table_row
   head_count_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount);
   TT_LAUNCH_CHECK();
   head_write_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount, n_unique, unique_rows, seg_offsets);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+size_t tt_dedup_keyed_workspace_bytes(int64_t M, int32_t n_keys) {
+  return align256(sizeof(int32_t) * (size_t)(M > 0 ? M : 1)) * 2 + align256(sizeof(int32_t) * (size_t)(n_keys > 0 ? n_keys : 1));
+}
+
+int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K, int32_t n_sides, int64_t B, int32_t* sorted_src,
+                        int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
+                        tt_stream stream) {
+  TT_CHECK_ARG(ctx && rows && side_K && sorted_src && unique_rows && seg_offsets && n_unique && workspace, "tt_dedup_plan_keyed: NULL argument");
+  TT_CHECK_ARG(n_sides >= 1 && n_sides <= TT_MAX_SIDES, "tt_dedup_plan_keyed: n_sides=%d", n_sides);
+  if (B < 1 || B > kKeyedB) {
+    tt_set_error("tt_dedup_plan_keyed: B=%lld not in [1, %d]; use tt_dedup_plan", (long long)B, kKeyedB);
+    return TT_ERR_UNSUPPORTED;
+  }
+  KeyedArgs a{};
+  a.n_sides = n_sides;
+  a.B = (int32_t)B;
+  int n_keys = 0;
+  int64_t slots = 0;
+  for (int i = 0; i < n_sides; ++i) {
+    TT_CHECK_ARG(side_K[i] >= 0, "tt_dedup_plan_keyed: negative K");
+    a.side_base[i] = (int32_t)slots;
+    a.key_base[i] = n_keys;
+    a.K[i] = side_K[i];
+    n_keys += side_K[i];
+    slots += B * side_K[i];
+  }
+  a.side_base[n_sides] = (int32_t)slots;
+  a.key_base[n_sides] = n_keys;
+  TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_dedup_plan_keyed: too many slots");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (n_keys == 0) {
+    TT_HIP(hipMemsetAsync(n_unique, 0, sizeof(int32_t), st));
+    TT_HIP(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), st));
+    return TT_OK;
+  }
+  if (workspace_bytes < tt_dedup_keyed_workspace_bytes(slots, n_keys)) {
+    tt_set_error("tt_dedup_plan_keyed: workspace %zu < required %zu", workspace_bytes, tt_dedup_keyed_workspace_bytes(slots, n_keys));
+    return TT_ERR_WORKSPACE;
+  }
+  char* w = reinterpret_cast<char*>(workspace);
+  int32_t* uniq_stage = reinterpret_cast<int32_t*>(w);
+  int32_t* seg_stage = reinterpret_cast<int32_t*>(w + align256(sizeof(int32_t) * (size_t)slots));
+  int32_t* ucount = reinterpret_cast<int32_t*>(w + 2 * align256(sizeof(int32_t) * (size_t)slots));
+  keyed_sort_kernel<<<n_keys, kKeyedThreads, 0, st>>>(a, rows, sorted_src, uniq_stage, seg_stage, ucount);
+  TT_LAUNCH_CHECK();
+  keyed_compact_kernel<<<n_keys, kThreads, 0, st>>>(uniq_stage, seg_stage, ucount, n_keys, (int)B, slots, unique_rows, seg_offsets, n_unique);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

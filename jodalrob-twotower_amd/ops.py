@@ -151,6 +151,26 @@ def dedup_plan(rows: torch.Tensor, table_rows: int) -> DedupPlan:
     return plan
 
 
+KEYED_MAX_B = 8192
+
+
+def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int) -> DedupPlan:
+    """Plan for slot rows straight from embed_lookup (slot = side_base + b*K + k): per-key LDS sorts, 2 launches."""
+    dev, M = rows.device, rows.numel()
+    assert M == B * sum(side_K)
+    buf = torch.empty(3 * M + 2, dtype=torch.int32, device=dev)
+    plan = DedupPlan(buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:], M)
+    lib = L.load()
+    nk = sum(side_K)
+    ws = L.workspace(dev, lib.tt_dedup_keyed_workspace_bytes(M, nk))
+    ks = (L.i32 * len(side_K))(*side_K)
+    with _timed("tt_dedup_plan_keyed"):
+        L.check(lib.tt_dedup_plan_keyed(L.ctx(dev), L.ptr(rows), ks, len(side_K), B, L.ptr(plan.sorted_src), L.ptr(plan.unique_rows),
+                                        L.ptr(plan.seg_offsets), L.ptr(plan.n_unique), L.ptr(ws), ws.numel(), L.stream(dev)),
+                "tt_dedup_plan_keyed")
+    return plan
+
+
 def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int, out: torch.Tensor):
     """srcs: [(d_out 2-D view [B, K*E], K)]."""
     dev = out.device

@@ -274,7 +274,11 @@ class _TowersFn(torch.autograd.Function):
                     ds = _side_streams(store.device, len(sides) + 1)[-1]
                     ds.wait_event(ev)
                     with torch.cuda.stream(ds):
-                        plan = ops.dedup_plan(rows, store.rows)
+                        Bs = psides[0].B
+                        if 0 < Bs <= ops.KEYED_MAX_B:       # per-key LDS sorts (2 launches)
+                            plan = ops.dedup_plan_keyed(rows, [len(q.tower.categorical_embedder.keys) for q in psides], Bs)
+                        else:
+                            plan = ops.dedup_plan(rows, store.rows)
                     plan.keep, plan.stream = rows, ds              # keep the sort input alive until it has run
                 pl[:] = [store, psides, plan]
         ctx.sides, ctx.plans, ctx.spans, ctx.n_flat = sides, plans, spans, len(flat)

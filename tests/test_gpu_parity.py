@@ -510,9 +510,34 @@ def test_bf16_mlp_close_to_fp32(tt, manifest, schema_real):
     np.testing.assert_allclose(outs["bf16"][0], outs["fp32"][0], rtol=5e-3)
     for k, g32 in outs["fp32"][1].items():
         gb = outs["bf16"][1][k]
-        # three chained bf16-operand GEMMs (8-bit mantissa) with cancelling sums over the batch: 6e-2 norm-wise
-        tol = 6e-2
+        # three chained bf16-operand GEMMs (8-bit mantissa): 6e-2 norm-wise for matrices; the 1-D gradients (biases,
+        # BN scale/shift) are column sums over the batch whose terms largely cancel, so their RELATIVE error is larger
+        tol = 6e-2 if g32.ndim > 1 else 1.5e-1
         assert np.linalg.norm(gb - g32) <= tol * np.linalg.norm(g32) + 1e-9, (k, np.linalg.norm(gb - g32) / np.linalg.norm(g32))
     for k, v in outs["fp32"][2].items():
         np.testing.assert_allclose(outs["bf16"][2][k], v, rtol=2e-2, atol=2e-3, err_msg=k)
     assert all(int(v) == 1 for k, v in outs["bf16"][2].items() if "num_batches" in k)       # counter bumped in-kernel
+
+
+@pytest.mark.parametrize("B,Ks,vocabs", [(8192, [32, 6], None), (1000, [5, 2], None), (1, [3], None), (4097, [4, 3, 2], None)])
+def test_dedup_plan_keyed_equals_general(tt, B, Ks, vocabs):
+    """Per-key LDS plan == the general radix-sort plan (and numpy's stable argsort), bit for bit."""
+    from jodalrob_twotower_amd import ops
+    rng = np.random.default_rng(B + len(Ks))
+    rows_sides, off = [], 0
+    for K in Ks:
+        v = rng.choice([2, 12, 300, 70000, 1_000_000], size=K)
+        offs = off + np.concatenate([[0], np.cumsum(v)[:-1]])
+        ids = np.stack([rng.integers(0, vk, B) for vk in v], axis=1)
+        rows_sides.append((ids + offs[None, :]).reshape(-1))
+        off += int(v.sum())
+    rows = np.concatenate(rows_sides).astype(np.int32)
+    t = torch.from_numpy(rows).to(DEV)
+    pk = ops.dedup_plan_keyed(t, Ks, B)
+    pg = ops.dedup_plan(t, off)
+    U = int(pk.n_unique.item())
+    assert U == int(pg.n_unique.item())
+    order = np.argsort(rows, kind="stable")
+    assert np.array_equal(pk.sorted_src.cpu().numpy(), order.astype(np.int32))
+    assert torch.equal(pk.sorted_src, pg.sorted_src)
+    assert torch.equal(pk.unique_rows[:U], pg.unique_rows[:U]) and torch.equal(pk.seg_offsets[:U + 1], pg.seg_offsets[:U + 1])
