@@ -344,6 +344,14 @@ int tt_batch_gather(tt_ctx* ctx, const int64_t* entity, int64_t B, const float* 
                     int32_t dense_dim, const int64_t* cat_store, int32_t K, float* dense_out,
                     int64_t* ids_out, tt_stream stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * n (<= 8) device-to-device copies in ONE launch -- the per-step refresh of a captured step's static input
+ * buffers (dense features and ids of both towers); sizes in bytes, all pointers 16-byte aligned.
+ * ---------------------------------------------------------------------------------------------- */
+#define TT_MAX_COPIES 8
+int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
+                  tt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

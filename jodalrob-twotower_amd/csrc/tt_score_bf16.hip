@@ -8,10 +8,11 @@
 //     X[b = rowmap(reg, lane>>5)][a = lane&31]: every per-`a` quantity (1/sumexp_a, the diagonal score,
 //     the running exp-sum and rank count) is ONE value per lane, and the accumulator registers of a tile,
 //     converted pairwise to bf16, ARE the A operand of the second MFMA (X^T . Bm) -- no lane movement.
-//   * Bm is read in two images written once per step by tt_score_pack_bf16: row-major [Rp, Dp] (operand
-//     of the first product; a wave-instruction reads 32 rows x 32 B, contiguous) and a fragment-ordered
-//     image [tile][k-step][half][d][8] whose 16-B chunks are exactly the B operand of the second product
-//     in the k-permutation the accumulator registers impose.
+//   * Bm is read in two images written once per step by tt_score_pack_bf16, both in MFMA fragment order so
+//     that every wave-instruction reads 1 KB contiguous (a row-major image made each load touch 32 cache
+//     lines and left the kernels bound by L1 tag throughput): [tile][k-step][half][row][8] for the operands
+//     of the first product, and [tile][k-step][half][d][8] whose 16-B chunks are exactly the B operand of
+//     the second product in the k-permutation the accumulator registers impose.
 //   * partial results of the NW waves are combined through LDS in a fixed tree order.
 #include "tt_common.h"
 
@@ -52,9 +53,12 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBatch batch, int D, 
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < 2 * nchunk; c += stride) {
     bf16x8 v;
-    if (c < nchunk) {                                   // row-major image
-      const int64_t row = c / (Dp / 8);
-      const int d0 = (int)(c % (Dp / 8)) * 8;
+    if (c < nchunk) {                                   // k-fragment image [t][k-step][half][row in tile][8]
+      const int ci = (int)(c & 31), hh = (int)((c >> 5) & 1);
+      const int64_t q = c >> 6;
+      const int ks = (int)(q % (Dp / 16));
+      const int64_t row = 32 * (q / (Dp / 16)) + ci;
+      const int d0 = 16 * ks + 8 * hh;
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (__bf16)((row < R && d0 + j < D) ? X[row * D + d0 + j] : 0.f);
       *reinterpret_cast<bf16x8*>(rows + c * 8) = v;
@@ -107,10 +111,9 @@ struct BwdArgs {
 
 template <int KS>
 __device__ __forceinline__ void load_bfrag(const __bf16* __restrict__ b_rows, int64_t t, int c, int h, bf16x8 (&bf)[KS]) {
-  constexpr int Dp = KS * 16;
-  const __bf16* p = b_rows + (32 * t + c) * Dp + 8 * h;
+  const __bf16* p = b_rows + ((t * KS * 2 + h) * 32 + c) * 8;      // a wave-instruction reads 1 KB contiguous
 #pragma unroll
-  for (int s = 0; s < KS; ++s) bf[s] = *reinterpret_cast<const bf16x8*>(p + 16 * s);
+  for (int s = 0; s < KS; ++s) bf[s] = *reinterpret_cast<const bf16x8*>(p + s * 512);
 }
 
 template <int KS, int AT>
@@ -136,7 +139,7 @@ __device__ __forceinline__ void gemm1(const __bf16* __restrict__ b_rows, int64_t
 // ---- forward ---------------------------------------------------------------------------------------
 template <int KS, int AT, int NW>
 __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
-  constexpr int Dp = KS * 16, ROWS = 32 * AT;
+  constexpr int ROWS = 32 * AT;
   __shared__ float part_e[NW][ROWS];
   __shared__ float part_s[NW][ROWS];
   __shared__ int part_c[NW][ROWS];
@@ -147,9 +150,7 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
   const int64_t nT = rup(dr.Rb, 32) / 32;
   bf16x8 ares[AT][KS];
 #pragma unroll
-  for (int i = 0; i < AT; ++i)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) ares[i][s] = *reinterpret_cast<const bf16x8*>(dr.a_rows + (a0 + 32 * i + c) * Dp + 16 * s + 8 * h);
+  for (int i = 0; i < AT; ++i) load_bfrag<KS>(dr.a_rows, a0 / 32 + i, c, h, ares[i]);
   int64_t pos[AT];
   float dg[AT];
 #pragma unroll
@@ -306,8 +307,7 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
   int64_t pos[AT];
 #pragma unroll
   for (int i = 0; i < AT; ++i) {
-#pragma unroll
-    for (int s = 0; s < KS; ++s) ares[i][s] = *reinterpret_cast<const bf16x8*>(dr.a_rows + (a0 + 32 * i + c) * Dp + 16 * s + 8 * h);
+    load_bfrag<KS>(dr.a_rows, a0 / 32 + i, c, h, ares[i]);
     const int64_t a = a0 + 32 * i + c;
     ia[i] = a < dr.Ra ? __builtin_amdgcn_rcpf(dr.sumexp_a[a]) : 0.f;
     pos[i] = a + dr.off;

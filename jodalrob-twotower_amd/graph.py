@@ -87,9 +87,16 @@ class GraphedTrainStep:
     def step(self, batch: Optional[Dict] = None):
         """Train on `batch` (or on whatever the static buffers hold); returns the static result."""
         if batch is not None:
+            pairs = []
             for side in ("notice", "company"):
-                self.static[side]["dense"].copy_(batch[side]["dense"], non_blocking=True)
-                self.static[side]["kjt"].values().copy_(batch[side]["kjt"].values(), non_blocking=True)
+                d, v = batch[side]["dense"], batch[side]["kjt"].values()
+                sd, sv = self.static[side]["dense"], self.static[side]["kjt"].values()
+                if d.device == sd.device and d.dtype == sd.dtype and v.dtype == sv.dtype and d.is_contiguous() and v.is_contiguous():
+                    pairs += [(sd, d), (sv, v)]
+                else:                                           # host batch / other dtype: ordinary copies
+                    sd.copy_(d, non_blocking=True)
+                    sv.copy_(v, non_blocking=True)
+            ops.copy_multi(pairs)                               # one launch for all four buffers
         self._push_scalars()
         self.graph.replay()
         self._steps_done += 1

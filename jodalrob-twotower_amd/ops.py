@@ -419,6 +419,21 @@ def linear_fwd(X, W, bias, relu=False):
     return Y
 
 
+def copy_multi(pairs):
+    """pairs: [(dst, src)] contiguous same-sized tensors on one device -> one launch."""
+    if not pairs:
+        return
+    dev, n = pairs[0][0].device, len(pairs)
+    dst = (L.vp * n)(*[d.data_ptr() for d, _ in pairs])
+    src = (L.vp * n)(*[s.data_ptr() for _, s in pairs])
+    nb = (L.i64 * n)(*[d.numel() * d.element_size() for d, _ in pairs])
+    for d, s_ in pairs:
+        if d.numel() * d.element_size() != s_.numel() * s_.element_size() or not d.is_contiguous() or not s_.is_contiguous():
+            raise ValueError("copy_multi: segments must be contiguous and equally sized")
+    with _timed("tt_copy_multi"):
+        L.check(L.load().tt_copy_multi(L.ctx(dev), n, dst, src, nb, L.stream(dev)), "tt_copy_multi")
+
+
 def batch_gather(entity, dense_store, cat_store):
     dev, B = entity.device, entity.numel()
     dd = dense_store.shape[1] if dense_store is not None else 0

@@ -44,12 +44,15 @@ class _ScoreCEFn(torch.autograd.Function):
         ctx.save_for_backward(n, c, rowsum, colsum)
         ctx.inv_t, ctx.shift = inv_t, shift
         ctx.mark_non_differentiable(out8, row_rank)
+        ctx.set_materialize_grads(False)                     # else autograd zero-fills grads for out8 / row_rank every step
         return loss, out8, row_rank
 
     @staticmethod
     def backward(ctx, d_loss, _d_out8, _d_rank):
         n, c, rowsum, colsum = ctx.saved_tensors
         B, D = n.shape
+        if d_loss is None:
+            return None, None, None, None, None, None
         if d_loss.dtype != torch.float32 or not d_loss.is_contiguous():
             d_loss = d_loss.contiguous().float()
         scale = ctx.inv_t / (2.0 * B)

@@ -170,9 +170,13 @@ def test_dedup_plan_bit_exact(tt, M, table_rows, dist):
     assert np.array_equal(plan.seg_offsets[:U + 1].cpu().numpy(), np.concatenate([start, [M]]).astype(np.int32))
 
 
-@pytest.mark.parametrize("E,B,vocabs", [(32, 2048, [[2, 2, 12, 5000], [3, 100000]]), (8, 300, [[5, 9], [4]]),
-                                         (6, 64, [[3, 1000]])])
-def test_embed_grad_sparse_and_dense(tt, E, B, vocabs):
+@pytest.mark.parametrize("E,B,vocabs,src_dtype", [(32, 2048, [[2, 2, 12, 5000], [3, 100000]], "f32"), (8, 300, [[5, 9], [4]], "f32"),
+                                                   (6, 64, [[3, 1000]], "f32"), (64, 512, [[2, 300], [7]], "f32"),
+                                                   (16, 700, [[2, 50]], "f32"), (32, 1500, [[3, 40, 9000], [2]], "bf16"),
+                                                   (12, 200, [[2, 30]], "bf16")])
+def test_embed_grad_sparse_and_dense(tt, E, B, vocabs, src_dtype):
+    """lane-group widths 8 / 2 / generic / 16 / 4 of the segmented reduction, f32 and bf16 gradient sources,
+    segments longer than the chunking threshold (vocab 2-3 at B >= 512)."""
     from jodalrob_twotower_amd import ops
     rng = np.random.default_rng(E + B)
     offs, rows_total = [], 0
@@ -185,6 +189,9 @@ def test_embed_grad_sparse_and_dense(tt, E, B, vocabs):
         ids = np.stack([rng.integers(0, vk, B) for vk in v], axis=1)
         d = rng.standard_normal((B, 16 + K * E)).astype(np.float32)
         td = torch.from_numpy(d).to(DEV)
+        if src_dtype == "bf16":
+            td = td.to(torch.bfloat16)
+            d = td.float().cpu().numpy()
         srcs.append((td[:, 16:], K))
         rows_all.append((ids + off[None, :]).reshape(-1))
         d_all.append(d[:, 16:].reshape(B * K, E))
