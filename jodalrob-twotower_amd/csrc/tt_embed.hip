@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __
 // ------------------------------------------------------------------------------------------------
 // Keyed dedup plan: one 1024-thread workgroup per (side, key) sorts that key's B slot rows in LDS.
 // ------------------------------------------------------------------------------------------------
-constexpr int kKeyedB = 8192;          // max ids per key (LDS: 2 x 32 KB keys + 2 x 16 KB values + 16 KB histograms)
+constexpr int kKeyedB = 8192;          // max ids per key (LDS: 2 x 32 KB keys + 2 x 16 KB values + 16 KB histograms + 32 KB lane sets)
 constexpr int kKeyedThreads = 1024;
 
 struct KeyedArgs {
@@ -580,9 +580,11 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
   __shared__ uint32_t keys[2][kKeyedB];
   __shared__ uint16_t vals[2][kKeyedB];
   __shared__ uint32_t whist[16][256];
+  __shared__ unsigned long long peers_mask[16][256];   // lane sets per (wave, digit); all zero between batches
   __shared__ uint32_t red[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ki = blockIdx.x, B = a.B;
+  for (int d = tid; d < 16 * 256; d += kKeyedThreads) (&peers_mask[0][0])[d] = 0ull;
   int side = 0;
 #pragma unroll
   for (int i = 1; i < TT_MAX_SIDES; ++i)
@@ -590,12 +592,25 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
   const int K = a.K[side], k = ki - a.key_base[side], sbase = a.side_base[side];
   // load this key's ids (stride K in the slot-major array) and find the row range
   uint32_t lo = 0xFFFFFFFFu, hi = 0;
-  for (int b = tid; b < B; b += kKeyedThreads) {
-    const uint32_t r = (uint32_t)rows[sbase + b * K + k];
-    keys[0][b] = r;
-    vals[0][b] = (uint16_t)b;
-    lo = r < lo ? r : lo;
-    hi = r > hi ? r : hi;
+  {
+    // stride-K gather (one id per 4*K-byte step): all loads of a thread are issued before the first LDS store
+    constexpr int PERL = kKeyedB / kKeyedThreads;
+    uint32_t r[PERL];
+#pragma unroll
+    for (int j = 0; j < PERL; ++j) {
+      const int b = tid + j * kKeyedThreads;
+      r[j] = b < B ? (uint32_t)rows[sbase + b * K + k] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < PERL; ++j) {
+      const int b = tid + j * kKeyedThreads;
+      if (b < B) {
+        keys[0][b] = r[j];
+        vals[0][b] = (uint16_t)b;
+        lo = r[j] < lo ? r[j] : lo;
+        hi = r[j] > hi ? r[j] : hi;
+      }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -610,68 +625,95 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
   int bits = 0;
   while (bits < 32 && ((hi - lo) >> bits) != 0) ++bits;
   const int passes = (bits + 7) / 8;
+  // digits of equal width (a 9-bit range as 5 + 4 bits, not 8 + 1: a 1-bit digit sends all 64 lanes of a batch
+  // to two LDS words and that pass ran 2x longer than an 8-bit one)
+  const int dbits = passes > 0 ? (bits + passes - 1) / passes : 8;
+  const uint32_t dmask = (1u << dbits) - 1u;
   // every wave owns a contiguous span of the array: stable LSD passes with per-wave digit histograms
   const int span = (B + 15) / 16;
   const int wlo = wave * span < B ? wave * span : B, whi = wlo + span < B ? wlo + span : B;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
   int cur = 0;
+  volatile uint32_t(*wh)[256] = whist;
+  volatile unsigned long long(*pm)[256] = peers_mask;
+  constexpr int NB = kKeyedB / 16 / 64;                // batches of 64 lanes per wave span
   for (int p = 0; p < passes; ++p) {
-    const int shift = 8 * p;
+    const int shift = dbits * p;
     for (int d = tid; d < 16 * 256; d += kKeyedThreads) (&whist[0][0])[d] = 0;
-    __syncthreads();
-    for (int i = wlo + lane; i < whi; i += 64) atomicAdd(&whist[wave][((keys[cur][i] - lo) >> shift) & 255u], 1u);
-    __syncthreads();
-    if (wave == 0) {                                  // exclusive prefix over (digit, wave), digit-major: one wave, 4 digits per lane
-      uint32_t own[4], tot = 0;
+    uint32_t kreg[NB];
+    uint16_t vreg[NB];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint32_t sum = 0;
+    for (int q = 0; q < NB; ++q) {                      // the span's elements up front: one LDS round trip, not NB
+      const int i = wlo + q * 64 + lane;
+      kreg[q] = i < whi ? keys[cur][i] : 0u;
+      vreg[q] = i < whi ? vals[cur][i] : (uint16_t)0;
+    }
+    // phase 1 -- who shares my digit in my batch: every lane ORs its bit into a per-(wave, digit) LDS word (the
+    // result of an OR does not depend on the order the lanes are served in), reads the word back and clears it.
+    // One 64-bit LDS atomic + one read per batch instead of eight ballots with per-lane 64-bit selects (that
+    // loop was VALU-bound), and nothing in batch q+1 waits for batch q: the NB batches pipeline in the LDS queue.
+    uint64_t peers[NB];
 #pragma unroll
-        for (int w = 0; w < 16; ++w) sum += whist[w][lane * 4 + j];
-        own[j] = sum;
-        tot += sum;
-      }
+    for (int q = 0; q < NB; ++q) {
+      const bool valid = wlo + q * 64 + lane < whi;
+      const uint32_t d = ((kreg[q] - lo) >> shift) & dmask;
+      if (valid) __hip_atomic_fetch_or(const_cast<unsigned long long*>(&pm[wave][d]), 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      __builtin_amdgcn_wave_barrier();
+      peers[q] = valid ? pm[wave][d] : 0ull;
+      __builtin_amdgcn_wave_barrier();
+      if (valid) pm[wave][d] = 0ull;                    // every peer writes the same zero: no leader needed yet
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();                                    // whist zeroed by everyone
+    // per-(wave, digit) counts: one lane per distinct digit of a batch adds the batch's count
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const uint32_t d = ((kreg[q] - lo) >> shift) & dmask;
+      const bool leader = peers[q] != 0ull && (peers[q] & lt_mask) == 0ull;
+      if (leader) atomicAdd(&whist[wave][d], (uint32_t)__popcll(peers[q]));
+    }
+    __syncthreads();
+    {
+      // exclusive prefix over the 4096 (digit, wave) counters in digit-major order: thread t owns digit t/4,
+      // waves 4*(t%4) .. +3; wave-level scan of the thread sums, then the 16 wave totals
+      const int d = tid >> 2, w0 = (tid & 3) * 4;
+      uint32_t c4[4], tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { c4[j] = whist[w0 + j][d]; tot += c4[j]; }
       uint32_t x = tot;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         const uint32_t y = __shfl_up(x, o);
         if (lane >= o) x += y;
       }
+      if (lane == 63) red[wave] = x;
+      __syncthreads();
       uint32_t run = x - tot;
+      for (int w = 0; w < wave; ++w) run += red[w];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint32_t base = run;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-          const uint32_t c = whist[w][lane * 4 + j];
-          whist[w][lane * 4 + j] = base;
-          base += c;
-        }
-        run += own[j];
-      }
+      for (int j = 0; j < 4; ++j) { whist[w0 + j][d] = run; run += c4[j]; }
     }
     __syncthreads();
-    volatile uint32_t(*wh)[256] = whist;
-    for (int i0 = wlo; i0 < whi; i0 += 64) {
-      const int i = i0 + lane;
-      const bool valid = i < whi;
-      const uint32_t key = valid ? keys[cur][i] : 0u;
-      const uint16_t val = valid ? vals[cur][i] : (uint16_t)0;
-      const uint32_t d = ((key - lo) >> shift) & 255u;
-      uint64_t peers = __ballot(valid);
+    // phase 2 -- positions: the batch's leader of a digit takes the running offset (one lane per address and
+    // instruction, batches in program order => deterministic) and hands it to its peers with a bpermute
+    uint32_t base[NB];
 #pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
-        const bool one = (d >> bit) & 1u;
-        const uint64_t bm = __ballot(one);
-        peers &= one ? bm : ~bm;
+    for (int q = 0; q < NB; ++q) {
+      const uint32_t d = ((kreg[q] - lo) >> shift) & dmask;
+      const bool leader = peers[q] != 0ull && (peers[q] & lt_mask) == 0ull;
+      base[q] = 0;
+      if (leader) base[q] = atomicAdd(const_cast<uint32_t*>(&wh[wave][d]), (uint32_t)__popcll(peers[q]));
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+      const bool valid = peers[q] != 0ull;
+      const int leader_lane = valid ? (int)__builtin_ctzll(peers[q]) : lane;
+      const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute(leader_lane << 2, (int)base[q]);
+      if (valid) {
+        const uint32_t pos = b0 + (uint32_t)__popcll(peers[q] & lt_mask);
+        keys[cur ^ 1][pos] = kreg[q];
+        vals[cur ^ 1][pos] = vreg[q];
       }
-      const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-      uint32_t pos = 0;
-      if (valid) pos = wh[wave][d] + rank;
-      __builtin_amdgcn_wave_barrier();
-      if (valid && rank == 0) wh[wave][d] = pos + (uint32_t)__popcll(peers);
-      __builtin_amdgcn_wave_barrier();
-      if (valid) { keys[cur ^ 1][pos] = key; vals[cur ^ 1][pos] = val; }
     }
     __syncthreads();
     cur ^= 1;
@@ -711,7 +753,7 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
   if (tid == kKeyedThreads - 1) ucount[ki] = (int32_t)u;
 }
 
-__global__ __launch_bounds__(kThreads) void keyed_compact_kernel(const int32_t* __restrict__ uniq_stage, const int32_t* __restrict__ seg_stage,
+__global__ __launch_bounds__(kKeyedThreads) void keyed_compact_kernel(const int32_t* __restrict__ uniq_stage, const int32_t* __restrict__ seg_stage,
                                                                 const int32_t* __restrict__ ucount, int n_keys, int B, int64_t M,
                                                                 int32_t* __restrict__ unique_rows, int32_t* __restrict__ seg_offsets,
                                                                 int32_t* __restrict__ n_unique) {
@@ -724,7 +766,7 @@ __global__ __launch_bounds__(kThreads) void keyed_compact_kernel(const int32_t* 
   }
   const int U = ucount[ki];
   const int64_t gbase = (int64_t)ki * B;
-  for (int u = threadIdx.x; u < U; u += kThreads) {
+  for (int u = threadIdx.x; u < U; u += kKeyedThreads) {
     unique_rows[before + u] = uniq_stage[gbase + u];
     seg_offsets[before + u] = seg_stage[gbase + u];
   }
@@ -1412,7 +1454,7 @@ int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K,
   int32_t* ucount = reinterpret_cast<int32_t*>(w + 2 * align256(sizeof(int32_t) * (size_t)slots));
   keyed_sort_kernel<<<n_keys, kKeyedThreads, 0, st>>>(a, rows, sorted_src, uniq_stage, seg_stage, ucount);
   TT_LAUNCH_CHECK();
-  keyed_compact_kernel<<<n_keys, kThreads, 0, st>>>(uniq_stage, seg_stage, ucount, n_keys, (int)B, slots, unique_rows, seg_offsets, n_unique);
+  keyed_compact_kernel<<<n_keys, kKeyedThreads, 0, st>>>(uniq_stage, seg_stage, ucount, n_keys, (int)B, slots, unique_rows, seg_offsets, n_unique);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

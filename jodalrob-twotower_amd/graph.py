@@ -33,11 +33,18 @@ class GraphedTrainStep:
                               "kjt": KeyedJaggedTensor(example_batch[side]["kjt"].keys(), example_batch[side]["kjt"].values().clone())}
                        for side in ("notice", "company")}
         ng = len(optimizer.param_groups)
-        self._host = torch.zeros(ng * 8 + 2, dtype=torch.float32).pin_memory()
+        # per-step scalars (Adam step sizes, dropout seed) travel through a RING of pinned host slots: the copy
+        # kernel reads the slot when it executes, and the host may be many steps ahead of the GPU by then
+        self._n_scalar = ng * 8 + 2
+        self._slot_len = (self._n_scalar + 3) // 4 * 4                 # 16-byte slots
+        self._ring = 64
+        self._host_ring = torch.zeros(self._ring, self._slot_len, dtype=torch.float32).pin_memory()
+        self._slot_events = [None] * self._ring
+        self._slot = 0
+        self._host = self._host_ring[0, :self._n_scalar]
         self._dev = torch.zeros(ng * 8 + 2, dtype=torch.float32, device=dev)
         self._hp_dev = self._dev[:ng * 8].view(ng, 8)
         self._seed_dev = self._dev[ng * 8:].view(torch.int64)          # 2 floats = one 64-bit word
-        self._seed_host = self._host[ng * 8:].view(torch.int64)
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
         self._towers = [m for m in task.modules() if hasattr(m, "_seed_dev") and hasattr(m, "dense_parameters")]
         self._steps_done = 0
@@ -76,13 +83,30 @@ class GraphedTrainStep:
     def _eager_once(self):
         self._body()
 
-    def _push_scalars(self):
+    def _fill_slot(self):
+        """Writes this step's scalars into the next ring slot; returns the (dst, src) copy pair."""
+        self._slot = (self._slot + 1) % self._ring
+        ev = self._slot_events[self._slot]
+        if ev is not None:
+            ev.synchronize()                                        # the copy that last read this slot has run
+        host = self._host_ring[self._slot, :self._n_scalar]
+        ng = len(self.opt.param_groups)
         step = self._base_step + self._steps_done + 1
         for gi, g in enumerate(self.opt.param_groups):
             hp = ops.adam_hparams(step, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])
-            self._host[gi * 8: gi * 8 + 6] = torch.tensor(hp)
-        self._seed_host.random_()
-        self._dev.copy_(self._host, non_blocking=True)
+            host[gi * 8: gi * 8 + 6] = torch.tensor(hp)
+        host[ng * 8:].view(torch.int64).random_()
+        return (self._dev, host)
+
+    def _mark_slot(self):
+        ev = self._slot_events[self._slot]
+        if ev is None:
+            ev = self._slot_events[self._slot] = torch.cuda.Event()
+        ev.record()
+
+    def _push_scalars(self):
+        ops.copy_multi([self._fill_slot()])
+        self._mark_slot()
 
     def step(self, batch: Optional[Dict] = None):
         """Train on `batch` (or on whatever the static buffers hold); returns the static result."""
@@ -96,8 +120,10 @@ class GraphedTrainStep:
                 else:                                           # host batch / other dtype: ordinary copies
                     sd.copy_(d, non_blocking=True)
                     sv.copy_(v, non_blocking=True)
-            ops.copy_multi(pairs)                               # one launch for all four buffers
-        self._push_scalars()
+        else:
+            pairs = []
+        ops.copy_multi(pairs + [self._fill_slot()])             # ONE launch: the four batch buffers + the scalars
+        self._mark_slot()
         self.graph.replay()
         self._steps_done += 1
         self.opt.advance_steps(1)

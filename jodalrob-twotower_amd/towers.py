@@ -264,22 +264,26 @@ class _TowersFn(torch.autograd.Function):
             for s in live:
                 tw = s.tower
                 ops.tower_fwd(tw._params(), s.acts_struct, s.B, s.train, s.p_drop, s.seed, s.emb.device, tw._seed_dev)
-        # duplicate-row plans: depend on ids only, first needed in the backward -> side stream, enqueued AFTER the
-        # towers so that it fills idle CUs under the score kernels instead of delaying the towers
+        # duplicate-row plans: depend on ids only, first needed in the backward.  Default: in line on the launch
+        # stream.  A side stream (TT_DEDUP_STREAM=side) overlaps the 38-workgroup sort with the score kernels, but a
+        # captured graph with two streams is replayed node by node with cross-queue signals: 4-6 us gaps in front of
+        # eight kernels and 0.20 ms instead of 0.05 ms of host time per replay -- as much as the overlap saves.
         for pl in plans:
             if len(pl) == 5:
                 store, psides, _, rows, ev = pl
                 plan = None
                 if ev is not None:
-                    ds = _side_streams(store.device, len(sides) + 1)[-1]
-                    ds.wait_event(ev)
+                    inline = os.environ.get("TT_DEDUP_STREAM", "inline") != "side"
+                    ds = torch.cuda.current_stream(store.device) if inline else _side_streams(store.device, len(sides) + 1)[-1]
+                    if not inline:
+                        ds.wait_event(ev)
                     with torch.cuda.stream(ds):
                         Bs = psides[0].B
                         if 0 < Bs <= ops.KEYED_MAX_B:       # per-key LDS sorts (2 launches)
                             plan = ops.dedup_plan_keyed(rows, [len(q.tower.categorical_embedder.keys) for q in psides], Bs)
                         else:
                             plan = ops.dedup_plan(rows, store.rows)
-                    plan.keep, plan.stream = rows, ds              # keep the sort input alive until it has run
+                    plan.keep, plan.stream = rows, (None if inline else ds)   # keep the sort input alive until it has run
                 pl[:] = [store, psides, plan]
         ctx.sides, ctx.plans, ctx.spans, ctx.n_flat = sides, plans, spans, len(flat)
         # hand out aliases: keeping the returned objects themselves on ctx would form a reference cycle
