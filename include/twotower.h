@@ -171,6 +171,14 @@ int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E
                         int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,
                         float weight_decay, const float* hparams_dev, tt_stream stream);
 
+/* tt_adam_multi_step (<= 32 tensors) and tt_sparse_adam_step with the same hyper-parameters in ONE launch: the
+ * tower weights and the looked-up table rows of a step (optim.FusedAdam uses it when both share a parameter group
+ * and step number). */
+int tt_adam_fused_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, float* table, float* m, float* v,
+                       int32_t E, const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique, int64_t M,
+                       int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       const float* hparams_dev, tt_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Tower MLP -- replaces BaseTower.forward after the lookup (src/towers/tower/base_tower.py:133-145)
  * and its autograd backward:

@@ -84,6 +84,8 @@ SIGNATURES = {
     "tt_adam_dense_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp, vp]),
     "tt_adam_multi_step": (C.c_int, [vp, C.POINTER(AdamTensor), i32, i64, f32, f32, f32, f32, f32, vp, vp]),
     "tt_sparse_adam_step": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp, vp]),
+    "tt_adam_fused_step": (C.c_int, [vp, C.POINTER(AdamTensor), i32, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32,
+                                     vp, vp]),
     "tt_tower_workspace_bytes": (sz, [C.POINTER(TowerParams), i64]),
     "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, vp, sz, vp]),
     "tt_tower_mlp_bwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), vp, C.POINTER(TowerGrads), i64, i32,

@@ -1152,6 +1152,62 @@ __global__ __launch_bounds__(kThreads) void adam_sparse_kernel(float* __restrict
   }
 }
 
+// dense tensors + the looked-up table rows in ONE launch: blocks [0, nd) walk the dense tensors (prefix table),
+// the rest are the row-sparse update (every small launch in the step's dependent chain costs ~5 us)
+struct AdamFusedArgs {
+  tt_adam_tensor t[kAdamMulti];
+  int32_t blk0[kAdamMulti + 1];   // first block of dense tensor i; blk0[n] = nd
+  int32_t n;
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void adam_fused_kernel(AdamFusedArgs a, float* __restrict__ table, float* __restrict__ m,
+                                                             float* __restrict__ v, int32_t E, uint32_t C,
+                                                             const int32_t* __restrict__ unique_rows, const float* __restrict__ grad_rows,
+                                                             const int32_t* __restrict__ n_unique, AdamK k0, uint32_t LG) {
+  const AdamK k = adam_resolve(k0);
+  const int nd = a.blk0[a.n];
+  if ((int)blockIdx.x < nd) {
+    int ti = 0;
+    for (int i = 1; i < a.n; ++i)
+      if ((int)blockIdx.x >= a.blk0[i]) ti = i;
+    const tt_adam_tensor t = a.t[ti];
+    const int64_t nb = a.blk0[ti + 1] - a.blk0[ti];
+    const int64_t stride = nb * blockDim.x;
+    for (int64_t i = (int64_t)((int)blockIdx.x - a.blk0[ti]) * blockDim.x + threadIdx.x; i < t.n; i += stride) {
+      float pp = t.p[i], mm = t.m[i], vv = t.v[i];
+      adam1(pp, t.g[i], mm, vv, k);
+      t.p[i] = pp; t.m[i] = mm; t.v[i] = vv;
+    }
+    return;
+  }
+  const uint32_t U = (uint32_t)*n_unique;
+  const uint32_t gthread = (blockIdx.x - nd) * blockDim.x + threadIdx.x;
+  const uint32_t lig = gthread % LG;
+  const uint32_t ngroups = (gridDim.x - nd) * blockDim.x / LG;
+  for (uint32_t u = gthread / LG; u < U; u += ngroups) {
+    const int64_t row = unique_rows[u];
+    for (uint32_t chunk = lig; chunk < C; chunk += LG) {
+      const int64_t o = row * E + chunk * VEC;
+      const float* gp = grad_rows + (int64_t)u * E + chunk * VEC;
+      if (VEC == 4) {
+        float4 pp = *reinterpret_cast<float4*>(table + o), mm = *reinterpret_cast<float4*>(m + o),
+               vv = *reinterpret_cast<float4*>(v + o);
+        const float4 gg = *reinterpret_cast<const float4*>(gp);
+        adam1(pp.x, gg.x, mm.x, vv.x, k); adam1(pp.y, gg.y, mm.y, vv.y, k);
+        adam1(pp.z, gg.z, mm.z, vv.z, k); adam1(pp.w, gg.w, mm.w, vv.w, k);
+        *reinterpret_cast<float4*>(table + o) = pp;
+        *reinterpret_cast<float4*>(m + o) = mm;
+        *reinterpret_cast<float4*>(v + o) = vv;
+      } else {
+        float pp = table[o], mm = m[o], vv = v[o];
+        adam1(pp, gp[0], mm, vv, k);
+        table[o] = pp; m[o] = mm; v[o] = vv;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // a1/a2: device-side batch assembly
 // ------------------------------------------------------------------------------------------------
@@ -1589,6 +1645,36 @@ int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E
   const int grid = grid_for(ctx, M * LG);
   if (vec4) adam_sparse_kernel<4><<<grid, kThreads, 0, st>>>(table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG);
   else adam_sparse_kernel<1><<<grid, kThreads, 0, st>>>(table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_adam_fused_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, float* table, float* m, float* v, int32_t E,
+                       const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique, int64_t M, int64_t step, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream) {
+  TT_CHECK_ARG(ctx && tensors && table && m && v && unique_rows && grad_rows && n_unique, "tt_adam_fused_step: NULL argument");
+  TT_CHECK_ARG(n_tensors >= 1 && n_tensors <= kAdamMulti, "tt_adam_fused_step: n_tensors=%d not in [1,%d]", n_tensors, kAdamMulti);
+  TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 1, "tt_adam_fused_step: bad step/E/M");
+  AdamFusedArgs a{};
+  a.n = n_tensors;
+  int nd = 0;
+  for (int i = 0; i < n_tensors; ++i) {
+    const tt_adam_tensor& t = tensors[i];
+    TT_CHECK_ARG(t.n >= 0 && (t.n == 0 || (t.p && t.g && t.m && t.v)), "tt_adam_fused_step: tensor %d has NULL pointers", i);
+    a.t[i] = t;
+    a.blk0[i] = nd;
+    int64_t nb = tt_cdiv(t.n > 0 ? t.n : 1, kThreads);
+    nd += (int)(nb > 64 ? 64 : nb);
+  }
+  a.blk0[n_tensors] = nd;
+  const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay, hparams_dev);
+  const bool vec4 = (E % 4 == 0) && tt_aligned(table, 16) && tt_aligned(m, 16) && tt_aligned(v, 16) && tt_aligned(grad_rows, 16);
+  const uint32_t C = vec4 ? E / 4 : E;
+  const uint32_t LG = pow2_at_least(C) > 64 ? 64 : pow2_at_least(C);
+  const int grid = nd + grid_for(ctx, M * LG);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (vec4) adam_fused_kernel<4><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG);
+  else adam_fused_kernel<1><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

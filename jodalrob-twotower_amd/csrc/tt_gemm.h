@@ -28,4 +28,11 @@ struct GemmTN {
   const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t M, N, R;
   void* workspace; size_t workspace_bytes; float* colsum_out; bool bf16 = false;
 };
-int tt_gemm_tn_batched(hipStream_t st, const GemmTN* items, int n);
+// `pending` (optional): the split-K slab reductions are queued there instead of being launched, and
+// tt_gemm_tn_flush() covers everything queued with ONE launch (each small launch in a dependent chain costs ~5 us
+// on this part).  Every queued problem needs its own workspace until the flush.
+struct TnPending;
+TnPending* tt_gemm_tn_pending_create();
+void tt_gemm_tn_pending_destroy(TnPending*);
+int tt_gemm_tn_batched(hipStream_t st, const GemmTN* items, int n, TnPending* pending = nullptr);
+int tt_gemm_tn_flush(hipStream_t st, TnPending* pending);

@@ -142,40 +142,48 @@ struct SlabArgs {
   const float* colsum_slab; float* colsum_out;
   const float* bias; int relu;          // split-K forward GEMMs finish bias / ReLU here
 };
-struct SlabBatch { SlabArgs a[TT_MAX_SIDES]; };
+constexpr int kSlabItems = 16;
+struct SlabBatch { SlabArgs a[kSlabItems]; };
 
 // ---- bf16-operand variant: f32 tensors in memory, rounded to bf16 (RNE) on the way into LDS, f32 accumulate on
 // v_mfma_f32_32x32x16_bf16 (16x fewer matrix cycles than the exact-f32 form).  LDS tiles are [x][k] with k
 // contiguous (80-B rows: conflict-free ds_read_b128 fragments of 8 consecutive k).
 using bf16x8g = __attribute__((ext_vector_type(8))) __bf16;
-constexpr int BK16 = 32, LDS16 = 40;
+// (BK = 64 per step measured 1-2 us SLOWER per GEMM than 32: these loops are HBM-bandwidth-bound -- 3.5-3.7 TB/s
+// counting the split-K slabs -- not latency-bound.)
+constexpr int BK16 = 32, LDS16 = 40, KR = BK16 / 4;
 
 template <int MODE>
 struct TileLoader16 {
-  float r[8];
+  float r[KR];
   __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int x0, int X, int k0, int kend, int t, bool vec) {
-    if (MODE == 0) {                       // K-contiguous: 8 consecutive k of one row per thread
-      const int x = x0 + (t >> 2), k = k0 + (t & 3) * 8;
-      if (vec && x < X && k + 7 < kend) {
-        const float4 a = *reinterpret_cast<const float4*>(P + (int64_t)x * ld + k);
-        const float4 b = *reinterpret_cast<const float4*>(P + (int64_t)x * ld + k + 4);
-        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+    if (MODE == 0) {                       // K-contiguous: KR consecutive k of one row per thread
+      const int x = x0 + (t >> 2), k = k0 + (t & 3) * KR;
+      if (vec && x < X && k + KR - 1 < kend) {
+#pragma unroll
+        for (int q = 0; q < KR / 4; ++q) {
+          const float4 a = *reinterpret_cast<const float4*>(P + (int64_t)x * ld + k + 4 * q);
+          r[4 * q] = a.x; r[4 * q + 1] = a.y; r[4 * q + 2] = a.z; r[4 * q + 3] = a.w;
+        }
       } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = (x < X && k + j < kend) ? P[(int64_t)x * ld + k + j] : 0.f;
+        for (int j = 0; j < KR; ++j) r[j] = (x < X && k + j < kend) ? P[(int64_t)x * ld + k + j] : 0.f;
       }
-    } else {                               // X-contiguous: one x, 8 consecutive k (coalesced dword loads across x)
-      const int x = x0 + (t & 63), k = k0 + (t >> 6) * 8;
+    } else {                               // X-contiguous: one x, KR consecutive k (coalesced dword loads across x)
+      const int x = x0 + (t & 63), k = k0 + (t >> 6) * KR;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = (x < X && k + j < kend) ? P[(int64_t)(k + j) * ld + x] : 0.f;
+      for (int j = 0; j < KR; ++j) r[j] = (x < X && k + j < kend) ? P[(int64_t)(k + j) * ld + x] : 0.f;
     }
   }
   __device__ __forceinline__ void store(__bf16* __restrict__ S, int t) const {
-    bf16x8g v;
+    const int row = MODE == 0 ? (t >> 2) : (t & 63), kq = MODE == 0 ? (t & 3) * KR : (t >> 6) * KR;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (__bf16)r[j];
-    const int row = MODE == 0 ? (t >> 2) : (t & 63), kq = MODE == 0 ? (t & 3) * 8 : (t >> 6) * 8;
-    *reinterpret_cast<bf16x8g*>(S + row * LDS16 + kq) = v;
+    for (int q = 0; q < KR / 8; ++q) {
+      bf16x8g v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (__bf16)r[8 * q + j];
+      *reinterpret_cast<bf16x8g*>(S + row * LDS16 + kq + 8 * q) = v;
+    }
   }
 };
 
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(GemmBatch batch, int
     lb.store(Bs, t);
     if (COLSUM) {                          // MODE_A == 1 there: this thread holds column (t & 63), 8 batch rows
 #pragma unroll
-      for (int j = 0; j < 8; ++j) cs += la.r[j];
+      for (int j = 0; j < KR; ++j) cs += la.r[j];
     }
     __syncthreads();
     if (k0 + BK16 < kend) {
@@ -215,7 +223,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(GemmBatch batch, int
       lb.load(g.B, g.ldb, n0, N, k0 + BK16, kend, t, vec);
     }
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    for (int s2 = 0; s2 < BK16 / 16; ++s2) {
       const bf16x8g a = *reinterpret_cast<const bf16x8g*>(As + (wr * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
       const bf16x8g b = *reinterpret_cast<const bf16x8g*>(Bs + (wc * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
@@ -383,7 +391,26 @@ size_t tt_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
   return sizeof(float) * (size_t)tn_splits(M, N, R) * ((size_t)M * (size_t)N + (size_t)M) + 256;
 }
 
-int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n) {
+struct TnPending {
+  SlabBatch sb;
+  int n = 0;
+  int64_t maxtotal = 1;
+};
+TnPending* tt_gemm_tn_pending_create() { return new TnPending(); }
+void tt_gemm_tn_pending_destroy(TnPending* p) { delete p; }
+
+int tt_gemm_tn_flush(hipStream_t st, TnPending* p) {
+  if (!p || p->n == 0) return TT_OK;
+  int blocks = (int)tt_cdiv(p->maxtotal, THREADS);
+  if (blocks > 1024) blocks = 1024;
+  slab_reduce_kernel<<<dim3((unsigned)blocks, (unsigned)p->n), THREADS, 0, st>>>(p->sb);
+  p->n = 0;
+  p->maxtotal = 1;
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n, TnPending* pending) {
   GemmBatch b{};
   SlabBatch sb{};
   bool vec = true, colsum = false;
@@ -412,6 +439,13 @@ int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n) {
   }
   if (!m) return TT_OK;
   if (int rc = launch_gemm<1, 1>(st, b, m, zs, vec, colsum, it[0].bf16)) return rc;
+  if (pending) {
+    if (pending->n + m > kSlabItems)
+      if (int rc = tt_gemm_tn_flush(st, pending)) return rc;
+    for (int i = 0; i < m; ++i) pending->sb.a[pending->n++] = sb.a[i];
+    pending->maxtotal = maxtotal > pending->maxtotal ? maxtotal : pending->maxtotal;
+    return TT_OK;
+  }
   int blocks = (int)tt_cdiv(maxtotal, THREADS);
   if (blocks > 1024) blocks = 1024;
   slab_reduce_kernel<<<dim3((unsigned)blocks, (unsigned)m), THREADS, 0, st>>>(sb);

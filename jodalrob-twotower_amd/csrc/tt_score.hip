@@ -244,8 +244,9 @@ __global__ __launch_bounds__(1024) void loss_finish_kernel(int64_t B, float shif
                                                            const int32_t* __restrict__ row_rank, const int32_t* __restrict__ col_rank,
                                                            const float* __restrict__ sumscore, float* __restrict__ out,
                                                            float* __restrict__ loss_out) {
-  __shared__ float sh[16];
+  __shared__ float sh5[5][16];
   float l = 0.f, hit = 0.f, chit = 0.f, dsum = 0.f, tot = 0.f;
+#pragma unroll 4
   for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
     const float d = diag[i];
     l += (logf(rowsum[i]) + shift - d) + (logf(colsum[i]) + shift - d);
@@ -254,8 +255,26 @@ __global__ __launch_bounds__(1024) void loss_finish_kernel(int64_t B, float shif
     dsum += d;
     tot += sumscore ? sumscore[i] : 0.f;
   }
-  l = block_sum(l, sh); hit = block_sum(hit, sh); chit = block_sum(chit, sh);
-  dsum = block_sum(dsum, sh); tot = block_sum(tot, sh);
+  // the five sums together: butterfly inside the wave, one LDS exchange, fixed order across the 16 waves
+  float v[5] = {l, hit, chit, dsum, tot};
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) v[j] += __shfl_xor(v[j], o);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) sh5[j][threadIdx.x >> 6] = v[j];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float t = 0.f;
+      for (int w = 0; w < nw; ++w) t += sh5[j][w];
+      v[j] = t;
+    }
+    l = v[0]; hit = v[1]; chit = v[2]; dsum = v[3]; tot = v[4];
+  }
   if (threadIdx.x == 0) {
     const float fb = (float)B;
     const float pos = dsum / fb;

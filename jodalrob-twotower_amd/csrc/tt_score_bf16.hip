@@ -146,7 +146,8 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
   const DirFwd dr = args.d[blockIdx.y];
   const int64_t a0 = (int64_t)blockIdx.x * ROWS;
   if (a0 >= dr.Ra) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile loop and its branches run on the SALU
   const int64_t nT = rup(dr.Rb, 32) / 32;
   bf16x8 ares[AT][KS];
 #pragma unroll
@@ -500,7 +501,9 @@ int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs,
   const int Dp = padded_d(D);
 #define TT_FWD(KS, AT, NW)                                                                                     \
   score_fwd_bf16_kernel<KS, AT, NW><<<dim3((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs), NW * 64, 0, st>>>(a)
+  static const int fwd_nw = getenv("TT_SCORE_FWD_NW") ? atoi(getenv("TT_SCORE_FWD_NW")) : 8;
   if (Dp == 32) TT_FWD(2, 2, 8);
+  else if (Dp == 64 && fwd_nw == 16) TT_FWD(4, 2, 16);
   else if (Dp == 64) TT_FWD(4, 2, 8);
   else if (Dp == 128) TT_FWD(8, 2, 8);
   else TT_FWD(16, 1, 8);

@@ -7,7 +7,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr float kBnEps = 1e-5f, kBnMomentum = 0.1f, kNormEps = 1e-12f;
-constexpr int kMaxChunks = 64;   // row chunks of the two-stage column reductions
+constexpr int kMaxChunks = 128;  // row chunks of the two-stage column reductions
 
 __device__ __forceinline__ float dropout_scale(bool on, float p, uint64_t seed, uint64_t idx) {
   if (!on) return 1.f;
@@ -45,15 +45,23 @@ __global__ __launch_bounds__(kThreads) void bn_stats_partial_kernel(Batch<BnStat
   __shared__ Wf sh[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * a.rows_per_chunk, r1 = min(a.B, r0 + a.rows_per_chunk);
+  // per thread: sums of (x - x0) and (x - x0)^2 over its <= a few dozen rows, x0 = its first value (no division
+  // and no dependent chain per element; the shift keeps the tiny-sample variance free of cancellation), turned
+  // into (n, mean, M2) once and merged with Chan's formula from there on
   Wf w{0.f, 0.f, 0.f};
-  if (c < H) {
+  if (c < H && r0 + rl < r1) {
+    const float x0 = fmaxf(a.pre[(int64_t)(r0 + rl) * H + c], 0.f);
+    float s = 0.f, q = 0.f, cnt = 0.f;
+#pragma unroll 16
     for (int r = r0 + rl; r < r1; r += 4) {
-      const float x = fmaxf(a.pre[(int64_t)r * H + c], 0.f);
-      w.n += 1.f;
-      const float d = x - w.mean;
-      w.mean += d / w.n;
-      w.m2 += d * (x - w.mean);
+      const float d = fmaxf(a.pre[(int64_t)r * H + c], 0.f) - x0;
+      s += d;
+      q += d * d;
+      cnt += 1.f;
     }
+    w.n = cnt;
+    w.mean = x0 + s / cnt;
+    w.m2 = fmaxf(q - s * (s / cnt), 0.f);
   }
   sh[rl][threadIdx.x & 63] = w;
   __syncthreads();
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void colsum_partial_kernel(Batch<ColArgs>
   float s0 = 0.f, s1 = 0.f;
   const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
   if (c < H) {
-#pragma unroll 8
+#pragma unroll 16
     for (int r = r0 + rl; r < r1; r += 4) {
       const int64_t i = (int64_t)r * H + c;
       const float da = a.x[(int64_t)r * a.ldx + c] * dropout_scale(drop, p, seed, a.salt + (uint64_t)i);
@@ -273,7 +281,7 @@ inline int ew_grid(const tt_ctx* ctx, int64_t n, int towers) {
 }
 
 inline int chunks_for(int64_t B, int H) {
-  int64_t n = 256 / tt_cdiv(H, 64);
+  int64_t n = 512 / tt_cdiv(H, 64);
   if (n > kMaxChunks) n = kMaxChunks;
   const int64_t mx = tt_cdiv(B, 64);
   if (n > mx) n = mx;
@@ -283,6 +291,8 @@ inline int chunks_for(int64_t B, int H) {
 struct WsLayout {
   char* gemm;
   size_t gemm_bytes;
+  char* tn[TT_MAX_HIDDEN + 2];        // own slab region per weight-gradient GEMM (0 = projection, 1 + i = block i, last = output):
+  size_t tn_bytes[TT_MAX_HIDDEN + 2]; // their reductions are deferred into one launch at the end of the backward pass
   float* col;
   size_t col_bytes;
   size_t total;
@@ -312,7 +322,16 @@ inline WsLayout ws_layout(const tt_tower_params* p, int64_t B, char* base) {
   w.col_bytes = sizeof(float) * 3 * (size_t)hmax * (size_t)kMaxChunks + 256;
   w.gemm = base;
   w.col = reinterpret_cast<float*>(base ? base + w.gemm_bytes : nullptr);
-  w.total = w.gemm_bytes + w.col_bytes;
+  size_t o = w.gemm_bytes + ((w.col_bytes + 255) & ~size_t(255));
+  for (int l = 0; l < p->n_hidden + 2; ++l) {
+    const size_t nb = l == 0 ? tt_gemm_tn_workspace_bytes(p->h0, p->din, B)
+                    : l == p->n_hidden + 1 ? tt_gemm_tn_workspace_bytes(p->d_out, last_width(p), B)
+                                           : tt_gemm_tn_workspace_bytes(p->hidden[l - 1], in_width(p, l - 1), B);
+    w.tn[l] = base ? base + o : nullptr;
+    w.tn_bytes[l] = (nb + 255) & ~size_t(255);
+    o += w.tn_bytes[l];
+  }
+  w.total = o;
   return w;
 }
 
@@ -457,13 +476,18 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     const tt_tower_grads* g = G[t];
     const float* in_last = nh == 0 ? A[t]->x : A[t]->act[nh - 1];
     const int lw = last_width(P[t]);
-    tn[t] = GemmTN{g->d_y, P[t]->d_out, in_last, lw, g->w_out, lw, P[t]->d_out, lw, B, ws[t].gemm, ws[t].gemm_bytes, g->b_out};
+    tn[t] = GemmTN{g->d_y, P[t]->d_out, in_last, lw, g->w_out, lw, P[t]->d_out, lw, B, ws[t].tn[nh + 1], ws[t].tn_bytes[nh + 1], g->b_out};
     dcur[t] = nh == 0 ? g->d_x : g->scratch[nh - 1];
     TT_CHECK_ARG(dcur[t], "tt_towers_mlp_bwd: NULL scratch buffer");
     nn[t] = GemmNN{g->d_y, P[t]->d_out, P[t]->w_out, lw, dcur[t], lw, B, lw, P[t]->d_out};
   }
   for (int t = 0; t < n; ++t) tn[t].bf16 = nn[t].bf16 = P[0]->compute_dtype == TT_BF16;
-  if (int rc = tt_gemm_tn_batched(st, tn, n)) return rc;
+  // the slab reductions of all weight-gradient GEMMs run as ONE launch at the end (nothing in this pass reads them)
+  struct PendingGuard {
+    TnPending* p = tt_gemm_tn_pending_create();
+    ~PendingGuard() { tt_gemm_tn_pending_destroy(p); }
+  } pend;
+  if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;
   if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
   for (int i = nh - 1; i >= 0; --i) {
     Batch<ColArgs> cb{};
@@ -496,24 +520,25 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       const int H = P[t]->hidden[i];
       const int iw = in_width(P[t], i);
       const float* in_i = i == 0 ? A[t]->x : A[t]->act[i - 1];
-      tn[t] = GemmTN{dcur[t], H, in_i, iw, g->w[i], iw, H, iw, B, ws[t].gemm, ws[t].gemm_bytes, g->b[i]};
+      tn[t] = GemmTN{dcur[t], H, in_i, iw, g->w[i], iw, H, iw, B, ws[t].tn[1 + i], ws[t].tn_bytes[1 + i], g->b[i]};
       float* dnext = i == 0 ? g->d_x : g->scratch[i - 1];
       TT_CHECK_ARG(dnext, "tt_towers_mlp_bwd: NULL scratch buffer");
       nn[t] = GemmNN{dcur[t], H, P[t]->w[i], iw, dnext, iw, B, iw, H};
       dcur[t] = dnext;
     }
     for (int t = 0; t < n; ++t) tn[t].bf16 = nn[t].bf16 = P[0]->compute_dtype == TT_BF16;
-    if (int rc = tt_gemm_tn_batched(st, tn, n)) return rc;
+    if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;
     if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
   }
   // dense projection: d_x[:, 0:h0]
   for (int t = 0; t < n; ++t) {
     const tt_tower_grads* g = G[t];
     const int wx = P[t]->h0 + P[t]->kcat_e;
-    tn[t] = GemmTN{g->d_x, wx, A[t]->dense, P[t]->din, g->w_proj, P[t]->din, P[t]->h0, P[t]->din, B, ws[t].gemm, ws[t].gemm_bytes, g->b_proj};
+    tn[t] = GemmTN{g->d_x, wx, A[t]->dense, P[t]->din, g->w_proj, P[t]->din, P[t]->h0, P[t]->din, B, ws[t].tn[0], ws[t].tn_bytes[0], g->b_proj};
   }
   for (int t = 0; t < n; ++t) tn[t].bf16 = P[0]->compute_dtype == TT_BF16;
-  return tt_gemm_tn_batched(st, tn, n);
+  if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;
+  return tt_gemm_tn_flush(st, pend.p);
 }
 
 int tt_tower_mlp_fwd(tt_ctx* ctx, const tt_tower_params* p, const tt_tower_acts* a, int64_t B, int32_t train, float dropout_p,

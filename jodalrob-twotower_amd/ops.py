@@ -216,6 +216,18 @@ def adam_sparse(table, m, v, plan: DedupPlan, grad_rows, step, lr, b1, b2, eps, 
                                              lr, b1, b2, eps, wd, L.ptr(hp_dev), L.stream(dev)), "tt_sparse_adam_step")
 
 
+def adam_fused(items, table, m, v, plan: DedupPlan, grad_rows, step, lr, b1, b2, eps, wd, hp_dev=None):
+    """adam_multi(items) + adam_sparse(table rows) with one set of hyper-parameters, one launch."""
+    dev = table.device
+    arr = (L.AdamTensor * len(items))()
+    for i, (p, g, mm, vv) in enumerate(items):
+        arr[i] = L.AdamTensor(p.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel())
+    with _timed("tt_adam_fused_step"):
+        L.check(L.load().tt_adam_fused_step(L.ctx(dev), arr, len(items), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[1],
+                                            L.ptr(plan.unique_rows), L.ptr(grad_rows), L.ptr(plan.n_unique), plan.M, step,
+                                            lr, b1, b2, eps, wd, L.ptr(hp_dev), L.stream(dev)), "tt_adam_fused_step")
+
+
 # ---------------------------------------------------------------------------------------------- tower MLP
 def _fill(arr, tensors):
     for i, t in enumerate(tensors):

@@ -94,6 +94,17 @@ class FusedAdam(torch.optim.Optimizer):
             for it in items:
                 by_step.setdefault(it[4], []).append(it[:4])
             for s_no, its in by_step.items():
+                fuse = self._fusable_store(group, s_no, len(its), len(by_step))
+                if fuse is not None:      # tower weights + looked-up table rows: one launch
+                    store, st = fuse
+                    plan, grad_rows = store.sparse_grad
+                    st["step"] += 1
+                    ops.adam_fused(its, store.weight, st["m"], st["v"], plan, grad_rows, s_no, group["lr"], b1, b2,
+                                   group["eps"], group["weight_decay"], hp)
+                    store.sparse_grad = None
+                    for p in store.optim_parameters():
+                        self.state[p]["step"] = torch.tensor(float(st["step"]))
+                    continue
                 ops.adam_multi(its, s_no, group["lr"], b1, b2, group["eps"], group["weight_decay"], hp)
         # ---- embedding stores ----
         for store in self._stores:
@@ -123,6 +134,23 @@ class FusedAdam(torch.optim.Optimizer):
             for p in members:
                 self.state[p]["step"] = torch.tensor(float(st["step"]))
         return loss
+
+    def _fusable_store(self, group, s_no: int, n_items: int, n_buckets: int):
+        """The one sparse-gradient store of `group` whose next step number is s_no (else None)."""
+        if n_buckets != 1 or not (1 <= n_items <= 32):
+            return None
+        cands = []
+        for store in self._stores:
+            members = store.optim_parameters()
+            if members and any(members[0] is p for p in group["params"]):
+                cands.append(store)
+        if len(cands) != 1:
+            return None
+        store = cands[0]
+        if store.grad_mode != "sparse" or store.sparse_grad is None or store.sparse_grad[0].M < 1:
+            return None
+        st = self._state_of(store)
+        return (store, st) if st["step"] + 1 == s_no else None
 
     def advance_steps(self, n: int):
         """Account for `n` optimiser steps executed by graph replays (step counters live on the host;
