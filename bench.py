@@ -186,11 +186,13 @@ def main():
             dist.destroy_process_group()
         return
     K_tot = len(keys_n) + len(keys_c)
-    bytes_per_pair = K_tot * (E * 4 + 8 + E * 4)             # table row + i64 id + f32 output row
+    x_bf16 = args.mlp_dtype == "bf16" and os.environ.get("TT_TOWER_IO_DTYPE", "x") in ("x", "both")
+    s_out = 2 if x_bf16 else 4                                # the lookup writes straight into the tower input x
+    bytes_per_pair = K_tot * (E * 4 + 8 + E * s_out)         # table row + i64 id + output row (10,032 / 7,600 B)
     algo_bytes = B * bytes_per_pair                          # one launch = one batch on this GPU
     achieved = algo_bytes / (lookup_ms * 1e-3) / 1e9 if lookup_ms == lookup_ms and lookup_ms > 0 else None
     traffic = None
-    pmc = ROOT / "profiles" / "lookup_pmc.json"
+    pmc = ROOT / "profiles" / ("lookup_pmc_bf16out.json" if x_bf16 else "lookup_pmc.json")
     if pmc.exists():
         try:
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
@@ -202,7 +204,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": ("bf16" if (args.score_dtype == "bf16" and args.mlp_dtype == "bf16") else
-                  f"score {args.score_dtype} / mlp {args.mlp_dtype}") + " MFMA operands, f32 accumulate; f32 tables, activations and master weights",
+                  f"score {args.score_dtype} / mlp {args.mlp_dtype}") + " MFMA operands, f32 accumulate; f32 tables, master weights and activations" +
+                 (" (the tower input x, which the GEMMs round to bf16 anyway, is stored bf16)" if x_bf16 else ""),
         "data": "synthetic",
         "config": {"workload": "configs[1]: 32+6 real keys, 1M-row notice + 1M-row company tables per GPU, batch 8192 per GPU, "
                                "E=32, towers [128,64], final 64, in-batch negatives, dropout 0.1",

@@ -203,12 +203,16 @@ typedef struct tt_tower_params {
   const float* w_out;          /* [d_out, in_last] */
   const float* b_out;
   int32_t compute_dtype; /* TT_F32: exact-f32 MFMA (parity); TT_BF16: GEMM operands rounded to bf16 (RNE) on the way
-                            into LDS, f32 accumulate on v_mfma_f32_32x32x16_bf16; tensors in memory stay f32 */
+                            into LDS, f32 accumulate on v_mfma_f32_32x32x16_bf16 */
+  int32_t x_dtype;       /* element type of tt_tower_acts.x  (TT_BF16 only with compute_dtype TT_BF16: the GEMMs that read x
+                            round it to bf16 anyway, so results are bit-identical and x costs half the HBM bytes) */
+  int32_t dx_dtype;      /* element type of tt_tower_grads.d_x (TT_BF16 only with compute_dtype TT_BF16; the per-slot row
+                            gradients are then rounded to bf16 before tt_embed_grad_bwd sums them in f32) */
 } tt_tower_params;
 
 typedef struct tt_tower_acts { /* caller-allocated; kept between forward and backward */
   const float* dense;          /* [B, din] */
-  float* x;                    /* [B, h0 + kcat_e] */
+  void* x;                     /* [B, h0 + kcat_e] of params.x_dtype */
   float* pre[TT_MAX_HIDDEN];   /* [B, hidden[i]] Linear output before ReLU */
   float* act[TT_MAX_HIDDEN];   /* [B, hidden[i]] block output (after BN and dropout) */
   float* mean[TT_MAX_HIDDEN];  /* [hidden[i]] statistics used by BN in this pass */
@@ -226,7 +230,7 @@ typedef struct tt_tower_grads { /* every buffer is overwritten, not accumulated 
   float* bn_b[TT_MAX_HIDDEN];
   float* w_out;
   float* b_out;
-  float* d_x;                    /* [B, h0 + kcat_e]; columns [h0, ..) feed tt_embed_grad_bwd */
+  void* d_x;                     /* [B, h0 + kcat_e] of params.dx_dtype; columns [h0, ..) feed tt_embed_grad_bwd */
   float* scratch[TT_MAX_HIDDEN]; /* [B, hidden[i]] */
   float* d_y;                    /* [B, d_out] */
 } tt_tower_grads;

@@ -53,7 +53,8 @@ class TowerParams(C.Structure):
     _fields_ = [("din", i32), ("h0", i32), ("kcat_e", i32), ("n_hidden", i32), ("d_out", i32),
                 ("hidden", i32 * TT_MAX_HIDDEN),
                 ("w_proj", vp), ("b_proj", vp), ("w", _H), ("b", _H), ("bn_w", _H), ("bn_b", _H),
-                ("bn_rm", _H), ("bn_rv", _H), ("bn_nbt", _H), ("w_out", vp), ("b_out", vp), ("compute_dtype", i32)]
+                ("bn_rm", _H), ("bn_rv", _H), ("bn_nbt", _H), ("w_out", vp), ("b_out", vp), ("compute_dtype", i32),
+                ("x_dtype", i32), ("dx_dtype", i32)]
 
 
 class TowerActs(C.Structure):

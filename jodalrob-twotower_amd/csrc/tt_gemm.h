@@ -9,6 +9,9 @@ struct GemmNT {
   const float* A; int64_t lda; const float* W; int64_t ldw; const float* bias; float* C; int64_t ldc;
   int64_t M, N, K; bool relu; float alpha; bool bf16 = false;   // bf16: operands rounded to bf16, f32 accumulate
   void* workspace = nullptr; size_t workspace_bytes = 0;         // optional: enables split-K (tt_gemm_nt_workspace_bytes)
+  // bf16 path only: A / C actually point at bf16 elements (lda / ldc in elements); the rounding the MFMA operand
+  // needs anyway then happens where the tensor is produced, and the tensor costs half the HBM bytes
+  bool a_bf16 = false, c_bf16 = false;
 };
 size_t tt_gemm_nt_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int tt_gemm_nt_batched(hipStream_t st, const GemmNT* items, int n);
@@ -18,6 +21,7 @@ int tt_gemm_nt(hipStream_t st, const float* A, int64_t lda, const float* W, int6
 // C[M,N] = A[M,K] . W[K,N]                        (data gradient: dX = dY . W)
 struct GemmNN {
   const float* A; int64_t lda; const float* W; int64_t ldw; float* C; int64_t ldc; int64_t M, N, K; bool bf16 = false;
+  bool c_bf16 = false;                                           // bf16 path only: C holds bf16 elements
 };
 int tt_gemm_nn_batched(hipStream_t st, const GemmNN* items, int n);
 
@@ -27,6 +31,7 @@ size_t tt_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t R);
 struct GemmTN {
   const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t M, N, R;
   void* workspace; size_t workspace_bytes; float* colsum_out; bool bf16 = false;
+  bool a_bf16 = false, b_bf16 = false;                           // bf16 path only: A / B hold bf16 elements
 };
 // `pending` (optional): the split-K slab reductions are queued there instead of being launched, and
 // tt_gemm_tn_flush() covers everything queued with ONE launch (each small launch in a dependent chain costs ~5 us

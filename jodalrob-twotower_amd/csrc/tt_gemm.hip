@@ -13,6 +13,7 @@ struct GemmArgs {
   const float* A; int64_t lda; const float* B; int64_t ldb; float* C; int64_t ldc; int64_t slab_stride;
   int M, N, K, kchunk, splits;
   const float* bias; int relu; float alpha; float* colsum_slab;
+  int a_bf16 = 0, b_bf16 = 0, c_bf16 = 0;   // bf16 kernel only: element type of A / B / C in memory
 };
 struct GemmBatch { GemmArgs a[TT_MAX_SIDES]; };
 
@@ -141,6 +142,7 @@ struct SlabArgs {
   const float* slabs; int64_t slab_stride; int splits; float* C; int64_t ldc; int M, N;
   const float* colsum_slab; float* colsum_out;
   const float* bias; int relu;          // split-K forward GEMMs finish bias / ReLU here
+  int c_bf16 = 0;                        // C holds bf16 elements
 };
 constexpr int kSlabItems = 16;
 struct SlabBatch { SlabArgs a[kSlabItems]; };
@@ -175,6 +177,36 @@ struct TileLoader16 {
       for (int j = 0; j < KR; ++j) r[j] = (x < X && k + j < kend) ? P[(int64_t)(k + j) * ld + x] : 0.f;
     }
   }
+  // same tile from a bf16 tensor (held widened in r[]: the conversion back in store() is exact)
+  __device__ __forceinline__ void load_bf16(const uint16_t* __restrict__ P, int64_t ld, int x0, int X, int k0, int kend, int t, bool vec) {
+    if (MODE == 0) {
+      const int x = x0 + (t >> 2), k = k0 + (t & 3) * KR;
+      if (vec && x < X && k + KR - 1 < kend) {
+#pragma unroll
+        for (int q = 0; q < KR / 8; ++q) {
+          const uint4 a = *reinterpret_cast<const uint4*>(P + (int64_t)x * ld + k + 8 * q);
+          const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            r[8 * q + 2 * j] = __builtin_bit_cast(float, w[j] << 16);
+            r[8 * q + 2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xFFFF0000u);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < KR; ++j) r[j] = (x < X && k + j < kend) ? tt_bf2f(P[(int64_t)x * ld + k + j]) : 0.f;
+      }
+    } else {
+      const int x = x0 + (t & 63), k = k0 + (t >> 6) * KR;
+#pragma unroll
+      for (int j = 0; j < KR; ++j) r[j] = (x < X && k + j < kend) ? tt_bf2f(P[(int64_t)(k + j) * ld + x]) : 0.f;
+    }
+  }
+  __device__ __forceinline__ void load_any(const float* __restrict__ P, int is_bf16, int64_t ld, int x0, int X, int k0, int kend, int t,
+                                           bool vec) {
+    if (is_bf16) load_bf16(reinterpret_cast<const uint16_t*>(P), ld, x0, X, k0, kend, t, vec);
+    else load(P, ld, x0, X, k0, kend, t, vec);
+  }
   __device__ __forceinline__ void store(__bf16* __restrict__ S, int t) const {
     const int row = MODE == 0 ? (t >> 2) : (t & 63), kq = MODE == 0 ? (t & 3) * KR : (t >> 6) * KR;
 #pragma unroll
@@ -207,8 +239,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(GemmBatch batch, int
   TileLoader16<MODE_B> lb;
   float cs = 0.f;
   if (kbeg < kend) {
-    la.load(g.A, g.lda, m0, M, kbeg, kend, t, vec);
-    lb.load(g.B, g.ldb, n0, N, kbeg, kend, t, vec);
+    la.load_any(g.A, g.a_bf16, g.lda, m0, M, kbeg, kend, t, vec);
+    lb.load_any(g.B, g.b_bf16, g.ldb, n0, N, kbeg, kend, t, vec);
   }
   for (int k0 = kbeg; k0 < kend; k0 += BK16) {
     la.store(As, t);
@@ -219,8 +251,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(GemmBatch batch, int
     }
     __syncthreads();
     if (k0 + BK16 < kend) {
-      la.load(g.A, g.lda, m0, M, k0 + BK16, kend, t, vec);
-      lb.load(g.B, g.ldb, n0, N, k0 + BK16, kend, t, vec);
+      la.load_any(g.A, g.a_bf16, g.lda, m0, M, k0 + BK16, kend, t, vec);
+      lb.load_any(g.B, g.b_bf16, g.ldb, n0, N, k0 + BK16, kend, t, vec);
     }
 #pragma unroll
     for (int s2 = 0; s2 < BK16 / 16; ++s2) {
@@ -244,7 +276,8 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(GemmBatch batch, int
     if (m < M && n < N) {
       float v = acc[r] * g.alpha + bv;
       if (g.relu) v = fmaxf(v, 0.f);
-      Cz[(int64_t)m * g.ldc + n] = v;
+      if (g.c_bf16) reinterpret_cast<uint16_t*>(Cz)[(int64_t)m * g.ldc + n] = tt_f2bf(v);
+      else Cz[(int64_t)m * g.ldc + n] = v;
     }
   }
 }
@@ -262,7 +295,8 @@ __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(SlabBatch batch) {
       const int64_t m = i / a.N, n = i - m * a.N;
       if (a.bias) s += a.bias[n];
       if (a.relu) s = fmaxf(s, 0.f);
-      a.C[m * a.ldc + n] = s;
+      if (a.c_bf16) reinterpret_cast<uint16_t*>(a.C)[m * a.ldc + n] = tt_f2bf(s);
+      else a.C[m * a.ldc + n] = s;
     } else {
       const int64_t m = i - total;
 #pragma unroll 8
@@ -272,7 +306,9 @@ __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(SlabBatch batch) {
   }
 }
 
-inline bool vec_ok(const float* p, int64_t ld) { return tt_aligned(p, 16) && (ld % 4 == 0); }
+inline bool vec_ok(const float* p, int64_t ld, bool bf16_elems = false) {
+  return tt_aligned(p, 16) && (ld % (bf16_elems ? 8 : 4) == 0);
+}
 
 inline int tn_splits(int64_t M, int64_t N, int64_t R) {
   const int64_t tiles = tt_cdiv(M, BM) * tt_cdiv(N, BN);
@@ -352,15 +388,19 @@ int tt_gemm_nt_batched(hipStream_t st, const GemmNT* it, int n) {
     if (any_split) {
       float* slabs = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(it[i].workspace) + 255) & ~uintptr_t(255));
       b.a[m] = GemmArgs{it[i].A, it[i].lda, it[i].W, it[i].ldw, slabs, it[i].N, it[i].M * it[i].N, (int)it[i].M, (int)it[i].N,
-                        (int)it[i].K, kchunk, splits, nullptr, 0, it[i].alpha, nullptr};
+                        (int)it[i].K, kchunk, splits, nullptr, 0, it[i].alpha, nullptr, it[i].a_bf16 ? 1 : 0, 0, 0};
       sb.a[m] = SlabArgs{slabs, it[i].M * it[i].N, splits, it[i].C, it[i].ldc, (int)it[i].M, (int)it[i].N, nullptr, nullptr,
-                         it[i].bias, it[i].relu ? 1 : 0};
+                         it[i].bias, it[i].relu ? 1 : 0, it[i].c_bf16 ? 1 : 0};
       maxtotal = it[i].M * it[i].N > maxtotal ? it[i].M * it[i].N : maxtotal;
     } else {
       b.a[m] = GemmArgs{it[i].A, it[i].lda, it[i].W, it[i].ldw, it[i].C, it[i].ldc, 0, (int)it[i].M, (int)it[i].N, (int)it[i].K,
-                        kchunk, 1, it[i].bias, it[i].relu ? 1 : 0, it[i].alpha, nullptr};
+                        kchunk, 1, it[i].bias, it[i].relu ? 1 : 0, it[i].alpha, nullptr, it[i].a_bf16 ? 1 : 0, 0, it[i].c_bf16 ? 1 : 0};
     }
-    vec = vec && vec_ok(it[i].A, it[i].lda) && vec_ok(it[i].W, it[i].ldw);
+    if ((it[i].a_bf16 || it[i].c_bf16) && !it[0].bf16) {
+      tt_set_error("tt_gemm_nt: bf16 tensors need the bf16 compute path");
+      return TT_ERR_INVALID_ARG;
+    }
+    vec = vec && vec_ok(it[i].A, it[i].lda, it[i].a_bf16) && vec_ok(it[i].W, it[i].ldw);
     ++m;
   }
   if (!m) return TT_OK;
@@ -381,7 +421,11 @@ int tt_gemm_nn_batched(hipStream_t st, const GemmNN* it, int n) {
   for (int i = 0; i < n; ++i) {
     if (it[i].M == 0 || it[i].N == 0) continue;
     b.a[m++] = GemmArgs{it[i].A, it[i].lda, it[i].W, it[i].ldw, it[i].C, it[i].ldc, 0, (int)it[i].M, (int)it[i].N, (int)it[i].K,
-                        (int)(tt_cdiv(it[i].K > 0 ? it[i].K : 1, BK16) * BK16), 1, nullptr, 0, 1.f, nullptr};
+                        (int)(tt_cdiv(it[i].K > 0 ? it[i].K : 1, BK16) * BK16), 1, nullptr, 0, 1.f, nullptr, 0, 0, it[i].c_bf16 ? 1 : 0};
+    if (it[i].c_bf16 && !it[0].bf16) {
+      tt_set_error("tt_gemm_nn: a bf16 output needs the bf16 compute path");
+      return TT_ERR_INVALID_ARG;
+    }
     vec = vec && vec_ok(it[i].A, it[i].lda) && vec_ok(it[i].W, it[i].ldw);
   }
   return m ? launch_gemm<0, 1>(st, b, m, 1, vec, false, n > 0 && it[0].bf16) : TT_OK;
@@ -428,9 +472,13 @@ int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n, TnPending* pendi
     float* cslab = slabs + (size_t)splits * (size_t)t.M * (size_t)t.N;
     const int kchunk = (int)(tt_cdiv(tt_cdiv(t.R > 0 ? t.R : 1, splits), BK16) * BK16);
     b.a[m] = GemmArgs{t.A, t.lda, t.B, t.ldb, slabs, t.N, t.M * t.N, (int)t.M, (int)t.N, (int)t.R, kchunk, splits, nullptr, 0, 1.f,
-                      t.colsum_out ? cslab : nullptr};
+                      t.colsum_out ? cslab : nullptr, t.a_bf16 ? 1 : 0, t.b_bf16 ? 1 : 0, 0};
+    if ((t.a_bf16 || t.b_bf16) && !it[0].bf16) {
+      tt_set_error("tt_gemm_tn: bf16 tensors need the bf16 compute path");
+      return TT_ERR_INVALID_ARG;
+    }
     sb.a[m] = SlabArgs{slabs, t.M * t.N, splits, t.C, t.ldc, (int)t.M, (int)t.N, cslab, t.colsum_out, nullptr, 0};
-    vec = vec && vec_ok(t.A, t.lda) && vec_ok(t.B, t.ldb);
+    vec = vec && vec_ok(t.A, t.lda, t.a_bf16) && vec_ok(t.B, t.ldb, t.b_bf16);
     colsum = colsum || t.colsum_out != nullptr;
     zs = splits > zs ? splits : zs;
     const int64_t tot = t.M * t.N + (t.colsum_out ? t.M : 0);

@@ -356,6 +356,10 @@ int check_batch(int32_t n, const tt_tower_params* const* P, int64_t B, float dro
     if (int rc = check_params(P[t], who)) return rc;
     TT_CHECK_ARG(P[t]->n_hidden == P[0]->n_hidden, "%s: towers fused into one launch must have the same number of hidden blocks", who);
     TT_CHECK_ARG(P[t]->compute_dtype == P[0]->compute_dtype, "%s: towers fused into one launch must share compute_dtype", who);
+    TT_CHECK_ARG((P[t]->x_dtype == TT_F32 && P[t]->dx_dtype == TT_F32) || P[t]->compute_dtype == TT_BF16,
+                 "%s: bf16 x / d_x need compute_dtype TT_BF16", who);
+    TT_CHECK_ARG((P[t]->x_dtype == TT_F32 || P[t]->x_dtype == TT_BF16) && (P[t]->dx_dtype == TT_F32 || P[t]->dx_dtype == TT_BF16),
+                 "%s: bad x_dtype / dx_dtype", who);
     if (B > 0 && (!ws[t] || wsb[t] < tt_tower_workspace_bytes(P[t], B))) {
       tt_set_error("%s: workspace of tower %d: %zu < required %zu", who, t, wsb[t], tt_tower_workspace_bytes(P[t], B));
       return TT_ERR_WORKSPACE;
@@ -389,8 +393,10 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     ws[t] = ws_layout(P[t], B, reinterpret_cast<char*>(workspaces[t]));
     const int wx = P[t]->h0 + P[t]->kcat_e;
     // x[:, 0:h0] = dense W_proj^T + b_proj        (base_tower.py:133)
-    nt[t] = GemmNT{A[t]->dense, P[t]->din, P[t]->w_proj, P[t]->din, P[t]->b_proj, A[t]->x, wx, B, P[t]->h0, P[t]->din, false, 1.f};
-    in[t] = A[t]->x;
+    nt[t] = GemmNT{A[t]->dense, P[t]->din, P[t]->w_proj, P[t]->din, P[t]->b_proj, reinterpret_cast<float*>(A[t]->x), wx, B, P[t]->h0,
+                   P[t]->din, false, 1.f};
+    nt[t].c_bf16 = P[t]->x_dtype == TT_BF16;
+    in[t] = reinterpret_cast<const float*>(A[t]->x);
     in_w[t] = wx;
   }
   for (int t = 0; t < n; ++t) { nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes; }
@@ -406,6 +412,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       const int H = P[t]->hidden[i];
       TT_CHECK_ARG(A[t]->pre[i] && A[t]->act[i] && A[t]->mean[i] && A[t]->rstd[i], "tt_towers_mlp_fwd: NULL buffers of block %d", i);
       nt[t] = GemmNT{in[t], in_w[t], P[t]->w[i], in_w[t], P[t]->b[i], A[t]->pre[i], H, B, H, in_w[t], false, 1.f};
+      nt[t].a_bf16 = i == 0 && P[t]->x_dtype == TT_BF16;
       const int nchunks = chunks_for(B, H);
       bs.a[t] = BnStatArgs{A[t]->pre[i], (int)B, H, (int)tt_cdiv(B, nchunks), nchunks, ws[t].col, A[t]->mean[i], A[t]->rstd[i],
                            P[t]->bn_rm[i], P[t]->bn_rv[i], P[t]->bn_nbt[i]};
@@ -437,6 +444,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
   int dmax = 1;
   for (int t = 0; t < n; ++t) {
     nt[t] = GemmNT{in[t], in_w[t], P[t]->w_out, in_w[t], P[t]->b_out, A[t]->y, P[t]->d_out, B, P[t]->d_out, in_w[t], false, 1.f};
+    nt[t].a_bf16 = nh == 0 && P[t]->x_dtype == TT_BF16;
     na.a[t] = NormArgs{A[t]->y, nullptr, nullptr, (int)B, P[t]->d_out, A[t]->emb};
     dmax = P[t]->d_out > dmax ? P[t]->d_out : dmax;
   }
@@ -474,12 +482,14 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
   TT_LAUNCH_CHECK();
   for (int t = 0; t < n; ++t) {
     const tt_tower_grads* g = G[t];
-    const float* in_last = nh == 0 ? A[t]->x : A[t]->act[nh - 1];
+    const float* in_last = nh == 0 ? reinterpret_cast<const float*>(A[t]->x) : A[t]->act[nh - 1];
     const int lw = last_width(P[t]);
     tn[t] = GemmTN{g->d_y, P[t]->d_out, in_last, lw, g->w_out, lw, P[t]->d_out, lw, B, ws[t].tn[nh + 1], ws[t].tn_bytes[nh + 1], g->b_out};
-    dcur[t] = nh == 0 ? g->d_x : g->scratch[nh - 1];
+    dcur[t] = nh == 0 ? reinterpret_cast<float*>(g->d_x) : g->scratch[nh - 1];
     TT_CHECK_ARG(dcur[t], "tt_towers_mlp_bwd: NULL scratch buffer");
     nn[t] = GemmNN{g->d_y, P[t]->d_out, P[t]->w_out, lw, dcur[t], lw, B, lw, P[t]->d_out};
+    tn[t].b_bf16 = nh == 0 && P[t]->x_dtype == TT_BF16;
+    nn[t].c_bf16 = nh == 0 && P[t]->dx_dtype == TT_BF16;
   }
   for (int t = 0; t < n; ++t) tn[t].bf16 = nn[t].bf16 = P[0]->compute_dtype == TT_BF16;
   // the slab reductions of all weight-gradient GEMMs run as ONE launch at the end (nothing in this pass reads them)
@@ -519,11 +529,13 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       const tt_tower_grads* g = G[t];
       const int H = P[t]->hidden[i];
       const int iw = in_width(P[t], i);
-      const float* in_i = i == 0 ? A[t]->x : A[t]->act[i - 1];
+      const float* in_i = i == 0 ? reinterpret_cast<const float*>(A[t]->x) : A[t]->act[i - 1];
       tn[t] = GemmTN{dcur[t], H, in_i, iw, g->w[i], iw, H, iw, B, ws[t].tn[1 + i], ws[t].tn_bytes[1 + i], g->b[i]};
-      float* dnext = i == 0 ? g->d_x : g->scratch[i - 1];
+      tn[t].b_bf16 = i == 0 && P[t]->x_dtype == TT_BF16;
+      float* dnext = i == 0 ? reinterpret_cast<float*>(g->d_x) : g->scratch[i - 1];
       TT_CHECK_ARG(dnext, "tt_towers_mlp_bwd: NULL scratch buffer");
       nn[t] = GemmNN{dcur[t], H, P[t]->w[i], iw, dnext, iw, B, iw, H};
+      nn[t].c_bf16 = i == 0 && P[t]->dx_dtype == TT_BF16;
       dcur[t] = dnext;
     }
     for (int t = 0; t < n; ++t) tn[t].bf16 = nn[t].bf16 = P[0]->compute_dtype == TT_BF16;
@@ -534,7 +546,9 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
   for (int t = 0; t < n; ++t) {
     const tt_tower_grads* g = G[t];
     const int wx = P[t]->h0 + P[t]->kcat_e;
-    tn[t] = GemmTN{g->d_x, wx, A[t]->dense, P[t]->din, g->w_proj, P[t]->din, P[t]->h0, P[t]->din, B, ws[t].tn[0], ws[t].tn_bytes[0], g->b_proj};
+    tn[t] = GemmTN{reinterpret_cast<const float*>(g->d_x), wx, A[t]->dense, P[t]->din, g->w_proj, P[t]->din, P[t]->h0, P[t]->din, B,
+                   ws[t].tn[0], ws[t].tn_bytes[0], g->b_proj};
+    tn[t].a_bf16 = P[t]->dx_dtype == TT_BF16;
   }
   for (int t = 0; t < n; ++t) tn[t].bf16 = P[0]->compute_dtype == TT_BF16;
   if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;

@@ -56,6 +56,16 @@ class BaseTower(nn.Module):
         self.mlp_dtype = mlp_dtype or os.environ.get("TT_MLP_DTYPE", "fp32")
         if self.mlp_dtype not in ("fp32", "bf16"):
             raise ValueError(f"mlp_dtype must be 'fp32' or 'bf16', got {self.mlp_dtype!r}")
+        # bf16 MLP: the tower input x = [projection | embedding rows] lives in bf16 -- bit-identical results (the GEMMs
+        # that read x round it to bf16 anyway) at half the bytes: lookup 15.7 -> 9.2 us, step -7 us at B = 8192.
+        # A bf16 d_x (TT_TOWER_IO_DTYPE = dx | both) is implemented but measured 30 us SLOWER per step (2-byte
+        # scattered stores of the data-gradient GEMM, 8-byte gathers in the segmented reduction) and rounds the
+        # per-slot row gradients, so it stays off.
+        io = os.environ.get("TT_TOWER_IO_DTYPE", "x") if self.mlp_dtype == "bf16" else "none"
+        if io not in ("none", "x", "dx", "both"):
+            raise ValueError(f"TT_TOWER_IO_DTYPE must be none|x|dx|both, got {io!r}")
+        self.x_dtype = torch.bfloat16 if io in ("x", "both") else torch.float32
+        self.dx_dtype = torch.bfloat16 if io in ("dx", "both") else torch.float32
         self.categorical_keys = list(categorical_keys)
         self.exchange = None            # set by the distributed task: sharded-table row exchange
         self._seed_dev = None           # set by GraphedTrainStep: device word added to the dropout seed
@@ -106,7 +116,7 @@ class BaseTower(nn.Module):
         tensors = [self.dense_projection.weight, self.dense_projection.bias, out.weight, out.bias]
         for lin, bn in zip(lins, bns):
             tensors += [lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype,)
+        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype, self.x_dtype, self.dx_dtype)
         if key != self._struct_key:
             for t in tensors:
                 if t.dtype != torch.float32 or not t.is_contiguous():
@@ -118,7 +128,9 @@ class BaseTower(nn.Module):
                 [l.weight for l in lins], [l.bias for l in lins], [b.weight for b in bns], [b.bias for b in bns],
                 [b.running_mean for b in bns], [b.running_var for b in bns], out.weight, out.bias,
                 bn_nbt=[b.num_batches_tracked for b in bns],
-                compute_dtype=ops.TT_BF16 if self.mlp_dtype == "bf16" else ops.TT_F32)
+                compute_dtype=ops.TT_BF16 if self.mlp_dtype == "bf16" else ops.TT_F32,
+                x_dtype=ops.TT_BF16 if self.x_dtype == torch.bfloat16 else ops.TT_F32,
+                dx_dtype=ops.TT_BF16 if self.dx_dtype == torch.bfloat16 else ops.TT_F32)
             self._struct_key = key
         return self._params_struct
 
@@ -204,17 +216,19 @@ class _TowersFn(torch.autograd.Function):
             s.seed = int(torch.empty((), dtype=torch.int64).random_().item()) if s.p_drop > 0 else 0
             # one flat activation buffer: x | (pre_i, act_i)* | (mean_i, rstd_i)* | y
             hid = tw.tower_hidden_dims[1:]
-            sizes = [_al(B * tw.x_width)] + [_al(B * h) for h in hid for _ in (0, 1)] + [_al(h) for h in hid for _ in (0, 1)] + \
-                    [_al(B * tw.final_embedding_dim)]
+            x_f32 = tw.x_dtype == torch.float32
+            sizes = [_al(B * tw.x_width) if x_f32 else 0] + [_al(B * h) for h in hid for _ in (0, 1)] + \
+                    [_al(h) for h in hid for _ in (0, 1)] + [_al(B * tw.final_embedding_dim)]
             s.buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
             offs = [0]
             for z in sizes:
                 offs.append(offs[-1] + z)
-            s.x = s.buf[:B * tw.x_width].view(B, tw.x_width)
+            s.x = s.buf[:B * tw.x_width].view(B, tw.x_width) if x_f32 else \
+                torch.empty((B, tw.x_width), dtype=tw.x_dtype, device=dev)
             s.emb = torch.empty((B, tw.final_embedding_dim), dtype=torch.float32, device=dev)
             a = L.TowerActs()
             base, esz = s.buf.data_ptr(), 4
-            a.dense, a.x, a.emb = dense.data_ptr(), base, s.emb.data_ptr()
+            a.dense, a.x, a.emb = dense.data_ptr(), s.x.data_ptr(), s.emb.data_ptr()
             nh = len(hid)
             for i in range(nh):
                 a.pre[i] = base + esz * offs[1 + 2 * i]
@@ -308,7 +322,8 @@ class _TowersFn(torch.autograd.Function):
             dps = tw.dense_parameters()
             hid = tw.tower_hidden_dims[1:]
             B = s.B
-            sizes = [_al(p.numel()) for p in dps] + [_al(B * tw.x_width)] + [_al(B * h) for h in hid] + \
+            dx_f32 = tw.dx_dtype == torch.float32
+            sizes = [_al(p.numel()) for p in dps] + [_al(B * tw.x_width) if dx_f32 else 0] + [_al(B * h) for h in hid] + \
                     [_al(B * tw.final_embedding_dim)]
             buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
             offs = [0]
@@ -323,13 +338,14 @@ class _TowersFn(torch.autograd.Function):
                 g.bn_w[i], g.bn_b[i] = base + 4 * offs[4 + 4 * i], base + 4 * offs[5 + 4 * i]
                 g.scratch[i] = base + 4 * offs[len(dps) + 1 + i]
             g.w_out, g.b_out = base + 4 * offs[len(dps) - 2], base + 4 * offs[len(dps) - 1]
-            g.d_x = base + 4 * offs[len(dps)]
+            d_x = buf[offs[len(dps)]:offs[len(dps)] + B * tw.x_width].view(B, tw.x_width) if dx_f32 else \
+                torch.empty((B, tw.x_width), dtype=tw.dx_dtype, device=dev)
+            g.d_x = d_x.data_ptr()
             g.d_y = base + 4 * offs[len(dps) + 1 + len(hid)]
             prepared.append((s, d_emb, g))
             for i, v in enumerate(views):
                 grads[pos + 2 + i] = v
             flat_grads.append(buf[:offs[len(dps)]])
-            d_x = buf[offs[len(dps)]:offs[len(dps)] + B * tw.x_width].view(B, tw.x_width)
             dxs[id(s)] = d_x[:, tw.tower_hidden_dims[0]:]
         fused = len(prepared) > 1 and len({s.B for s, _, _ in prepared}) == 1 and \
             len({s.tower.n_hidden for s, _, _ in prepared}) == 1 and len({(s.train, s.p_drop, s.seed) for s, _, _ in prepared}) == 1
@@ -350,7 +366,7 @@ class _TowersFn(torch.autograd.Function):
                     K = len(s.tower.categorical_embedder.keys)
                     d = dxs.get(id(s))
                     if d is None:
-                        d = torch.zeros((s.B, K * exch.E), dtype=torch.float32, device=s.emb.device)
+                        d = torch.zeros((s.B, K * exch.E), dtype=s.tower.dx_dtype, device=s.emb.device)
                     srcs.append((d, K))
                 exch.backward(ctx.exch_state, srcs, ctx.exch_sides[0].B)
         # table gradients: one fused segmented reduction per store
@@ -362,7 +378,7 @@ class _TowersFn(torch.autograd.Function):
                 K = len(s.tower.categorical_embedder.keys)
                 d = dxs.get(id(s))
                 if d is None:       # this tower received no gradient: contribute zeros
-                    d = torch.zeros((s.B, K * store.E), dtype=torch.float32, device=store.device)
+                    d = torch.zeros((s.B, K * store.E), dtype=s.tower.dx_dtype, device=store.device)
                 srcs.append((d, K))
             if plan.stream is not None:                                           # join the plan's side stream
                 torch.cuda.current_stream(store.device).wait_stream(plan.stream)
