@@ -780,7 +780,10 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_compact_kernel(const int3
 // a16: segmented gradient reduction.  A lane-group of LG lanes owns one distinct row and walks its
 // segment in ascending slot order (4 independent loads in flight, added in order).
 // ------------------------------------------------------------------------------------------------
-constexpr int kLongSeg = 64;    // segments longer than this are split into kLongSeg-slot chunks
+// segments longer than this are split into kLongSeg-slot chunks (4 trips each) summed by their own lane groups.
+// (16 = one trip per chunk was tried: at the bench's 6,200 rows of 17-64 slots the two same-address atomics per long
+//  row and a workgroup-per-row finish cost more than the serial trips save: 25 + 8 + 11 us against 14 + 9 + 5.)
+constexpr int kLongSeg = 64;
 
 struct GradWs {
   int32_t* counters;     // [0] chunks allocated, [1] long rows
@@ -979,16 +982,18 @@ __global__ __launch_bounds__(kThreads) void seg_reduce_kernel(SideSet a, const i
   for (uint32_t u = gthread / LG; u < U; u += ngroups) {
     const int32_t s0 = seg[u], s1 = seg[u + 1];
     if (s1 - s0 > kLongSeg) {
+      const int32_t nch = (s1 - s0 + kLongSeg - 1) / kLongSeg;
+      int32_t base = 0;
       if (lig == 0) {
-        const int32_t nch = (s1 - s0 + kLongSeg - 1) / kLongSeg;
-        const int32_t base = atomicAdd(&ws.counters[0], nch);
+        base = atomicAdd(&ws.counters[0], nch);
         const int32_t li = atomicAdd(&ws.counters[1], 1);
         ws.long_row[li] = (int32_t)u;
         ws.long_base[li] = base;
-        for (int32_t c = 0; c < nch; ++c) {
-          ws.chunk_lo[base + c] = s0 + c * kLongSeg;
-          ws.chunk_hi[base + c] = min(s1, s0 + (c + 1) * kLongSeg);
-        }
+      }
+      base = __shfl(base, 0, (int)LG);                     // the group's lanes write the chunk list together
+      for (int32_t c = (int32_t)lig; c < nch; c += (int32_t)LG) {
+        ws.chunk_lo[base + c] = s0 + c * kLongSeg;
+        ws.chunk_hi[base + c] = min(s1, s0 + (c + 1) * kLongSeg);
       }
       continue;
     }
@@ -1018,24 +1023,28 @@ __global__ __launch_bounds__(kThreads) void seg_chunk_kernel(SideSet a, const in
   }
 }
 
+// one WORKGROUP per long row: its lane groups sum contiguous ranges of the row's chunk partials (8 loads in flight,
+// chunk order), the group sums are added in group order through LDS -- one or two trips however long the row is
+// (a binary key at B = 8192 has ~4096-slot rows = 256 partials)
+constexpr int kFinishMaxFloats = 4096;     // (kThreads / LG) * E floats of LDS
 template <int VEC>
 __global__ __launch_bounds__(kThreads) void seg_long_finish_kernel(int32_t E, uint32_t C, const int32_t* __restrict__ seg,
                                                                   const int32_t* __restrict__ unique_rows, int32_t mode,
                                                                   float* __restrict__ out, GradWs ws, uint32_t LG) {
+  __shared__ float part[kFinishMaxFloats];
   const uint32_t nlong = (uint32_t)ws.counters[1];
-  const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lig = gthread % LG;
-  const uint32_t ngroups = gridDim.x * blockDim.x / LG;
-  for (uint32_t li = gthread / LG; li < nlong; li += ngroups) {
+  const uint32_t grp = threadIdx.x / LG, lig = threadIdx.x % LG, ngrp = blockDim.x / LG;
+  for (uint32_t li = blockIdx.x; li < nlong; li += gridDim.x) {
     const int32_t u = ws.long_row[li], base = ws.long_base[li];
     const int32_t nch = (seg[u + 1] - seg[u] + kLongSeg - 1) / kLongSeg;
-    const int64_t orow = mode == TT_GRAD_SPARSE ? (int64_t)u : (int64_t)unique_rows[u];
+    const int32_t per = (nch + (int32_t)ngrp - 1) / (int32_t)ngrp;
+    const int32_t c0 = min(nch, (int32_t)grp * per), c1 = min(nch, c0 + per);
     for (uint32_t chunk = lig; chunk < C; chunk += LG) {
       Acc<VEC> acc;
       acc.zero();
       const float* p0 = ws.chunk_partial + (int64_t)base * E + chunk * VEC;
-      int32_t c = 0;
-      for (; c + 8 <= nch; c += 8) {          // 8 partial loads in flight, added in chunk order
+      int32_t c = c0;
+      for (; c + 8 <= c1; c += 8) {
         float t[8][VEC];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
@@ -1046,12 +1055,22 @@ __global__ __launch_bounds__(kThreads) void seg_long_finish_kernel(int32_t E, ui
 #pragma unroll
           for (int e = 0; e < VEC; ++e) acc.v[e] += t[j][e];
       }
-      for (; c < nch; ++c) {
+      for (; c < c1; ++c) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc.v[e] += p0[(int64_t)c * E + e];
       }
-      write_row<VEC>(out, orow, E, chunk, acc, mode == TT_GRAD_DENSE_ACC);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) part[grp * E + chunk * VEC + e] = acc.v[e];
     }
+    __syncthreads();
+    const int64_t orow = mode == TT_GRAD_SPARSE ? (int64_t)u : (int64_t)unique_rows[u];
+    for (int32_t col = threadIdx.x; col < E; col += blockDim.x) {
+      float tot = 0.f;
+      for (uint32_t g = 0; g < ngrp; ++g) tot += part[g * E + col];
+      float* o = out + orow * E + col;
+      *o = mode == TT_GRAD_DENSE_ACC ? *o + tot : tot;
+    }
+    __syncthreads();
   }
 }
 
@@ -1555,7 +1574,11 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   TT_HIP(hipMemsetAsync(gl.ws.counters, 0, 2 * sizeof(int32_t), st));
   const int g1 = grid_for(ctx, M * LG);
   const int g2 = grid_for(ctx, gl.max_chunks * LG);
-  const int g3 = grid_for(ctx, gl.max_long * LG);
+  const int g3 = (int)(gl.max_long < (int64_t)ctx->num_cus * 8 ? gl.max_long : (int64_t)ctx->num_cus * 8);   // a workgroup per long row
+  if ((int64_t)(kThreads / LG) * E > kFinishMaxFloats) {
+    tt_set_error("tt_embed_grad_bwd: E=%d too wide for the long-row finish (max %d)", E, kFinishMaxFloats * (int)LG / kThreads);
+    return TT_ERR_UNSUPPORTED;
+  }
   // all sources share one element type (checked above): it is a template parameter of the kernels, and so is
   // the lane-group width when every lane of a group owns exactly one chunk (shared decode, see sum_range)
 #define TT_SEG_LAUNCH(V, D, G)                                                                                                  \

@@ -143,25 +143,38 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
   __shared__ float part_e[NW][ROWS];
   __shared__ float part_s[NW][ROWS];
   __shared__ int part_c[NW][ROWS];
-  const DirFwd dr = args.d[blockIdx.y];
-  const int64_t a0 = (int64_t)blockIdx.x * ROWS;
-  if (a0 >= dr.Ra) return;
+  // the direction's fields are picked with scalar selects (indexing the by-value argument with blockIdx.y made
+  // every field -- and with it the whole tile loop's control flow -- live in vector registers), and row counts /
+  // positions are 32-bit: the loop counter, the tile classification and their branches then run on the SALU
+  const bool d1 = blockIdx.y != 0;
+  DirFwd dr;
+  dr.a_rows = d1 ? args.d[1].a_rows : args.d[0].a_rows;
+  dr.b_rows = d1 ? args.d[1].b_rows : args.d[0].b_rows;
+  dr.sumexp = d1 ? args.d[1].sumexp : args.d[0].sumexp;
+  dr.diag = d1 ? args.d[1].diag : args.d[0].diag;
+  dr.rank = d1 ? args.d[1].rank : args.d[0].rank;
+  dr.sumscore = d1 ? args.d[1].sumscore : args.d[0].sumscore;
+  dr.rank_mode = d1 ? args.d[1].rank_mode : args.d[0].rank_mode;
+  const int Ra = (int)(d1 ? args.d[1].Ra : args.d[0].Ra), Rb = (int)(d1 ? args.d[1].Rb : args.d[0].Rb);
+  const int off = (int)(d1 ? args.d[1].off : args.d[0].off);
+  const int a0 = (int)blockIdx.x * ROWS;
+  if (a0 >= Ra) return;
   const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile loop and its branches run on the SALU
-  const int64_t nT = rup(dr.Rb, 32) / 32;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nT = (Rb + 31) / 32;
   bf16x8 ares[AT][KS];
 #pragma unroll
   for (int i = 0; i < AT; ++i) load_bfrag<KS>(dr.a_rows, a0 / 32 + i, c, h, ares[i]);
-  int64_t pos[AT];
+  int pos[AT];
   float dg[AT];
 #pragma unroll
-  for (int i = 0; i < AT; ++i) { pos[i] = a0 + 32 * i + c + dr.off; dg[i] = kNegBig; }
-  const int64_t posmin = a0 + dr.off, posmax = a0 + ROWS - 1 + dr.off;
+  for (int i = 0; i < AT; ++i) { pos[i] = a0 + 32 * i + c + off; dg[i] = kNegBig; }
+  const int posmin = a0 + off, posmax = a0 + ROWS - 1 + off;
   // the diagonal scores, taken from the MFMA result itself so that ties compare bit-for-bit
-  if (posmax >= 0 && posmin < dr.Rb) {
-    const int64_t td0 = posmin > 0 ? posmin / 32 : 0;
-    const int64_t td1 = (posmax / 32) < nT - 1 ? posmax / 32 : nT - 1;
-    for (int64_t t = td0; t <= td1; ++t) {
+  if (posmax >= 0 && posmin < Rb) {
+    const int td0 = posmin > 0 ? posmin / 32 : 0;
+    const int td1 = (posmax / 32) < nT - 1 ? posmax / 32 : nT - 1;
+    for (int t = td0; t <= td1; ++t) {
       f32x16 acc[AT];
       gemm1<KS, AT>(dr.b_rows, t, c, h, ares, acc);
 #pragma unroll
@@ -182,9 +195,9 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
   const bool want_ss = dr.sumscore != nullptr;
   // (a two-accumulator variant that issues tile t+NW's MFMAs before the epilogue of tile t measured SLOWER:
   //  199 VGPRs, 72-78 us vs 63-65 us -- kept single-buffered)
-  auto epilogue = [&](const f32x16 (&acc)[AT], int64_t t) {
-    const int64_t b_lo = 32 * t, b_hi = 32 * t + 31;
-    const bool full_tile = b_hi < dr.Rb;
+  auto epilogue = [&](const f32x16 (&acc)[AT], int t) {
+    const int b_lo = 32 * t, b_hi = 32 * t + 31;
+    const bool full_tile = b_hi < Rb;
     const bool before = full_tile && b_hi < posmin, after = full_tile && b_lo > posmax;
     if (before || after) {
 #pragma unroll
@@ -227,9 +240,9 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
       for (int i = 0; i < AT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t b = b_lo + rowmap(r, h);
+          const int b = b_lo + rowmap(r, h);
           const float x = acc[i][r];
-          const bool valid = b < dr.Rb, bef = valid && b < pos[i], aft = valid && b > pos[i];
+          const bool valid = b < Rb, bef = valid && b < pos[i], aft = valid && b > pos[i];
           se[i] += valid ? __builtin_amdgcn_exp2f(__builtin_fmaf(x, args.c1, args.c2)) : 0.f;
           ss[i] += valid ? x : 0.f;
           mb[i] = bef ? fmaxf(mb[i], x) : mb[i];
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
   };
   bf16x8 bnext[KS];
   if (wave < nT) load_bfrag<KS>(dr.b_rows, wave, c, h, bnext);
-  for (int64_t t = wave; t < nT; t += NW) {
+  for (int t = wave; t < nT; t += NW) {
     f32x16 acc[AT];
     bf16x8 bcur[KS];
 #pragma unroll
@@ -269,8 +282,8 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
   }
   __syncthreads();
   if (threadIdx.x < ROWS) {
-    const int64_t a = a0 + threadIdx.x;
-    if (a < dr.Ra) {
+    const int a = a0 + threadIdx.x;
+    if (a < Ra) {
       float e = 0.f, sc = 0.f, xb = kNegBig, xa = kNegBig;
       int k = 0;
 #pragma unroll
@@ -287,8 +300,8 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
   if (wave == 0 && h == 0 && dr.diag) {
 #pragma unroll
     for (int i = 0; i < AT; ++i) {
-      const int64_t a = a0 + 32 * i + c;
-      if (a < dr.Ra) dr.diag[a] = dg[i] > -1.0e38f ? dg[i] * args.inv_t : 0.f;
+      const int a = a0 + 32 * i + c;
+      if (a < Ra) dr.diag[a] = dg[i] > -1.0e38f ? dg[i] * args.inv_t : 0.f;
     }
   }
 }
@@ -298,22 +311,32 @@ template <int KS, int AT, int NW, bool PF_B, bool EARLY_BM>
 __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
   constexpr int Dp = KS * 16, ROWS = 32 * AT, DT = KS / 2;
   __shared__ float red[(NW / 2) * ROWS * Dp];
-  const DirBwd dr = args.d[blockIdx.y];
-  const int64_t a0 = (int64_t)blockIdx.x * ROWS;
-  if (a0 >= dr.Ra) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane & 31, h = lane >> 5;
-  const int64_t nT = rup(dr.Rb, 32) / 32;
+  const bool d1 = blockIdx.y != 0;                    // scalar selects, 32-bit positions: see the forward kernel
+  DirBwd dr;
+  dr.a_rows = d1 ? args.d[1].a_rows : args.d[0].a_rows;
+  dr.b_rows = d1 ? args.d[1].b_rows : args.d[0].b_rows;
+  dr.b_frag = d1 ? args.d[1].b_frag : args.d[0].b_frag;
+  dr.sumexp_a = d1 ? args.d[1].sumexp_a : args.d[0].sumexp_a;
+  dr.sumexp_b = d1 ? args.d[1].sumexp_b : args.d[0].sumexp_b;
+  dr.dA = d1 ? args.d[1].dA : args.d[0].dA;
+  const int Ra = (int)(d1 ? args.d[1].Ra : args.d[0].Ra), Rb = (int)(d1 ? args.d[1].Rb : args.d[0].Rb);
+  const int off = (int)(d1 ? args.d[1].off : args.d[0].off);
+  const int a0 = (int)blockIdx.x * ROWS;
+  if (a0 >= Ra) return;
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nT = (Rb + 31) / 32;
   bf16x8 ares[AT][KS];
   float ia[AT];
-  int64_t pos[AT];
+  int pos[AT];
 #pragma unroll
   for (int i = 0; i < AT; ++i) {
     load_bfrag<KS>(dr.a_rows, a0 / 32 + i, c, h, ares[i]);
-    const int64_t a = a0 + 32 * i + c;
-    ia[i] = a < dr.Ra ? __builtin_amdgcn_rcpf(dr.sumexp_a[a]) : 0.f;
-    pos[i] = a + dr.off;
+    const int a = a0 + 32 * i + c;
+    ia[i] = a < Ra ? __builtin_amdgcn_rcpf(dr.sumexp_a[a]) : 0.f;
+    pos[i] = a + off;
   }
-  const int64_t posmin = a0 + dr.off, posmax = a0 + ROWS - 1 + dr.off;
+  const int posmin = a0 + off, posmax = a0 + ROWS - 1 + off;
   f32x16 dacc[AT][DT];
 #pragma unroll
   for (int i = 0; i < AT; ++i)
@@ -323,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
       for (int r = 0; r < 16; ++r) dacc[i][d][r] = 0.f;
   bf16x8 bnext[PF_B ? KS : 1];
   if (PF_B && wave < nT) load_bfrag<KS>(dr.b_rows, wave, c, h, reinterpret_cast<bf16x8(&)[KS]>(bnext));
-  for (int64_t t = wave; t < nT; t += NW) {
+  for (int t = wave; t < nT; t += NW) {
     f32x16 acc[AT];
     bf16x8 bcur[KS];
     if (PF_B) {
@@ -340,12 +363,12 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int d = 0; d < DT; ++d)
-          bm[s][d] = *reinterpret_cast<const bf16x8*>(dr.b_frag + ((((t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
+          bm[s][d] = *reinterpret_cast<const bf16x8*>(dr.b_frag + (((((int64_t)t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
     }
     mfma1<KS, AT>(bcur, ares, acc);
-    const int64_t b_lo = 32 * t;
+    const int b_lo = 32 * t;
     float ib[16];
-    if (b_lo + 31 < dr.Rb) {
+    if (b_lo + 31 < Rb) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float4 v = *reinterpret_cast<const float4*>(dr.sumexp_b + b_lo + 4 * h + 8 * q);
@@ -355,8 +378,8 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t b = b_lo + rowmap(r, h);
-        ib[r] = b < dr.Rb ? __builtin_amdgcn_rcpf(dr.sumexp_b[b]) : 0.f;
+        const int b = b_lo + rowmap(r, h);
+        ib[r] = b < Rb ? __builtin_amdgcn_rcpf(dr.sumexp_b[b]) : 0.f;
       }
     }
     const bool band = !(b_lo + 31 < posmin || b_lo > posmax);
@@ -381,7 +404,7 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         if (!EARLY_BM)
-          bm[s][d] = *reinterpret_cast<const bf16x8*>(dr.b_frag + ((((t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
+          bm[s][d] = *reinterpret_cast<const bf16x8*>(dr.b_frag + (((((int64_t)t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
 #pragma unroll
         for (int i = 0; i < AT; ++i) dacc[i][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][s], bm[s][d], dacc[i][d], 0, 0, 0);
       }
@@ -418,9 +441,9 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
       for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int64_t a = a0 + 32 * i + rowmap(r, h);
+          const int a = a0 + 32 * i + rowmap(r, h);
           const int dd = 32 * d + c;
-          if (a < dr.Ra && dd < args.D) dr.dA[a * args.D + dd] = dacc[i][d][r] * g;
+          if (a < Ra && dd < args.D) dr.dA[(int64_t)a * args.D + dd] = dacc[i][d][r] * g;
         }
   }
 }
