@@ -197,6 +197,9 @@ struct TileLoader16 {
         for (int j = 0; j < KR; ++j) r[j] = (x < X && k + j < kend) ? tt_bf2f(P[(int64_t)x * ld + k + j]) : 0.f;
       }
     } else {
+      // (tried for the 64 x 1152 weight gradient, 24 us with this form, 19 us when x was f32: two adjacent x per
+      //  thread with 4-byte loads: 29 us; two adjacent 64-column tiles per workgroup (256-B row pieces, half the
+      //  workgroups): 37 us -- the kernel is bound by workgroup-level parallelism, not by piece size)
       const int x = x0 + (t & 63), k = k0 + (t >> 6) * KR;
 #pragma unroll
       for (int j = 0; j < KR; ++j) r[j] = (x < X && k + j < kend) ? tt_bf2f(P[(int64_t)(k + j) * ld + x]) : 0.f;

@@ -456,7 +456,8 @@ def test_fused_adam_matches_oracle(tt, manifest):
             np.testing.assert_allclose(val.cpu().numpy(), st[k], rtol=2e-4, atol=2e-6, err_msg=f"{mode}:{k}")
 
 
-def test_graphed_step_equals_eager(tt, manifest):
+@pytest.mark.parametrize("mlp_dtype", ["fp32", "bf16"])
+def test_graphed_step_equals_eager(tt, manifest, mlp_dtype):
     """HIP-graph replay of the whole step == the same steps launched eagerly (bitwise: same kernels,
     same order), with the learning rate changing between steps (LambdaLR warm-up) and new batches."""
     from jodalrob_twotower_amd.graph import GraphedTrainStep
@@ -466,7 +467,7 @@ def test_graphed_step_equals_eager(tt, manifest):
     batches = [synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 900 + i, oob=False) for i in range(6)]
     finals = {}
     for mode in ("eager", "graph"):
-        task = make_task(tt, cfg, embedding_grad="sparse", score_dtype="bf16")
+        task = make_task(tt, cfg, embedding_grad="sparse", score_dtype="bf16", mlp_dtype=mlp_dtype)
         shapes = {k: tuple(v.shape) for k, v in task.state_dict().items()}
         load_state(task, init_state_numpy(shapes, 55))
         task.train()
@@ -548,3 +549,72 @@ def test_dedup_plan_keyed_equals_general(tt, B, Ks, vocabs):
     assert np.array_equal(pk.sorted_src.cpu().numpy(), order.astype(np.int32))
     assert torch.equal(pk.sorted_src, pg.sorted_src)
     assert torch.equal(pk.unique_rows[:U], pg.unique_rows[:U]) and torch.equal(pk.seg_offsets[:U + 1], pg.seg_offsets[:U + 1])
+
+
+def test_bf16_tower_input_is_bit_identical(tt, manifest, schema_real, monkeypatch):
+    """mlp_dtype='bf16' with the tower input x stored in bf16 (default) == the same mode with x in f32: the GEMMs round x
+    to bf16 on the way into LDS either way, so loss and every gradient agree to the last bit; a bf16 d_x (opt-in) only
+    rounds the per-slot row gradients: table gradients within 1e-2 norm-wise, everything else still bit-identical
+    except the projection weights that read d_x."""
+    cfg = dict(manifest["cases"]["real_schema"])
+    cfg.update(keys_n=schema_real["notice"]["categorical"], keys_c=schema_real["company"]["categorical"], B=300)
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    shapes = {k: tuple(v) for k, v in manifest["state_dict_keys_real"].items()}
+    state = init_state_numpy(shapes, 77)
+    b = synth_batch_numpy(cfg["B"], vn, vc, cfg["din_n"], cfg["din_c"], 78, oob=False)
+    outs = {}
+    for io in ("none", "x", "both"):
+        monkeypatch.setenv("TT_TOWER_IO_DTYPE", io)
+        task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", mlp_dtype="bf16")
+        load_state(task, state)
+        task.train()
+        res = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+        res["loss"].backward()
+        outs[io] = (res["loss"].item(), {n: p.grad.cpu().numpy() for n, p in task.named_parameters()})
+    assert outs["x"][0] == outs["none"][0]
+    for k, g in outs["none"][1].items():
+        assert np.array_equal(outs["x"][1][k], g), k
+    assert outs["both"][0] == outs["none"][0]
+    for k, g in outs["none"][1].items():
+        gb = outs["both"][1][k]
+        if "embeddings" in k or "dense_projection" in k:
+            assert np.linalg.norm(gb - g) <= 1e-2 * np.linalg.norm(g) + 1e-12, k
+        else:
+            assert np.array_equal(gb, g), k
+
+
+def test_copy_multi(tt):
+    """tt_copy_multi: several device segments of odd sizes (16-byte body + byte tail) and a pinned-host source."""
+    from jodalrob_twotower_amd import ops
+    g = torch.Generator().manual_seed(5)
+    srcs = [torch.randint(0, 255, (n,), dtype=torch.uint8, generator=g) for n in (1 << 20, 4099, 16, 7, 0, 33)]
+    dev_src = [s.to(DEV) for s in srcs[:-1]] + [srcs[-1].pin_memory()]
+    dsts = [torch.zeros(s.numel() + 32, dtype=torch.uint8, device=DEV) for s in srcs]
+    ops.copy_multi([(d[:s.numel()], s) for d, s in zip(dsts, dev_src)])
+    torch.cuda.synchronize()
+    for d, s in zip(dsts, srcs):
+        assert torch.equal(d[:s.numel()].cpu(), s) and int(d[s.numel():].sum()) == 0
+
+
+def test_adam_fused_equals_separate_launches(tt, manifest, monkeypatch):
+    """tt_adam_fused_step (tower weights + looked-up rows in one launch) == tt_adam_multi_step + tt_sparse_adam_step."""
+    from jodalrob_twotower_amd.optim import FusedAdam
+    cfg = dict(manifest["cases"]["wide_b40"])
+    batches = [synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 300 + s, oob=False) for s in range(3)]
+    finals = []
+    for fused in (True, False):
+        if not fused:
+            monkeypatch.setattr(FusedAdam, "_fusable_store", lambda self, *a, **k: None)
+        task = make_task(tt, cfg, embedding_grad="sparse")
+        shapes = {k: tuple(v.shape) for k, v in task.state_dict().items()}
+        load_state(task, init_state_numpy(shapes, 9))
+        opt = FusedAdam.for_task(task, lr=3e-3, weight_decay=1e-5)
+        task.train()
+        for b in batches:
+            opt.zero_grad()
+            task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"])).backward()
+            opt.step()
+        finals.append({k: v.detach().cpu().numpy().copy() for k, v in task.state_dict().items()})
+        finals[-1]["__steps"] = np.array(opt.current_step())
+    for k, v in finals[0].items():
+        assert np.array_equal(v, finals[1][k]), k
