@@ -351,6 +351,7 @@ static int launch_gemm(hipStream_t st, const GemmBatch& b, int n, int zsplits, b
 }
 
 static int nt_splits(int64_t tiles_all, int64_t K) {
+  if (tiles_all >= 512) return 1;                     // two workgroups per CU already: a slab pass (~7 us) costs more than it buys
   int64_t sp = 1024 / (tiles_all > 0 ? tiles_all : 1);
   const int64_t maxs = K / 128;                       // at least 128 of K per split
   if (sp > maxs) sp = maxs;

@@ -524,10 +524,12 @@ int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs,
   const int Dp = padded_d(D);
 #define TT_FWD(KS, AT, NW)                                                                                     \
   score_fwd_bf16_kernel<KS, AT, NW><<<dim3((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs), NW * 64, 0, st>>>(a)
-  static const int fwd_nw = getenv("TT_SCORE_FWD_NW") ? atoi(getenv("TT_SCORE_FWD_NW")) : 8;
+  // D <= 64: 32 rows per wave (AT = 1), 8 waves, 2 workgroups per CU measured best (43.6 us; AT = 2: 48.0, 4 waves: 53.4,
+  // 16 waves: 48.7 at B = 8192); TT_SCORE_FWD_VARIANT = 2 selects the 64-row form
+  static const int fvar = getenv("TT_SCORE_FWD_VARIANT") ? atoi(getenv("TT_SCORE_FWD_VARIANT")) : 0;
   if (Dp == 32) TT_FWD(2, 2, 8);
-  else if (Dp == 64 && fwd_nw == 16) TT_FWD(4, 2, 16);
-  else if (Dp == 64) TT_FWD(4, 2, 8);
+  else if (Dp == 64 && fvar == 2) TT_FWD(4, 2, 8);
+  else if (Dp == 64) TT_FWD(4, 1, 8);
   else if (Dp == 128) TT_FWD(8, 2, 8);
   else TT_FWD(16, 1, 8);
 #undef TT_FWD
