@@ -75,7 +75,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's version banner off stdout (ONE JSON line)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # barriers / the max-over-ranks of the timing go through a gloo group: an eager RCCL collective issued between
+        # replays of a graph that CONTAINS RCCL collectives faulted the GPU here (the replayed kernels read work
+        # descriptors that the eager launch had recycled)
+        cpu_group = dist.new_group(backend="gloo")
 
     schema = synthetic.load_real_schema(ROOT / "jodalrob-twotower_amd" / "schema_real.json")
     keys_n, keys_c = schema["notice"]["categorical"], schema["company"]["categorical"]
@@ -97,7 +102,9 @@ def main():
                                                  notice_dense_input_dim=din_n, company_dense_input_dim=din_c,
                                                  tower_hidden_dims=hidden, final_embedding_dim=D, dropout_rate=0.1,
                                                  temperature=1.0, device=dev, embedding_grad=grad_mode, score_dtype=args.score_dtype,
-                                                 mlp_dtype=args.mlp_dtype)
+                                                 mlp_dtype=args.mlp_dtype,
+                                                 # dedup-first, fixed-capacity all-to-alls: the whole step incl. RCCL is one graph replay
+                                                 exchange="padded" if grad_mode == "sparse" else "exact")
         else:
             task = tt.create_two_tower_train_task(keys_n, keys_c, metadata_path=str(meta), categorical_embedding_dim=E,
                                                   notice_dense_input_dim=din_n, company_dense_input_dim=din_c,
@@ -116,12 +123,18 @@ def main():
     pool = [synthetic.make_batch(B, vocab_n, vocab_c, keys_n, keys_c, din_n, din_c, dev, seed=1234 + 7919 * (rank * args.pool + i),
                                  zipf_alpha=args.zipf) for i in range(args.pool)]
 
-    use_graph = args.mode == "graph" and dist is None and args.optimizer != "torch_adam"
+    # Sharded step: the fixed-capacity exchange makes it capturable (RCCL all-to-alls inside the graph; tested at world 1,
+    # B = 256), but at B = 8192 the second replay faulted the GPU on this stack (eagerly the same body runs clean), so the
+    # captured form is opt-in (TT_DIST_GRAPH=1) and the sharded bench launches eagerly.
+    use_graph = (args.mode == "graph" and args.optimizer == "fused_sparse" and bool(os.environ.get("TT_DIST_GRAPH"))) \
+        if dist is not None else (args.mode == "graph" and args.optimizer != "torch_adam")
     gstep = None
-    profile = ops.LookupProfile(dev) if use_graph else None      # device-clock stamps: work inside a graph
+    profile = ops.LookupProfile(dev) if (use_graph and not os.environ.get("TT_BENCH_NO_PROFILE")) else None   # device-clock stamps: work inside a graph
     if use_graph:
         from jodalrob_twotower_amd.graph import GraphedTrainStep
         gstep = GraphedTrainStep(task, opt, pool[0], return_metrics=True, warmup=3)
+        if os.environ.get("TT_BENCH_TRACE"):
+            torch.cuda.synchronize(); print("[bench] captured", file=sys.stderr, flush=True)
 
     def step(i, eager=False):
         if gstep is not None and not eager:
@@ -137,11 +150,14 @@ def main():
 
     def fence():
         if dist is not None:
-            dist.barrier()
+            torch.cuda.synchronize()
+            dist.barrier(group=cpu_group)
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         res = step(i)
+        if os.environ.get("TT_BENCH_TRACE"):
+            torch.cuda.synchronize(); print(f"[bench] warm-up replay {i} ok", file=sys.stderr, flush=True)
     fence()
     # In eager mode the lookup launches are timed with HIP events inside the timed region.  A graph replay
     # has no per-kernel host call to bracket, so in graph mode the same launches are timed in an eager pass
@@ -150,7 +166,8 @@ def main():
     if gstep is None:
         ops.set_timer(timer)
     else:
-        profile.reset()
+        if profile is not None:
+            profile.reset()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -162,9 +179,15 @@ def main():
     lookup_us = profile.durations_us() if profile is not None else []
     if profile is not None:
         profile.close()
+    if dist is not None and gstep is not None:
+        # sharded step: three stamped lookup launches per replay (owner gather, PLACE into the tower inputs, gradient
+        # gather); the placing launch moves the same bytes as the single-GPU lookup and is the one reported
+        lookup_us = lookup_us[1::3] if len(lookup_us) == 3 * args.steps else []
+        if task.exchange.overflowed():
+            raise RuntimeError("bench: a fixed-capacity bucket overflowed during the timed region -- result invalid")
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=cpu_group)
         dt = float(tmax.item())
     loss_val = float(res["loss"])
     ksum = timer.summary()
@@ -183,6 +206,10 @@ def main():
 
     if rank != 0:
         if dist is not None:
+            gstep = None
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
             dist.destroy_process_group()
         return
     K_tot = len(keys_n) + len(keys_c)
@@ -212,7 +239,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "rows_notice": sum(vocab_n), "rows_company": sum(vocab_c),
                    "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})", "optimizer": args.optimizer,
                    "score_dtype": args.score_dtype, "mlp_dtype": args.mlp_dtype, "launch": "hip graph replay" if gstep is not None else "eager",
-                   "parallelism": "single GPU" if world == 1 else f"row-wise sharded tables x{world} + data parallel towers"},
+                   "parallelism": ("single GPU" if dist is None else f"row-wise sharded tables x{world} (dedup-first fixed-capacity all-to-all, RCCL inside the graph) + data parallel towers")},
         "roofline": {"kernel": "lookup_kernel (tt_embed_lookup_fwd)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": n_launch, "mean_launch_us": lookup_ms * 1e3,
@@ -226,8 +253,12 @@ def main():
         out["kernel_breakdown"] = breakdown
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(task, pool[0], keys_n, keys_c, vocab_n, vocab_c, B, args.cpu_steps)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if dist is not None:
+        gstep = None                    # the captured graph holds the communicator: drop it before the process group
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -142,7 +142,8 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
  * Adam -- replaces torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay coupled)
  * (scripts/train.py:231, :327).  `step` is the 1-based step count used for bias correction.
  *   tt_adam_dense_step : exact dense Adam over n contiguous elements (tower weights / small tables)
- *   tt_sparse_adam_step: the same update applied only to the U looked-up rows (rows not in the batch
+ *   tt_sparse_adam_step: the same update applied only to the U looked-up rows; entries of unique_rows that
+ *   are >= table_rows are skipped (pads of the multi-GPU fixed-capacity routing) (rows not in the batch
  *                        keep weight, m and v untouched -- the documented difference to the
  *                        reference's dense update; DESIGN.md "optimiser semantics")
  * ---------------------------------------------------------------------------------------------- */
@@ -166,7 +167,7 @@ typedef struct tt_adam_tensor {
 int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors /* host array */, int32_t n_tensors,
                        int64_t step, float lr, float beta1, float beta2, float eps,
                        float weight_decay, const float* hparams_dev, tt_stream stream);
-int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E,
+int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int64_t table_rows, int32_t E,
                         const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique,
                         int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,
                         float weight_decay, const float* hparams_dev, tt_stream stream);
@@ -175,7 +176,7 @@ int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E
  * tower weights and the looked-up table rows of a step (optim.FusedAdam uses it when both share a parameter group
  * and step number). */
 int tt_adam_fused_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, float* table, float* m, float* v,
-                       int32_t E, const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique, int64_t M,
+                       int64_t table_rows, int32_t E, const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique, int64_t M,
                        int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                        const float* hparams_dev, tt_stream stream);
 
@@ -355,6 +356,24 @@ int tt_linear_fwd(tt_ctx* ctx, const float* X, int64_t ldx, const float* W, cons
 int tt_batch_gather(tt_ctx* ctx, const int64_t* entity, int64_t B, const float* dense_store,
                     int32_t dense_dim, const int64_t* cat_store, int32_t K, float* dense_out,
                     int64_t* ids_out, tt_stream stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row-wise sharded tables (multi-GPU; the reference is single-process): owner(row) = row % G, local
+ * index at the owner = row / G.  The U distinct rows of a duplicate-row plan are routed to their owners through
+ * FIXED-CAPACITY buckets, so no size ever travels to the host and the whole exchange can sit inside a captured graph:
+ *   send_ids [G, C] int32  local row index at owner g, in plan order; unused entries = pad_id[g]
+ *   send_u   [G, C] int32  plan index u of each entry; unused entries = pad_u (caller: index of an all-zero row)
+ *   pos_u    [M]    int32  g*C + position of plan row u (0 for rows that did not fit)
+ *   counts   [G]    int32  entries wanted per owner; overflow[0] is set to 1 when any count exceeds C
+ * tt_route_expand: idx_slot[slot] = pos_u[u] for every slot of plan row u (int64: ids of the placing lookup).
+ * ---------------------------------------------------------------------------------------------- */
+#define TT_MAX_RANKS 64
+size_t tt_route_workspace_bytes(int64_t M, int32_t G);
+int tt_route_bucket(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t G, int32_t C,
+                    const int32_t* pad_id, int32_t pad_u, int32_t* send_ids, int32_t* send_u, int32_t* pos_u,
+                    int32_t* counts, int32_t* overflow, void* workspace, size_t workspace_bytes, tt_stream stream);
+int tt_route_expand(tt_ctx* ctx, const int32_t* sorted_src, const int32_t* seg_offsets, const int32_t* n_unique,
+                    const int32_t* pos_u, int64_t M, int64_t* idx_slot, tt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * n (<= 8) device-to-device copies in ONE launch -- the per-step refresh of a captured step's static input

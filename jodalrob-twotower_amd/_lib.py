@@ -84,9 +84,9 @@ SIGNATURES = {
     "tt_adam_hparams": (None, [i64, f32, f32, f32, f32, f32, C.POINTER(f32 * 6)]),
     "tt_adam_dense_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp, vp]),
     "tt_adam_multi_step": (C.c_int, [vp, C.POINTER(AdamTensor), i32, i64, f32, f32, f32, f32, f32, vp, vp]),
-    "tt_sparse_adam_step": (C.c_int, [vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp, vp]),
-    "tt_adam_fused_step": (C.c_int, [vp, C.POINTER(AdamTensor), i32, vp, vp, vp, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32,
-                                     vp, vp]),
+    "tt_sparse_adam_step": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp, vp]),
+    "tt_adam_fused_step": (C.c_int, [vp, C.POINTER(AdamTensor), i32, vp, vp, vp, i64, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32,
+                                     f32, vp, vp]),
     "tt_tower_workspace_bytes": (sz, [C.POINTER(TowerParams), i64]),
     "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, vp, sz, vp]),
     "tt_tower_mlp_bwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), vp, C.POINTER(TowerGrads), i64, i32,
@@ -107,6 +107,9 @@ SIGNATURES = {
     "tt_diag_rank_rows": (C.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),
     "tt_topk_rows": (C.c_int, [vp, vp, i64, i64, i64, i32, vp, vp, vp]),
     "tt_linear_fwd": (C.c_int, [vp, vp, i64, vp, vp, vp, i64, i64, i32, i32, i32, vp]),
+    "tt_route_workspace_bytes": (sz, [i64, i32]),
+    "tt_route_bucket": (C.c_int, [vp, vp, vp, i64, i32, i32, C.POINTER(i32), i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "tt_route_expand": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp]),
     "tt_copy_multi": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]),
     "tt_batch_gather": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]),
 }

@@ -1142,7 +1142,7 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void adam_sparse_kernel(float* __restrict__ table, float* __restrict__ m, float* __restrict__ v,
                                                               int32_t E, uint32_t C, const int32_t* __restrict__ unique_rows,
                                                               const float* __restrict__ grad_rows, const int32_t* __restrict__ n_unique,
-                                                              AdamK k0, uint32_t LG) {
+                                                              AdamK k0, uint32_t LG, int64_t table_rows) {
   const AdamK k = adam_resolve(k0);
   const uint32_t U = (uint32_t)*n_unique;
   const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1150,6 +1150,7 @@ __global__ __launch_bounds__(kThreads) void adam_sparse_kernel(float* __restrict
   const uint32_t ngroups = gridDim.x * blockDim.x / LG;
   for (uint32_t u = gthread / LG; u < U; u += ngroups) {
     const int64_t row = unique_rows[u];
+    if (row >= table_rows) continue;                   // routing pad (multi-GPU fixed-capacity buckets)
     for (uint32_t chunk = lig; chunk < C; chunk += LG) {
       const int64_t o = row * E + chunk * VEC;
       const float* gp = grad_rows + (int64_t)u * E + chunk * VEC;
@@ -1183,7 +1184,7 @@ template <int VEC>
 __global__ __launch_bounds__(kThreads) void adam_fused_kernel(AdamFusedArgs a, float* __restrict__ table, float* __restrict__ m,
                                                              float* __restrict__ v, int32_t E, uint32_t C,
                                                              const int32_t* __restrict__ unique_rows, const float* __restrict__ grad_rows,
-                                                             const int32_t* __restrict__ n_unique, AdamK k0, uint32_t LG) {
+                                                             const int32_t* __restrict__ n_unique, AdamK k0, uint32_t LG, int64_t table_rows) {
   const AdamK k = adam_resolve(k0);
   const int nd = a.blk0[a.n];
   if ((int)blockIdx.x < nd) {
@@ -1206,6 +1207,7 @@ __global__ __launch_bounds__(kThreads) void adam_fused_kernel(AdamFusedArgs a, f
   const uint32_t ngroups = (gridDim.x - nd) * blockDim.x / LG;
   for (uint32_t u = gthread / LG; u < U; u += ngroups) {
     const int64_t row = unique_rows[u];
+    if (row >= table_rows) continue;                   // routing pad (multi-GPU fixed-capacity buckets)
     for (uint32_t chunk = lig; chunk < C; chunk += LG) {
       const int64_t o = row * E + chunk * VEC;
       const float* gp = grad_rows + (int64_t)u * E + chunk * VEC;
@@ -1260,6 +1262,124 @@ __global__ __launch_bounds__(kThreads) void copy_multi_kernel(CopyArgs a) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) d[i] = s[i];
   if (blockIdx.x == 0)
     for (int64_t i = tail0 + threadIdx.x; i < a.bytes[seg]; i += blockDim.x) a.dst[seg][i] = a.src[seg][i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// multi-GPU routing: distinct rows -> fixed-capacity owner buckets (stable, no host sync)
+//   a workgroup of 4 waves covers 2048 consecutive plan rows, a wave 512 of them in 8 batches of 64
+// ------------------------------------------------------------------------------------------------
+constexpr int kRouteChunk = 2048, kRouteWaves = 4;
+
+struct RoutePads { int32_t id[TT_MAX_RANKS]; };
+
+__global__ __launch_bounds__(kThreads) void route_count_kernel(const int32_t* __restrict__ unique_rows, const int32_t* __restrict__ n_unique,
+                                                              uint32_t G, uint32_t* __restrict__ seg_counts) {
+  __shared__ uint32_t cnt[kRouteWaves][TT_MAX_RANKS];
+  const uint32_t U = (uint32_t)*n_unique, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < G) cnt[wave][lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t u0 = blockIdx.x * kRouteChunk + wave * (kRouteChunk / kRouteWaves);
+#pragma unroll
+  for (int q = 0; q < kRouteChunk / kRouteWaves / 64; ++q) {
+    const uint32_t u = u0 + q * 64 + lane;
+    if (u < U) atomicAdd(&cnt[wave][(uint32_t)unique_rows[u] % G], 1u);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (lane < G) seg_counts[((size_t)blockIdx.x * kRouteWaves + wave) * G + lane] = cnt[wave][lane];
+}
+
+// one workgroup: per owner an exclusive prefix over the (block, wave) segments; totals, overflow flag, pad fill
+__global__ __launch_bounds__(1024) void route_scan_kernel(uint32_t* __restrict__ seg_counts, uint32_t nseg, uint32_t G, uint32_t C,
+                                                         RoutePads pads, int32_t pad_u, int32_t* __restrict__ send_ids,
+                                                         int32_t* __restrict__ send_u, int32_t* __restrict__ counts,
+                                                         int32_t* __restrict__ overflow) {
+  __shared__ uint32_t total[TT_MAX_RANKS];
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t g = wave; g < G; g += 16) {             // a wave per owner, 64 segments per trip
+    uint32_t carry = 0;
+    for (uint32_t s0 = 0; s0 < nseg; s0 += 64) {
+      const uint32_t s = s0 + lane;
+      const uint32_t c = s < nseg ? seg_counts[(size_t)s * G + g] : 0u;
+      uint32_t x = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if (lane >= (uint32_t)o) x += y;
+      }
+      if (s < nseg) seg_counts[(size_t)s * G + g] = carry + x - c;
+      carry += __shfl(x, 63);
+    }
+    if (lane == 0) {
+      total[g] = carry;
+      counts[g] = (int32_t)carry;
+      if (carry > C) overflow[0] = 1;
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < G * C; i += blockDim.x) {      // unused tail of every bucket
+    const uint32_t g = i / C, p = i - g * C;
+    if (p >= total[g]) { send_ids[i] = pads.id[g]; send_u[i] = pad_u; }
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void route_scatter_kernel(const int32_t* __restrict__ unique_rows, const int32_t* __restrict__ n_unique,
+                                                                uint32_t G, uint32_t C, const uint32_t* __restrict__ seg_base,
+                                                                int32_t* __restrict__ send_ids, int32_t* __restrict__ send_u,
+                                                                int32_t* __restrict__ pos_u) {
+  __shared__ uint32_t off[kRouteWaves][TT_MAX_RANKS];
+  __shared__ unsigned long long pm[kRouteWaves][TT_MAX_RANKS];
+  const uint32_t U = (uint32_t)*n_unique, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < G) {
+    off[wave][lane] = seg_base[((size_t)blockIdx.x * kRouteWaves + wave) * G + lane];
+    pm[wave][lane] = 0ull;
+  }
+  __builtin_amdgcn_wave_barrier();
+  volatile uint32_t(*vo)[TT_MAX_RANKS] = off;
+  volatile unsigned long long(*vp)[TT_MAX_RANKS] = pm;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  const uint32_t u0 = blockIdx.x * kRouteChunk + wave * (kRouteChunk / kRouteWaves);
+#pragma unroll 1
+  for (int q = 0; q < kRouteChunk / kRouteWaves / 64; ++q) {
+    const uint32_t u = u0 + q * 64 + lane;
+    const bool valid = u < U;
+    const uint32_t row = valid ? (uint32_t)unique_rows[u] : 0u;
+    const uint32_t g = row % G;
+    // rank among the lanes of this batch with the same owner: OR-ed lane set (order-independent), as in the keyed sort
+    if (valid) __hip_atomic_fetch_or(const_cast<unsigned long long*>(&vp[wave][g]), 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t peers = valid ? vp[wave][g] : 0ull;
+    __builtin_amdgcn_wave_barrier();
+    if (valid) vp[wave][g] = 0ull;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+    uint32_t pos = 0;
+    if (valid) pos = vo[wave][g] + rank;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && rank == 0) vo[wave][g] = pos + (uint32_t)__popcll(peers);
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      if (pos < C) {
+        send_ids[(size_t)g * C + pos] = (int32_t)(row / G);
+        send_u[(size_t)g * C + pos] = (int32_t)u;
+        pos_u[u] = (int32_t)(g * C + pos);
+      } else {
+        pos_u[u] = 0;                                   // did not fit: flagged by route_scan_kernel
+      }
+    }
+  }
+}
+
+// idx_slot[slot] = pos_u[u] for the slots of plan row u: an 8-lane group per row
+__global__ __launch_bounds__(kThreads) void route_expand_kernel(const int32_t* __restrict__ sorted_src, const int32_t* __restrict__ seg,
+                                                               const int32_t* __restrict__ n_unique, const int32_t* __restrict__ pos_u,
+                                                               int64_t* __restrict__ idx_slot) {
+  const uint32_t U = (uint32_t)*n_unique;
+  const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x, lig = gthread & 7u;
+  const uint32_t ngroups = gridDim.x * blockDim.x / 8;
+  for (uint32_t u = gthread / 8; u < U; u += ngroups) {
+    const int64_t v = pos_u[u];
+    for (int32_t p = seg[u] + (int32_t)lig; p < seg[u + 1]; p += 8) idx_slot[sorted_src[p]] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1653,11 +1773,11 @@ int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_ten
   return TT_OK;
 }
 
-int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E, const int32_t* unique_rows, const float* grad_rows,
-                        const int32_t* n_unique, int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,
+int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int64_t table_rows, int32_t E, const int32_t* unique_rows,
+                        const float* grad_rows, const int32_t* n_unique, int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,
                         float weight_decay, const float* hparams_dev, tt_stream stream) {
   TT_CHECK_ARG(ctx && table && m && v, "tt_sparse_adam_step: NULL state");
-  TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 0, "tt_sparse_adam_step: bad step/E/M");
+  TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 0 && table_rows >= 1, "tt_sparse_adam_step: bad step/E/M/table_rows");
   if (M == 0) return TT_OK;
   TT_CHECK_ARG(unique_rows && grad_rows && n_unique, "tt_sparse_adam_step: NULL plan");
   const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay, hparams_dev);
@@ -1666,18 +1786,19 @@ int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int32_t E
   const uint32_t LG = pow2_at_least(C) > 64 ? 64 : pow2_at_least(C);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int grid = grid_for(ctx, M * LG);
-  if (vec4) adam_sparse_kernel<4><<<grid, kThreads, 0, st>>>(table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG);
-  else adam_sparse_kernel<1><<<grid, kThreads, 0, st>>>(table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG);
+  if (vec4) adam_sparse_kernel<4><<<grid, kThreads, 0, st>>>(table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG, table_rows);
+  else adam_sparse_kernel<1><<<grid, kThreads, 0, st>>>(table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG, table_rows);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }
 
-int tt_adam_fused_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, float* table, float* m, float* v, int32_t E,
+int tt_adam_fused_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, float* table, float* m, float* v, int64_t table_rows,
+                       int32_t E,
                        const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique, int64_t M, int64_t step, float lr,
                        float beta1, float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream) {
   TT_CHECK_ARG(ctx && tensors && table && m && v && unique_rows && grad_rows && n_unique, "tt_adam_fused_step: NULL argument");
   TT_CHECK_ARG(n_tensors >= 1 && n_tensors <= kAdamMulti, "tt_adam_fused_step: n_tensors=%d not in [1,%d]", n_tensors, kAdamMulti);
-  TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 1, "tt_adam_fused_step: bad step/E/M");
+  TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 1 && table_rows >= 1, "tt_adam_fused_step: bad step/E/M/table_rows");
   AdamFusedArgs a{};
   a.n = n_tensors;
   int nd = 0;
@@ -1696,8 +1817,48 @@ int tt_adam_fused_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_ten
   const uint32_t LG = pow2_at_least(C) > 64 ? 64 : pow2_at_least(C);
   const int grid = nd + grid_for(ctx, M * LG);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (vec4) adam_fused_kernel<4><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG);
-  else adam_fused_kernel<1><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG);
+  if (vec4) adam_fused_kernel<4><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG, table_rows);
+  else adam_fused_kernel<1><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG, table_rows);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+size_t tt_route_workspace_bytes(int64_t M, int32_t G) {
+  const int64_t nb = tt_cdiv(M > 0 ? M : 1, kRouteChunk);
+  return align256(sizeof(uint32_t) * (size_t)nb * kRouteWaves * (size_t)(G > 0 ? G : 1));
+}
+
+int tt_route_bucket(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t G, int32_t C,
+                    const int32_t* pad_id, int32_t pad_u, int32_t* send_ids, int32_t* send_u, int32_t* pos_u, int32_t* counts,
+                    int32_t* overflow, void* workspace, size_t workspace_bytes, tt_stream stream) {
+  TT_CHECK_ARG(ctx && unique_rows && n_unique && pad_id && send_ids && send_u && pos_u && counts && overflow && workspace,
+               "tt_route_bucket: NULL argument");
+  TT_CHECK_ARG(M >= 1 && M < ((int64_t)1 << 31) && G >= 1 && G <= TT_MAX_RANKS && C >= 1 && (int64_t)G * C < ((int64_t)1 << 31),
+               "tt_route_bucket: bad M / G / C");
+  if (workspace_bytes < tt_route_workspace_bytes(M, G)) {
+    tt_set_error("tt_route_bucket: workspace %zu < required %zu", workspace_bytes, tt_route_workspace_bytes(M, G));
+    return TT_ERR_WORKSPACE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const unsigned nb = (unsigned)tt_cdiv(M, kRouteChunk);
+  uint32_t* seg = reinterpret_cast<uint32_t*>(workspace);
+  RoutePads pads{};
+  for (int g = 0; g < G; ++g) pads.id[g] = pad_id[g];
+  route_count_kernel<<<nb, kThreads, 0, st>>>(unique_rows, n_unique, (uint32_t)G, seg);
+  TT_LAUNCH_CHECK();
+  route_scan_kernel<<<1, 1024, 0, st>>>(seg, nb * kRouteWaves, (uint32_t)G, (uint32_t)C, pads, pad_u, send_ids, send_u, counts, overflow);
+  TT_LAUNCH_CHECK();
+  route_scatter_kernel<<<nb, kThreads, 0, st>>>(unique_rows, n_unique, (uint32_t)G, (uint32_t)C, seg, send_ids, send_u, pos_u);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_route_expand(tt_ctx* ctx, const int32_t* sorted_src, const int32_t* seg_offsets, const int32_t* n_unique, const int32_t* pos_u,
+                    int64_t M, int64_t* idx_slot, tt_stream stream) {
+  TT_CHECK_ARG(ctx && sorted_src && seg_offsets && n_unique && pos_u && idx_slot, "tt_route_expand: NULL argument");
+  TT_CHECK_ARG(M >= 1, "tt_route_expand: M < 1");
+  route_expand_kernel<<<grid_for(ctx, M * 8), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(sorted_src, seg_offsets, n_unique, pos_u,
+                                                                                                      idx_slot);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

@@ -126,6 +126,39 @@ class HipBackend:
     def owner_accumulate(self, store: ShardedStore, plan, d_rows: torch.Tensor):
         store.accumulate_grad(plan, [(d_rows, 1)], d_rows.shape[0])
 
+    # ---- steps of the fixed-capacity exchange (PaddedRowExchange) --------------------------------------------
+    def local_plan(self, rows: torch.Tensor, side_K: Sequence[int], B: int):
+        """duplicate-row plan of this rank's slots over the GLOBAL row space"""
+        if 0 < B <= ops.KEYED_MAX_B:
+            return ops.dedup_plan_keyed(rows, list(side_K), B)
+        return ops.dedup_plan(rows, int(rows.max().item()) + 1)
+
+    def route_bucket(self, plan, G: int, C: int, pad_id: Sequence[int], pad_u: int):
+        return ops.route_bucket(plan, G, C, pad_id, pad_u)
+
+    def route_expand(self, plan, pos_u: torch.Tensor) -> torch.Tensor:
+        return ops.route_expand(plan, pos_u)
+
+    def gather_rows(self, table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """out[i] = table[idx[i]] (idx int32/int64, clamped into the table): the lookup kernel with one key."""
+        n, E, dev = idx.numel(), table.shape[1], table.device
+        out = torch.empty((n, E), dtype=torch.float32, device=dev)
+        off = torch.zeros(1, dtype=torch.int64, device=dev)
+        voc = torch.full((1,), table.shape[0], dtype=torch.int64, device=dev)
+        ops.embed_lookup(table, [ops.LookupSide(idx.to(torch.int64), off, voc, out, 1)], n, want_rows=False, tag="[gather]")
+        return out
+
+    def owner_plan(self, recv_ids: torch.Tensor, local_rows: int):
+        """plan over the received local row ids; the pad value `local_rows` groups into one (last) row that Adam skips"""
+        return ops.dedup_plan(recv_ids, local_rows + 1)
+
+    def reduce_local(self, plan, srcs, B: int, E: int) -> torch.Tensor:
+        """[M + 1, E]: row u = summed gradient of plan row u, row M = 0 (the target of unused bucket entries)"""
+        out = torch.empty((plan.M + 1, E), dtype=torch.float32, device=plan.unique_rows.device)
+        out[plan.M].zero_()
+        ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_SPARSE, out)
+        return out
+
 
 class RowExchange:
     """Routing of row ids / pooled rows / row gradients between ranks (device-agnostic)."""
@@ -168,18 +201,95 @@ class RowExchange:
             be.owner_accumulate(self.store, state["plan"], d_rows)
 
     def all_reduce_dense(self, flat_grads: Sequence[torch.Tensor]):
+        if self.world == 1 and __import__("os").environ.get("TT_DIST_FAKE_A2A"):     # fault hunting only
+            return
         for g in flat_grads:                                                     # one call per tower
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+
+
+class PaddedRowExchange(RowExchange):
+    """The same routing with (1) the duplicate-row plan BEFORE the exchange -- a rank sends each distinct row once:
+    65 k instead of 311 k entries at B = 8192 on the real schema, and a hot row no longer floods one owner -- and
+    (2) fixed-capacity buckets: no bucket size ever reaches the host, every all-to-all has equal splits, and the whole
+    training step -- collectives included -- can be captured into ONE graph and replayed.
+
+    Capacity C (entries per (source, owner) pair, identical on all ranks) is calibrated on the first forward (one
+    host sync): 1.5 x the largest bucket any rank needs, rounded up to 256.  A later batch that needs more sets a
+    device-side flag (`overflowed()`); its over-capacity rows were not exchanged, so the caller must re-calibrate
+    (`reset_capacity()`) and redo the step -- bench.py checks the flag after the timed region."""
+
+    def __init__(self, store: ShardedStore, group=None, backend=None, capacity: Optional[int] = None, slack: float = 1.5):
+        super().__init__(store, group, backend)
+        if store.grad_mode != "sparse":
+            raise ValueError("the fixed-capacity exchange needs embedding_grad='sparse' (its bucket pads are skipped by the "
+                             "row-sparse Adam; a dense gradient buffer has no row for them)")
+        self.C, self.slack = capacity, slack
+        self._overflow = None
+
+    def local_rows_of(self, g: int) -> int:
+        R = self.store.global_rows
+        return (R - g + self.world - 1) // self.world if R > g else 0
+
+    def reset_capacity(self):
+        self.C = None
+        if self._overflow is not None:
+            self._overflow.zero_()
+
+    def overflowed(self) -> bool:
+        return self._overflow is not None and bool(self._overflow.item())
+
+    def _a2a_equal(self, send: torch.Tensor) -> torch.Tensor:
+        if self.world == 1 and __import__("os").environ.get("TT_DIST_FAKE_A2A"):     # fault hunting only
+            return send.clone()
+        out = torch.empty_like(send)
+        dist.all_to_all_single(out, send.contiguous(), group=self.group)
+        return out
+
+    def _calibrate(self, plan, dev):
+        G = self.world
+        probe = max(256, -(-plan.M // 256) * 256)                                 # generous probe capacity: counts only
+        _, _, _, counts, _ = self.backend.route_bucket(plan, G, probe, [self.local_rows_of(g) for g in range(G)], plan.M)
+        mx = counts.max().to(torch.int64).reshape(1)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        need = int(mx.item())                                                     # the one host sync of the exchange
+        self.C = max(256, -(-int(need * self.slack) // 256) * 256)
+
+    def forward(self, sides: Sequence[ops.LookupSide], B: int, want_grad: bool):
+        G, be, E = self.world, self.backend, self.E
+        rows = be.global_rows(sides, B, E, self.store.global_rows)               # int32 [M], slot order
+        plan = be.local_plan(rows, [s.K for s in sides], B)
+        if self.C is None:
+            self._calibrate(plan, rows.device)
+        pads = [self.local_rows_of(g) for g in range(G)]
+        send_ids, send_u, pos_u, _counts, ovf = be.route_bucket(plan, G, self.C, pads, plan.M)
+        if self._overflow is None:
+            self._overflow = torch.zeros(1, dtype=torch.int32, device=rows.device)
+        torch.maximum(self._overflow, ovf, out=self._overflow)
+        recv_ids = self._a2a_equal(send_ids)                                     # [G*C] local row ids, pad = my local_rows
+        pooled_local = be.gather_rows(self.store.weight, recv_ids)               # pads clamp to the last row (unused)
+        got = self._a2a_equal(pooled_local)                                      # [G*C, E] in my send order
+        be.place_rows(got, be.route_expand(plan, pos_u), sides, B)
+        if not want_grad:
+            return None
+        return {"plan": plan, "send_u": send_u, "owner_plan": be.owner_plan(recv_ids, self.store.local_rows), "padded": True}
+
+    def backward(self, state, srcs, B: int):
+        be = self.backend
+        grad_u = be.reduce_local(state["plan"], srcs, B, self.E)                 # one row per distinct row (+ a zero row)
+        d_rows = self._a2a_equal(be.gather_rows(grad_u, state["send_u"]))        # to the owners, pads carry zeros
+        be.owner_accumulate(self.store, state["owner_plan"], d_rows)
 
 
 class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
     """TwoTowerTrainTask whose tables are row-wise sharded over the process group."""
 
-    def __init__(self, two_tower_model: TwoTowerModel, store: ShardedStore, group=None, backend=None, **kw):
+    def __init__(self, two_tower_model: TwoTowerModel, store: ShardedStore, group=None, backend=None, exchange: str = "exact", **kw):
         super().__init__(two_tower_model, **kw)
         self.sharded_store = store
         self.embedding_shard = store.shard_param                       # registered => in .parameters()
-        self.exchange = RowExchange(store, group, backend)
+        if exchange not in ("exact", "padded"):
+            raise ValueError(f"exchange must be 'exact' or 'padded', got {exchange!r}")
+        self.exchange = (PaddedRowExchange if exchange == "padded" else RowExchange)(store, group, backend)
         two_tower_model.notice_tower.exchange = self.exchange
         two_tower_model.company_tower.exchange = self.exchange
         for p in self._dense_parameters():                             # replicas start identical
@@ -233,7 +343,7 @@ def create_distributed_train_task(notice_categorical_keys, company_categorical_k
                                   company_dense_input_dim: int = 128, tower_hidden_dims=None, final_embedding_dim: int = 128,
                                   dropout_rate: float = 0.2, temperature: float = 1.0, loss_type: str = "cross_entropy",
                                   device="cuda:0", embedding_grad: Optional[str] = "sparse", score_dtype=None, mlp_dtype=None,
-                                  group=None, backend=None, seed: int = 0) -> DistributedTwoTowerTrainTask:
+                                  group=None, backend=None, seed: int = 0, exchange: str = "exact") -> DistributedTwoTowerTrainTask:
     """Same arguments as create_two_tower_train_task; requires an initialised process group."""
     if not dist.is_initialized():
         raise RuntimeError("create_distributed_train_task needs torch.distributed.init_process_group first")
@@ -251,5 +361,5 @@ def create_distributed_train_task(notice_categorical_keys, company_categorical_k
     ce.set_row_base(ne.total_rows)
     store = ShardedStore(categorical_embedding_dim, ne.total_rows + ce.total_rows, dist.get_rank(group),
                          dist.get_world_size(group), torch.device(device), embedding_grad or "sparse", seed)
-    return DistributedTwoTowerTrainTask(model, store, group=group, backend=backend, temperature=temperature,
+    return DistributedTwoTowerTrainTask(model, store, group=group, backend=backend, exchange=exchange, temperature=temperature,
                                         loss_type=loss_type, score_dtype=score_dtype)

@@ -61,6 +61,10 @@ class GraphedTrainStep:
         for t in self._towers:
             t._seed_dev = self._seed_dev
         optimizer._hp_dev = self._hp_dev
+        self._no_capture = bool(int(__import__("os").environ.get("TT_GRAPH_DEBUG", "0")))   # fault hunting: same body, eager
+        if self._no_capture:
+            self.graph = None
+            return
         self.graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(self.graph):
@@ -124,6 +128,10 @@ class GraphedTrainStep:
             pairs = []
         ops.copy_multi(pairs + [self._fill_slot()])             # ONE launch: the four batch buffers + the scalars
         self._mark_slot()
+        if self._no_capture:
+            self.result = self._body()
+            self._steps_done += 1
+            return self.result
         self.graph.replay()
         self._steps_done += 1
         self.opt.advance_steps(1)

@@ -29,6 +29,7 @@ class KernelTimer:
 
 
 _TIMER: Optional[KernelTimer] = None
+_SYNC_DEBUG = bool(int(__import__("os").environ.get("TT_SYNC_DEBUG", "0")))
 
 
 def set_timer(t: Optional[KernelTimer]):
@@ -50,6 +51,11 @@ class _timed:
         return self
 
     def __exit__(self, *exc):
+        if _SYNC_DEBUG:                              # TT_SYNC_DEBUG=1: name every C-ABI call and wait for it (fault hunting)
+            import sys
+            print(f"[tt] {self.name} ...", end="", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            print(" done", file=sys.stderr, flush=True)
         if self.a is not None:
             b = torch.cuda.Event(enable_timing=True)
             b.record()
@@ -211,7 +217,7 @@ def adam_multi(items, step, lr, b1, b2, eps, wd, hp_dev=None):
 def adam_sparse(table, m, v, plan: DedupPlan, grad_rows, step, lr, b1, b2, eps, wd, hp_dev=None):
     dev = table.device
     with _timed("tt_sparse_adam_step"):
-        L.check(L.load().tt_sparse_adam_step(L.ctx(dev), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[1],
+        L.check(L.load().tt_sparse_adam_step(L.ctx(dev), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[0], table.shape[1],
                                              L.ptr(plan.unique_rows), L.ptr(grad_rows), L.ptr(plan.n_unique), plan.M, step,
                                              lr, b1, b2, eps, wd, L.ptr(hp_dev), L.stream(dev)), "tt_sparse_adam_step")
 
@@ -223,7 +229,7 @@ def adam_fused(items, table, m, v, plan: DedupPlan, grad_rows, step, lr, b1, b2,
     for i, (p, g, mm, vv) in enumerate(items):
         arr[i] = L.AdamTensor(p.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel())
     with _timed("tt_adam_fused_step"):
-        L.check(L.load().tt_adam_fused_step(L.ctx(dev), arr, len(items), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[1],
+        L.check(L.load().tt_adam_fused_step(L.ctx(dev), arr, len(items), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[0], table.shape[1],
                                             L.ptr(plan.unique_rows), L.ptr(grad_rows), L.ptr(plan.n_unique), plan.M, step,
                                             lr, b1, b2, eps, wd, L.ptr(hp_dev), L.stream(dev)), "tt_adam_fused_step")
 
@@ -444,6 +450,35 @@ def copy_multi(pairs):
             raise ValueError("copy_multi: segments must be contiguous and equally sized")
     with _timed("tt_copy_multi"):
         L.check(L.load().tt_copy_multi(L.ctx(dev), n, dst, src, nb, L.stream(dev)), "tt_copy_multi")
+
+
+# ---------------------------------------------------------------------------------------------- multi-GPU routing
+def route_bucket(plan: DedupPlan, G: int, C: int, pad_id: Sequence[int], pad_u: int):
+    """Distinct rows of `plan` -> fixed-capacity owner buckets.  Returns (send_ids [G*C] i32, send_u [G*C] i32,
+    pos_u [M] i32, counts [G] i32, overflow [1] i32) -- all on the device, no host sync."""
+    dev, M = plan.unique_rows.device, plan.M
+    buf = torch.empty(2 * G * C + M + G + 1, dtype=torch.int32, device=dev)
+    send_ids, send_u = buf[:G * C], buf[G * C:2 * G * C]
+    pos_u, counts, overflow = buf[2 * G * C:2 * G * C + M], buf[2 * G * C + M:2 * G * C + M + G], buf[2 * G * C + M + G:]
+    overflow.zero_()
+    lib = L.load()
+    ws = L.workspace(dev, lib.tt_route_workspace_bytes(M, G))
+    pads = (L.i32 * G)(*[int(p) for p in pad_id])
+    with _timed("tt_route_bucket"):
+        L.check(lib.tt_route_bucket(L.ctx(dev), L.ptr(plan.unique_rows), L.ptr(plan.n_unique), M, G, C, pads, pad_u, L.ptr(send_ids),
+                                    L.ptr(send_u), L.ptr(pos_u), L.ptr(counts), L.ptr(overflow), L.ptr(ws), ws.numel(), L.stream(dev)),
+                "tt_route_bucket")
+    return send_ids, send_u, pos_u, counts, overflow
+
+
+def route_expand(plan: DedupPlan, pos_u: torch.Tensor) -> torch.Tensor:
+    """idx_slot [M] int64 = pos_u[u(slot)]."""
+    dev = pos_u.device
+    idx = torch.empty(plan.M, dtype=torch.int64, device=dev)
+    with _timed("tt_route_expand"):
+        L.check(L.load().tt_route_expand(L.ctx(dev), L.ptr(plan.sorted_src), L.ptr(plan.seg_offsets), L.ptr(plan.n_unique), L.ptr(pos_u),
+                                         plan.M, L.ptr(idx), L.stream(dev)), "tt_route_expand")
+    return idx
 
 
 def batch_gather(entity, dense_store, cat_store):

@@ -47,9 +47,58 @@ class CheckerBackend:
         return flat[order.long()]
 
     def owner_accumulate(self, store, plan, d_rows):
-        g = torch.zeros_like(store.weight)
-        g.index_add_(0, plan, d_rows)
-        self.dense_grad = g
+        g = torch.zeros((store.weight.shape[0] + 1, store.weight.shape[1]))      # + the pad row of the fixed-capacity exchange
+        g.index_add_(0, plan.long(), d_rows)
+        self.dense_grad = g[:-1]
+
+    # ---- fixed-capacity exchange (PaddedRowExchange): same contracts as HipBackend's steps, plain numpy ----
+    def local_plan(self, rows, side_K, B):
+        from types import SimpleNamespace
+        r = rows.numpy()
+        order = np.argsort(r, kind="stable").astype(np.int32)
+        sr = r[order]
+        heads = np.flatnonzero(np.concatenate([[True], sr[1:] != sr[:-1]])) if len(sr) else np.zeros(0, np.int64)
+        M, U = len(r), len(heads)
+        uniq = np.full(M, -1, np.int32); uniq[:U] = sr[heads]
+        seg = np.full(M + 1, -1, np.int32); seg[:U] = heads; seg[U] = M
+        return SimpleNamespace(sorted_src=torch.from_numpy(order), unique_rows=torch.from_numpy(uniq), seg_offsets=torch.from_numpy(seg),
+                               n_unique=torch.tensor([U], dtype=torch.int32), M=M)
+
+    def route_bucket(self, plan, G, C, pad_id, pad_u):
+        U = int(plan.n_unique)
+        send_ids = np.repeat(np.asarray(pad_id, np.int32), C)
+        send_u = np.full(G * C, pad_u, np.int32)
+        pos_u = np.zeros(plan.M, np.int32)
+        counts = np.zeros(G, np.int32)
+        for u in range(U):
+            row = int(plan.unique_rows[u]); g = row % G
+            p = counts[g]; counts[g] += 1
+            if p < C:
+                send_ids[g * C + p] = row // G; send_u[g * C + p] = u; pos_u[u] = g * C + p
+        ovf = np.array([int((counts > C).any())], np.int32)
+        return tuple(torch.from_numpy(a) for a in (send_ids, send_u, pos_u, counts, ovf))
+
+    def route_expand(self, plan, pos_u):
+        idx = torch.zeros(plan.M, dtype=torch.int64)
+        U = int(plan.n_unique)
+        for u in range(U):
+            for p in range(int(plan.seg_offsets[u]), int(plan.seg_offsets[u + 1])):
+                idx[int(plan.sorted_src[p])] = int(pos_u[u])
+        return idx
+
+    def gather_rows(self, table, idx):
+        return table[torch.clamp(idx.long(), 0, table.shape[0] - 1)].clone()
+
+    def owner_plan(self, recv_ids, local_rows):
+        return recv_ids.clone()
+
+    def reduce_local(self, plan, srcs, B, E):
+        flat = torch.cat([d.reshape(B * K, E) for d, K in srcs])
+        out = torch.zeros((plan.M + 1, E))
+        for u in range(int(plan.n_unique)):
+            sl = plan.sorted_src[int(plan.seg_offsets[u]):int(plan.seg_offsets[u + 1])].long()
+            out[u] = flat[sl].sum(0)
+        return out
 
 
 def _free_port():
@@ -60,7 +109,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, kind="exact"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -69,18 +118,18 @@ def _worker(rank, world, port, q):
         root = Path(__file__).resolve().parents[1]
         sys.path.insert(0, str(root))
         from jodalrob_twotower_amd import ops
-        from jodalrob_twotower_amd.distributed import RowExchange, ShardedStore
+        from jodalrob_twotower_amd.distributed import PaddedRowExchange, RowExchange, ShardedStore
         E, B = 4, 9
         vocabs = [[5, 11, 3], [7, 2]]                      # two "towers"
         R = sum(map(sum, vocabs))
         rng = np.random.default_rng(123)
         table = torch.from_numpy(rng.standard_normal((R, E)).astype(np.float32))      # same on every rank
-        store = ShardedStore(E, R, rank, world, "cpu", "dense")
+        store = ShardedStore(E, R, rank, world, "cpu", "dense" if kind == "exact" else "sparse")
         store.load_global(table)
         assert store.local_rows == len(range(rank, R, world))
         np.testing.assert_array_equal(store.gather_global().numpy(), table.numpy())   # shard <-> global round trip
         be = CheckerBackend()
-        ex = RowExchange(store, backend=be)
+        ex = RowExchange(store, backend=be) if kind == "exact" else PaddedRowExchange(store, backend=be)
         r2 = np.random.default_rng(1000 + rank)            # every rank has its own batch
         sides, outs, exp = [], [], []
         base = 0
@@ -114,6 +163,12 @@ def _worker(rank, world, port, q):
             np.add.at(ref, rws, vls.astype(np.float64))
         mine = ref[rank::world]
         np.testing.assert_allclose(be.dense_grad.numpy()[:mine.shape[0]], mine, rtol=1e-5, atol=1e-6)
+        if kind == "padded":
+            assert not ex.overflowed() and ex.C >= 256
+            # a capacity that is too small must be flagged, never silently wrong-and-quiet
+            ex2 = PaddedRowExchange(store, backend=be, capacity=1)
+            ex2.forward(sides, B, False)
+            assert ex2.overflowed()
         # dense-gradient reduction = SUM over ranks (the towers pre-scale by 1/world)
         g = [torch.full((5,), float(rank + 1))]
         ex.all_reduce_dense(g)
@@ -126,12 +181,12 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_row_exchange_gloo(world):
+@pytest.mark.parametrize("world,kind", [(2, "exact"), (3, "exact"), (2, "padded"), (3, "padded")])
+def test_row_exchange_gloo(world, kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, kind)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in procs]

@@ -417,6 +417,47 @@ def test_distributed_world1_matches_single_gpu(tt, manifest):
         touched = np.zeros(len(changed), bool)
         touched[np.flatnonzero(np.abs(fused.cpu().numpy()).sum(1) > 0)] = True
         assert np.array_equal(changed[:len(touched)], touched)
+        # fixed-capacity exchange (dedup first, padded buckets, no host sync) == the exact-size exchange, eagerly and as ONE
+        # captured graph with the all-to-alls inside
+        from jodalrob_twotower_amd.graph import GraphedTrainStep
+        batches = [to_batch(tt, synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 790 + i, oob=True),
+                            cfg["keys_n"], cfg["keys_c"]) for i in range(4)]
+        finals = {}
+        for mode in ("exact", "padded", "padded-graph"):
+            t = create_distributed_train_task(
+                cfg["keys_n"], cfg["keys_c"], metadata_path=str(GOLD / "synthetic_metadata.csv"), categorical_embedding_dim=cfg["E"],
+                notice_dense_input_dim=cfg["din_n"], company_dense_input_dim=cfg["din_c"], tower_hidden_dims=list(cfg["hidden"]),
+                final_embedding_dim=cfg["D"], dropout_rate=0.0, temperature=cfg["T"], device=DEV, embedding_grad="sparse",
+                exchange="exact" if mode == "exact" else "padded")
+            t.load_full_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in state.items()})
+            t.train()
+            o = FusedAdam.for_task(t, lr=1e-2, weight_decay=1e-5)
+            losses = []
+            if mode == "padded-graph":
+                gs = GraphedTrainStep(t, o, batches[0], warmup=1)       # the eager warm-up step calibrates the bucket capacity
+                for bt in batches:
+                    losses.append(gs.step(bt)["loss"].item())
+            else:
+                o.zero_grad(); t(batches[0], return_metrics=True)["loss"].backward(); o.step()     # the same warm-up step
+                for bt in batches:
+                    o.zero_grad()
+                    r = t(bt, return_metrics=True)
+                    r["loss"].backward()
+                    o.step()
+                    losses.append(r["loss"].item())
+            if mode != "exact":
+                assert not t.exchange.overflowed()
+            finals[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in t.full_state_dict().items()})
+            if mode == "padded-graph":                                  # the captured graph holds the communicator: drop it first
+                del gs
+            del t, o
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+        for mode in ("padded", "padded-graph"):
+            assert finals[mode][0] == finals["exact"][0], mode
+            for k, v in finals["exact"][1].items():
+                np.testing.assert_allclose(finals[mode][1][k], v, rtol=1e-6, atol=1e-7, err_msg=f"{mode}:{k}")
     finally:
         dist.destroy_process_group()
 
