@@ -71,11 +71,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
+    if os.environ.get("TT_BENCH_INIT_PG"):          # fault hunting: a process group exists, the task stays single-GPU
+        import torch.distributed as _d
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29545")
+        _d.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        _t = torch.ones(4, device=dev); _d.all_reduce(_t); torch.cuda.synchronize()
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29544")
-        os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's version banner off stdout (ONE JSON line)
+        # RCCL and gloo print banners to stdout when their communicators come up: park fd 1 on stderr until the JSON line
+        sys.stdout.flush()
+        _saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         # barriers / the max-over-ranks of the timing go through a gloo group: an eager RCCL collective issued between
         # replays of a graph that CONTAINS RCCL collectives faulted the GPU here (the replayed kernels read work
@@ -123,10 +132,9 @@ def main():
     pool = [synthetic.make_batch(B, vocab_n, vocab_c, keys_n, keys_c, din_n, din_c, dev, seed=1234 + 7919 * (rank * args.pool + i),
                                  zipf_alpha=args.zipf) for i in range(args.pool)]
 
-    # Sharded step: the fixed-capacity exchange makes it capturable (RCCL all-to-alls inside the graph; tested at world 1,
-    # B = 256), but at B = 8192 the second replay faulted the GPU on this stack (eagerly the same body runs clean), so the
-    # captured form is opt-in (TT_DIST_GRAPH=1) and the sharded bench launches eagerly.
-    use_graph = (args.mode == "graph" and args.optimizer == "fused_sparse" and bool(os.environ.get("TT_DIST_GRAPH"))) \
+    # Sharded step: the fixed-capacity exchange makes it capturable (RCCL all-to-alls and the dense all-reduce inside the
+    # graph); TT_DIST_EAGER=1 launches it eagerly instead.
+    use_graph = (args.mode == "graph" and args.optimizer == "fused_sparse" and not os.environ.get("TT_DIST_EAGER")) \
         if dist is not None else (args.mode == "graph" and args.optimizer != "torch_adam")
     gstep = None
     profile = ops.LookupProfile(dev) if (use_graph and not os.environ.get("TT_BENCH_NO_PROFILE")) else None   # device-clock stamps: work inside a graph
@@ -136,7 +144,11 @@ def main():
         if os.environ.get("TT_BENCH_TRACE"):
             torch.cuda.synchronize(); print("[bench] captured", file=sys.stderr, flush=True)
 
+    same_batch = bool(os.environ.get("TT_BENCH_SAME_BATCH"))      # fault hunting: every step on pool[0]
+
     def step(i, eager=False):
+        if same_batch:
+            i = 0
         if gstep is not None and not eager:
             res = gstep.step(pool[i % args.pool])
             sched.step()
@@ -162,7 +174,8 @@ def main():
     # In eager mode the lookup launches are timed with HIP events inside the timed region.  A graph replay
     # has no per-kernel host call to bracket, so in graph mode the same launches are timed in an eager pass
     # of the same steps right after the timed region (same kernel, same batches, same stream).
-    timer = ops.KernelTimer(names=["tt_embed_lookup_fwd"])
+    lookup_name = "tt_embed_lookup_fwd" if dist is None else "tt_embed_lookup_fwd[place]"   # sharded: the launch that fills the tower inputs
+    timer = ops.KernelTimer(names=[lookup_name])
     if gstep is None:
         ops.set_timer(timer)
     else:
@@ -191,7 +204,7 @@ def main():
         dt = float(tmax.item())
     loss_val = float(res["loss"])
     ksum = timer.summary()
-    n_launch, lookup_ms = ksum.get("tt_embed_lookup_fwd", (0, float("nan")))
+    n_launch, lookup_ms = ksum.get(lookup_name, (0, float("nan")))
     if lookup_us:
         n_launch, lookup_ms = len(lookup_us), sum(lookup_us) / len(lookup_us) * 1e-3
 
@@ -239,7 +252,8 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "rows_notice": sum(vocab_n), "rows_company": sum(vocab_c),
                    "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})", "optimizer": args.optimizer,
                    "score_dtype": args.score_dtype, "mlp_dtype": args.mlp_dtype, "launch": "hip graph replay" if gstep is not None else "eager",
-                   "parallelism": ("single GPU" if dist is None else f"row-wise sharded tables x{world} (dedup-first fixed-capacity all-to-all, RCCL inside the graph) + data parallel towers")},
+                   "parallelism": ("single GPU" if dist is None else f"row-wise sharded tables x{world} (dedup-first fixed-capacity all-to-all" +
+                                   (", RCCL inside the graph" if gstep is not None else "") + ") + data parallel towers")},
         "roofline": {"kernel": "lookup_kernel (tt_embed_lookup_fwd)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": n_launch, "mean_launch_us": lookup_ms * 1e3,
@@ -253,8 +267,12 @@ def main():
         out["kernel_breakdown"] = breakdown
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(task, pool[0], keys_n, keys_c, vocab_n, vocab_c, B, args.cpu_steps)
+    if dist is not None:
+        sys.stdout.flush()
+        os.dup2(_saved_stdout, 1)
     print(json.dumps(out), flush=True)
     if dist is not None:
+        os.dup2(2, 1)
         gstep = None                    # the captured graph holds the communicator: drop it before the process group
         import gc
         gc.collect()

@@ -794,6 +794,10 @@ struct GradWs {
   float* chunk_partial;  // [maxChunks, E]
 };
 
+__global__ void zero_words_kernel(int32_t* __restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
+}
+
 template <int VEC>
 struct Acc {
   float v[VEC];
@@ -1691,7 +1695,8 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   const int dt = srcs[0].dtype;
   GradLayout gl = grad_layout(reinterpret_cast<char*>(workspace), M, E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  TT_HIP(hipMemsetAsync(gl.ws.counters, 0, 2 * sizeof(int32_t), st));
+  zero_words_kernel<<<1, 64, 0, st>>>(gl.ws.counters, 2);      // (a kernel, not a memset node: see graph notes in DESIGN.md)
+  TT_LAUNCH_CHECK();
   const int g1 = grid_for(ctx, M * LG);
   const int g2 = grid_for(ctx, gl.max_chunks * LG);
   const int g3 = (int)(gl.max_long < (int64_t)ctx->num_cus * 8 ? gl.max_long : (int64_t)ctx->num_cus * 8);   // a workgroup per long row

@@ -96,10 +96,13 @@ class GraphedTrainStep:
         host = self._host_ring[self._slot, :self._n_scalar]
         ng = len(self.opt.param_groups)
         step = self._base_step + self._steps_done + 1
+        if __import__("os").environ.get("TT_GRAPH_PUSH_SAME"):       # fault hunting: identical scalars every step
+            step = self._base_step + 1
         for gi, g in enumerate(self.opt.param_groups):
             hp = ops.adam_hparams(step, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])
             host[gi * 8: gi * 8 + 6] = torch.tensor(hp)
-        host[ng * 8:].view(torch.int64).random_()
+        if not __import__("os").environ.get("TT_GRAPH_PUSH_SAME"):
+            host[ng * 8:].view(torch.int64).random_()
         return (self._dev, host)
 
     def _mark_slot(self):
@@ -126,8 +129,12 @@ class GraphedTrainStep:
                     sv.copy_(v, non_blocking=True)
         else:
             pairs = []
-        ops.copy_multi(pairs + [self._fill_slot()])             # ONE launch: the four batch buffers + the scalars
-        self._mark_slot()
+        if __import__("os").environ.get("TT_GRAPH_SKIP_PUSH"):       # fault hunting
+            if pairs:
+                ops.copy_multi(pairs)
+        else:
+            ops.copy_multi(pairs + [self._fill_slot()])         # ONE launch: the four batch buffers + the scalars
+            self._mark_slot()
         if self._no_capture:
             self.result = self._body()
             self._steps_done += 1
