@@ -193,9 +193,8 @@ def main():
     if profile is not None:
         profile.close()
     if dist is not None and gstep is not None:
-        # sharded step: three stamped lookup launches per replay (owner gather, PLACE into the tower inputs, gradient
-        # gather); the placing launch moves the same bytes as the single-GPU lookup and is the one reported
-        lookup_us = lookup_us[1::3] if len(lookup_us) == 3 * args.steps else []
+        # sharded step: the one stamped lookup launch per replay is the PLACE launch (pooled rows -> tower inputs; the same
+        # bytes as the single-GPU lookup); the owner-side gathers run in tt_gather_rows
         if task.exchange.overflowed():
             raise RuntimeError("bench: a fixed-capacity bucket overflowed during the timed region -- result invalid")
     if dist is not None:

@@ -364,7 +364,8 @@ int tt_batch_gather(tt_ctx* ctx, const int64_t* entity, int64_t B, const float* 
  *   send_ids [G, C] int32  local row index at owner g, in plan order; unused entries = pad_id[g]
  *   send_u   [G, C] int32  plan index u of each entry; unused entries = pad_u (caller: index of an all-zero row)
  *   pos_u    [M]    int32  g*C + position of plan row u (0 for rows that did not fit)
- *   counts   [G]    int32  entries wanted per owner; overflow[0] is set to 1 when any count exceeds C
+ *   counts   [G]    int32  entries wanted per owner; overflow[0] is set to 1 when any count exceeds C (sticky: never
+ *                          cleared here, the caller owns the flag)
  * tt_route_expand: idx_slot[slot] = pos_u[u] for every slot of plan row u (int64: ids of the placing lookup).
  * ---------------------------------------------------------------------------------------------- */
 #define TT_MAX_RANKS 64
@@ -374,6 +375,10 @@ int tt_route_bucket(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_un
                     int32_t* counts, int32_t* overflow, void* workspace, size_t workspace_bytes, tt_stream stream);
 int tt_route_expand(tt_ctx* ctx, const int32_t* sorted_src, const int32_t* seg_offsets, const int32_t* n_unique,
                     const int32_t* pos_u, int64_t M, int64_t* idx_slot, tt_stream stream);
+/* out[i, :] = table[clamp(rows[i], 0, table_rows - 1), :] -- the owner's gather of requested rows and the hand-over of
+ * per-row gradients into the send buckets (E a multiple of 4, 16-byte aligned f32 buffers). */
+int tt_gather_rows(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const int32_t* rows, int64_t n,
+                   float* out, tt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * n (<= 8) device-to-device copies in ONE launch -- the per-step refresh of a captured step's static input

@@ -1294,10 +1294,7 @@ __global__ __launch_bounds__(kThreads) void route_count_kernel(const int32_t* __
 
 // one workgroup: per owner an exclusive prefix over the (block, wave) segments; totals, overflow flag, pad fill
 __global__ __launch_bounds__(1024) void route_scan_kernel(uint32_t* __restrict__ seg_counts, uint32_t nseg, uint32_t G, uint32_t C,
-                                                         RoutePads pads, int32_t pad_u, int32_t* __restrict__ send_ids,
-                                                         int32_t* __restrict__ send_u, int32_t* __restrict__ counts,
-                                                         int32_t* __restrict__ overflow) {
-  __shared__ uint32_t total[TT_MAX_RANKS];
+                                                         int32_t* __restrict__ counts, int32_t* __restrict__ overflow) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t g = wave; g < G; g += 16) {             // a wave per owner, 64 segments per trip
     uint32_t carry = 0;
@@ -1314,22 +1311,22 @@ __global__ __launch_bounds__(1024) void route_scan_kernel(uint32_t* __restrict__
       carry += __shfl(x, 63);
     }
     if (lane == 0) {
-      total[g] = carry;
       counts[g] = (int32_t)carry;
-      if (carry > C) overflow[0] = 1;
+      if (carry > C) overflow[0] = 1;                   // sticky: the caller owns (and clears) the flag
     }
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < G * C; i += blockDim.x) {      // unused tail of every bucket
-    const uint32_t g = i / C, p = i - g * C;
-    if (p >= total[g]) { send_ids[i] = pads.id[g]; send_u[i] = pad_u; }
   }
 }
 
 __global__ __launch_bounds__(kThreads) void route_scatter_kernel(const int32_t* __restrict__ unique_rows, const int32_t* __restrict__ n_unique,
                                                                 uint32_t G, uint32_t C, const uint32_t* __restrict__ seg_base,
+                                                                const int32_t* __restrict__ counts, RoutePads pads, int32_t pad_u,
                                                                 int32_t* __restrict__ send_ids, int32_t* __restrict__ send_u,
                                                                 int32_t* __restrict__ pos_u) {
+  // unused tail of every bucket: pad entries, written by the whole grid
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G * C; i += gridDim.x * blockDim.x) {
+    const uint32_t g = i / C, p = i - g * C;
+    if (p >= (uint32_t)counts[g]) { send_ids[i] = pads.id[g]; send_u[i] = pad_u; }
+  }
   __shared__ uint32_t off[kRouteWaves][TT_MAX_RANKS];
   __shared__ unsigned long long pm[kRouteWaves][TT_MAX_RANKS];
   const uint32_t U = (uint32_t)*n_unique, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1370,6 +1367,18 @@ __global__ __launch_bounds__(kThreads) void route_scatter_kernel(const int32_t* 
         pos_u[u] = 0;                                   // did not fit: flagged by route_scan_kernel
       }
     }
+  }
+}
+
+// out[i, :] = table[clamp(rows[i], 0, R - 1), :]   (16-byte lanes; the owner-side gather / gradient hand-over)
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ rows, uint32_t n,
+                                                              int32_t R, uint32_t C4, float* __restrict__ out) {
+  const uint64_t total = (uint64_t)n * C4;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t i = (uint32_t)(t / C4), c = (uint32_t)(t - (uint64_t)i * C4);
+    int32_t r = rows[i];
+    r = r < 0 ? 0 : (r >= R ? R - 1 : r);
+    reinterpret_cast<float4*>(out)[(uint64_t)i * C4 + c] = reinterpret_cast<const float4*>(table)[(uint64_t)r * C4 + c];
   }
 }
 
@@ -1851,9 +1860,23 @@ int tt_route_bucket(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_un
   for (int g = 0; g < G; ++g) pads.id[g] = pad_id[g];
   route_count_kernel<<<nb, kThreads, 0, st>>>(unique_rows, n_unique, (uint32_t)G, seg);
   TT_LAUNCH_CHECK();
-  route_scan_kernel<<<1, 1024, 0, st>>>(seg, nb * kRouteWaves, (uint32_t)G, (uint32_t)C, pads, pad_u, send_ids, send_u, counts, overflow);
+  route_scan_kernel<<<1, 1024, 0, st>>>(seg, nb * kRouteWaves, (uint32_t)G, (uint32_t)C, counts, overflow);
   TT_LAUNCH_CHECK();
-  route_scatter_kernel<<<nb, kThreads, 0, st>>>(unique_rows, n_unique, (uint32_t)G, (uint32_t)C, seg, send_ids, send_u, pos_u);
+  route_scatter_kernel<<<nb, kThreads, 0, st>>>(unique_rows, n_unique, (uint32_t)G, (uint32_t)C, seg, counts, pads, pad_u, send_ids, send_u,
+                                                pos_u);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_gather_rows(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const int32_t* rows, int64_t n, float* out,
+                   tt_stream stream) {
+  TT_CHECK_ARG(ctx && table && rows && out, "tt_gather_rows: NULL argument");
+  TT_CHECK_ARG(table_rows >= 1 && table_rows <= INT32_MAX && n >= 0 && n < ((int64_t)1 << 31) && E >= 4 && E % 4 == 0,
+               "tt_gather_rows: bad shape (E must be a multiple of 4)");
+  TT_CHECK_ARG(tt_aligned(table, 16) && tt_aligned(out, 16), "tt_gather_rows: table / out must be 16-byte aligned");
+  if (n == 0) return TT_OK;
+  gather_rows_kernel<<<grid_for(ctx, n * (E / 4)), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(table, rows, (uint32_t)n,
+                                                                                                        (int32_t)table_rows, (uint32_t)(E / 4), out);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

@@ -77,6 +77,17 @@ class ShardedStore(EmbeddingStore):
         return out[:self.global_rows]
 
 
+_CONSTS: dict = {}
+
+
+def _const_i64(dev, n: int, value: int) -> torch.Tensor:
+    key = (str(dev), n, value)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.full((n,), value, dtype=torch.int64, device=dev)
+    return t
+
+
 class HipBackend:
     """Compute steps of the exchange on the MI355X (C ABI)."""
 
@@ -104,12 +115,10 @@ class HipBackend:
         """out_side[b, k*E:(k+1)*E] = pooled[inv[slot]]  -- the lookup kernel with `pooled` as the table."""
         M = pooled.shape[0]
         dev = pooled.device
-        voc_cache = {}
         lsides, base = [], 0
         for s in sides:
             n = B * s.K
-            off = torch.zeros(s.K, dtype=torch.int64, device=dev)
-            voc = voc_cache.setdefault(s.K, torch.full((s.K,), M, dtype=torch.int64, device=dev))
+            off, voc = _const_i64(dev, s.K, 0), _const_i64(dev, s.K, M)      # cached: no fill kernels per step
             lsides.append(ops.LookupSide(inv[base:base + n], off, voc, s.out, s.K))
             base += n
         ops.embed_lookup(pooled, lsides, B, want_rows=False, tag="[place]")
@@ -133,20 +142,18 @@ class HipBackend:
             return ops.dedup_plan_keyed(rows, list(side_K), B)
         return ops.dedup_plan(rows, int(rows.max().item()) + 1)
 
-    def route_bucket(self, plan, G: int, C: int, pad_id: Sequence[int], pad_u: int):
-        return ops.route_bucket(plan, G, C, pad_id, pad_u)
+    def route_bucket(self, plan, G: int, C: int, pad_id: Sequence[int], pad_u: int, overflow: torch.Tensor):
+        return ops.route_bucket(plan, G, C, pad_id, pad_u, overflow)
+
+    def new_flag(self, device) -> torch.Tensor:
+        return torch.zeros(1, dtype=torch.int32, device=device)
 
     def route_expand(self, plan, pos_u: torch.Tensor) -> torch.Tensor:
         return ops.route_expand(plan, pos_u)
 
     def gather_rows(self, table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-        """out[i] = table[idx[i]] (idx int32/int64, clamped into the table): the lookup kernel with one key."""
-        n, E, dev = idx.numel(), table.shape[1], table.device
-        out = torch.empty((n, E), dtype=torch.float32, device=dev)
-        off = torch.zeros(1, dtype=torch.int64, device=dev)
-        voc = torch.full((1,), table.shape[0], dtype=torch.int64, device=dev)
-        ops.embed_lookup(table, [ops.LookupSide(idx.to(torch.int64), off, voc, out, 1)], n, want_rows=False, tag="[gather]")
-        return out
+        """out[i] = table[idx[i]] (idx int32, clamped into the table)"""
+        return ops.gather_rows(table, idx)
 
     def owner_plan(self, recv_ids: torch.Tensor, local_rows: int):
         """plan over the received local row ids; the pad value `local_rows` groups into one (last) row that Adam skips"""
@@ -248,7 +255,8 @@ class PaddedRowExchange(RowExchange):
     def _calibrate(self, plan, dev):
         G = self.world
         probe = max(256, -(-plan.M // 256) * 256)                                 # generous probe capacity: counts only
-        _, _, _, counts, _ = self.backend.route_bucket(plan, G, probe, [self.local_rows_of(g) for g in range(G)], plan.M)
+        _, _, _, counts = self.backend.route_bucket(plan, G, probe, [self.local_rows_of(g) for g in range(G)], plan.M,
+                                                    self.backend.new_flag(dev))
         mx = counts.max().to(torch.int64).reshape(1)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
         need = int(mx.item())                                                     # the one host sync of the exchange
@@ -261,10 +269,9 @@ class PaddedRowExchange(RowExchange):
         if self.C is None:
             self._calibrate(plan, rows.device)
         pads = [self.local_rows_of(g) for g in range(G)]
-        send_ids, send_u, pos_u, _counts, ovf = be.route_bucket(plan, G, self.C, pads, plan.M)
         if self._overflow is None:
-            self._overflow = torch.zeros(1, dtype=torch.int32, device=rows.device)
-        torch.maximum(self._overflow, ovf, out=self._overflow)
+            self._overflow = be.new_flag(rows.device)
+        send_ids, send_u, pos_u, _counts = be.route_bucket(plan, G, self.C, pads, plan.M, self._overflow)
         recv_ids = self._a2a_equal(send_ids)                                     # [G*C] local row ids, pad = my local_rows
         pooled_local = be.gather_rows(self.store.weight, recv_ids)               # pads clamp to the last row (unused)
         got = self._a2a_equal(pooled_local)                                      # [G*C, E] in my send order

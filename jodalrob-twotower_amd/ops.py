@@ -453,14 +453,14 @@ def copy_multi(pairs):
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU routing
-def route_bucket(plan: DedupPlan, G: int, C: int, pad_id: Sequence[int], pad_u: int):
+def route_bucket(plan: DedupPlan, G: int, C: int, pad_id: Sequence[int], pad_u: int, overflow: torch.Tensor):
     """Distinct rows of `plan` -> fixed-capacity owner buckets.  Returns (send_ids [G*C] i32, send_u [G*C] i32,
-    pos_u [M] i32, counts [G] i32, overflow [1] i32) -- all on the device, no host sync."""
+    pos_u [M] i32, counts [G] i32) -- all on the device, no host sync; `overflow` (int32 [1], caller-owned, sticky)
+    is set to 1 when a bucket needed more than C entries."""
     dev, M = plan.unique_rows.device, plan.M
-    buf = torch.empty(2 * G * C + M + G + 1, dtype=torch.int32, device=dev)
+    buf = torch.empty(2 * G * C + M + G, dtype=torch.int32, device=dev)
     send_ids, send_u = buf[:G * C], buf[G * C:2 * G * C]
-    pos_u, counts, overflow = buf[2 * G * C:2 * G * C + M], buf[2 * G * C + M:2 * G * C + M + G], buf[2 * G * C + M + G:]
-    overflow.zero_()
+    pos_u, counts = buf[2 * G * C:2 * G * C + M], buf[2 * G * C + M:]
     lib = L.load()
     ws = L.workspace(dev, lib.tt_route_workspace_bytes(M, G))
     pads = (L.i32 * G)(*[int(p) for p in pad_id])
@@ -468,7 +468,17 @@ def route_bucket(plan: DedupPlan, G: int, C: int, pad_id: Sequence[int], pad_u: 
         L.check(lib.tt_route_bucket(L.ctx(dev), L.ptr(plan.unique_rows), L.ptr(plan.n_unique), M, G, C, pads, pad_u, L.ptr(send_ids),
                                     L.ptr(send_u), L.ptr(pos_u), L.ptr(counts), L.ptr(overflow), L.ptr(ws), ws.numel(), L.stream(dev)),
                 "tt_route_bucket")
-    return send_ids, send_u, pos_u, counts, overflow
+    return send_ids, send_u, pos_u, counts
+
+
+def gather_rows(table: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
+    """out[i] = table[clamp(rows[i])]  (rows int32)."""
+    dev, n, E = table.device, rows.numel(), table.shape[1]
+    out = torch.empty((n, E), dtype=torch.float32, device=dev)
+    with _timed("tt_gather_rows"):
+        L.check(L.load().tt_gather_rows(L.ctx(dev), L.ptr(table), table.shape[0], E, L.ptr(rows), n, L.ptr(out), L.stream(dev)),
+                "tt_gather_rows")
+    return out
 
 
 def route_expand(plan: DedupPlan, pos_u: torch.Tensor) -> torch.Tensor:

@@ -310,7 +310,7 @@ class _TowersFn(torch.autograd.Function):
         grads = [None] * ctx.n_flat
         dxs = {}
         exch = ctx.exch
-        if exch is not None:            # global objective = mean over ranks of the local losses
+        if exch is not None and exch.world > 1:            # global objective = mean over ranks of the local losses
             d_embs = [None if d is None else d * (1.0 / exch.world) for d in d_embs]
         flat_grads = []
         work = [(s, d, sp) for s, d, sp in zip(ctx.sides, d_embs, ctx.spans) if s.B and d is not None]

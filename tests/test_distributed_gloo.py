@@ -64,7 +64,10 @@ class CheckerBackend:
         return SimpleNamespace(sorted_src=torch.from_numpy(order), unique_rows=torch.from_numpy(uniq), seg_offsets=torch.from_numpy(seg),
                                n_unique=torch.tensor([U], dtype=torch.int32), M=M)
 
-    def route_bucket(self, plan, G, C, pad_id, pad_u):
+    def new_flag(self, device):
+        return torch.zeros(1, dtype=torch.int32)
+
+    def route_bucket(self, plan, G, C, pad_id, pad_u, overflow):
         U = int(plan.n_unique)
         send_ids = np.repeat(np.asarray(pad_id, np.int32), C)
         send_u = np.full(G * C, pad_u, np.int32)
@@ -75,8 +78,9 @@ class CheckerBackend:
             p = counts[g]; counts[g] += 1
             if p < C:
                 send_ids[g * C + p] = row // G; send_u[g * C + p] = u; pos_u[u] = g * C + p
-        ovf = np.array([int((counts > C).any())], np.int32)
-        return tuple(torch.from_numpy(a) for a in (send_ids, send_u, pos_u, counts, ovf))
+        if (counts > C).any():
+            overflow[0] = 1
+        return tuple(torch.from_numpy(a) for a in (send_ids, send_u, pos_u, counts))
 
     def route_expand(self, plan, pos_u):
         idx = torch.zeros(plan.M, dtype=torch.int64)
