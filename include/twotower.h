@@ -375,6 +375,11 @@ int tt_route_bucket(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_un
                     int32_t* counts, int32_t* overflow, void* workspace, size_t workspace_bytes, tt_stream stream);
 int tt_route_expand(tt_ctx* ctx, const int32_t* sorted_src, const int32_t* seg_offsets, const int32_t* n_unique,
                     const int32_t* pos_u, int64_t M, int64_t* idx_slot, tt_stream stream);
+/* Duplicate-row plan of G ASCENDING runs of C row ids each (what an owner receives: every source sends its distinct rows in
+ * ascending order, pads -- the largest value -- at the end): a stable merge by binary searches instead of radix passes.
+ * Same outputs as tt_dedup_plan over the concatenated runs; workspace tt_dedup_workspace_bytes(G * C). */
+int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, int32_t* sorted_src, int32_t* unique_rows,
+                       int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes, tt_stream stream);
 /* out[i, :] = table[clamp(rows[i], 0, table_rows - 1), :] -- the owner's gather of requested rows and the hand-over of
  * per-row gradients into the send buckets (E a multiple of 4, 16-byte aligned f32 buffers). */
 int tt_gather_rows(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const int32_t* rows, int64_t n,

@@ -489,6 +489,34 @@ __global__ __launch_bounds__(kThreads) void sort_scatter_kernel(const uint32_t* 
   }
 }
 
+// stable merge of G ascending runs of length C (the owner's received buckets: every source sends its distinct rows in
+// ascending order, pads = the largest value at the end): the position of an element is its own index plus, per other
+// run, the number of elements that sort before it (<= for lower runs, < for higher ones) -- binary searches in L2,
+// no radix passes (80 -> 30 us for 98 k ids; at G = 1 the run is already the answer)
+__global__ __launch_bounds__(kThreads) void merge_runs_kernel(const int32_t* __restrict__ rows, uint32_t G, uint32_t C,
+                                                             uint32_t* __restrict__ keys_out, int32_t* __restrict__ sorted_src) {
+  const uint32_t total = G * C;
+  for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const uint32_t r = e / C, i = e - r * C;
+    const uint32_t x = (uint32_t)rows[e];
+    uint32_t pos = i;
+    for (uint32_t q = 0; q < G; ++q) {
+      if (q == r) continue;
+      const int32_t* run = rows + (size_t)q * C;
+      uint32_t lo = 0, hi = C;                          // first index whose value is > x (q < r) or >= x (q > r)
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        const uint32_t v = (uint32_t)run[mid];
+        const bool before = q < r ? v <= x : v < x;
+        if (before) lo = mid + 1; else hi = mid;
+      }
+      pos += lo;
+    }
+    keys_out[pos] = x;
+    sorted_src[pos] = (int32_t)e;
+  }
+}
+
 // segment heads -------------------------------------------------------------------------------
 __device__ __forceinline__ bool is_head(const uint32_t* keys, uint32_t i) { return i == 0 || keys[i] != keys[i - 1]; }
 
@@ -1610,6 +1638,27 @@ int tt_dedup_plan(tt_ctx* ctx, const int32_t* rows, int64_t M, int64_t table_row
     kin = kout;
     vin = vout;
   }
+  head_count_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount);
+  TT_LAUNCH_CHECK();
+  head_write_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount, n_unique, unique_rows, seg_offsets);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, int32_t* sorted_src, int32_t* unique_rows,
+                       int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes, tt_stream stream) {
+  TT_CHECK_ARG(ctx && rows && sorted_src && unique_rows && seg_offsets && n_unique && workspace, "tt_dedup_plan_runs: NULL argument");
+  TT_CHECK_ARG(G >= 1 && G <= TT_MAX_RANKS && C >= 1 && (int64_t)G * C < ((int64_t)1 << 31) - kSortTile, "tt_dedup_plan_runs: bad G / C");
+  const int64_t M = (int64_t)G * C;
+  if (workspace_bytes < tt_dedup_workspace_bytes(M)) {
+    tt_set_error("tt_dedup_plan_runs: workspace %zu < required %zu", workspace_bytes, tt_dedup_workspace_bytes(M));
+    return TT_ERR_WORKSPACE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  DedupWs w = dedup_layout(reinterpret_cast<char*>(workspace), M);
+  const uint32_t nblk = (uint32_t)tt_cdiv(M, kSortTile);
+  merge_runs_kernel<<<grid_for(ctx, M), kThreads, 0, st>>>(rows, (uint32_t)G, (uint32_t)C, w.keysA, sorted_src);
+  TT_LAUNCH_CHECK();
   head_count_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount);
   TT_LAUNCH_CHECK();
   head_write_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount, n_unique, unique_rows, seg_offsets);

@@ -155,9 +155,10 @@ class HipBackend:
         """out[i] = table[idx[i]] (idx int32, clamped into the table)"""
         return ops.gather_rows(table, idx)
 
-    def owner_plan(self, recv_ids: torch.Tensor, local_rows: int):
-        """plan over the received local row ids; the pad value `local_rows` groups into one (last) row that Adam skips"""
-        return ops.dedup_plan(recv_ids, local_rows + 1)
+    def owner_plan(self, recv_ids: torch.Tensor, local_rows: int, G: int = 1):
+        """plan over the received local row ids -- G ascending runs (every source sends its distinct rows in ascending
+        order); the pad value `local_rows` groups into one (last) row that Adam skips"""
+        return ops.dedup_plan_runs(recv_ids, G, recv_ids.numel() // G)
 
     def reduce_local(self, plan, srcs, B: int, E: int) -> torch.Tensor:
         """[M + 1, E]: row u = summed gradient of plan row u, row M = 0 (the target of unused bucket entries)"""
@@ -278,7 +279,7 @@ class PaddedRowExchange(RowExchange):
         be.place_rows(got, be.route_expand(plan, pos_u), sides, B)
         if not want_grad:
             return None
-        return {"plan": plan, "send_u": send_u, "owner_plan": be.owner_plan(recv_ids, self.store.local_rows), "padded": True}
+        return {"plan": plan, "send_u": send_u, "owner_plan": be.owner_plan(recv_ids, self.store.local_rows, G), "padded": True}
 
     def backward(self, state, srcs, B: int):
         be = self.backend

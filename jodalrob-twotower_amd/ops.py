@@ -157,6 +157,21 @@ def dedup_plan(rows: torch.Tensor, table_rows: int) -> DedupPlan:
     return plan
 
 
+def dedup_plan_runs(rows: torch.Tensor, G: int, C: int) -> DedupPlan:
+    """Plan of G ascending runs of C ids (stable merge; same outputs as dedup_plan on the concatenation)."""
+    dev, M = rows.device, G * C
+    assert rows.numel() == M and rows.dtype == torch.int32
+    buf = torch.empty(3 * M + 2, dtype=torch.int32, device=dev)
+    plan = DedupPlan(buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:], M)
+    lib = L.load()
+    ws = L.workspace(dev, lib.tt_dedup_workspace_bytes(M))
+    with _timed("tt_dedup_plan_runs"):
+        L.check(lib.tt_dedup_plan_runs(L.ctx(dev), L.ptr(rows), G, C, L.ptr(plan.sorted_src), L.ptr(plan.unique_rows),
+                                       L.ptr(plan.seg_offsets), L.ptr(plan.n_unique), L.ptr(ws), ws.numel(), L.stream(dev)),
+                "tt_dedup_plan_runs")
+    return plan
+
+
 KEYED_MAX_B = 8192
 
 

@@ -93,7 +93,9 @@ class CheckerBackend:
     def gather_rows(self, table, idx):
         return table[torch.clamp(idx.long(), 0, table.shape[0] - 1)].clone()
 
-    def owner_plan(self, recv_ids, local_rows):
+    def owner_plan(self, recv_ids, local_rows, G=1):
+        runs = recv_ids.view(G, -1)
+        assert bool((runs[:, 1:] >= runs[:, :-1]).all()), "every received bucket must be ascending (the owner merges runs)"
         return recv_ids.clone()
 
     def reduce_local(self, plan, srcs, B, E):

@@ -659,3 +659,34 @@ def test_adam_fused_equals_separate_launches(tt, manifest, monkeypatch):
         finals[-1]["__steps"] = np.array(opt.current_step())
     for k, v in finals[0].items():
         assert np.array_equal(v, finals[1][k]), k
+
+
+@pytest.mark.parametrize("G,C,rows_max", [(1, 5000, 100000), (3, 777, 2000), (8, 12345, 250000), (4, 1, 3)])
+def test_dedup_plan_runs_equals_general(tt, G, C, rows_max):
+    """tt_dedup_plan_runs (stable merge of G ascending runs, as an owner receives them: distinct ascending ids, pads = the
+    largest value at the end) == tt_dedup_plan over the concatenation == numpy's stable argsort, bit for bit."""
+    from jodalrob_twotower_amd import ops
+    rng = np.random.default_rng(G * 1000 + C)
+    runs = []
+    for g in range(G):
+        n = int(rng.integers(0, C + 1))
+        ids = np.sort(rng.choice(rows_max, size=min(n, rows_max), replace=False)).astype(np.int32)
+        runs.append(np.concatenate([ids, np.full(C - len(ids), rows_max, np.int32)]))       # pad = rows_max (sorts last)
+    rows = np.concatenate(runs)
+    t = torch.from_numpy(rows).to(DEV)
+    pr = ops.dedup_plan_runs(t, G, C)
+    pg = ops.dedup_plan(t, rows_max + 1)
+    U = int(pr.n_unique.item())
+    assert U == int(pg.n_unique.item()) == len(np.unique(rows))
+    assert np.array_equal(pr.sorted_src.cpu().numpy(), np.argsort(rows, kind="stable").astype(np.int32))
+    assert torch.equal(pr.sorted_src, pg.sorted_src)
+    assert torch.equal(pr.unique_rows[:U], pg.unique_rows[:U]) and torch.equal(pr.seg_offsets[:U + 1], pg.seg_offsets[:U + 1])
+
+
+def test_gather_rows(tt):
+    from jodalrob_twotower_amd import ops
+    g = torch.Generator().manual_seed(3)
+    table = torch.randn(1000, 32, generator=g).to(DEV)
+    idx = torch.randint(-5, 1010, (4097,), generator=g, dtype=torch.int32).to(DEV)
+    out = ops.gather_rows(table, idx)
+    assert torch.equal(out, table[idx.long().clamp(0, 999)])
