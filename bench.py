@@ -140,7 +140,17 @@ def main():
     profile = ops.LookupProfile(dev) if (use_graph and not os.environ.get("TT_BENCH_NO_PROFILE")) else None   # device-clock stamps: work inside a graph
     if use_graph:
         from jodalrob_twotower_amd.graph import GraphedTrainStep
-        gstep = GraphedTrainStep(task, opt, pool[0], return_metrics=True, warmup=3)
+        try:
+            gstep = GraphedTrainStep(task, opt, pool[0], return_metrics=True, warmup=3)
+        except Exception as e:                      # a capture that fails on some RCCL / world size must not lose the run
+            if dist is None:
+                raise
+            print(f"[bench] rank {rank}: graph capture of the sharded step failed ({type(e).__name__}: {e}); running eagerly",
+                  file=sys.stderr, flush=True)
+            if profile is not None:
+                profile.close()
+            gstep, profile = None, None
+            torch.cuda.synchronize()
         if os.environ.get("TT_BENCH_TRACE"):
             torch.cuda.synchronize(); print("[bench] captured", file=sys.stderr, flush=True)
 
