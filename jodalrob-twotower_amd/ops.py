@@ -131,6 +131,9 @@ class LookupProfile:
     def close(self):
         L.check(L.load().tt_embed_lookup_set_profile(L.ctx(self.device), None, 0), "tt_embed_lookup_set_profile")
 
+    def reopen(self):
+        L.check(L.load().tt_embed_lookup_set_profile(L.ctx(self.device), L.ptr(self.ring), self.n), "tt_embed_lookup_set_profile")
+
 
 @dataclass
 class DedupPlan:
