@@ -690,3 +690,89 @@ def test_gather_rows(tt):
     idx = torch.randint(-5, 1010, (4097,), generator=g, dtype=torch.int32).to(DEV)
     out = ops.gather_rows(table, idx)
     assert torch.equal(out, table[idx.long().clamp(0, 999)])
+
+
+def test_full_size_properties(tt, schema_real):
+    """BASELINE configs[1] at full size (B = 8192, 38 real keys, 1 M + 1 M rows, E = 32) through size-independent properties:
+    lookup == table[rows] bit for bit (f32) / exact RNE (bf16); the plan is a stable sort of the rows; the segmented
+    reduction conserves the column sums of the slot gradients; the symmetric loss is invariant under swapping the towers;
+    a whole training step is bitwise reproducible."""
+    from jodalrob_twotower_amd import ops, synthetic
+    B, E = 8192, 32
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    vn = synthetic.scale_vocabs(schema_real["notice"]["vocab_sizes"], 1_000_000)
+    vc = synthetic.scale_vocabs(schema_real["company"]["vocab_sizes"], 1_000_000)
+    batch = synthetic.make_batch(B, vn, vc, kn, kc, 256, 128, torch.device(DEV), seed=99)
+    R = sum(vn) + sum(vc)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    table = torch.randn((R, E), generator=g, device=DEV)
+    offs, base = [], 0
+    for v in (vn, vc):
+        offs.append(torch.tensor([base + sum(v[:i]) for i in range(len(v))], dtype=torch.int64, device=DEV))
+        base += sum(v)
+    vocs = [torch.tensor(v, dtype=torch.int64, device=DEV) for v in (vn, vc)]
+    ids = [batch["notice"]["kjt"].values(), batch["company"]["kjt"].values()]
+    Ks = [len(vn), len(vc)]
+    exp_rows = torch.cat([(ids[i].view(B, Ks[i]).clamp(min=0).minimum(vocs[i][None, :] - 1) + offs[i][None, :]).reshape(-1)
+                          for i in range(2)])
+    for dt in (torch.float32, torch.bfloat16):
+        outs = [torch.empty((B, 128 + Ks[i] * E), dtype=dt, device=DEV) for i in range(2)]
+        sides = [ops.LookupSide(ids[i], offs[i], vocs[i], outs[i][:, 128:], Ks[i]) for i in range(2)]
+        rows = ops.embed_lookup(table, sides, B, want_rows=True)
+        assert torch.equal(rows.long(), exp_rows)
+        for i in range(2):
+            sl = exp_rows[:B * Ks[0]] if i == 0 else exp_rows[B * Ks[0]:]
+            assert torch.equal(outs[i][:, 128:].reshape(B * Ks[i], E), table[sl].to(dt))
+    plan = ops.dedup_plan_keyed(rows, Ks, B)
+    U = int(plan.n_unique.item())
+    srt = rows[plan.sorted_src.long()]
+    assert bool((srt[1:] >= srt[:-1]).all()) and torch.equal(torch.sort(plan.sorted_src).values, torch.arange(rows.numel(), dtype=torch.int32, device=DEV))
+    same = srt[1:] == srt[:-1]
+    assert bool((plan.sorted_src[1:][same] > plan.sorted_src[:-1][same]).all())              # stable
+    assert torch.equal(plan.unique_rows[:U].long(), torch.unique(exp_rows))
+    d = [torch.randn((B, 128 + Ks[i] * E), generator=g, device=DEV) for i in range(2)]
+    grad_rows = torch.empty((rows.numel(), E), device=DEV)
+    ops.embed_grad(plan, [(d[i][:, 128:], Ks[i]) for i in range(2)], B, E, ops.TT_GRAD_SPARSE, grad_rows)
+    tot = sum(d[i][:, 128:].reshape(-1, E).double().sum(0) for i in range(2))
+    torch.testing.assert_close(grad_rows[:U].double().sum(0), tot, rtol=1e-6, atol=1e-3)
+    # symmetric loss: swapping the towers leaves loss untouched and swaps the directional metrics
+    n = torch.nn.functional.normalize(torch.randn((B, 64), generator=g, device=DEV), dim=1)
+    c = torch.nn.functional.normalize(torch.randn((B, 64), generator=g, device=DEV), dim=1)
+    Np, Cp = ops.score_pack2_bf16(n, c)
+    f1 = ops.score_fwd_bf16(Np, Cp, B, 64, 1.0, 1.0, True, True)
+    f2 = ops.score_fwd_bf16(Cp, Np, B, 64, 1.0, 1.0, True, True)
+    assert torch.equal(f1[0], f2[1]) and torch.equal(f1[1], f2[0]) and torch.equal(f1[3], f2[4])   # rowsum <-> colsum, ranks
+    o1, l1 = ops.score_loss_finish(B, 1.0, *f1)
+    o2, l2 = ops.score_loss_finish(B, 1.0, *f2)
+    assert l1.item() == l2.item()
+
+
+def test_full_size_step_is_reproducible(tt, schema_real, tmp_path):
+    from jodalrob_twotower_amd import synthetic
+    from jodalrob_twotower_amd.optim import FusedAdam
+    B = 8192
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    vn = synthetic.scale_vocabs(schema_real["notice"]["vocab_sizes"], 1_000_000)
+    vc = synthetic.scale_vocabs(schema_real["company"]["vocab_sizes"], 1_000_000)
+    meta = synthetic.write_metadata(tmp_path / "m.csv", {"notice": dict(zip(kn, vn)), "company": dict(zip(kc, vc))})
+    batches = [synthetic.make_batch(B, vn, vc, kn, kc, 256, 128, torch.device(DEV), seed=7 + i) for i in range(2)]
+    finals = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        task = tt.create_two_tower_train_task(kn, kc, metadata_path=str(meta), categorical_embedding_dim=32, notice_dense_input_dim=256,
+                                              company_dense_input_dim=128, tower_hidden_dims=[128, 64], final_embedding_dim=64,
+                                              dropout_rate=0.0, temperature=1.0, device=DEV, embedding_grad="sparse", score_dtype="bf16",
+                                              mlp_dtype="bf16")
+        task.train(); task._pair_check_done = True
+        opt = FusedAdam.for_task(task, lr=1e-3, weight_decay=1e-5)
+        losses = []
+        for b in batches:
+            opt.zero_grad()
+            r = task(b, return_metrics=True)
+            r["loss"].backward()
+            opt.step()
+            losses.append(r["loss"].item())
+        finals.append((losses, [p.detach().clone() for p in task.parameters()]))
+    assert finals[0][0] == finals[1][0] and finals[0][0][0] > 8.5           # ln(8192) = 9.01 at random init
+    for a, b in zip(finals[0][1], finals[1][1]):
+        assert torch.equal(a, b)
