@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--mlp-dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--pool", type=int, default=8, help="distinct pre-generated batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=8, help="oracle steps timed for cpu_baseline (~1.4 s each on the box)")
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: whole step replayed from one captured HIP graph; eager: launched from Python")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded-table path even on one GPU")
