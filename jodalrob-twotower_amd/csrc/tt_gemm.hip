@@ -178,7 +178,8 @@ struct TileLoader16 {
     }
   }
   // same tile from a bf16 tensor (held widened in r[]: the conversion back in store() is exact)
-  __device__ __forceinline__ void load_bf16(const uint16_t* __restrict__ P, int64_t ld, int x0, int X, int k0, int kend, int t, bool vec) {
+  __device__ __forceinline__ void load_bf16(const uint16_t* __restrict__ P, int64_t ld, int x0, int X, int k0, int kend, int t, bool vec,
+                                            bool allow_tr) {
     if (MODE == 0) {
       const int x = x0 + (t >> 2), k = k0 + (t & 3) * KR;
       if (vec && x < X && k + KR - 1 < kend) {
@@ -196,21 +197,43 @@ struct TileLoader16 {
 #pragma unroll
         for (int j = 0; j < KR; ++j) r[j] = (x < X && k + j < kend) ? tt_bf2f(P[(int64_t)x * ld + k + j]) : 0.f;
       }
+    } else if (vec && allow_tr && KR == 8) {
+      // X-contiguous bf16 (the weight gradient reads x [batch, 1152] bf16 with k = batch row): ONE 16-byte load of 8
+      // adjacent x at one k per thread, transposed on the way into LDS (8 ds_write_b16) -- the 2-byte-load form issued
+      // 8 global loads per thread and ran at 24 us against 19 us when x was f32.  r[j] = element (x + j, k).
+      const int x = x0 + 8 * (t & 7), k = k0 + (t >> 3);
+      if (k < kend && x + 7 < X) {
+        const uint4 a = *reinterpret_cast<const uint4*>(P + (int64_t)k * ld + x);
+        const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          r[2 * j] = __builtin_bit_cast(float, w[j] << 16);
+          r[2 * j + 1] = __builtin_bit_cast(float, w[j] & 0xFFFF0000u);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = (k < kend && x + j < X) ? tt_bf2f(P[(int64_t)k * ld + x + j]) : 0.f;
+      }
+      transposed = true;
     } else {
-      // (tried for the 64 x 1152 weight gradient, 24 us with this form, 19 us when x was f32: two adjacent x per
-      //  thread with 4-byte loads: 29 us; two adjacent 64-column tiles per workgroup (256-B row pieces, half the
-      //  workgroups): 37 us -- the kernel is bound by workgroup-level parallelism, not by piece size)
       const int x = x0 + (t & 63), k = k0 + (t >> 6) * KR;
 #pragma unroll
       for (int j = 0; j < KR; ++j) r[j] = (x < X && k + j < kend) ? tt_bf2f(P[(int64_t)(k + j) * ld + x]) : 0.f;
     }
   }
   __device__ __forceinline__ void load_any(const float* __restrict__ P, int is_bf16, int64_t ld, int x0, int X, int k0, int kend, int t,
-                                           bool vec) {
-    if (is_bf16) load_bf16(reinterpret_cast<const uint16_t*>(P), ld, x0, X, k0, kend, t, vec);
+                                           bool vec, bool allow_tr = false) {     // allow_tr: B operand only (COLSUM reads la.r per x)
+    if (is_bf16) load_bf16(reinterpret_cast<const uint16_t*>(P), ld, x0, X, k0, kend, t, vec, allow_tr);
     else load(P, ld, x0, X, k0, kend, t, vec);
   }
+  bool transposed = false;   // r[] holds 8 x at ONE k (16-byte load of an X-contiguous bf16 source)
   __device__ __forceinline__ void store(__bf16* __restrict__ S, int t) const {
+    if (MODE == 1 && transposed) {
+      const int row = 8 * (t & 7), k = t >> 3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) S[(row + j) * LDS16 + k] = (__bf16)r[j];
+      return;
+    }
     const int row = MODE == 0 ? (t >> 2) : (t & 63), kq = MODE == 0 ? (t & 3) * KR : (t >> 6) * KR;
 #pragma unroll
     for (int q = 0; q < KR / 8; ++q) {
@@ -243,7 +266,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(GemmBatch batch, int
   float cs = 0.f;
   if (kbeg < kend) {
     la.load_any(g.A, g.a_bf16, g.lda, m0, M, kbeg, kend, t, vec);
-    lb.load_any(g.B, g.b_bf16, g.ldb, n0, N, kbeg, kend, t, vec);
+    lb.load_any(g.B, g.b_bf16, g.ldb, n0, N, kbeg, kend, t, vec, true);
   }
   for (int k0 = kbeg; k0 < kend; k0 += BK16) {
     la.store(As, t);
@@ -255,7 +278,7 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(GemmBatch batch, int
     __syncthreads();
     if (k0 + BK16 < kend) {
       la.load_any(g.A, g.a_bf16, g.lda, m0, M, k0 + BK16, kend, t, vec);
-      lb.load_any(g.B, g.b_bf16, g.ldb, n0, N, k0 + BK16, kend, t, vec);
+      lb.load_any(g.B, g.b_bf16, g.ldb, n0, N, k0 + BK16, kend, t, vec, true);
     }
 #pragma unroll
     for (int s2 = 0; s2 < BK16 / 16; ++s2) {
