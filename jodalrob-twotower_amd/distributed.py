@@ -168,13 +168,36 @@ class HipBackend:
         return out
 
 
+class DistComm:
+    """The collectives the exchanges need, on torch.distributed (RCCL on the GPUs, gloo in the CPU tests).  Tests may pass
+    another object with the same four members (an in-process simulator of several ranks on one GPU)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def all_to_all_equal(self, send: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(send)
+        dist.all_to_all_single(out, send.contiguous(), group=self.group)
+        return out
+
+    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
 class RowExchange:
     """Routing of row ids / pooled rows / row gradients between ranks (device-agnostic)."""
 
-    def __init__(self, store: ShardedStore, group=None, backend=None):
+    def __init__(self, store: ShardedStore, group=None, backend=None, comm=None):
         self.store, self.group = store, group
-        self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.comm = comm or DistComm(group)
+        self.world, self.rank = self.comm.world, self.comm.rank
         self.backend = backend or HipBackend()
         self.E = store.E
 
@@ -212,7 +235,7 @@ class RowExchange:
         if self.world == 1 and __import__("os").environ.get("TT_DIST_FAKE_A2A"):     # fault hunting only
             return
         for g in flat_grads:                                                     # one call per tower
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            self.comm.all_reduce_sum(g)
 
 
 class PaddedRowExchange(RowExchange):
@@ -226,8 +249,8 @@ class PaddedRowExchange(RowExchange):
     device-side flag (`overflowed()`); its over-capacity rows were not exchanged, so the caller must re-calibrate
     (`reset_capacity()`) and redo the step -- bench.py checks the flag after the timed region."""
 
-    def __init__(self, store: ShardedStore, group=None, backend=None, capacity: Optional[int] = None, slack: float = 1.5):
-        super().__init__(store, group, backend)
+    def __init__(self, store: ShardedStore, group=None, backend=None, capacity: Optional[int] = None, slack: float = 1.5, comm=None):
+        super().__init__(store, group, backend, comm)
         if store.grad_mode != "sparse":
             raise ValueError("the fixed-capacity exchange needs embedding_grad='sparse' (its bucket pads are skipped by the "
                              "row-sparse Adam; a dense gradient buffer has no row for them)")
@@ -249,17 +272,14 @@ class PaddedRowExchange(RowExchange):
     def _a2a_equal(self, send: torch.Tensor) -> torch.Tensor:
         if self.world == 1 and __import__("os").environ.get("TT_DIST_FAKE_A2A"):     # fault hunting only
             return send.clone()
-        out = torch.empty_like(send)
-        dist.all_to_all_single(out, send.contiguous(), group=self.group)
-        return out
+        return self.comm.all_to_all_equal(send)
 
     def _calibrate(self, plan, dev):
         G = self.world
         probe = max(256, -(-plan.M // 256) * 256)                                 # generous probe capacity: counts only
         _, _, _, counts = self.backend.route_bucket(plan, G, probe, [self.local_rows_of(g) for g in range(G)], plan.M,
                                                     self.backend.new_flag(dev))
-        mx = counts.max().to(torch.int64).reshape(1)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        mx = self.comm.all_reduce_max(counts.max().to(torch.int64).reshape(1))
         need = int(mx.item())                                                     # the one host sync of the exchange
         self.C = max(256, -(-int(need * self.slack) // 256) * 256)
 

@@ -66,8 +66,13 @@ class GraphedTrainStep:
             self.graph = None
             return
         self.graph = torch.cuda.CUDAGraph()
+        # With a process group alive, its watchdog thread polls events while we capture; under the default "global" capture
+        # mode that poll is an error ("operation not permitted when stream is capturing") that aborts the process --
+        # now and then, depending on timing.  "thread_local" restricts the check to the capturing thread.
+        import torch.distributed as _dist
+        mode = "thread_local" if (_dist.is_available() and _dist.is_initialized()) else "global"
         try:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.result = self._body()
         finally:
             optimizer._hp_dev = None

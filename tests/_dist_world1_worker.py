@@ -1,0 +1,90 @@
+"""Worker of test_padded_exchange_graph_world1_subprocess (not collected by pytest: no test_ prefix).
+
+exact-size exchange (eager) == fixed-capacity exchange (eager) == fixed-capacity exchange captured as ONE graph with the RCCL
+all-to-alls / all-reduce inside, over a warm-up step + 4 steps with different batches (bf16 and fp32 MLP): same losses, final
+state equal to 1e-6.  Prints DIST_WORLD1_OK and leaves with os._exit (no communicator teardown)."""
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parents[1]
+for p in (ROOT, ROOT / "tests", ROOT / "oracle"):
+    sys.path.insert(0, str(p))
+import jodalrob_twotower_amd as tt  # noqa: E402
+from jodalrob_twotower_amd.distributed import create_distributed_train_task  # noqa: E402
+from jodalrob_twotower_amd.graph import GraphedTrainStep  # noqa: E402
+from jodalrob_twotower_amd.optim import FusedAdam  # noqa: E402
+from params_init import init_state_numpy, synth_batch_numpy  # noqa: E402
+
+DEV = "cuda:0"
+GOLD = ROOT / "tests" / "golden"
+
+
+def main():
+    import socket
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)     # never the parent's rendezvous port
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    cfg = dict(json.load(open(GOLD / "manifest.json"))["cases"]["wide_b40"])
+    cfg["B"] = 256
+
+    def to_batch(b):
+        return {"notice": {"dense": torch.from_numpy(b["notice_dense"]).to(DEV),
+                           "kjt": tt.build_batch_kjt(torch.from_numpy(b["notice_ids"]), cfg["keys_n"]).to(DEV)},
+                "company": {"dense": torch.from_numpy(b["company_dense"]).to(DEV),
+                            "kjt": tt.build_batch_kjt(torch.from_numpy(b["company_ids"]), cfg["keys_c"]).to(DEV)}}
+
+    batches = [to_batch(synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 790 + i, oob=True))
+               for i in range(4)]
+    for mlp in ("fp32", "bf16"):
+        finals, state = {}, None
+        for mode in ("exact", "padded", "padded-graph"):
+            t = create_distributed_train_task(
+                cfg["keys_n"], cfg["keys_c"], metadata_path=str(GOLD / "synthetic_metadata.csv"), categorical_embedding_dim=cfg["E"],
+                notice_dense_input_dim=cfg["din_n"], company_dense_input_dim=cfg["din_c"], tower_hidden_dims=list(cfg["hidden"]),
+                final_embedding_dim=cfg["D"], dropout_rate=0.0, temperature=cfg["T"], device=DEV, embedding_grad="sparse",
+                mlp_dtype=mlp, exchange="exact" if mode == "exact" else "padded")
+            if state is None:
+                shapes = {k: tuple(v.shape) for k, v in t.full_state_dict().items()}
+                state = {k: torch.from_numpy(np.asarray(v)) for k, v in init_state_numpy(shapes, 777).items()}
+            t.load_full_state_dict(state)
+            t.train()
+            o = FusedAdam.for_task(t, lr=1e-2, weight_decay=1e-5)
+            losses = []
+            if mode == "padded-graph":
+                gs = GraphedTrainStep(t, o, batches[0], warmup=1)       # the eager warm-up step calibrates the bucket capacity
+                for bt in batches:
+                    losses.append(gs.step(bt)["loss"].item())
+            else:
+                o.zero_grad(); t(batches[0], return_metrics=True)["loss"].backward(); o.step()     # the same warm-up step
+                for bt in batches:
+                    o.zero_grad()
+                    r = t(bt, return_metrics=True)
+                    r["loss"].backward()
+                    o.step()
+                    losses.append(r["loss"].item())
+            if mode != "exact":
+                assert not t.exchange.overflowed()
+            finals[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in t.full_state_dict().items()})
+        for mode in ("padded", "padded-graph"):
+            assert finals[mode][0] == finals["exact"][0], (mlp, mode, finals[mode][0], finals["exact"][0])
+            for k, v in finals["exact"][1].items():
+                np.testing.assert_allclose(finals[mode][1][k], v, rtol=1e-6, atol=1e-7, err_msg=f"{mlp}:{mode}:{k}")
+    print("DIST_WORLD1_OK", flush=True)
+
+
+if __name__ == "__main__":
+    try:
+        main()
+    except BaseException:
+        import traceback
+        traceback.print_exc()
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(1)
+    sys.stdout.flush()
+    os._exit(0)
