@@ -201,7 +201,8 @@ def main():
     ops.set_timer(None)
     lookup_us = profile.durations_us() if profile is not None else []
     dispatch_us = None
-    if profile is not None and dist is None:
+    if profile is not None:
+        # (sharded runs: the same procedure on the local shard -- the overhead is a property of the dispatch, not of the rows)
         dispatch_us = lookup_dispatch_overhead_us(task, pool, dev, profile)
     if profile is not None:
         profile.close()
@@ -302,7 +303,7 @@ def lookup_dispatch_overhead_us(task, pool, dev, profile, iters: int = 48):
     `mean_launch_us` is the quantity rocprofv3 --kernel-trace reports for this kernel."""
     from jodalrob_twotower_amd import ops
     towers = [task.two_tower_model.notice_tower, task.two_tower_model.company_tower]
-    store = towers[0].categorical_embedder.store
+    store = task.sharded_store if hasattr(task, "sharded_store") else towers[0].categorical_embedder.store
     sides_per_batch = []
     for batch in pool:
         sides = []
@@ -324,7 +325,9 @@ def lookup_dispatch_overhead_us(task, pool, dev, profile, iters: int = 48):
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     REP = 4                                                     # 4 x K launches per replay: the replay's own launch cost amortises
-    with torch.cuda.graph(g):
+    import torch.distributed as _d
+    mode = "thread_local" if _d.is_initialized() else "global"       # a process group's watchdog polls events from its own thread
+    with torch.cuda.graph(g, capture_error_mode=mode):
         keep = [ops.embed_lookup(store.weight, sides, B, want_rows=True) for _ in range(REP) for sides, B in sides_per_batch]
     ev_us = []
     for rep in range(6):
