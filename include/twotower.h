@@ -380,8 +380,9 @@ int tt_route_expand(tt_ctx* ctx, const int32_t* sorted_src, const int32_t* seg_o
  * Same outputs as tt_dedup_plan over the concatenated runs; workspace tt_dedup_workspace_bytes(G * C). */
 int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, int32_t* sorted_src, int32_t* unique_rows,
                        int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes, tt_stream stream);
-/* out[i, :] = table[clamp(rows[i], 0, table_rows - 1), :] -- the owner's gather of requested rows and the hand-over of
- * per-row gradients into the send buckets (E a multiple of 4, 16-byte aligned f32 buffers). */
+/* out[i, :] = rows[i] < 0 ? 0 : table[min(rows[i], table_rows - 1), :] -- the owner's gather of requested rows and the
+ * hand-over of per-row gradients into the send buckets, whose unused entries carry -1 (E a multiple of 4, 16-byte aligned
+ * f32 buffers). */
 int tt_gather_rows(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const int32_t* rows, int64_t n,
                    float* out, tt_stream stream);
 

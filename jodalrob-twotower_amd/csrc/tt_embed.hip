@@ -1398,15 +1398,16 @@ __global__ __launch_bounds__(kThreads) void route_scatter_kernel(const int32_t* 
   }
 }
 
-// out[i, :] = table[clamp(rows[i], 0, R - 1), :]   (16-byte lanes; the owner-side gather / gradient hand-over)
+// out[i, :] = rows[i] < 0 ? 0 : table[min(rows[i], R - 1), :]   (16-byte lanes; the owner-side gather / gradient hand-over)
 __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ rows, uint32_t n,
                                                               int32_t R, uint32_t C4, float* __restrict__ out) {
   const uint64_t total = (uint64_t)n * C4;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t i = (uint32_t)(t / C4), c = (uint32_t)(t - (uint64_t)i * C4);
     int32_t r = rows[i];
-    r = r < 0 ? 0 : (r >= R ? R - 1 : r);
-    reinterpret_cast<float4*>(out)[(uint64_t)i * C4 + c] = reinterpret_cast<const float4*>(table)[(uint64_t)r * C4 + c];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                  // negative index: a zero row (unused bucket entries)
+    if (r >= 0) v = reinterpret_cast<const float4*>(table)[(uint64_t)(r >= R ? R - 1 : r) * C4 + c];
+    reinterpret_cast<float4*>(out)[(uint64_t)i * C4 + c] = v;
   }
 }
 

@@ -152,7 +152,7 @@ class HipBackend:
         return ops.route_expand(plan, pos_u)
 
     def gather_rows(self, table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-        """out[i] = table[idx[i]] (idx int32, clamped into the table)"""
+        """out[i] = table[idx[i]] (idx int32; above the table: last row; negative: a zero row)"""
         return ops.gather_rows(table, idx)
 
     def owner_plan(self, recv_ids: torch.Tensor, local_rows: int, G: int = 1):
@@ -161,9 +161,8 @@ class HipBackend:
         return ops.dedup_plan_runs(recv_ids, G, recv_ids.numel() // G)
 
     def reduce_local(self, plan, srcs, B: int, E: int) -> torch.Tensor:
-        """[M + 1, E]: row u = summed gradient of plan row u, row M = 0 (the target of unused bucket entries)"""
-        out = torch.empty((plan.M + 1, E), dtype=torch.float32, device=plan.unique_rows.device)
-        out[plan.M].zero_()
+        """[M, E]: row u = summed gradient of plan row u (unused bucket entries carry u = -1: gather_rows gives them zeros)"""
+        out = torch.empty((max(plan.M, 1), E), dtype=torch.float32, device=plan.unique_rows.device)
         ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_SPARSE, out)
         return out
 
@@ -277,7 +276,7 @@ class PaddedRowExchange(RowExchange):
     def _calibrate(self, plan, dev):
         G = self.world
         probe = max(256, -(-plan.M // 256) * 256)                                 # generous probe capacity: counts only
-        _, _, _, counts = self.backend.route_bucket(plan, G, probe, [self.local_rows_of(g) for g in range(G)], plan.M,
+        _, _, _, counts = self.backend.route_bucket(plan, G, probe, [self.local_rows_of(g) for g in range(G)], -1,
                                                     self.backend.new_flag(dev))
         mx = self.comm.all_reduce_max(counts.max().to(torch.int64).reshape(1))
         need = int(mx.item())                                                     # the one host sync of the exchange
@@ -292,7 +291,7 @@ class PaddedRowExchange(RowExchange):
         pads = [self.local_rows_of(g) for g in range(G)]
         if self._overflow is None:
             self._overflow = be.new_flag(rows.device)
-        send_ids, send_u, pos_u, _counts = be.route_bucket(plan, G, self.C, pads, plan.M, self._overflow)
+        send_ids, send_u, pos_u, _counts = be.route_bucket(plan, G, self.C, pads, -1, self._overflow)
         recv_ids = self._a2a_equal(send_ids)                                     # [G*C] local row ids, pad = my local_rows
         pooled_local = be.gather_rows(self.store.weight, recv_ids)               # pads clamp to the last row (unused)
         got = self._a2a_equal(pooled_local)                                      # [G*C, E] in my send order

@@ -490,7 +490,7 @@ def route_bucket(plan: DedupPlan, G: int, C: int, pad_id: Sequence[int], pad_u: 
 
 
 def gather_rows(table: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
-    """out[i] = table[clamp(rows[i])]  (rows int32)."""
+    """out[i] = 0 if rows[i] < 0 else table[min(rows[i], R - 1)]  (rows int32)."""
     dev, n, E = table.device, rows.numel(), table.shape[1]
     out = torch.empty((n, E), dtype=torch.float32, device=dev)
     with _timed("tt_gather_rows"):

@@ -91,7 +91,9 @@ class CheckerBackend:
         return idx
 
     def gather_rows(self, table, idx):
-        return table[torch.clamp(idx.long(), 0, table.shape[0] - 1)].clone()
+        out = table[torch.clamp(idx.long(), 0, table.shape[0] - 1)].clone()
+        out[idx < 0] = 0
+        return out
 
     def owner_plan(self, recv_ids, local_rows, G=1):
         runs = recv_ids.view(G, -1)
@@ -100,7 +102,7 @@ class CheckerBackend:
 
     def reduce_local(self, plan, srcs, B, E):
         flat = torch.cat([d.reshape(B * K, E) for d, K in srcs])
-        out = torch.zeros((plan.M + 1, E))
+        out = torch.zeros((max(plan.M, 1), E))
         for u in range(int(plan.n_unique)):
             sl = plan.sorted_src[int(plan.seg_offsets[u]):int(plan.seg_offsets[u + 1])].long()
             out[u] = flat[sl].sum(0)

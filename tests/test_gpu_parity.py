@@ -664,7 +664,9 @@ def test_gather_rows(tt):
     table = torch.randn(1000, 32, generator=g).to(DEV)
     idx = torch.randint(-5, 1010, (4097,), generator=g, dtype=torch.int32).to(DEV)
     out = ops.gather_rows(table, idx)
-    assert torch.equal(out, table[idx.long().clamp(0, 999)])
+    exp = table[idx.long().clamp(0, 999)].clone()
+    exp[idx < 0] = 0                                         # negative index: a zero row (unused bucket entries)
+    assert torch.equal(out, exp)
 
 
 def test_full_size_properties(tt, schema_real):
@@ -775,8 +777,8 @@ def test_route_bucket_and_expand(tt, G, M, U, C):
                          torch.tensor([U], dtype=torch.int32, device=DEV), M)
     pads = [1_000_000 + g for g in range(G)]
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
-    send_ids, send_u, pos_u, counts = ops.route_bucket(plan, G, C, pads, M, flag)
-    e_ids = np.repeat(np.asarray(pads, np.int32), C); e_u = np.full(G * C, M, np.int32)
+    send_ids, send_u, pos_u, counts = ops.route_bucket(plan, G, C, pads, -1, flag)
+    e_ids = np.repeat(np.asarray(pads, np.int32), C); e_u = np.full(G * C, -1, np.int32)
     e_pos = np.zeros(U, np.int32); cnt = np.zeros(G, np.int64)
     for u in range(U):
         g = int(uniq[u]) % G
