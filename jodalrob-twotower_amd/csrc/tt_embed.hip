@@ -237,98 +237,6 @@ __global__ __launch_bounds__(kThreads) void lookup_profile_reduce_kernel(unsigne
   }
 }
 
-// Software-pipelined form: a wave walks several 64-slot chunks and issues the row loads of chunk i+1
-// BEFORE the stores of chunk i, so HBM reads and writes of one wave overlap (two register / LDS sets).
-template <int C>
-__device__ __forceinline__ void lk_decode(const SideSet& a, const float* __restrict__ table, int32_t* __restrict__ rows_out,
-                                          uint32_t chunk, uint32_t lane, SlotRec* recs, int* dts) {
-  const uint32_t slot = chunk * 64 + lane;
-  SlotRec rec{nullptr, nullptr};
-  int dt = TT_F32;
-  if (slot < a.total_slots) {
-    const int si = side_of(a, slot);
-    const SideDev& s = a.s[si];
-    const uint32_t local = slot - s.slot_base;
-    const uint32_t b = local / (uint32_t)s.K;
-    const uint32_t k = local - b * (uint32_t)s.K;
-    int64_t id = s.ids[local];
-    const int64_t hi = s.vocab[k] - 1;
-    id = id < 0 ? 0 : (id > hi ? hi : id);
-    const int64_t row = s.off[k] + id;
-    if (rows_out) rows_out[slot] = (int32_t)row;
-    rec.src = table + row * a.E;
-    dt = s.dtype;
-    rec.dst = s.out + ((int64_t)b * s.ld + (int64_t)k * a.E) * (dt == TT_BF16 ? 2 : 4);
-  }
-  recs[lane] = rec;
-  dts[lane] = dt;
-}
-
-template <int C>
-__device__ __forceinline__ void lk_gather(const SlotRec* recs, uint32_t sub, uint32_t part, float4 (&v)[C]) {
-#pragma unroll
-  for (int j = 0; j < C; ++j) {
-    const SlotRec r = recs[j * (64 / C) + sub];
-    v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r.src != nullptr) v[j] = *reinterpret_cast<const float4*>(r.src + part * 4);
-  }
-}
-
-template <int C>
-__device__ __forceinline__ void lk_store(const SlotRec* recs, const int* dts, uint32_t sub, uint32_t part, const float4 (&v)[C]) {
-#pragma unroll
-  for (int j = 0; j < C; ++j) {
-    const SlotRec r = recs[j * (64 / C) + sub];
-    if (r.dst == nullptr) continue;
-    if (dts[j * (64 / C) + sub] == TT_F32) {
-      f32x4n t;
-      t[0] = v[j].x; t[1] = v[j].y; t[2] = v[j].z; t[3] = v[j].w;
-      __builtin_nontemporal_store(t, reinterpret_cast<f32x4n*>(r.dst + part * 16));
-    } else {
-      ushort4 o;
-      o.x = tt_f2bf(v[j].x); o.y = tt_f2bf(v[j].y); o.z = tt_f2bf(v[j].z); o.w = tt_f2bf(v[j].w);
-      *reinterpret_cast<ushort4*>(r.dst + part * 8) = o;
-    }
-  }
-}
-
-template <int C>
-__global__ __launch_bounds__(kThreads) void lookup_pipe_kernel(SideSet a, const float* __restrict__ table,
-                                                              int32_t* __restrict__ rows_out) {
-  __shared__ SlotRec recs[2][kThreads / 64][64];
-  __shared__ int dts[2][kThreads / 64][64];
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t sub = lane / C, part = lane % C;
-  const uint32_t nchunks = (a.total_slots + 63) / 64;
-  const uint32_t wstride = gridDim.x * (kThreads / 64);
-  uint32_t chunk = blockIdx.x * (kThreads / 64) + wave;
-  if (chunk >= nchunks) return;
-  float4 va[C], vb[C];
-  lk_decode<C>(a, table, rows_out, chunk, lane, recs[0][wave], dts[0][wave]);
-  __builtin_amdgcn_wave_barrier();
-  lk_gather<C>(recs[0][wave], sub, part, va);
-  while (true) {
-    // ---- B: next chunk's loads, then A's stores
-    uint32_t next = chunk + wstride;
-    if (next >= nchunks) { lk_store<C>(recs[0][wave], dts[0][wave], sub, part, va); return; }
-    lk_decode<C>(a, table, rows_out, next, lane, recs[1][wave], dts[1][wave]);
-    __builtin_amdgcn_wave_barrier();
-    lk_gather<C>(recs[1][wave], sub, part, vb);
-    lk_store<C>(recs[0][wave], dts[0][wave], sub, part, va);
-    __builtin_amdgcn_wave_barrier();
-    chunk = next;
-    // ---- A: next chunk's loads, then B's stores
-    next = chunk + wstride;
-    if (next >= nchunks) { lk_store<C>(recs[1][wave], dts[1][wave], sub, part, vb); return; }
-    lk_decode<C>(a, table, rows_out, next, lane, recs[0][wave], dts[0][wave]);
-    __builtin_amdgcn_wave_barrier();
-    lk_gather<C>(recs[0][wave], sub, part, va);
-    lk_store<C>(recs[1][wave], dts[1][wave], sub, part, vb);
-    __builtin_amdgcn_wave_barrier();
-    chunk = next;
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Dedup plan: LSD radix sort (BITS per pass) of (row, slot) pairs.
 //   hist    : per-tile digit histogram        -> hist[digit * nblk + tile]
@@ -376,36 +284,6 @@ __global__ __launch_bounds__(kThreads) void sort_colscan_kernel(uint32_t* __rest
     run += t;
   }
   if (seg == 3) total[d] = run;
-}
-
-// in-place exclusive scan of n uint32 by ONE workgroup of 1024 threads; optional total output
-__global__ __launch_bounds__(1024) void scan_kernel(uint32_t* __restrict__ data, uint32_t n, int32_t* __restrict__ total_out) {
-  __shared__ uint32_t wsum[16];
-  const uint32_t tid = threadIdx.x;
-  const uint32_t per = (n + 1023u) / 1024u;
-  const uint32_t lo = tid * per < n ? tid * per : n;
-  const uint32_t hi = lo + per < n ? lo + per : n;
-  uint32_t s = 0;
-  for (uint32_t i = lo; i < hi; ++i) s += data[i];
-  // inclusive scan of s over the 1024 threads
-  uint32_t x = s;
-  const uint32_t lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t y = __shfl_up(x, o);
-    if (lane >= (uint32_t)o) x += y;
-  }
-  if (lane == 63) wsum[wave] = x;
-  __syncthreads();
-  uint32_t woff = 0;
-  for (uint32_t w = 0; w < wave; ++w) woff += wsum[w];
-  uint32_t run = woff + x - s;                  // exclusive prefix of this thread's range
-  for (uint32_t i = lo; i < hi; ++i) {
-    const uint32_t t = data[i];
-    data[i] = run;
-    run += t;
-  }
-  if (total_out && tid == 1023) *total_out = (int32_t)(woff + x);
 }
 
 template <int BITS>
@@ -1549,14 +1427,6 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
   constexpr int U = 4;
   static const int variant = getenv("TT_LOOKUP_VARIANT") ? atoi(getenv("TT_LOOKUP_VARIANT")) : 0;
   const bool pow2c = vec4 && table && C <= 64 && (C & (C - 1)) == 0;
-  static const int cpw = getenv("TT_LOOKUP_CPW") ? atoi(getenv("TT_LOOKUP_CPW")) : 0;
-  if (pow2c && cpw > 0 && C == 8) {
-    const int64_t nchunks = tt_cdiv(slots, 64);
-    const int grid = (int)tt_cdiv(nchunks, (int64_t)(kThreads / 64) * cpw);
-    lookup_pipe_kernel<8><<<grid, kThreads, 0, st>>>(a, table, rows_out);
-    TT_LAUNCH_CHECK();
-    return TT_OK;
-  }
   if (pow2c && variant != 1) {
     static const int spw_env = getenv("TT_LOOKUP_SPW") ? atoi(getenv("TT_LOOKUP_SPW")) : 0;
     const int rpi = 64 / (int)C;

@@ -228,17 +228,6 @@ __global__ __launch_bounds__(kThreads) void score_dir_bwd_kernel(const float* __
 }
 
 // loss + metrics from the per-row results of both directions (one workgroup, fixed-order sums)
-__device__ __forceinline__ float block_sum(float x, float* sh) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
-  __syncthreads();
-  float s = 0.f;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
-  return s;
-}
-
 __global__ __launch_bounds__(1024) void loss_finish_kernel(int64_t B, float shift, const float* __restrict__ rowsum,
                                                            const float* __restrict__ colsum, const float* __restrict__ diag,
                                                            const int32_t* __restrict__ row_rank, const int32_t* __restrict__ col_rank,
