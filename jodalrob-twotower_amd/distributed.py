@@ -185,6 +185,12 @@ class DistComm:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
+    def all_gather(self, t: torch.Tensor) -> torch.Tensor:
+        """[world * n, ...] in rank order"""
+        out = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
+
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
@@ -307,11 +313,57 @@ class PaddedRowExchange(RowExchange):
         be.owner_accumulate(self.store, state["owner_plan"], d_rows)
 
 
+class _GlobalScoreCEFn(torch.autograd.Function):
+    """In-batch negatives over the GLOBAL batch (two_tower_train_task.py:99-134 at B_global = world * B): every rank scores
+    its B notice rows against all world*B company rows (and its company rows against all notices).  Collectives: all-gather
+    of both towers' outputs (forward) and of the per-row softmax sums (2 floats per pair); NO gradient collective -- the
+    weight E * (1/sum_a + 1/sum_b) that the backward kernel applies already holds the terms in which a local row is some
+    other rank's negative, because sum_b is the gathered sum of the row's owner.  bf16-operand MFMA path only."""
+
+    @staticmethod
+    def forward(ctx, n, c, inv_t, comm):
+        n, c = n.contiguous().float(), c.contiguous().float()
+        B, D = n.shape
+        G, off = comm.world, comm.rank * B
+        shift = abs(inv_t)
+        n_all, c_all = comm.all_gather(n), comm.all_gather(c)
+        Np, Cp = ops.score_pack2_bf16(n, c)
+        NpA, CpA = ops.score_pack2_bf16(n_all, c_all)
+        rs1, rs2, diag, rk1, rk2, ss = ops.score_fwd_bf16_rect(Np, CpA, Cp, NpA, B, G * B, off, D, inv_t, shift, True)
+        out8, loss = ops.score_loss_finish(B, shift, rs1, rs2, diag, rk1, rk2, ss)
+        out8 = out8.clone()
+        neg = (out8[6] - out8[2] * B) / float(B * G * B - B)      # mean over the off-diagonal of the B x (G*B) block
+        out8[3], out8[4] = neg, out8[2] - neg
+        ctx.packed = (Np, Cp, NpA, CpA)
+        ctx.save_for_backward(rs1, rs2, comm.all_gather(rs1), comm.all_gather(rs2))
+        ctx.inv_t, ctx.shift, ctx.dims = inv_t, shift, (B, G * B, off, D)
+        ctx.mark_non_differentiable(out8, rk1)
+        ctx.set_materialize_grads(False)
+        return loss, out8, rk1
+
+    @staticmethod
+    def backward(ctx, d_loss, _d8, _dr):
+        if d_loss is None:
+            return None, None, None, None
+        rs1, rs2, rs1_all, rs2_all = ctx.saved_tensors
+        B, Rb, off, D = ctx.dims
+        Np, Cp, NpA, CpA = ctx.packed
+        if d_loss.dtype != torch.float32 or not d_loss.is_contiguous():
+            d_loss = d_loss.contiguous().float()
+        dN, dC = ops.score_bwd_bf16_rect(Np, CpA, Cp, NpA, B, Rb, off, D, ctx.inv_t, ctx.shift, rs1, rs2_all, rs2, rs1_all, d_loss,
+                                         ctx.inv_t / (2.0 * B))
+        return dN, dC, None, None
+
+
 class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
     """TwoTowerTrainTask whose tables are row-wise sharded over the process group."""
 
-    def __init__(self, two_tower_model: TwoTowerModel, store: ShardedStore, group=None, backend=None, exchange: str = "exact", **kw):
+    def __init__(self, two_tower_model: TwoTowerModel, store: ShardedStore, group=None, backend=None, exchange: str = "exact",
+                 negatives: str = "local", **kw):
         super().__init__(two_tower_model, **kw)
+        if negatives not in ("local", "global"):
+            raise ValueError(f"negatives must be 'local' or 'global', got {negatives!r}")
+        self.negatives = negatives
         self.sharded_store = store
         self.embedding_shard = store.shard_param                       # registered => in .parameters()
         if exchange not in ("exact", "padded"):
@@ -324,6 +376,13 @@ class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
         for b in self.buffers():
             if b.is_floating_point():
                 dist.broadcast(b, src=0, group=group)
+
+    def _score_ce(self, n, c, inv_t, first_call):
+        if self.negatives == "global" and self.exchange.world > 1:
+            if self.score_dtype != "bf16":
+                raise NotImplementedError("global in-batch negatives run on the bf16 score kernels (score_dtype='bf16')")
+            return _GlobalScoreCEFn.apply(n, c, inv_t, self.exchange.comm)
+        return super()._score_ce(n, c, inv_t, first_call)
 
     def _dense_parameters(self):
         return [p for n, p in self.named_parameters() if n != "embedding_shard"]
@@ -370,7 +429,8 @@ def create_distributed_train_task(notice_categorical_keys, company_categorical_k
                                   company_dense_input_dim: int = 128, tower_hidden_dims=None, final_embedding_dim: int = 128,
                                   dropout_rate: float = 0.2, temperature: float = 1.0, loss_type: str = "cross_entropy",
                                   device="cuda:0", embedding_grad: Optional[str] = "sparse", score_dtype=None, mlp_dtype=None,
-                                  group=None, backend=None, seed: int = 0, exchange: str = "exact") -> DistributedTwoTowerTrainTask:
+                                  group=None, backend=None, seed: int = 0, exchange: str = "exact",
+                                  negatives: str = "local") -> DistributedTwoTowerTrainTask:
     """Same arguments as create_two_tower_train_task; requires an initialised process group."""
     if not dist.is_initialized():
         raise RuntimeError("create_distributed_train_task needs torch.distributed.init_process_group first")
@@ -388,5 +448,6 @@ def create_distributed_train_task(notice_categorical_keys, company_categorical_k
     ce.set_row_base(ne.total_rows)
     store = ShardedStore(categorical_embedding_dim, ne.total_rows + ce.total_rows, dist.get_rank(group),
                          dist.get_world_size(group), torch.device(device), embedding_grad or "sparse", seed)
-    return DistributedTwoTowerTrainTask(model, store, group=group, backend=backend, exchange=exchange, temperature=temperature,
+    return DistributedTwoTowerTrainTask(model, store, group=group, backend=backend, exchange=exchange, negatives=negatives,
+                                        temperature=temperature,
                                         loss_type=loss_type, score_dtype=score_dtype)

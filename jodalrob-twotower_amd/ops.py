@@ -416,6 +416,38 @@ def score_bwd_bf16(Np, Cp, B, D, inv_t, shift, rowsum, colsum, d_loss, scale):
     return dN, dC
 
 
+def score_fwd_bf16_rect(Ap0, Bp0, Ap1, Bp1, Ra, Rb, off, D, inv_t, shift, full_rank=True):
+    """Rectangular form (global in-batch negatives): direction 0 = rows of A0 [Ra] against all rows of B0 [Rb], direction 1 =
+    rows of A1 [Ra] against B1 [Rb]; the positive of local row a sits at column a + off.  Returns (sumexp0, sumexp1, diag,
+    rank0, rank1, sumscore0)."""
+    dev = Ap0.device
+    Rp = (Ra + 3) // 4 * 4
+    f = torch.empty((4, Rp), dtype=torch.float32, device=dev)
+    ranks = torch.empty((2, Ra), dtype=torch.int32, device=dev)
+    arr = (L.ScoreFwdDir * 2)()
+    rm = 2 if full_rank else 1
+    arr[0] = L.ScoreFwdDir(L.ptr(Ap0), L.ptr(Bp0), Ra, Rb, off, L.ptr(f[0]), L.ptr(f[2]), L.ptr(ranks[0]), L.ptr(f[3]), rm)
+    arr[1] = L.ScoreFwdDir(L.ptr(Ap1), L.ptr(Bp1), Ra, Rb, off, L.ptr(f[1]), None, L.ptr(ranks[1]), None, rm)
+    with _timed("tt_score_fwd_bf16"):
+        L.check(L.load().tt_score_fwd_bf16(L.ctx(dev), arr, 2, D, inv_t, shift, L.stream(dev)), "tt_score_fwd_bf16")
+    return f[0][:Ra], f[1][:Ra], f[2][:Ra], ranks[0], ranks[1], f[3][:Ra]
+
+
+def score_bwd_bf16_rect(Ap0, Bp0, Ap1, Bp1, Ra, Rb, off, D, inv_t, shift, sa0, sb0, sa1, sb1, d_loss, scale):
+    """dA0 [Ra, D], dA1 [Ra, D]: sa* = sum-exp of the A rows (this direction), sb* = sum-exp of the B rows in the OTHER
+    direction (all Rb of them: gathered from their owners)."""
+    dev = Ap0.device
+    d0 = torch.empty((Ra, D), dtype=torch.float32, device=dev)
+    d1 = torch.empty((Ra, D), dtype=torch.float32, device=dev)
+    arr = (L.ScoreBwdDir * 2)()
+    arr[0] = L.ScoreBwdDir(L.ptr(Ap0), L.ptr(Bp0), Ra, Rb, off, L.ptr(sa0), L.ptr(sb0), L.ptr(d0))
+    arr[1] = L.ScoreBwdDir(L.ptr(Ap1), L.ptr(Bp1), Ra, Rb, off, L.ptr(sa1), L.ptr(sb1), L.ptr(d1))
+    with _timed("tt_score_bwd_bf16"):
+        L.check(L.load().tt_score_bwd_bf16(L.ctx(dev), arr, 2, D, inv_t, shift, L.ptr(d_loss), scale, L.stream(dev)),
+                "tt_score_bwd_bf16")
+    return d0, d1
+
+
 def score_matrix(A, Bm, inv_t):
     dev, Ra, Rb, D = A.device, A.shape[0], Bm.shape[0], A.shape[1]
     S = torch.empty((Ra, Rb), dtype=torch.float32, device=dev)

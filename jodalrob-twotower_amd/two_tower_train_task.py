@@ -130,8 +130,8 @@ class TwoTowerTrainTask(nn.Module):
         if nb != cb:                                                                         # :64-67
             raise ValueError(f"Notice와 Company 배치 크기가 다릅니다: {nb} vs {cb}")
         notice_embeddings, company_embeddings = self.two_tower_model(notice_input, company_input)
-        loss, out8, _ = _ScoreCEFn.apply(notice_embeddings, company_embeddings, 1.0 / float(self.temperature), self.score_dtype,
-                                         not hasattr(self, "_pair_check_done"), False)
+        loss, out8, _ = self._score_ce(notice_embeddings, company_embeddings, 1.0 / float(self.temperature),
+                                       not hasattr(self, "_pair_check_done"))
         if not hasattr(self, "_pair_check_done"):                                            # :82-84
             self._verify_positive_pair_alignment(out8)
             self._pair_check_done = True
@@ -144,6 +144,10 @@ class TwoTowerTrainTask(nn.Module):
         if nb <= LAZY_SIM_BATCH:
             res._materialise()
         return res
+
+    def _score_ce(self, n, c, inv_t, first_call):
+        """(loss, out8, row_rank) of the symmetric in-batch-negative softmax-CE (:99-134); the sharded task overrides it."""
+        return _ScoreCEFn.apply(n, c, inv_t, self.score_dtype, first_call, False)
 
     def _compute_similarity_matrix(self, notice_embeddings, company_embeddings):                # :99-112
         return self.two_tower_model.compute_similarity(notice_embeddings, company_embeddings, self.temperature)

@@ -817,6 +817,9 @@ class _ThreadComm:
     def all_reduce_max(self, t):
         return torch.stack(self._exchange(t.clone())).max(0).values
 
+    def all_gather(self, t):
+        return torch.cat(self._exchange(t.contiguous())).clone()
+
     def all_reduce_sum(self, t):
         t.copy_(torch.stack(self._exchange(t.clone())).sum(0))
         return t
@@ -890,3 +893,50 @@ def test_padded_exchange_multi_rank_on_one_gpu(tt, G):
         got[r["uniq"][real]] = r["grads"][real]
         np.testing.assert_allclose(got, mine, rtol=1e-5, atol=1e-5)
         assert set(np.flatnonzero(np.abs(mine).sum(1) > 0)) <= set(r["uniq"][real].tolist())
+
+
+@pytest.mark.parametrize("G,B,D", [(2, 300, 64), (3, 129, 32), (4, 256, 64)])
+def test_global_negatives_equal_single_process(tt, G, B, D):
+    """Global in-batch negatives on G virtual ranks == the single-process loss over the concatenated batch of G*B pairs
+    (the reference's semantics at the global batch): loss = mean of the ranks' losses, every rank's gradient = G x its
+    slice of the single-process gradient (the towers scale by 1/G afterwards), metrics from the same rows."""
+    import threading
+    from jodalrob_twotower_amd.distributed import _GlobalScoreCEFn
+    from jodalrob_twotower_amd.two_tower_train_task import _ScoreCEFn
+    g = torch.Generator().manual_seed(G * 100 + B)
+    n_all = torch.nn.functional.normalize(torch.randn(G * B, D, generator=g), dim=1).to(DEV)
+    c_all = torch.nn.functional.normalize(n_all.cpu() + 0.7 * torch.randn(G * B, D, generator=g), dim=1).to(DEV)
+    inv_t = 2.0
+    ns, cs = n_all.clone().requires_grad_(True), c_all.clone().requires_grad_(True)
+    loss_s, out_s, _ = _ScoreCEFn.apply(ns, cs, inv_t, "bf16", True, True)
+    loss_s.backward()
+    shared = {"slots": [None] * G, "bar": threading.Barrier(G)}
+    res, errors = [None] * G, []
+
+    def rank_fn(r):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=DEV)):
+                n = n_all[r * B:(r + 1) * B].clone().requires_grad_(True)
+                c = c_all[r * B:(r + 1) * B].clone().requires_grad_(True)
+                loss, out8, rank = _GlobalScoreCEFn.apply(n, c, inv_t, _ThreadComm(G, r, shared))
+                loss.backward()
+                torch.cuda.current_stream().synchronize()
+                res[r] = (loss.item(), n.grad.cpu(), c.grad.cpu(), out8.cpu(), rank.cpu())
+        except Exception:                                       # pragma: no cover
+            import traceback
+            errors.append(traceback.format_exc())
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(G)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors[0]
+    np.testing.assert_allclose(np.mean([x[0] for x in res]), loss_s.item(), rtol=2e-6)
+    for r, (l, dn, dc, out8, rank) in enumerate(res):
+        torch.testing.assert_close(dn, G * ns.grad[r * B:(r + 1) * B].cpu(), rtol=2e-5, atol=2e-7)
+        torch.testing.assert_close(dc, G * cs.grad[r * B:(r + 1) * B].cpu(), rtol=2e-5, atol=2e-7)
+    acc = np.mean([float(x[3][1]) for x in res])
+    np.testing.assert_allclose(acc, float(out_s[1]), rtol=1e-6)                     # row top-1 rate over the global batch
+    np.testing.assert_allclose(np.mean([float(x[3][3]) for x in res]), float(out_s[3]), rtol=1e-4, atol=1e-6)   # negative mean
