@@ -209,7 +209,11 @@ typedef struct tt_tower_params {
                             round it to bf16 anyway, so results are bit-identical and x costs half the HBM bytes) */
   int32_t dx_dtype;      /* element type of tt_tower_grads.d_x (TT_BF16 only with compute_dtype TT_BF16; the per-slot row
                             gradients are then rounded to bf16 before tt_embed_grad_bwd sums them in f32) */
+  int32_t flags;         /* TT_TOWER_*: 0 by default */
 } tt_tower_params;
+/* run the tail of a training pass (BN of the last block, output Linear, L2 normalise) as the separate kernels even when
+   the fused form applies (last hidden width and d_out <= 64, compute_dtype TT_BF16): for A/B comparison */
+#define TT_TOWER_UNFUSED_TAIL 1
 
 typedef struct tt_tower_acts { /* caller-allocated; kept between forward and backward */
   const float* dense;          /* [B, din] */

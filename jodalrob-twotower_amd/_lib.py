@@ -18,6 +18,7 @@ LIB_PATH = _PKG / "libtwotower_hip.so"
 TT_F32, TT_BF16 = 0, 1
 TT_MAX_SIDES, TT_MAX_HIDDEN = 4, 8
 TT_GRAD_SPARSE, TT_GRAD_DENSE_SET, TT_GRAD_DENSE_ACC = 0, 1, 2
+TT_TOWER_UNFUSED_TAIL = 1
 
 vp = C.c_void_p
 i32, i64, f32, u64, sz = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -54,7 +55,7 @@ class TowerParams(C.Structure):
                 ("hidden", i32 * TT_MAX_HIDDEN),
                 ("w_proj", vp), ("b_proj", vp), ("w", _H), ("b", _H), ("bn_w", _H), ("bn_b", _H),
                 ("bn_rm", _H), ("bn_rv", _H), ("bn_nbt", _H), ("w_out", vp), ("b_out", vp), ("compute_dtype", i32),
-                ("x_dtype", i32), ("dx_dtype", i32)]
+                ("x_dtype", i32), ("dx_dtype", i32), ("flags", i32)]
 
 
 class TowerActs(C.Structure):

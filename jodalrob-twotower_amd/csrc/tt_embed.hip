@@ -766,6 +766,9 @@ __device__ __forceinline__ void load_grad_chunk(const SideSet& a, uint32_t slot,
 //   decodes (kBatch / LGT each) and hand the addresses round with ds_bpermute, instead of all decoding all.
 //   LGT == 0: every lane decodes every slot (any group width).
 constexpr int kBatch = 16;
+#define TT_GLOBAL __attribute__((address_space(1)))
+using tt_u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using tt_u32x2 = __attribute__((ext_vector_type(2))) uint32_t;
 
 __device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src, int width) {
   const uint32_t lo = __shfl((uint32_t)v, src, width), hi = __shfl((uint32_t)(v >> 32), src, width);
@@ -794,36 +797,40 @@ __device__ __forceinline__ void sum_range(const SideSet& a, const int32_t* __res
         const int32_t s = i + kBatch + p * LGT + (int32_t)lig;
         idx[p] = s < hi ? sorted_src[s] : 0;
       }
-      float t[kBatch][VEC];
+      // raw bits first, decode after the last load: a bf16 -> f32 convert inside the `j < n` branch makes the
+      // compiler wait for each load where it stands (vmcnt(0) per slot: 27 us against 14 for the kernel)
+      constexpr int RW = VEC * ESZ >= 4 ? VEC * ESZ / 4 : 1;
+      uint32_t raw[kBatch][RW];
 #pragma unroll
       for (int j = 0; j < kBatch; ++j) {
-        const char* ptr = reinterpret_cast<const char*>(shfl_u64(mine[j / LGT], j % LGT, LGT)) + (size_t)chunk * VEC * ESZ;
+        const uint64_t ptr = shfl_u64(mine[j / LGT], j % LGT, LGT) + (uint64_t)chunk * VEC * ESZ;
         if (j < n) {
-          if (DT == TT_F32) {
-            if (VEC == 4) {
-              const float4 q = *reinterpret_cast<const float4*>(ptr);
-              t[j][0] = q.x; t[j][1 % VEC] = q.y; t[j][2 % VEC] = q.z; t[j][3 % VEC] = q.w;
-            } else {
-              t[j][0] = *reinterpret_cast<const float*>(ptr);
-            }
+          if (RW == 4) {
+            const tt_u32x4 q = *reinterpret_cast<const TT_GLOBAL tt_u32x4*>(ptr);
+            raw[j][0] = q.x; raw[j][1 % RW] = q.y; raw[j][2 % RW] = q.z; raw[j][3 % RW] = q.w;
+          } else if (RW == 2) {
+            const tt_u32x2 q = *reinterpret_cast<const TT_GLOBAL tt_u32x2*>(ptr);
+            raw[j][0] = q.x; raw[j][1 % RW] = q.y;
+          } else if (ESZ == 4) {
+            raw[j][0] = *reinterpret_cast<const TT_GLOBAL uint32_t*>(ptr);
           } else {
-            if (VEC == 4) {
-              const ushort4 q = *reinterpret_cast<const ushort4*>(ptr);
-              t[j][0] = tt_bf2f(q.x); t[j][1 % VEC] = tt_bf2f(q.y); t[j][2 % VEC] = tt_bf2f(q.z); t[j][3 % VEC] = tt_bf2f(q.w);
-            } else {
-              t[j][0] = tt_bf2f(*reinterpret_cast<const uint16_t*>(ptr));
-            }
+            raw[j][0] = *reinterpret_cast<const TT_GLOBAL uint16_t*>(ptr);
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) t[j][e] = 0.f;
+          for (int e = 0; e < RW; ++e) raw[j][e] = 0u;
         }
       }
 #pragma unroll
       for (int j = 0; j < kBatch; ++j)
         if (j < n) {
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) acc.v[e] += t[j][e];
+          for (int e = 0; e < VEC; ++e) {
+            float f;
+            if (DT == TT_F32) f = __uint_as_float(raw[j][e % RW]);
+            else f = __uint_as_float((e & 1) ? (raw[j][(e / 2) % RW] & 0xffff0000u) : (raw[j][(e / 2) % RW] << 16));
+            acc.v[e] += f;
+          }
         }
     }
     return;

@@ -12,7 +12,11 @@ struct GemmNT {
   // bf16 path only: A / C actually point at bf16 elements (lda / ldc in elements); the rounding the MFMA operand
   // needs anyway then happens where the tensor is produced, and the tensor costs half the HBM bytes
   bool a_bf16 = false, c_bf16 = false;
+  // optional (all problems of a launch or none): the caller finishes a split-K launch itself (bias included) from the
+  // slabs described here instead of this launcher's slab-reduction pass; splits == 0 means C was written directly
+  struct NtDeferred* defer = nullptr;
 };
+struct NtDeferred { const float* slabs; int64_t slab_stride; int splits; };
 size_t tt_gemm_nt_workspace_bytes(int64_t M, int64_t N, int64_t K);
 int tt_gemm_nt_batched(hipStream_t st, const GemmNT* items, int n);
 int tt_gemm_nt(hipStream_t st, const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, float* C,
@@ -41,3 +45,6 @@ TnPending* tt_gemm_tn_pending_create();
 void tt_gemm_tn_pending_destroy(TnPending*);
 int tt_gemm_tn_batched(hipStream_t st, const GemmTN* items, int n, TnPending* pending = nullptr);
 int tt_gemm_tn_flush(hipStream_t st, TnPending* pending);
+// queue the reduction of slabs a caller's own kernel wrote: C[M,N] = sum_z slabs[z], colsum_out[M] = sum_z colsum_slab[z]
+int tt_gemm_tn_pending_add(TnPending* pending, const float* slabs, int64_t slab_stride, int splits, float* C, int64_t ldc, int M, int N,
+                           const float* colsum_slab, float* colsum_out);

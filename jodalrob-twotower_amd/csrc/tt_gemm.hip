@@ -432,6 +432,15 @@ int tt_gemm_nt_batched(hipStream_t st, const GemmNT* it, int n) {
   }
   if (!m) return TT_OK;
   if (int rc = launch_gemm<0, 0>(st, b, m, zsplits, vec, false, it[0].bf16)) return rc;
+  if (it[0].defer) {
+    for (int i = 0, k = 0; i < n; ++i) {
+      if (!it[i].defer) { tt_set_error("tt_gemm_nt: defer must be set on every problem of a launch"); return TT_ERR_INVALID_ARG; }
+      if (it[i].M == 0 || it[i].N == 0) { *it[i].defer = NtDeferred{nullptr, 0, 0}; continue; }
+      *it[i].defer = any_split ? NtDeferred{sb.a[k].slabs, sb.a[k].slab_stride, sb.a[k].splits} : NtDeferred{nullptr, 0, 0};
+      ++k;
+    }
+    return TT_OK;
+  }
   if (any_split) {
     int blocks = (int)tt_cdiv(maxtotal, THREADS);
     if (blocks > 1024) blocks = 1024;
@@ -478,6 +487,15 @@ int tt_gemm_tn_flush(hipStream_t st, TnPending* p) {
   p->n = 0;
   p->maxtotal = 1;
   TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_gemm_tn_pending_add(TnPending* p, const float* slabs, int64_t slab_stride, int splits, float* C, int64_t ldc, int M, int N,
+                           const float* colsum_slab, float* colsum_out) {
+  if (!p || p->n >= kSlabItems) { tt_set_error("tt_gemm_tn_pending_add: no room"); return TT_ERR_INVALID_ARG; }
+  p->sb.a[p->n++] = SlabArgs{slabs, slab_stride, splits, C, ldc, M, N, colsum_slab, colsum_out, nullptr, 0};
+  const int64_t tot = (int64_t)M * N + (colsum_out ? M : 0);
+  p->maxtotal = tot > p->maxtotal ? tot : p->maxtotal;
   return TT_OK;
 }
 

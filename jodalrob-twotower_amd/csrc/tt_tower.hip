@@ -233,6 +233,11 @@ __global__ __launch_bounds__(kThreads) void bn_bwd_apply_kernel(Batch<BnBwdArgs>
 }
 
 // ---- row-wise L2 normalise: one wave per row ---------------------------------------------------
+// a product that is rounded on its own (HIP's __fmul_rn is a plain `*`, which the compiler still contracts)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -273,6 +278,450 @@ __global__ __launch_bounds__(kThreads) void l2norm_bwd_kernel(Batch<NormArgs> ba
   }
 }
 
+// ---- fused narrow tail -------------------------------------------------------------------------
+// When the last hidden block and the output are at most 64 wide (the [128, 64] towers of the reference's config)
+// everything after the block's Linear is a few MB of data in a chain of ~5 us launches: slab reduction, BN
+// statistics (2), BN apply, the 64x64 output Linear, L2 normalise -- and the mirror image in the backward pass.
+// Training with bf16 GEMM operands, that chain runs as two kernels per pass (the split is the batch-wide reduction
+// of the BN statistics).  Arithmetic and summation order follow the unfused kernels above step for step (the forward
+// and the BN gradients come out bit-identical); only the output-layer weight / bias gradients are summed over
+// different row chunks.  Workgroups of 1024 threads cover 64 rows: thread (c, rq) = column c, rows rq + 16 j; the
+// ordered column reductions run on the first 256 threads (c, rl) exactly as in the unfused kernels.
+using tl_f32x16 = __attribute__((ext_vector_type(16))) float;
+using tl_bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+constexpr int kTailThreads = 1024;
+constexpr int kTailLd = 72;      // bf16 elements per LDS row of a 64-wide operand tile (144 B: aligned 16-B fragments)
+constexpr int kTailLdF = 65;     // f32 row stride of the staging tiles
+
+// (A) finish the split-K block GEMM (slabs + bias -> pre) and take the per-chunk BN statistics of relu(pre) in the same
+// pass over the rows: slab_reduce_kernel + bn_stats_partial_kernel.  grid (nchunks, towers)
+struct HeadArgs { const float* slabs; int64_t slab_stride; int splits; const float* bias; float* pre; BnStatArgs s; };
+
+__global__ __launch_bounds__(kTailThreads) void tail_head_kernel(Batch<HeadArgs> batch) {
+  const HeadArgs& h = batch.a[blockIdx.y];
+  const BnStatArgs& a = h.s;
+  const int H = a.H;
+  if ((int)blockIdx.x >= a.nchunks) return;
+  __shared__ float X[64 * kTailLdF];
+  __shared__ Wf sh[4][64];
+  const int t = threadIdx.x, c = t & 63, rq = t >> 6;
+  const int r0 = blockIdx.x * a.rows_per_chunk, r1 = min(a.B, r0 + a.rows_per_chunk);
+  const float bias = (h.bias && c < H) ? h.bias[c] : 0.f;
+  float x0 = 0.f, s = 0.f, q = 0.f, cnt = 0.f;
+  for (int b0 = r0; b0 < r1; b0 += 64) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < H) {
+#pragma unroll 4
+      for (int z = 0; z < h.splits; ++z) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = b0 + rq + 16 * j;
+          if (r < r1) v[j] += h.slabs[(int64_t)z * h.slab_stride + (int64_t)r * H + c];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = rq + 16 * j, r = b0 + row;
+        if (r < r1) {
+          const float o = v[j] + bias;
+          h.pre[(int64_t)r * H + c] = o;
+          X[row * kTailLdF + c] = fmaxf(o, 0.f);
+        }
+      }
+    }
+    __syncthreads();
+    if (t < 256 && c < H) {               // rq = row lane: rows r0 + rq, + 4, ... in bn_stats_partial_kernel's order
+      const int nrow = min(64, r1 - b0);
+      for (int row = rq; row < nrow; row += 4) {
+        const float xv = X[row * kTailLdF + c];
+        if (cnt == 0.f) x0 = xv;
+        const float d = xv - x0;
+        s += d;
+        q += d * d;
+        cnt += 1.f;
+      }
+    }
+    __syncthreads();
+  }
+  if (t < 256) {
+    Wf w{0.f, 0.f, 0.f};
+    if (c < H && cnt > 0.f) {
+      w.n = cnt;
+      w.mean = x0 + s / cnt;
+      w.m2 = fmaxf(q - s * (s / cnt), 0.f);
+    }
+    sh[rq][c] = w;
+  }
+  __syncthreads();
+  if (t < 64 && c < H) {
+    Wf o = sh[0][c];
+    o = wf_combine(o, sh[1][c]);
+    o = wf_combine(o, sh[2][c]);
+    o = wf_combine(o, sh[3][c]);
+    float* p = a.partial + (int64_t)blockIdx.x * 3 * H;
+    p[c] = o.n; p[H + c] = o.mean; p[2 * H + c] = o.m2;
+  }
+}
+
+// (B) BN statistics finish (every workgroup, same order as bn_stats_finish_kernel) + BN apply + dropout + output Linear
+// (one 64 x 64 x 64 bf16 MFMA tile) + L2 normalise, for 64 rows per workgroup.  grid (cdiv(B, 64), towers)
+struct TailFwdArgs {
+  BnStatArgs s;
+  const float* g; const float* b; uint64_t salt; float* act;
+  const float* w_out; const float* b_out; int D; float* y; float* emb;
+};
+
+__global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed0,
+                                                               const uint64_t* __restrict__ seed_dev) {
+  const TailFwdArgs& f = batch.a[blockIdx.y];
+  const BnStatArgs& a = f.s;
+  const int H = a.H, D = f.D, B = a.B;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= B) return;
+  __shared__ Wf sh[4][64];
+  __shared__ float s_mean[64], s_rstd[64];
+  __shared__ __attribute__((aligned(16))) __bf16 As[64 * kTailLd];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[64 * kTailLd];
+  __shared__ float Y[64 * kTailLdF];
+  const int t = threadIdx.x, c = t & 63, rq = t >> 6;
+  // the rows' pre-activations are in flight while the statistics settle
+  float pre[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = m0 + rq + 16 * j;
+    pre[j] = (c < H && r < B) ? a.pre[(int64_t)r * H + c] : 0.f;
+  }
+  if (t < 256) {
+    Wf o{0.f, 0.f, 0.f};
+    if (c < H) {
+      Wf v[kMaxChunks / 4];
+#pragma unroll
+      for (int i = 0; i < kMaxChunks / 4; ++i) {
+        const int k = rq + 4 * i;
+        const float* q = a.partial + (int64_t)k * 3 * H;
+        v[i] = k < a.nchunks ? Wf{q[c], q[H + c], q[2 * H + c]} : Wf{0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxChunks / 4; ++i) o = wf_combine(o, v[i]);
+    }
+    sh[rq][c] = o;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                          // W_out [D, H] -> Bs[n][k]
+    const int n = rq + 16 * j;
+    Bs[n * kTailLd + c] = (__bf16)((n < D && c < H) ? f.w_out[(int64_t)n * H + c] : 0.f);
+  }
+  __syncthreads();
+  if (t < 64 && c < H) {
+    const Wf o = wf_combine(wf_combine(sh[0][c], sh[1][c]), wf_combine(sh[2][c], sh[3][c]));
+    const float var = o.n > 0.f ? o.m2 / o.n : 0.f;
+    const float rstd = 1.f / sqrtf(var + kBnEps);
+    s_mean[c] = o.mean;
+    s_rstd[c] = rstd;
+    if (blockIdx.x == 0) {
+      a.mean[c] = o.mean;
+      a.rstd[c] = rstd;
+      if (a.rm) {
+        a.rm[c] = (1.f - kBnMomentum) * a.rm[c] + kBnMomentum * o.mean;
+        a.rv[c] = (1.f - kBnMomentum) * a.rv[c] + kBnMomentum * (o.n > 1.f ? o.m2 / (o.n - 1.f) : var);
+      }
+      if (a.nbt && c == 0) a.nbt[0] += 1;
+    }
+  }
+  __syncthreads();
+  {
+    const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
+    const float mean = c < H ? s_mean[c] : 0.f, rstd = c < H ? s_rstd[c] : 0.f;
+    const float g = c < H ? f.g[c] : 0.f, bb = c < H ? f.b[c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = rq + 16 * j, r = m0 + row;
+      float v = 0.f;
+      if (c < H && r < B) {
+        const int64_t i = (int64_t)r * H + c;
+        const float x = fmaxf(pre[j], 0.f);
+        const float yv = (x - mean) * rstd * g + bb;
+        v = yv * dropout_scale(drop, p, seed, f.salt + (uint64_t)i);
+        f.act[i] = v;
+      }
+      As[row * kTailLd + c] = (__bf16)v;
+    }
+  }
+  __syncthreads();
+  const int lane = t & 63, wave = t >> 6;
+  if (wave < 4) {
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+    tl_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      const tl_bf16x8 av = *reinterpret_cast<const tl_bf16x8*>(As + (wr * 32 + li) * kTailLd + 16 * s2 + 8 * lh);
+      const tl_bf16x8 bv = *reinterpret_cast<const tl_bf16x8*>(Bs + (wc * 32 + li) * kTailLd + 16 * s2 + 8 * lh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+    }
+    const int n = wc * 32 + li;
+    const float bv = n < D ? f.b_out[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      Y[m * kTailLdF + n] = acc[r] + bv;
+    }
+  }
+  __syncthreads();
+  // one wave per row as l2norm_fwd_kernel, four independent rows per wave in flight.  mul_rn: a plain v * v is
+  // contracted into the first butterfly add (fma(v, v, partner's square)), which leaves the two partners -- and so the
+  // lanes of one row -- with differently rounded sums
+  float v[4], den[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[j] = lane < D ? Y[(wave * 4 + j) * kTailLdF + lane] : 0.f;
+    den[j] = mul_rn(v[j], v[j]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) den[j] += __shfl_xor(den[j], o);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = m0 + wave * 4 + j;
+    const float d = fmaxf(sqrtf(den[j]), kNormEps);
+    if (r < B && lane < D) {
+      f.y[(int64_t)r * D + lane] = v[j];
+      f.emb[(int64_t)r * D + lane] = v[j] / d;
+    }
+  }
+}
+
+// (C) backward head: L2-normalise backward -> d_y; d_act = d_y . W_out; the chunk's share of the output-layer weight /
+// bias gradients (d_y^T . act, column sums of d_y) into slabs; per-chunk BN column sums S1 / S2.  One workgroup per
+// row chunk (the chunks of colsum_partial_kernel), 64 rows at a time.  d_act leaves this kernel already multiplied by
+// the dropout scale (tail_bwd_apply_kernel does not regenerate the mask).  grid (nchunks, towers)
+struct TailBwdArgs {
+  const float* y; const float* emb; const float* d_emb; float* d_y; int D;
+  const float* w_out; const float* act; float* d_act;
+  ColArgs col;                       // x / ldx unused: d_act is taken from the tile
+  float* w_slab; float* b_slab;      // [nchunks][D * H], [nchunks][D]
+};
+
+__global__ __launch_bounds__(kTailThreads) void tail_bwd_kernel(Batch<TailBwdArgs> batch, bool drop, float p, uint64_t seed0,
+                                                               const uint64_t* __restrict__ seed_dev) {
+  const TailBwdArgs& f = batch.a[blockIdx.y];
+  const ColArgs& a = f.col;
+  const int H = a.H, D = f.D;
+  if ((int)blockIdx.x >= a.nchunks) return;
+  // dyA [row][d] | dyT [d][row] | (XH f32 tile aliases these two once the MFMAs are done) ; Wn [h][d] ; actT [h][row]
+  __shared__ __attribute__((aligned(16))) __bf16 dy2[2 * 64 * kTailLd];
+  __shared__ __attribute__((aligned(16))) __bf16 Wn[64 * kTailLd];
+  __shared__ __attribute__((aligned(16))) __bf16 actT[64 * kTailLd];
+  __shared__ float DY[64 * kTailLdF];                                   // d_y, then d_act, of the 64 rows
+  __shared__ float sh[3][4][64];
+  static_assert(sizeof(float) * 64 * kTailLdF <= sizeof(__bf16) * 2 * 64 * kTailLd, "XH must fit over dyA | dyT");
+  __bf16* dyA = dy2;
+  __bf16* dyT = dy2 + 64 * kTailLd;
+  float* XH = reinterpret_cast<float*>(dy2);
+  const int t = threadIdx.x, c = t & 63, rq = t >> 6;
+  const int lane = c, wave = rq;
+  const int r0 = blockIdx.x * a.rows_per_chunk, r1 = min(a.B, r0 + a.rows_per_chunk);
+  const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {                         // W_out [D, H]: element (k = d, n = h) -> Wn[h][d]
+    const int d = rq + 16 * j;
+    Wn[c * kTailLd + d] = (__bf16)((d < D && c < H) ? f.w_out[(int64_t)d * H + c] : 0.f);
+  }
+  const float mean = c < H ? a.mean[c] : 0.f, rstd = c < H ? a.rstd[c] : 0.f;
+  tl_f32x16 accw;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accw[i] = 0.f;
+  float s0 = 0.f, s1 = 0.f, cs = 0.f;
+  for (int b0 = r0; b0 < r1; b0 += 64) {
+    // 1. d_y of rows b0 .. b0 + 63: one wave per row as l2norm_bwd_kernel, four independent rows per wave in flight
+    float yv[4], e[4], de[4], ss[4], dot[4], xh[4], sc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = b0 + wave * 4 + j;
+      const bool ok = r < r1 && lane < D;
+      const int64_t i = (int64_t)r * D + lane;
+      yv[j] = ok ? f.y[i] : 0.f;
+      e[j] = ok ? f.emb[i] : 0.f;
+      de[j] = ok ? f.d_emb[i] : 0.f;
+    }
+    float av[4], pr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                       // thread (c, rq): rows rq + 16 j of act / pre
+      const int r = b0 + rq + 16 * j;
+      const bool ok = c < H && r < r1;
+      av[j] = ok ? f.act[(int64_t)r * H + c] : 0.f;
+      pr[j] = ok ? a.pre[(int64_t)r * H + c] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ss[j] = mul_rn(yv[j], yv[j]);
+      dot[j] = mul_rn(e[j], de[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        ss[j] += __shfl_xor(ss[j], o);
+        dot[j] += __shfl_xor(dot[j], o);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave * 4 + j, r = b0 + row;
+      const float nrm = sqrtf(ss[j]);
+      const float den = fmaxf(nrm, kNormEps);
+      float out = nrm > kNormEps ? (de[j] - e[j] * dot[j]) / den : de[j] / den;
+      if (r < r1 && lane < D) f.d_y[(int64_t)r * D + lane] = out;
+      else out = 0.f;
+      DY[row * kTailLdF + lane] = out;
+      dyA[row * kTailLd + lane] = (__bf16)out;
+      dyT[lane * kTailLd + row] = (__bf16)out;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = rq + 16 * j, r = b0 + row;
+      actT[c * kTailLd + row] = (__bf16)av[j];
+      xh[j] = (fmaxf(pr[j], 0.f) - mean) * rstd;
+      sc[j] = (c < H && r < r1) ? dropout_scale(drop, p, seed, a.salt + (uint64_t)((int64_t)r * H + c)) : 0.f;
+    }
+    __syncthreads();
+    // 2. bias-gradient column sums of d_y, data gradient d_act = d_y . W_out, weight-gradient tile += d_y^T . act
+    const int wr = (wave >> 1) & 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+    tl_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (wave < 4) {
+      if (c < D) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cs += DY[(rq + 4 * j) * kTailLdF + c];
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const int ko = 16 * s2 + 8 * lh;
+        const tl_bf16x8 a1 = *reinterpret_cast<const tl_bf16x8*>(dyA + (wr * 32 + li) * kTailLd + ko);
+        const tl_bf16x8 b1 = *reinterpret_cast<const tl_bf16x8*>(Wn + (wc * 32 + li) * kTailLd + ko);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
+        const tl_bf16x8 a2 = *reinterpret_cast<const tl_bf16x8*>(dyT + (wr * 32 + li) * kTailLd + ko);
+        const tl_bf16x8 b2 = *reinterpret_cast<const tl_bf16x8*>(actT + (wc * 32 + li) * kTailLd + ko);
+        accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, accw, 0, 0, 0);
+      }
+    }
+    __syncthreads();                                     // DY (as d_y), dyA and dyT have been read
+    if (wave < 4) {
+      const int n = wc * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) DY[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * kTailLdF + n] = acc[r];
+    }
+    __syncthreads();
+    // 3. d_act (times the dropout scale) out; da and xhat staged for the ordered column sums
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = rq + 16 * j, r = b0 + row;
+      const float da = DY[row * kTailLdF + c] * sc[j];
+      if (c < H && r < r1) f.d_act[(int64_t)r * H + c] = da;
+      DY[row * kTailLdF + c] = da;
+      XH[row * kTailLdF + c] = xh[j];
+    }
+    __syncthreads();
+    if (t < 256 && c < H) {                              // colsum_partial_kernel's order: rows r0 + rq, + 4, ...
+      const int nrow = min(64, r1 - b0);
+      for (int row = rq; row < nrow; row += 4) {
+        const float da = DY[row * kTailLdF + c];
+        s0 += da;
+        s1 += da * XH[row * kTailLdF + c];
+      }
+    }
+    __syncthreads();
+  }
+  if (t < 256) {
+    sh[0][rq][c] = s0;
+    sh[1][rq][c] = s1;
+    sh[2][rq][c] = cs;
+  }
+  __syncthreads();
+  if (t < 64) {
+    if (c < H) {
+      float* q = a.partial + (int64_t)blockIdx.x * 2 * H;
+      q[c] = ((sh[0][0][c] + sh[0][1][c]) + sh[0][2][c]) + sh[0][3][c];
+      q[H + c] = ((sh[1][0][c] + sh[1][1][c]) + sh[1][2][c]) + sh[1][3][c];
+    }
+    if (c < D) f.b_slab[(int64_t)blockIdx.x * D + c] = ((sh[2][0][c] + sh[2][1][c]) + sh[2][2][c]) + sh[2][3][c];
+  }
+  if (wave < 4) {
+    const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+    float* ws = f.w_slab + (int64_t)blockIdx.x * D * H;
+    const int n = wc * 32 + li;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m < D && n < H) ws[(int64_t)m * H + n] = accw[r];
+    }
+  }
+}
+
+// (D) S1 / S2 finish (every workgroup, colsum_finish_kernel's order) + BN backward apply in place on the (already
+// dropout-scaled) d_act, 64 rows per workgroup.  grid (cdiv(B, 64), towers)
+struct TailApplyArgs { ColArgs col; BnBwdArgs bn; };
+
+__global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<TailApplyArgs> batch) {
+  const ColArgs& a = batch.a[blockIdx.y].col;
+  const BnBwdArgs& b = batch.a[blockIdx.y].bn;
+  const int H = a.H, B = a.B;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= B) return;
+  __shared__ float sh[2][4][64];
+  __shared__ float S[2][64];
+  const int t = threadIdx.x, c = t & 63, rq = t >> 6;
+  float pr[4], da[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = m0 + rq + 16 * j;
+    const bool ok = c < H && r < B;
+    pr[j] = ok ? b.pre[(int64_t)r * H + c] : 0.f;
+    da[j] = ok ? b.d[(int64_t)r * H + c] : 0.f;
+  }
+  if (t < 256) {
+    float s0 = 0.f, s1 = 0.f;
+    if (c < H) {
+      float v0[kMaxChunks / 4], v1[kMaxChunks / 4];
+#pragma unroll
+      for (int i = 0; i < kMaxChunks / 4; ++i) {
+        const int k = rq + 4 * i;
+        const float* q = a.partial + (int64_t)k * 2 * H;
+        v0[i] = k < a.nchunks ? q[c] : 0.f;
+        v1[i] = k < a.nchunks ? q[H + c] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxChunks / 4; ++i) { s0 += v0[i]; s1 += v1[i]; }
+    }
+    sh[0][rq][c] = s0;
+    sh[1][rq][c] = s1;
+  }
+  __syncthreads();
+  if (t < 64 && c < H) {
+    const float t0 = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+    const float t1 = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+    S[0][c] = t0;
+    S[1][c] = t1;
+    if (blockIdx.x == 0) { a.out0[c] = t0; a.out1[c] = t1; }
+  }
+  __syncthreads();
+  if (c >= H) return;
+  const float mean = b.mean[c], rstd = b.rstd[c], g = b.g[c], S1 = S[0][c], S2 = S[1][c];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = m0 + rq + 16 * j;
+    if (r < B) {
+      const float xh = (fmaxf(pr[j], 0.f) - mean) * rstd;
+      const float dv = g * rstd * (da[j] - S1 * b.invB - xh * (S2 * b.invB));
+      b.d[(int64_t)r * H + c] = pr[j] > 0.f ? dv : 0.f;
+    }
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 inline int ew_grid(const tt_ctx* ctx, int64_t n, int towers) {
   const int64_t cap = (int64_t)ctx->num_cus * 8 / (towers > 0 ? towers : 1);
@@ -301,6 +750,21 @@ struct WsLayout {
 inline int in_width(const tt_tower_params* p, int i) { return i == 0 ? p->h0 + p->kcat_e : p->hidden[i - 1]; }
 inline int last_width(const tt_tower_params* p) { return p->n_hidden == 0 ? p->h0 + p->kcat_e : p->hidden[p->n_hidden - 1]; }
 
+// the fused narrow tail (tail_*_kernel) applies to a training pass with bf16 GEMM operands whose last hidden block and
+// output are at most 64 wide
+inline bool tail_shape_ok(const tt_tower_params* p) {
+  return p->n_hidden >= 1 && p->hidden[p->n_hidden - 1] <= 64 && p->d_out <= 64;
+}
+inline bool tail_fusable(int n, const tt_tower_params* const* P, int train) {
+  if (!train || P[0]->compute_dtype != TT_BF16) return false;
+  for (int t = 0; t < n; ++t)
+    if (!tail_shape_ok(P[t]) || (P[t]->flags & TT_TOWER_UNFUSED_TAIL)) return false;
+  return true;
+}
+inline size_t tail_slab_bytes(const tt_tower_params* p) {   // per-chunk output-layer gradient slabs of tail_bwd_kernel
+  return sizeof(float) * (size_t)kMaxChunks * ((size_t)p->d_out * p->hidden[p->n_hidden - 1] + (size_t)p->d_out) + 256;
+}
+
 inline WsLayout ws_layout(const tt_tower_params* p, int64_t B, char* base) {
   size_t g = tt_gemm_tn_workspace_bytes(p->h0, p->din, B);
   int hmax = p->d_out > p->h0 ? p->d_out : p->h0;
@@ -324,9 +788,10 @@ inline WsLayout ws_layout(const tt_tower_params* p, int64_t B, char* base) {
   w.col = reinterpret_cast<float*>(base ? base + w.gemm_bytes : nullptr);
   size_t o = w.gemm_bytes + ((w.col_bytes + 255) & ~size_t(255));
   for (int l = 0; l < p->n_hidden + 2; ++l) {
-    const size_t nb = l == 0 ? tt_gemm_tn_workspace_bytes(p->h0, p->din, B)
-                    : l == p->n_hidden + 1 ? tt_gemm_tn_workspace_bytes(p->d_out, last_width(p), B)
-                                           : tt_gemm_tn_workspace_bytes(p->hidden[l - 1], in_width(p, l - 1), B);
+    size_t nb = l == 0 ? tt_gemm_tn_workspace_bytes(p->h0, p->din, B)
+              : l == p->n_hidden + 1 ? tt_gemm_tn_workspace_bytes(p->d_out, last_width(p), B)
+                                     : tt_gemm_tn_workspace_bytes(p->hidden[l - 1], in_width(p, l - 1), B);
+    if (l == p->n_hidden + 1 && tail_shape_ok(p) && tail_slab_bytes(p) > nb) nb = tail_slab_bytes(p);
     w.tn[l] = base ? base + o : nullptr;
     w.tn_bytes[l] = (nb + 255) & ~size_t(255);
     o += w.tn_bytes[l];
@@ -403,7 +868,10 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
   if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
   const bool drop = train && dropout_p > 0.f;
   const int nh = P[0]->n_hidden;
+  const bool fused = tail_fusable(n, P, train);
+  NtDeferred nd[TT_MAX_SIDES];
   for (int i = 0; i < nh; ++i) {
+    const bool tail = fused && i == nh - 1;
     Batch<BnStatArgs> bs{};
     Batch<BnApplyArgs> ba{};
     int hmax = 1, cmax = 1;
@@ -422,8 +890,29 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       cmax = nchunks > cmax ? nchunks : cmax;
       tmax = B * H > tmax ? B * H : tmax;
     }
-    for (int t = 0; t < n; ++t) { nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes; }
-  if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
+    for (int t = 0; t < n; ++t) {
+      nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes;
+      nt[t].defer = tail ? &nd[t] : nullptr;
+    }
+    if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
+    if (tail) {
+      // slabs (+ bias) -> pre with the chunk statistics in the same pass, then everything up to the unit rows in one kernel
+      if (nd[0].splits > 0) {
+        Batch<HeadArgs> hb{};
+        for (int t = 0; t < n; ++t) hb.a[t] = HeadArgs{nd[t].slabs, nd[t].slab_stride, nd[t].splits, P[t]->b[i], A[t]->pre[i], bs.a[t]};
+        tail_head_kernel<<<dim3((unsigned)cmax, (unsigned)n), kTailThreads, 0, st>>>(hb);
+      } else {
+        bn_stats_partial_kernel<<<dim3(1, (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(bs);
+      }
+      TT_LAUNCH_CHECK();
+      Batch<TailFwdArgs> tf{};
+      for (int t = 0; t < n; ++t)
+        tf.a[t] = TailFwdArgs{bs.a[t], P[t]->bn_w[i], P[t]->bn_b[i], ba.a[t].salt, A[t]->act[i], P[t]->w_out, P[t]->b_out, P[t]->d_out,
+                              A[t]->y, A[t]->emb};
+      tail_fwd_kernel<<<dim3((unsigned)tt_cdiv(B, 64), (unsigned)n), kTailThreads, 0, st>>>(tf, drop, dropout_p, seed, seed_dev);
+      TT_LAUNCH_CHECK();
+      return TT_OK;
+    }
     if (train) {
       bn_stats_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(bs);
       TT_LAUNCH_CHECK();
@@ -478,8 +967,11 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     ws[t] = ws_layout(P[t], B, reinterpret_cast<char*>(workspaces[t]));
     na.a[t] = NormArgs{A[t]->y, A[t]->emb, d_emb[t], (int)B, P[t]->d_out, g->d_y};
   }
-  l2norm_bwd_kernel<<<dim3((unsigned)tt_cdiv(B, 4), (unsigned)n), kThreads, 0, st>>>(na);
-  TT_LAUNCH_CHECK();
+  const bool fused = tail_fusable(n, P, train);
+  if (!fused) {
+    l2norm_bwd_kernel<<<dim3((unsigned)tt_cdiv(B, 4), (unsigned)n), kThreads, 0, st>>>(na);
+    TT_LAUNCH_CHECK();
+  }
   for (int t = 0; t < n; ++t) {
     const tt_tower_grads* g = G[t];
     const float* in_last = nh == 0 ? reinterpret_cast<const float*>(A[t]->x) : A[t]->act[nh - 1];
@@ -497,8 +989,37 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     TnPending* p = tt_gemm_tn_pending_create();
     ~PendingGuard() { tt_gemm_tn_pending_destroy(p); }
   } pend;
-  if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;
-  if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
+  if (fused) {
+    // L2-normalise backward, both output-layer GEMMs and the BN column sums of the last block in one kernel; the BN
+    // backward apply (after the batch-wide S1 / S2) in a second
+    const int i = nh - 1;
+    Batch<TailBwdArgs> tb{};
+    Batch<TailApplyArgs> tp{};
+    int cmax = 1;
+    for (int t = 0; t < n; ++t) {
+      const tt_tower_grads* g = G[t];
+      const int H = P[t]->hidden[i], D = P[t]->d_out;
+      TT_CHECK_ARG(g->w[i] && g->b[i] && g->bn_w[i] && g->bn_b[i], "tt_towers_mlp_bwd: NULL gradient buffers of block %d", i);
+      const int nchunks = chunks_for(B, H);
+      const uint64_t salt = ((uint64_t)(i + 1) << 40) ^ ((uint64_t)t << 52);
+      const ColArgs col{nullptr, 0, A[t]->pre[i], A[t]->mean[i], A[t]->rstd[i], salt, (int)B, H, (int)tt_cdiv(B, nchunks), nchunks,
+                        ws[t].col, g->bn_b[i], g->bn_w[i]};
+      float* w_slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws[t].tn[nh + 1]) + 255) & ~uintptr_t(255));
+      float* b_slab = w_slab + (size_t)nchunks * D * H;
+      tb.a[t] = TailBwdArgs{A[t]->y, A[t]->emb, d_emb[t], g->d_y, D, P[t]->w_out, A[t]->act[i], dcur[t], col, w_slab, b_slab};
+      tp.a[t] = TailApplyArgs{col, BnBwdArgs{dcur[t], A[t]->pre[i], B * H, H, 1.f / (float)B, A[t]->mean[i], A[t]->rstd[i], P[t]->bn_w[i],
+                                             g->bn_b[i], g->bn_w[i], salt}};
+      if (int rc = tt_gemm_tn_pending_add(pend.p, w_slab, (int64_t)D * H, nchunks, g->w_out, H, D, H, b_slab, g->b_out)) return rc;
+      cmax = nchunks > cmax ? nchunks : cmax;
+    }
+    tail_bwd_kernel<<<dim3((unsigned)cmax, (unsigned)n), kTailThreads, 0, st>>>(tb, drop, dropout_p, seed, seed_dev);
+    TT_LAUNCH_CHECK();
+    tail_bwd_apply_kernel<<<dim3((unsigned)tt_cdiv(B, 64), (unsigned)n), kTailThreads, 0, st>>>(tp);
+    TT_LAUNCH_CHECK();
+  } else {
+    if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;
+    if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
+  }
   for (int i = nh - 1; i >= 0; --i) {
     Batch<ColArgs> cb{};
     Batch<BnBwdArgs> bb{};
@@ -519,12 +1040,14 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       cmax = nchunks > cmax ? nchunks : cmax;
       tmax = B * H > tmax ? B * H : tmax;
     }
-    colsum_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(cb, drop, dropout_p, seed, seed_dev);
-    TT_LAUNCH_CHECK();
-    colsum_finish_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)n), kThreads, 0, st>>>(cb);
-    TT_LAUNCH_CHECK();
-    bn_bwd_apply_kernel<<<dim3((unsigned)ew_grid(ctx, tmax, n), (unsigned)n), kThreads, 0, st>>>(bb, train != 0, drop, dropout_p, seed, seed_dev);
-    TT_LAUNCH_CHECK();
+    if (!(fused && i == nh - 1)) {
+      colsum_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(cb, drop, dropout_p, seed, seed_dev);
+      TT_LAUNCH_CHECK();
+      colsum_finish_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)n), kThreads, 0, st>>>(cb);
+      TT_LAUNCH_CHECK();
+      bn_bwd_apply_kernel<<<dim3((unsigned)ew_grid(ctx, tmax, n), (unsigned)n), kThreads, 0, st>>>(bb, train != 0, drop, dropout_p, seed, seed_dev);
+      TT_LAUNCH_CHECK();
+    }
     for (int t = 0; t < n; ++t) {
       const tt_tower_grads* g = G[t];
       const int H = P[t]->hidden[i];

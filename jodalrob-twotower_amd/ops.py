@@ -259,7 +259,7 @@ def _fill(arr, tensors):
 
 
 def tower_params_struct(din, h0, kcat_e, hidden, d_out, w_proj, b_proj, ws, bs, bn_w, bn_b, bn_rm, bn_rv, w_out, b_out,
-                        bn_nbt=(), compute_dtype=TT_F32, x_dtype=TT_F32, dx_dtype=TT_F32):
+                        bn_nbt=(), compute_dtype=TT_F32, x_dtype=TT_F32, dx_dtype=TT_F32, flags=0):
     if len(hidden) > L.TT_MAX_HIDDEN:
         raise ValueError(f"at most {L.TT_MAX_HIDDEN} hidden blocks per tower are supported")
     p = L.TowerParams()
@@ -269,7 +269,7 @@ def tower_params_struct(din, h0, kcat_e, hidden, d_out, w_proj, b_proj, ws, bs, 
     p.w_proj, p.b_proj, p.w_out, p.b_out = w_proj.data_ptr(), b_proj.data_ptr(), w_out.data_ptr(), b_out.data_ptr()
     _fill(p.w, ws); _fill(p.b, bs); _fill(p.bn_w, bn_w); _fill(p.bn_b, bn_b); _fill(p.bn_rm, bn_rm); _fill(p.bn_rv, bn_rv)
     _fill(p.bn_nbt, bn_nbt)
-    p.compute_dtype, p.x_dtype, p.dx_dtype = compute_dtype, x_dtype, dx_dtype
+    p.compute_dtype, p.x_dtype, p.dx_dtype, p.flags = compute_dtype, x_dtype, dx_dtype, flags
     return p
 
 

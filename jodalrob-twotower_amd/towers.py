@@ -27,6 +27,9 @@ from . import ops
 from .cat_embed import CategoricalEmbedder, EmbeddingStore
 
 
+_DEBUG_KEEP = None   # set to a list by debugging tools
+
+
 def _al(n: int) -> int:
     return (n + 63) // 64 * 64
 
@@ -66,6 +69,8 @@ class BaseTower(nn.Module):
             raise ValueError(f"TT_TOWER_IO_DTYPE must be none|x|dx|both, got {io!r}")
         self.x_dtype = torch.bfloat16 if io in ("x", "both") else torch.float32
         self.dx_dtype = torch.bfloat16 if io in ("dx", "both") else torch.float32
+        # TT_TOWER_UNFUSED_TAIL=1: run the BN / output-Linear / L2-normalise tail as the separate kernels (A/B runs)
+        self.unfused_tail = os.environ.get("TT_TOWER_UNFUSED_TAIL", "0") == "1"
         self.categorical_keys = list(categorical_keys)
         self.exchange = None            # set by the distributed task: sharded-table row exchange
         self._seed_dev = None           # set by GraphedTrainStep: device word added to the dropout seed
@@ -116,7 +121,7 @@ class BaseTower(nn.Module):
         tensors = [self.dense_projection.weight, self.dense_projection.bias, out.weight, out.bias]
         for lin, bn in zip(lins, bns):
             tensors += [lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype, self.x_dtype, self.dx_dtype)
+        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype, self.x_dtype, self.dx_dtype, self.unfused_tail)
         if key != self._struct_key:
             for t in tensors:
                 if t.dtype != torch.float32 or not t.is_contiguous():
@@ -130,7 +135,8 @@ class BaseTower(nn.Module):
                 bn_nbt=[b.num_batches_tracked for b in bns],
                 compute_dtype=ops.TT_BF16 if self.mlp_dtype == "bf16" else ops.TT_F32,
                 x_dtype=ops.TT_BF16 if self.x_dtype == torch.bfloat16 else ops.TT_F32,
-                dx_dtype=ops.TT_BF16 if self.dx_dtype == torch.bfloat16 else ops.TT_F32)
+                dx_dtype=ops.TT_BF16 if self.dx_dtype == torch.bfloat16 else ops.TT_F32,
+                flags=ops.L.TT_TOWER_UNFUSED_TAIL if self.unfused_tail else 0)
             self._struct_key = key
         return self._params_struct
 
@@ -343,6 +349,9 @@ class _TowersFn(torch.autograd.Function):
             g.d_x = d_x.data_ptr()
             g.d_y = base + 4 * offs[len(dps) + 1 + len(hid)]
             prepared.append((s, d_emb, g))
+            if _DEBUG_KEEP is not None:      # tools/tail_diff.py: keep the backward scratch for inspection
+                _DEBUG_KEEP.append({"buf": buf, "offs": offs, "n_dense": len(dps), "hidden": hid, "B": B, "acts": s.buf, "emb": s.emb,
+                                    "d_emb": d_emb})
             for i, v in enumerate(views):
                 grads[pos + 2 + i] = v
             flat_grads.append(buf[:offs[len(dps)]])

@@ -599,6 +599,46 @@ def test_bf16_tower_input_is_bit_identical(tt, manifest, schema_real, monkeypatc
             assert np.array_equal(gb, g), k
 
 
+@pytest.mark.parametrize("case,B,drop", [("real_schema", 300, 0.0), ("real_schema", 8200, 0.1), ("wide_b40", 40, 0.1),
+                                          ("deep_temp", 24, 0.0), ("single_hidden", 8, 0.0)])
+def test_fused_tower_tail_equals_separate_kernels(tt, manifest, schema_real, monkeypatch, case, B, drop):
+    """bf16 training pass: the fused tail (slab reduce + BN statistics | BN apply + output Linear + L2 normalise, and the
+    mirror image backward) against the same pass run as the separate kernels (TT_TOWER_UNFUSED_TAIL=1).  The fused
+    kernels keep the separate kernels' arithmetic and summation order, so the forward is expected bit-identical; the
+    output-layer weight / bias gradients are summed over different row chunks (tolerance), the rest to rounding."""
+    cfg = dict(manifest["cases"][case])
+    if case == "real_schema":
+        cfg.update(keys_n=schema_real["notice"]["categorical"], keys_c=schema_real["company"]["categorical"])
+        vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+        shapes = {k: tuple(v) for k, v in manifest["state_dict_keys_real"].items()}
+        meta = GOLD / "real_vocab_metadata.csv"
+    else:
+        vn, vc = cfg["vocab_n"], cfg["vocab_c"]
+        z = np.load(GOLD / f"case_{case}.npz")
+        shapes = {k[6:]: z[k].shape for k in z.files if k.startswith("state.")}
+        meta = None
+    state = init_state_numpy(shapes, 91)
+    b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 92, oob=False)
+    outs = {}
+    for unfused in ("1", "0"):
+        monkeypatch.setenv("TT_TOWER_UNFUSED_TAIL", unfused)
+        torch.manual_seed(1234)
+        task = make_task(tt, cfg, meta=meta, mlp_dtype="bf16", dropout_rate=drop)
+        load_state(task, state)
+        task.train()
+        res = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+        res["loss"].backward()
+        sd = {k: v.detach().cpu().numpy() for k, v in task.state_dict().items() if "running" in k or "num_batches" in k}
+        outs[unfused] = (res["loss"].item(), {n: p.grad.cpu().numpy() for n, p in task.named_parameters()}, sd)
+    assert outs["0"][0] == outs["1"][0], (outs["0"][0], outs["1"][0])
+    for k, v in outs["1"][2].items():
+        assert np.array_equal(outs["0"][2][k], v), k
+    for k, g in outs["1"][1].items():
+        gf = outs["0"][1][k]
+        assert np.isfinite(gf).all(), k
+        assert np.linalg.norm(gf - g) <= 5e-6 * np.linalg.norm(g) + 1e-12, (k, np.linalg.norm(gf - g), np.linalg.norm(g))
+
+
 def test_copy_multi(tt):
     """tt_copy_multi: several device segments of odd sizes (16-byte body + byte tail) and a pinned-host source."""
     from jodalrob_twotower_amd import ops
