@@ -45,6 +45,3 @@ TnPending* tt_gemm_tn_pending_create();
 void tt_gemm_tn_pending_destroy(TnPending*);
 int tt_gemm_tn_batched(hipStream_t st, const GemmTN* items, int n, TnPending* pending = nullptr);
 int tt_gemm_tn_flush(hipStream_t st, TnPending* pending);
-// queue the reduction of slabs a caller's own kernel wrote: C[M,N] = sum_z slabs[z], colsum_out[M] = sum_z colsum_slab[z]
-int tt_gemm_tn_pending_add(TnPending* pending, const float* slabs, int64_t slab_stride, int splits, float* C, int64_t ldc, int M, int N,
-                           const float* colsum_slab, float* colsum_out);

@@ -490,15 +490,6 @@ int tt_gemm_tn_flush(hipStream_t st, TnPending* p) {
   return TT_OK;
 }
 
-int tt_gemm_tn_pending_add(TnPending* p, const float* slabs, int64_t slab_stride, int splits, float* C, int64_t ldc, int M, int N,
-                           const float* colsum_slab, float* colsum_out) {
-  if (!p || p->n >= kSlabItems) { tt_set_error("tt_gemm_tn_pending_add: no room"); return TT_ERR_INVALID_ARG; }
-  p->sb.a[p->n++] = SlabArgs{slabs, slab_stride, splits, C, ldc, M, N, colsum_slab, colsum_out, nullptr, 0};
-  const int64_t tot = (int64_t)M * N + (colsum_out ? M : 0);
-  p->maxtotal = tot > p->maxtotal ? tot : p->maxtotal;
-  return TT_OK;
-}
-
 int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n, TnPending* pending) {
   GemmBatch b{};
   SlabBatch sb{};

@@ -24,9 +24,9 @@ __device__ __forceinline__ Wf wf_combine(Wf a, Wf b) {
   if (a.n == 0.f) return b;
   Wf o;
   o.n = a.n + b.n;
-  const float d = b.mean - a.mean;
-  o.mean = a.mean + d * (b.n / o.n);
-  o.m2 = a.m2 + b.m2 + d * d * (a.n * b.n / o.n);
+  const float d = b.mean - a.mean, w = b.n / o.n;      // one division per combine (the chains of 32 are latency-bound)
+  o.mean = a.mean + d * w;
+  o.m2 = a.m2 + b.m2 + d * d * (a.n * w);
   return o;
 }
 
@@ -664,17 +664,49 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_kernel(Batch<TailBwdArg
 
 // (D) S1 / S2 finish (every workgroup, colsum_finish_kernel's order) + BN backward apply in place on the (already
 // dropout-scaled) d_act, 64 rows per workgroup.  grid (cdiv(B, 64), towers)
-struct TailApplyArgs { ColArgs col; BnBwdArgs bn; };
+struct TailApplyArgs {
+  ColArgs col; BnBwdArgs bn;
+  const float* w_slab; const float* b_slab; int D; float* g_w_out; float* g_b_out;   // [nchunks][D * H], [nchunks][D] -> [D, H], [D]
+};
 
 __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<TailApplyArgs> batch) {
-  const ColArgs& a = batch.a[blockIdx.y].col;
-  const BnBwdArgs& b = batch.a[blockIdx.y].bn;
+  const TailApplyArgs& ta = batch.a[blockIdx.y];
+  const ColArgs& a = ta.col;
+  const BnBwdArgs& b = ta.bn;
   const int H = a.H, B = a.B;
+  const int t = threadIdx.x, c = t & 63, rq = t >> 6;
   const int m0 = blockIdx.x * 64;
   if (m0 >= B) return;
   __shared__ float sh[2][4][64];
   __shared__ float S[2][64];
-  const int t = threadIdx.x, c = t & 63, rq = t >> 6;
+  __shared__ float red[12][64];
+  // output-layer weight / bias gradients: the per-chunk slabs of tail_bwd_kernel summed in a fixed order, 64 elements
+  // per workgroup, by the 768 threads that are idle while the first 256 finish S1 / S2 -- thread (e, zl): slabs zl,
+  // zl + 12, ...; then the 12 partial sums in order (wave 1)
+  const int DH = ta.D * H, total = DH + ta.D, nseg = (total + 63) / 64;
+  auto slab_partial = [&](int seg) {
+    const int e = seg * 64 + c, zl = rq - 4;
+    float v[(kMaxChunks + 11) / 12];
+#pragma unroll
+    for (int i = 0; i < (kMaxChunks + 11) / 12; ++i) {
+      const int z = zl + 12 * i;
+      v[i] = (e < total && z < a.nchunks) ? (e < DH ? ta.w_slab[(int64_t)z * DH + e] : ta.b_slab[(int64_t)z * ta.D + (e - DH)]) : 0.f;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < (kMaxChunks + 11) / 12; ++i) sum += v[i];
+    red[zl][c] = sum;
+  };
+  auto slab_final = [&](int seg) {
+    const int e = seg * 64 + c;
+    if (e < total) {
+      float o = 0.f;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) o += red[k][c];
+      if (e < DH) ta.g_w_out[e] = o;
+      else ta.g_b_out[e - DH] = o;
+    }
+  };
   float pr[4], da[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -699,6 +731,8 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<Tail
     }
     sh[0][rq][c] = s0;
     sh[1][rq][c] = s1;
+  } else if ((int)blockIdx.x < nseg) {
+    slab_partial(blockIdx.x);
   }
   __syncthreads();
   if (t < 64 && c < H) {
@@ -707,18 +741,28 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<Tail
     S[0][c] = t0;
     S[1][c] = t1;
     if (blockIdx.x == 0) { a.out0[c] = t0; a.out1[c] = t1; }
+  } else if (rq == 1 && (int)blockIdx.x < nseg) {
+    slab_final(blockIdx.x);
   }
   __syncthreads();
-  if (c >= H) return;
-  const float mean = b.mean[c], rstd = b.rstd[c], g = b.g[c], S1 = S[0][c], S2 = S[1][c];
+  if (c < H) {
+    const float mean = b.mean[c], rstd = b.rstd[c], g = b.g[c], S1 = S[0][c], S2 = S[1][c];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int r = m0 + rq + 16 * j;
-    if (r < B) {
-      const float xh = (fmaxf(pr[j], 0.f) - mean) * rstd;
-      const float dv = g * rstd * (da[j] - S1 * b.invB - xh * (S2 * b.invB));
-      b.d[(int64_t)r * H + c] = pr[j] > 0.f ? dv : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const int r = m0 + rq + 16 * j;
+      if (r < B) {
+        const float xh = (fmaxf(pr[j], 0.f) - mean) * rstd;
+        const float dv = g * rstd * (da[j] - S1 * b.invB - xh * (S2 * b.invB));
+        b.d[(int64_t)r * H + c] = pr[j] > 0.f ? dv : 0.f;
+      }
     }
+  }
+  // fewer row blocks than slab segments (B < 64 * nseg): the remaining segments in further rounds
+  for (int seg = blockIdx.x + gridDim.x; seg < nseg; seg += gridDim.x) {
+    if (t >= 256) slab_partial(seg);
+    __syncthreads();
+    if (rq == 1) slab_final(seg);
+    __syncthreads();
   }
 }
 
@@ -1008,8 +1052,7 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       float* b_slab = w_slab + (size_t)nchunks * D * H;
       tb.a[t] = TailBwdArgs{A[t]->y, A[t]->emb, d_emb[t], g->d_y, D, P[t]->w_out, A[t]->act[i], dcur[t], col, w_slab, b_slab};
       tp.a[t] = TailApplyArgs{col, BnBwdArgs{dcur[t], A[t]->pre[i], B * H, H, 1.f / (float)B, A[t]->mean[i], A[t]->rstd[i], P[t]->bn_w[i],
-                                             g->bn_b[i], g->bn_w[i], salt}};
-      if (int rc = tt_gemm_tn_pending_add(pend.p, w_slab, (int64_t)D * H, nchunks, g->w_out, H, D, H, b_slab, g->b_out)) return rc;
+                                             g->bn_b[i], g->bn_w[i], salt}, w_slab, b_slab, D, g->w_out, g->b_out};
       cmax = nchunks > cmax ? nchunks : cmax;
     }
     tail_bwd_kernel<<<dim3((unsigned)cmax, (unsigned)n), kTailThreads, 0, st>>>(tb, drop, dropout_p, seed, seed_dev);
