@@ -115,15 +115,19 @@ int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K 
  * Embedding gradient -- replaces autograd's nn.Embedding backward (dense index_add; reference
  * builds its tables with sparse=False, src/towers/cat_embed.py:42-45; scripts/train.py:326).
  * Slot s of source i reads d_out_i[b*ld + k*E .. +E).  Atomic-free: one wave-group per distinct
- * row sums its contributions in ascending slot order; rows with more than 256 contributions are
- * summed in 256-slot chunks whose partial sums are then added in chunk order (bitwise reproducible).
+ * row sums its contributions in ascending slot order; rows with more than 64 contributions are
+ * summed in 64-slot chunks whose partial sums are then added in chunk order (bitwise reproducible).
  *   TT_GRAD_SPARSE     out[u*E .. +E)               = sum   (u < U; out has room for M rows)
  *   TT_GRAD_DENSE_SET  out[unique_rows[u]*E .. +E)  = sum   (caller zeroed the dense buffer)
  *   TT_GRAD_DENSE_ACC  out[unique_rows[u]*E .. +E) += sum
+ *   | TT_GRAD_SHORT_SEGMENTS (flag): every row is summed by one lane group whatever its length, and the chunk passes
+ *     are not launched -- for callers that know no row has many contributions (the owner side of the row exchange:
+ *     at most one per rank).  Results do not depend on the flag, only the time does.
  * ---------------------------------------------------------------------------------------------- */
 #define TT_GRAD_SPARSE 0
 #define TT_GRAD_DENSE_SET 1
 #define TT_GRAD_DENSE_ACC 2
+#define TT_GRAD_SHORT_SEGMENTS 0x100
 
 typedef struct tt_grad_src {
   const void* d_out; /* gradient w.r.t. the lookup output of this side */
@@ -381,9 +385,12 @@ int tt_route_expand(tt_ctx* ctx, const int32_t* sorted_src, const int32_t* seg_o
                     const int32_t* pos_u, int64_t M, int64_t* idx_slot, tt_stream stream);
 /* Duplicate-row plan of G ASCENDING runs of C row ids each (what an owner receives: every source sends its distinct rows in
  * ascending order, pads -- the largest value -- at the end): a stable merge by binary searches instead of radix passes.
- * Same outputs as tt_dedup_plan over the concatenated runs; workspace tt_dedup_workspace_bytes(G * C). */
-int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, int32_t* sorted_src, int32_t* unique_rows,
-                       int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes, tt_stream stream);
+ * Same outputs as tt_dedup_plan over the concatenated runs; workspace tt_dedup_workspace_bytes(G * C).
+ * row_limit > 0: ids >= row_limit are pads -- they sort to the end as ONE last group that is left out of n_unique (the
+ * gradient reduction and the optimiser then never touch the thousands of pad entries); row_limit <= 0: every id counts. */
+int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, int64_t row_limit, int32_t* sorted_src,
+                       int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique, void* workspace,
+                       size_t workspace_bytes, tt_stream stream);
 /* out[i, :] = rows[i] < 0 ? 0 : table[min(rows[i], table_rows - 1), :] -- the owner's gather of requested rows and the
  * hand-over of per-row gradients into the send buckets, whose unused entries carry -1 (E a multiple of 4, 16-byte aligned
  * f32 buffers). */

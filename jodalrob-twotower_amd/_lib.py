@@ -19,6 +19,7 @@ TT_F32, TT_BF16 = 0, 1
 TT_MAX_SIDES, TT_MAX_HIDDEN = 4, 8
 TT_GRAD_SPARSE, TT_GRAD_DENSE_SET, TT_GRAD_DENSE_ACC = 0, 1, 2
 TT_TOWER_UNFUSED_TAIL = 1
+TT_GRAD_SHORT_SEGMENTS = 0x100
 
 vp = C.c_void_p
 i32, i64, f32, u64, sz = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -111,7 +112,7 @@ SIGNATURES = {
     "tt_route_workspace_bytes": (sz, [i64, i32]),
     "tt_route_bucket": (C.c_int, [vp, vp, vp, i64, i32, i32, C.POINTER(i32), i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "tt_route_expand": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp]),
-    "tt_dedup_plan_runs": (C.c_int, [vp, vp, i32, i64, vp, vp, vp, vp, vp, sz, vp]),
+    "tt_dedup_plan_runs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_gather_rows": (C.c_int, [vp, vp, i64, i32, vp, i64, vp, vp]),
     "tt_copy_multi": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]),
     "tt_batch_gather": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]),

@@ -91,11 +91,11 @@ class EmbeddingStore:
             m._bind_grads()
 
     # ---- gradient bookkeeping (called from the autograd backward) ------------------------------
-    def accumulate_grad(self, plan: ops.DedupPlan, srcs, B: int):
+    def accumulate_grad(self, plan: ops.DedupPlan, srcs, B: int, short_segments: bool = False):
         """srcs: [(d_out view [B, K*E], K)] in slot order of `plan`."""
         if self.grad_mode == "sparse":
             grad_rows = torch.empty((max(plan.M, 1), self.E), dtype=torch.float32, device=self.device)
-            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_SPARSE, grad_rows)
+            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_SPARSE, grad_rows, short_segments)
             self.sparse_grad = (plan, grad_rows)
             return
         params = self.optim_parameters()

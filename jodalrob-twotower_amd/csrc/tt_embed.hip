@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __
                                                              const uint32_t* __restrict__ blockcount,
                                                              int32_t* __restrict__ n_unique,
                                                              int32_t* __restrict__ unique_rows,
-                                                             int32_t* __restrict__ seg_offsets) {
+                                                             int32_t* __restrict__ seg_offsets, uint32_t drop_from = 0xFFFFFFFFu) {
   __shared__ uint32_t wsum[4], wbefore[4], wall[4];
   constexpr uint32_t PER = kSortTile / kThreads;   // 16 contiguous elements per thread
   const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -461,7 +461,9 @@ __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __
     }
   }
   if (blockIdx.x == 0 && tid == 0) {
-    n_unique[0] = (int32_t)all;
+    // drop_from: the largest key is a pad value (>= drop_from) that the plan's consumers must not see as a row: it stays
+    // in unique_rows / seg_offsets (seg_offsets[n_unique] is still the end of the last real row) but is not counted
+    n_unique[0] = (int32_t)(all - ((M > 0 && keys[M - 1] >= drop_from) ? 1u : 0u));
     seg_offsets[all] = (int32_t)M;
   }
 }
@@ -891,14 +893,14 @@ template <int VEC, int DT, int LGT>
 __global__ __launch_bounds__(kThreads) void seg_reduce_kernel(SideSet a, const int32_t* __restrict__ sorted_src,
                                                              const int32_t* __restrict__ seg, const int32_t* __restrict__ unique_rows,
                                                              const int32_t* __restrict__ n_unique, int32_t mode,
-                                                             float* __restrict__ out, GradWs ws, uint32_t LG) {
+                                                             float* __restrict__ out, GradWs ws, uint32_t LG, bool all_short) {
   const uint32_t U = (uint32_t)*n_unique;
   const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lig = gthread % LG;
   const uint32_t ngroups = gridDim.x * blockDim.x / LG;
   for (uint32_t u = gthread / LG; u < U; u += ngroups) {
     const int32_t s0 = seg[u], s1 = seg[u + 1];
-    if (s1 - s0 > kLongSeg) {
+    if (!all_short && s1 - s0 > kLongSeg) {
       const int32_t nch = (s1 - s0 + kLongSeg - 1) / kLongSeg;
       int32_t base = 0;
       if (lig == 0) {
@@ -1523,8 +1525,9 @@ int tt_dedup_plan(tt_ctx* ctx, const int32_t* rows, int64_t M, int64_t table_row
   return TT_OK;
 }
 
-int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, int32_t* sorted_src, int32_t* unique_rows,
-                       int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes, tt_stream stream) {
+int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, int64_t row_limit, int32_t* sorted_src,
+                       int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
+                       tt_stream stream) {
   TT_CHECK_ARG(ctx && rows && sorted_src && unique_rows && seg_offsets && n_unique && workspace, "tt_dedup_plan_runs: NULL argument");
   TT_CHECK_ARG(G >= 1 && G <= TT_MAX_RANKS && C >= 1 && (int64_t)G * C < ((int64_t)1 << 31) - kSortTile, "tt_dedup_plan_runs: bad G / C");
   const int64_t M = (int64_t)G * C;
@@ -1539,7 +1542,8 @@ int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, i
   TT_LAUNCH_CHECK();
   head_count_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount);
   TT_LAUNCH_CHECK();
-  head_write_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount, n_unique, unique_rows, seg_offsets);
+  head_write_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount, n_unique, unique_rows, seg_offsets,
+                                               row_limit > 0 && row_limit < (int64_t)0xFFFFFFFFll ? (uint32_t)row_limit : 0xFFFFFFFFu);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }
@@ -1601,6 +1605,11 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
                       float* out, void* workspace, size_t workspace_bytes, tt_stream stream) {
   TT_CHECK_ARG(ctx && srcs && out, "tt_embed_grad_bwd: NULL argument");
   TT_CHECK_ARG(n_srcs >= 1 && n_srcs <= TT_MAX_SIDES, "tt_embed_grad_bwd: n_srcs=%d", n_srcs);
+  // TT_GRAD_SHORT_SEGMENTS: every segment is summed by its own lane group whatever its length -- the right choice (and
+  // three launches fewer) when the caller knows no segment is long, e.g. the owner side of the row exchange, where a
+  // row arrives at most once per rank.  Results do not depend on the flag.
+  const bool all_short = (mode & TT_GRAD_SHORT_SEGMENTS) != 0;
+  mode &= ~TT_GRAD_SHORT_SEGMENTS;
   TT_CHECK_ARG(mode >= TT_GRAD_SPARSE && mode <= TT_GRAD_DENSE_ACC, "tt_embed_grad_bwd: bad mode %d", mode);
   TT_CHECK_ARG(E >= 1 && B >= 0, "tt_embed_grad_bwd: bad E/B");
   if (M == 0) return TT_OK;
@@ -1631,8 +1640,10 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   const int dt = srcs[0].dtype;
   GradLayout gl = grad_layout(reinterpret_cast<char*>(workspace), M, E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  zero_words_kernel<<<1, 64, 0, st>>>(gl.ws.counters, 2);      // (a kernel, not a memset node: see graph notes in DESIGN.md)
-  TT_LAUNCH_CHECK();
+  if (!all_short) {
+    zero_words_kernel<<<1, 64, 0, st>>>(gl.ws.counters, 2);    // (a kernel, not a memset node: see graph notes in DESIGN.md)
+    TT_LAUNCH_CHECK();
+  }
   const int g1 = grid_for(ctx, M * LG);
   const int g2 = grid_for(ctx, gl.max_chunks * LG);
   const int g3 = (int)(gl.max_long < (int64_t)ctx->num_cus * 8 ? gl.max_long : (int64_t)ctx->num_cus * 8);   // a workgroup per long row
@@ -1644,8 +1655,10 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   // the lane-group width when every lane of a group owns exactly one chunk (shared decode, see sum_range)
 #define TT_SEG_LAUNCH(V, D, G)                                                                                                  \
   do {                                                                                                                          \
-    seg_reduce_kernel<V, D, G><<<g1, kThreads, 0, st>>>(a, sorted_src, seg_offsets, unique_rows, n_unique, mode, out, gl.ws, LG); \
+    seg_reduce_kernel<V, D, G><<<g1, kThreads, 0, st>>>(a, sorted_src, seg_offsets, unique_rows, n_unique, mode, out, gl.ws, LG, \
+                                                        all_short);                                                             \
     TT_LAUNCH_CHECK();                                                                                                          \
+    if (all_short) break;                                                                                                       \
     seg_chunk_kernel<V, D, G><<<g2, kThreads, 0, st>>>(a, sorted_src, gl.ws, LG);                                                \
     TT_LAUNCH_CHECK();                                                                                                          \
     seg_long_finish_kernel<V><<<g3, kThreads, 0, st>>>(E, a.C, seg_offsets, unique_rows, mode, out, gl.ws, LG);                 \

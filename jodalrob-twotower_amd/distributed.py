@@ -132,8 +132,9 @@ class HipBackend:
         ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_SPARSE, out)
         return out[:M]
 
-    def owner_accumulate(self, store: ShardedStore, plan, d_rows: torch.Tensor):
-        store.accumulate_grad(plan, [(d_rows, 1)], d_rows.shape[0])
+    def owner_accumulate(self, store: ShardedStore, plan, d_rows: torch.Tensor, max_per_row: int = 0):
+        # max_per_row: the most contributions a row can get (padded exchange: one per rank); 0 = unknown
+        store.accumulate_grad(plan, [(d_rows, 1)], d_rows.shape[0], short_segments=0 < max_per_row <= 64)
 
     # ---- steps of the fixed-capacity exchange (PaddedRowExchange) --------------------------------------------
     def local_plan(self, rows: torch.Tensor, side_K: Sequence[int], B: int):
@@ -157,8 +158,8 @@ class HipBackend:
 
     def owner_plan(self, recv_ids: torch.Tensor, local_rows: int, G: int = 1):
         """plan over the received local row ids -- G ascending runs (every source sends its distinct rows in ascending
-        order); the pad value `local_rows` groups into one (last) row that Adam skips"""
-        return ops.dedup_plan_runs(recv_ids, G, recv_ids.numel() // G)
+        order); the pad value `local_rows` groups into one (last) row that is left out of the plan's row count"""
+        return ops.dedup_plan_runs(recv_ids, G, recv_ids.numel() // G, local_rows)
 
     def reduce_local(self, plan, srcs, B: int, E: int) -> torch.Tensor:
         """[M, E]: row u = summed gradient of plan row u (unused bucket entries carry u = -1: gather_rows gives them zeros)"""
@@ -310,7 +311,7 @@ class PaddedRowExchange(RowExchange):
         be = self.backend
         grad_u = be.reduce_local(state["plan"], srcs, B, self.E)                 # one row per distinct row (+ a zero row)
         d_rows = self._a2a_equal(be.gather_rows(grad_u, state["send_u"]))        # to the owners, pads carry zeros
-        be.owner_accumulate(self.store, state["owner_plan"], d_rows)
+        be.owner_accumulate(self.store, state["owner_plan"], d_rows, self.world)
 
 
 class _GlobalScoreCEFn(torch.autograd.Function):

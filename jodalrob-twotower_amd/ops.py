@@ -160,8 +160,9 @@ def dedup_plan(rows: torch.Tensor, table_rows: int) -> DedupPlan:
     return plan
 
 
-def dedup_plan_runs(rows: torch.Tensor, G: int, C: int) -> DedupPlan:
-    """Plan of G ascending runs of C ids (stable merge; same outputs as dedup_plan on the concatenation)."""
+def dedup_plan_runs(rows: torch.Tensor, G: int, C: int, row_limit: int = 0) -> DedupPlan:
+    """Plan of G ascending runs of C ids (stable merge; same outputs as dedup_plan on the concatenation).  row_limit > 0:
+    ids >= row_limit are pads, grouped last and left out of n_unique."""
     dev, M = rows.device, G * C
     assert rows.numel() == M and rows.dtype == torch.int32
     buf = torch.empty(3 * M + 2, dtype=torch.int32, device=dev)
@@ -169,7 +170,7 @@ def dedup_plan_runs(rows: torch.Tensor, G: int, C: int) -> DedupPlan:
     lib = L.load()
     ws = L.workspace(dev, lib.tt_dedup_workspace_bytes(M))
     with _timed("tt_dedup_plan_runs"):
-        L.check(lib.tt_dedup_plan_runs(L.ctx(dev), L.ptr(rows), G, C, L.ptr(plan.sorted_src), L.ptr(plan.unique_rows),
+        L.check(lib.tt_dedup_plan_runs(L.ctx(dev), L.ptr(rows), G, C, row_limit, L.ptr(plan.sorted_src), L.ptr(plan.unique_rows),
                                        L.ptr(plan.seg_offsets), L.ptr(plan.n_unique), L.ptr(ws), ws.numel(), L.stream(dev)),
                 "tt_dedup_plan_runs")
     return plan
@@ -195,8 +196,11 @@ def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int) -> Dedup
     return plan
 
 
-def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int, out: torch.Tensor):
-    """srcs: [(d_out 2-D view [B, K*E], K)]."""
+def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int, out: torch.Tensor, short_segments: bool = False):
+    """srcs: [(d_out 2-D view [B, K*E], K)].  short_segments: the caller knows no row has many contributions (skips the
+    chunk passes; results do not depend on it)."""
+    if short_segments:
+        mode |= L.TT_GRAD_SHORT_SEGMENTS
     dev = out.device
     arr = (L.GradSrc * len(srcs))()
     for i, (d, K) in enumerate(srcs):

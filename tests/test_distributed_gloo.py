@@ -46,7 +46,7 @@ class CheckerBackend:
         flat = torch.cat([d.reshape(B * K, E) for d, K in srcs])
         return flat[order.long()]
 
-    def owner_accumulate(self, store, plan, d_rows):
+    def owner_accumulate(self, store, plan, d_rows, max_per_row=0):
         g = torch.zeros((store.weight.shape[0] + 1, store.weight.shape[1]))      # + the pad row of the fixed-capacity exchange
         g.index_add_(0, plan.long(), d_rows)
         self.dense_grad = g[:-1]

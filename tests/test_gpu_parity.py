@@ -213,6 +213,11 @@ def test_embed_grad_sparse_and_dense(tt, E, B, vocabs, src_dtype):
     out2 = torch.empty_like(out)
     ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_SPARSE, out2)
     assert torch.equal(out[:U], out2[:U])
+    # TT_GRAD_SHORT_SEGMENTS (one lane group per row, no chunk passes) changes the time, not the sums -- also when
+    # the caller's promise does not hold and some rows ARE long
+    out3 = torch.full_like(out, float("nan"))
+    ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_SPARSE, out3, short_segments=True)
+    np.testing.assert_allclose(out3[:U].cpu().numpy(), dense_ref[uniq], rtol=2e-5, atol=2e-5)
 
 
 def test_score_kernels_vs_oracle(tt):
@@ -696,6 +701,12 @@ def test_dedup_plan_runs_equals_general(tt, G, C, rows_max):
     assert np.array_equal(pr.sorted_src.cpu().numpy(), np.argsort(rows, kind="stable").astype(np.int32))
     assert torch.equal(pr.sorted_src, pg.sorted_src)
     assert torch.equal(pr.unique_rows[:U], pg.unique_rows[:U]) and torch.equal(pr.seg_offsets[:U + 1], pg.seg_offsets[:U + 1])
+    # row_limit: the pad group (ids >= rows_max, always last) is left out of the row count, nothing else changes
+    pl = ops.dedup_plan_runs(t, G, C, rows_max)
+    has_pad = bool((rows == rows_max).any())
+    assert int(pl.n_unique.item()) == U - (1 if has_pad else 0)
+    assert torch.equal(pl.sorted_src, pr.sorted_src) and torch.equal(pl.unique_rows[:U], pr.unique_rows[:U])
+    assert torch.equal(pl.seg_offsets[:U + 1], pr.seg_offsets[:U + 1])
 
 
 def test_gather_rows(tt):
