@@ -138,6 +138,17 @@ def main():
         if dist is not None else (args.mode == "graph" and args.optimizer != "torch_adam")
     gstep = None
     profile = ops.LookupProfile(dev) if (use_graph and not os.environ.get("TT_BENCH_NO_PROFILE")) else None   # device-clock stamps: work inside a graph
+    if dist is not None and getattr(task, "exchange", None) is not None and hasattr(task.exchange, "reset_capacity"):
+        # fixed-capacity exchange: size the buckets for the largest need over the whole batch pool (one forward per
+        # batch, outside the timed region), not just for the batch the capture happens to see
+        caps = []
+        with torch.no_grad():
+            for b in pool:
+                task.exchange.reset_capacity()
+                task(b, return_metrics=False)
+                caps.append(task.exchange.C)
+        task.exchange.C = max(caps)
+        torch.cuda.synchronize()
     if use_graph:
         from jodalrob_twotower_amd.graph import GraphedTrainStep
         try:
@@ -244,11 +255,15 @@ def main():
     x_bf16 = args.mlp_dtype == "bf16" and os.environ.get("TT_TOWER_IO_DTYPE", "x") in ("x", "both")
     s_out = 2 if x_bf16 else 4                                # the lookup writes straight into the tower input x
     bytes_per_pair = K_tot * (E * 4 + 8 + E * s_out)         # table row + i64 id + output row (10,032 / 7,600 B)
+    if dist is not None and x_bf16 and getattr(getattr(task, "exchange", None), "wire_bf16", False):
+        # sharded step: the stamped launch PLACES the exchanged rows, which arrive as bf16 (the f32 table rows are read by
+        # tt_gather_rows on their owners): bf16 row in + i64 index + bf16 row out
+        bytes_per_pair = K_tot * (E * 2 + 8 + E * 2)
     algo_bytes = B * bytes_per_pair                          # one launch = one batch on this GPU
     achieved = algo_bytes / (lookup_ms * 1e-3) / 1e9 if lookup_ms == lookup_ms and lookup_ms > 0 else None
     traffic = None
     pmc = ROOT / "profiles" / ("lookup_pmc_bf16out.json" if x_bf16 else "lookup_pmc.json")
-    if pmc.exists():
+    if pmc.exists() and dist is None:                        # the PMC passes were taken on the single-GPU lookup launch
         try:
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
         except Exception:

@@ -393,9 +393,10 @@ int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, i
                        size_t workspace_bytes, tt_stream stream);
 /* out[i, :] = rows[i] < 0 ? 0 : table[min(rows[i], table_rows - 1), :] -- the owner's gather of requested rows and the
  * hand-over of per-row gradients into the send buckets, whose unused entries carry -1 (E a multiple of 4, 16-byte aligned
- * f32 buffers). */
+ * f32 table).  out_dtype TT_BF16: rows leave rounded to bf16 (RNE) -- bit-identical to rounding them where a bf16 tower
+ * input is filled, at half the bytes on the wire. */
 int tt_gather_rows(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const int32_t* rows, int64_t n,
-                   float* out, tt_stream stream);
+                   void* out, int32_t out_dtype, tt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * n (<= 8) device-to-device copies in ONE launch -- the per-step refresh of a captured step's static input

@@ -113,7 +113,7 @@ SIGNATURES = {
     "tt_route_bucket": (C.c_int, [vp, vp, vp, i64, i32, i32, C.POINTER(i32), i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "tt_route_expand": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp]),
     "tt_dedup_plan_runs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
-    "tt_gather_rows": (C.c_int, [vp, vp, i64, i32, vp, i64, vp, vp]),
+    "tt_gather_rows": (C.c_int, [vp, vp, i64, i32, vp, i64, vp, i32, vp]),
     "tt_copy_multi": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]),
     "tt_batch_gather": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]),
 }

@@ -1286,15 +1286,23 @@ __global__ __launch_bounds__(kThreads) void route_scatter_kernel(const int32_t* 
 }
 
 // out[i, :] = rows[i] < 0 ? 0 : table[min(rows[i], R - 1), :]   (16-byte lanes; the owner-side gather / gradient hand-over)
+// OUT_BF16: rows leave as bf16 (RNE) -- what the bf16 tower input would round them to anyway, at half the wire bytes
+template <bool OUT_BF16>
 __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __restrict__ table, const int32_t* __restrict__ rows, uint32_t n,
-                                                              int32_t R, uint32_t C4, float* __restrict__ out) {
+                                                              int32_t R, uint32_t C4, void* __restrict__ out) {
   const uint64_t total = (uint64_t)n * C4;
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t i = (uint32_t)(t / C4), c = (uint32_t)(t - (uint64_t)i * C4);
     int32_t r = rows[i];
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                  // negative index: a zero row (unused bucket entries)
     if (r >= 0) v = reinterpret_cast<const float4*>(table)[(uint64_t)(r >= R ? R - 1 : r) * C4 + c];
-    reinterpret_cast<float4*>(out)[(uint64_t)i * C4 + c] = v;
+    if (OUT_BF16) {
+      ushort4 o;
+      o.x = tt_f2bf(v.x); o.y = tt_f2bf(v.y); o.z = tt_f2bf(v.z); o.w = tt_f2bf(v.w);
+      reinterpret_cast<ushort4*>(out)[(uint64_t)i * C4 + c] = o;
+    } else {
+      reinterpret_cast<float4*>(out)[(uint64_t)i * C4 + c] = v;
+    }
   }
 }
 
@@ -1808,15 +1816,18 @@ int tt_route_bucket(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_un
   return TT_OK;
 }
 
-int tt_gather_rows(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const int32_t* rows, int64_t n, float* out,
-                   tt_stream stream) {
+int tt_gather_rows(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const int32_t* rows, int64_t n, void* out,
+                   int32_t out_dtype, tt_stream stream) {
   TT_CHECK_ARG(ctx && table && rows && out, "tt_gather_rows: NULL argument");
   TT_CHECK_ARG(table_rows >= 1 && table_rows <= INT32_MAX && n >= 0 && n < ((int64_t)1 << 31) && E >= 4 && E % 4 == 0,
                "tt_gather_rows: bad shape (E must be a multiple of 4)");
-  TT_CHECK_ARG(tt_aligned(table, 16) && tt_aligned(out, 16), "tt_gather_rows: table / out must be 16-byte aligned");
+  TT_CHECK_ARG(out_dtype == TT_F32 || out_dtype == TT_BF16, "tt_gather_rows: bad out_dtype");
+  TT_CHECK_ARG(tt_aligned(table, 16) && tt_aligned(out, out_dtype == TT_BF16 ? 8 : 16), "tt_gather_rows: table / out alignment");
   if (n == 0) return TT_OK;
-  gather_rows_kernel<<<grid_for(ctx, n * (E / 4)), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(table, rows, (uint32_t)n,
-                                                                                                        (int32_t)table_rows, (uint32_t)(E / 4), out);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int grid = grid_for(ctx, n * (E / 4));
+  if (out_dtype == TT_BF16) gather_rows_kernel<true><<<grid, kThreads, 0, st>>>(table, rows, (uint32_t)n, (int32_t)table_rows, (uint32_t)(E / 4), out);
+  else gather_rows_kernel<false><<<grid, kThreads, 0, st>>>(table, rows, (uint32_t)n, (int32_t)table_rows, (uint32_t)(E / 4), out);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

@@ -115,6 +115,12 @@ class HipBackend:
         """out_side[b, k*E:(k+1)*E] = pooled[inv[slot]]  -- the lookup kernel with `pooled` as the table."""
         M = pooled.shape[0]
         dev = pooled.device
+        if pooled.dtype == torch.bfloat16:
+            # bf16 rows into bf16 tower inputs: a bit copy -- pairs of bf16 move as one f32 word (E/2 "floats" per row)
+            if any(s.out.dtype != torch.bfloat16 for s in sides) or pooled.shape[1] % 2:
+                raise ValueError("bf16 pooled rows need bf16 tower inputs and an even embedding dim")
+            pooled = pooled.view(torch.float32)
+            sides = [ops.LookupSide(s.ids, s.key_row_offset, s.key_vocab, s.out.view(torch.float32), s.K) for s in sides]
         lsides, base = [], 0
         for s in sides:
             n = B * s.K
@@ -152,9 +158,9 @@ class HipBackend:
     def route_expand(self, plan, pos_u: torch.Tensor) -> torch.Tensor:
         return ops.route_expand(plan, pos_u)
 
-    def gather_rows(self, table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    def gather_rows(self, table: torch.Tensor, idx: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
         """out[i] = table[idx[i]] (idx int32; above the table: last row; negative: a zero row)"""
-        return ops.gather_rows(table, idx)
+        return ops.gather_rows(table, idx, out_dtype)
 
     def owner_plan(self, recv_ids: torch.Tensor, local_rows: int, G: int = 1):
         """plan over the received local row ids -- G ascending runs (every source sends its distinct rows in ascending
@@ -251,17 +257,18 @@ class PaddedRowExchange(RowExchange):
     training step -- collectives included -- can be captured into ONE graph and replayed.
 
     Capacity C (entries per (source, owner) pair, identical on all ranks) is calibrated on the first forward (one
-    host sync): 1.5 x the largest bucket any rank needs, rounded up to 256.  A later batch that needs more sets a
+    host sync): 1.25 x the largest bucket any rank needs, rounded up to 256.  A later batch that needs more sets a
     device-side flag (`overflowed()`); its over-capacity rows were not exchanged, so the caller must re-calibrate
     (`reset_capacity()`) and redo the step -- bench.py checks the flag after the timed region."""
 
-    def __init__(self, store: ShardedStore, group=None, backend=None, capacity: Optional[int] = None, slack: float = 1.5, comm=None):
+    def __init__(self, store: ShardedStore, group=None, backend=None, capacity: Optional[int] = None, slack: float = 1.25, comm=None):
         super().__init__(store, group, backend, comm)
         if store.grad_mode != "sparse":
             raise ValueError("the fixed-capacity exchange needs embedding_grad='sparse' (its bucket pads are skipped by the "
                              "row-sparse Adam; a dense gradient buffer has no row for them)")
         self.C, self.slack = capacity, slack
         self._overflow = None
+        self.wire_bf16 = __import__("os").environ.get("TT_DIST_WIRE_F32", "0") != "1"      # TT_DIST_WIRE_F32=1: f32 rows on the wire (A/B)
 
     def local_rows_of(self, g: int) -> int:
         R = self.store.global_rows
@@ -300,7 +307,10 @@ class PaddedRowExchange(RowExchange):
             self._overflow = be.new_flag(rows.device)
         send_ids, send_u, pos_u, _counts = be.route_bucket(plan, G, self.C, pads, -1, self._overflow)
         recv_ids = self._a2a_equal(send_ids)                                     # [G*C] local row ids, pad = my local_rows
-        pooled_local = be.gather_rows(self.store.weight, recv_ids)               # pads clamp to the last row (unused)
+        # bf16 tower inputs (mlp_dtype="bf16"): the rows are rounded where they are gathered instead of where they are
+        # placed -- the same bits in x, half the bytes on the wire
+        wire = torch.bfloat16 if all(s.out.dtype == torch.bfloat16 for s in sides) and E % 8 == 0 and self.wire_bf16 else torch.float32
+        pooled_local = be.gather_rows(self.store.weight, recv_ids, wire)         # pads clamp to the last row (unused)
         got = self._a2a_equal(pooled_local)                                      # [G*C, E] in my send order
         be.place_rows(got, be.route_expand(plan, pos_u), sides, B)
         if not want_grad:

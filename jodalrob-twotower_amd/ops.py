@@ -525,13 +525,13 @@ def route_bucket(plan: DedupPlan, G: int, C: int, pad_id: Sequence[int], pad_u: 
     return send_ids, send_u, pos_u, counts
 
 
-def gather_rows(table: torch.Tensor, rows: torch.Tensor) -> torch.Tensor:
-    """out[i] = 0 if rows[i] < 0 else table[min(rows[i], R - 1)]  (rows int32)."""
+def gather_rows(table: torch.Tensor, rows: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """out[i] = 0 if rows[i] < 0 else table[min(rows[i], R - 1)]  (rows int32; out_dtype float32 or bfloat16)."""
     dev, n, E = table.device, rows.numel(), table.shape[1]
-    out = torch.empty((n, E), dtype=torch.float32, device=dev)
+    out = torch.empty((n, E), dtype=out_dtype, device=dev)
     with _timed("tt_gather_rows"):
-        L.check(L.load().tt_gather_rows(L.ctx(dev), L.ptr(table), table.shape[0], E, L.ptr(rows), n, L.ptr(out), L.stream(dev)),
-                "tt_gather_rows")
+        L.check(L.load().tt_gather_rows(L.ctx(dev), L.ptr(table), table.shape[0], E, L.ptr(rows), n, L.ptr(out), _dt(out),
+                                        L.stream(dev)), "tt_gather_rows")
     return out
 
 

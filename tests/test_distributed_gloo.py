@@ -90,10 +90,10 @@ class CheckerBackend:
                 idx[int(plan.sorted_src[p])] = int(pos_u[u])
         return idx
 
-    def gather_rows(self, table, idx):
+    def gather_rows(self, table, idx, out_dtype=torch.float32):
         out = table[torch.clamp(idx.long(), 0, table.shape[0] - 1)].clone()
         out[idx < 0] = 0
-        return out
+        return out.to(out_dtype)
 
     def owner_plan(self, recv_ids, local_rows, G=1):
         runs = recv_ids.view(G, -1)

@@ -718,6 +718,7 @@ def test_gather_rows(tt):
     exp = table[idx.long().clamp(0, 999)].clone()
     exp[idx < 0] = 0                                         # negative index: a zero row (unused bucket entries)
     assert torch.equal(out, exp)
+    assert torch.equal(ops.gather_rows(table, idx, torch.bfloat16), exp.to(torch.bfloat16))      # RNE on the way out
 
 
 def test_full_size_properties(tt, schema_real):
@@ -876,12 +877,13 @@ class _ThreadComm:
         return t
 
 
-@pytest.mark.parametrize("G", [2, 3])
-def test_padded_exchange_multi_rank_on_one_gpu(tt, G):
+@pytest.mark.parametrize("G,x_dtype", [(2, torch.float32), (3, torch.float32), (3, torch.bfloat16)])
+def test_padded_exchange_multi_rank_on_one_gpu(tt, G, x_dtype):
     """The fixed-capacity exchange with the REAL HIP steps (plan, tt_route_bucket, tt_gather_rows, tt_route_expand, placing
     lookup, local + owner-side reductions, tt_dedup_plan_runs) for G > 1: G virtual ranks as threads on one GPU.  Forward:
-    every rank's tower inputs == a direct gather from the unsharded table (bit-exact).  Backward: every owner's summed row
-    gradients == the global scatter-add over ALL ranks' slots restricted to its rows."""
+    every rank's tower inputs == a direct gather from the unsharded table (bit-exact; with bf16 tower inputs the rows
+    travel as bf16 and must equal the RNE rounding of the table rows).  Backward: every owner's summed row gradients ==
+    the global scatter-add over ALL ranks' slots restricted to its rows."""
     import threading
     from jodalrob_twotower_amd import ops
     from jodalrob_twotower_amd.distributed import PaddedRowExchange, ShardedStore
@@ -906,13 +908,13 @@ def test_padded_exchange_multi_rank_on_one_gpu(tt, G):
                     ids = np.stack([r2.integers(-2, vk + 2, B) for vk in v], axis=1).astype(np.int64)
                     off = np.concatenate([[0], np.cumsum(v)[:-1]]) + base
                     base += sum(v)
-                    out = torch.zeros((B, K * E), device=DEV)
+                    out = torch.zeros((B, 16 + K * E), dtype=x_dtype, device=DEV)[:, 16:]      # a view inside a wider buffer, as x
                     sides.append(ops.LookupSide(torch.from_numpy(ids.reshape(-1)).to(DEV), torch.from_numpy(off.astype(np.int64)).to(DEV),
                                                 torch.tensor(v, dtype=torch.int64, device=DEV), out, K))
                     outs.append(out)
                     rows_ref.append((np.minimum(np.maximum(ids, 0), np.array(v)[None, :] - 1) + off[None, :]).reshape(-1))
                 state = ex.forward(sides, B, True)
-                fwd_ok = all(torch.equal(o.cpu(), table[torch.from_numpy(rr)].view(B, -1)) for o, rr in zip(outs, rows_ref))
+                fwd_ok = all(torch.equal(o.cpu(), table[torch.from_numpy(rr)].view(B, -1).to(x_dtype)) for o, rr in zip(outs, rows_ref))
                 d = [torch.from_numpy(r2.standard_normal((B, s.K * E)).astype(np.float32)).to(DEV) for s in sides]
                 ex.backward(state, [(dd, s.K) for dd, s in zip(d, sides)], B)
                 plan, grad_rows = store.sparse_grad
