@@ -321,7 +321,18 @@ class _TowersFn(torch.autograd.Function):
         flat_grads = []
         work = [(s, d, sp) for s, d, sp in zip(ctx.sides, d_embs, ctx.spans) if s.B and d is not None]
         prepared = []
-        for s, d_emb, (pos, nd, nt) in work:
+        # one buffer for the whole pass: [dense gradients of every tower | per-tower scratch] -- the dense part is ONE
+        # contiguous range, so the data-parallel sum is a single all-reduce however many towers there are
+        side_sizes = []
+        for s, _, _ in work:
+            tw = s.tower
+            side_sizes.append(([_al(p.numel()) for p in tw.dense_parameters()],
+                               [_al(s.B * tw.x_width) if tw.dx_dtype == torch.float32 else 0] +
+                               [_al(s.B * h) for h in tw.tower_hidden_dims[1:]] + [_al(s.B * tw.final_embedding_dim)]))
+        dense_total = sum(sum(d) for d, _ in side_sizes)
+        buf = torch.empty(dense_total + sum(sum(r) for _, r in side_sizes), dtype=torch.float32, device=work[0][0].emb.device) if work else None
+        dense_at, scratch_at = 0, dense_total
+        for (s, d_emb, (pos, nd, nt)), (dsz, rsz) in zip(work, side_sizes):
             tw = s.tower
             dev = s.emb.device
             d_emb = d_emb.to(dtype=torch.float32).contiguous()
@@ -329,12 +340,14 @@ class _TowersFn(torch.autograd.Function):
             hid = tw.tower_hidden_dims[1:]
             B = s.B
             dx_f32 = tw.dx_dtype == torch.float32
-            sizes = [_al(p.numel()) for p in dps] + [_al(B * tw.x_width) if dx_f32 else 0] + [_al(B * h) for h in hid] + \
-                    [_al(B * tw.final_embedding_dim)]
-            buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-            offs = [0]
-            for z in sizes:
+            offs = [dense_at]                                   # absolute offsets in buf: dense entries, then this tower's scratch
+            for z in dsz[:-1]:
                 offs.append(offs[-1] + z)
+            dense_at += sum(dsz)
+            offs.append(scratch_at)
+            for z in rsz:
+                offs.append(offs[-1] + z)
+            scratch_at += sum(rsz)
             base = buf.data_ptr()
             views = [buf[offs[i]:offs[i] + p.numel()].view(p.shape) for i, p in enumerate(dps)]
             g = L.TowerGrads()
@@ -354,7 +367,6 @@ class _TowersFn(torch.autograd.Function):
                                     "d_emb": d_emb})
             for i, v in enumerate(views):
                 grads[pos + 2 + i] = v
-            flat_grads.append(buf[:offs[len(dps)]])
             dxs[id(s)] = d_x[:, tw.tower_hidden_dims[0]:]
         fused = len(prepared) > 1 and len({s.B for s, _, _ in prepared}) == 1 and \
             len({s.tower.n_hidden for s, _, _ in prepared}) == 1 and len({(s.train, s.p_drop, s.seed) for s, _, _ in prepared}) == 1
@@ -368,6 +380,8 @@ class _TowersFn(torch.autograd.Function):
                 ops.tower_bwd(s.tower._params(), s.acts_struct, d_emb, g, s.B, s.train, s.p_drop, s.seed, s.emb.device,
                               s.tower._seed_dev)
         if exch is not None:
+            if buf is not None and dense_total:
+                flat_grads.append(buf[:dense_total])
             exch.all_reduce_dense(flat_grads)
             if ctx.exch_state is not None:
                 srcs = []
