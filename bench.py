@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: whole step replayed from one captured HIP graph; eager: launched from Python")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded-table path even on one GPU")
+    ap.add_argument("--negatives", choices=["local", "global"], default="local",
+                    help="multi-GPU: in-batch negatives of the rank's own batch (data-parallel default) or of the GLOBAL batch")
+    ap.add_argument("--sync-bn", action="store_true", help="multi-GPU: BatchNorm statistics over all ranks' rows")
     ap.add_argument("--breakdown", action="store_true", help="extra instrumented pass: per-kernel HIP-event times")
     return ap.parse_args()
 
@@ -113,7 +116,8 @@ def main():
                                                  temperature=1.0, device=dev, embedding_grad=grad_mode, score_dtype=args.score_dtype,
                                                  mlp_dtype=args.mlp_dtype,
                                                  # dedup-first, fixed-capacity all-to-alls: the whole step incl. RCCL is one graph replay
-                                                 exchange="padded" if grad_mode == "sparse" else "exact")
+                                                 exchange="padded" if grad_mode == "sparse" else "exact",
+                                                 negatives=args.negatives, sync_bn=args.sync_bn)
         else:
             task = tt.create_two_tower_train_task(keys_n, keys_c, metadata_path=str(meta), categorical_embedding_dim=E,
                                                   notice_dense_input_dim=din_n, company_dense_input_dim=din_c,
@@ -283,7 +287,8 @@ def main():
                    "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})", "optimizer": args.optimizer,
                    "score_dtype": args.score_dtype, "mlp_dtype": args.mlp_dtype, "launch": "hip graph replay" if gstep is not None else "eager",
                    "parallelism": ("single GPU" if dist is None else f"row-wise sharded tables x{world} (dedup-first fixed-capacity all-to-all" +
-                                   (", RCCL inside the graph" if gstep is not None else "") + ") + data parallel towers")},
+                                   (", RCCL inside the graph" if gstep is not None else "") + ") + data parallel towers" +
+                                   (f", {args.negatives} in-batch negatives" + (", SyncBN" if args.sync_bn else "")))},
         "roofline": {"kernel": "lookup_kernel (tt_embed_lookup_fwd)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "launches_timed": n_launch, "mean_launch_us": lookup_ms * 1e3,

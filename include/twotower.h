@@ -214,6 +214,21 @@ typedef struct tt_tower_params {
   int32_t dx_dtype;      /* element type of tt_tower_grads.d_x (TT_BF16 only with compute_dtype TT_BF16; the per-slot row
                             gradients are then rounded to bf16 before tt_embed_grad_bwd sums them in f32) */
   int32_t flags;         /* TT_TOWER_*: 0 by default */
+  /* Data-parallel BatchNorm over several ranks (SyncBN): the pass is cut at the batch-wide reduction so that the caller
+   * can exchange the statistics in between (the library makes no collective calls).
+   *   sync_phase 0: the whole pass (default).
+   *   sync_phase 1: forward up to the local BN statistics -> acts.bn_sync_local [3][H] = (n, mean, M2) per column;
+   *                 backward up to the local column sums   -> grads.s_sync_local [2][H] = (S1, S2).
+   *   sync_phase 2: the rest, with the statistics of ALL ranks as acts.bn_sync_all [sync_ranks][3][H] (merged in rank
+   *                 order with Chan's formula) / grads.s_sync_all [sync_ranks][2][H] (added in rank order); BN normalises
+   *                 over sync_ranks * B rows, and the BN weight / bias gradients -- identical on every rank -- are stored
+   *                 divided by sync_ranks so that the caller's SUM over ranks of the dense gradients leaves them right.
+   * Phases 1 / 2 need the fused tail (training, TT_BF16 operands, ONE hidden block of width <= 64, d_out <= 64);
+   * anything else returns TT_ERR_UNSUPPORTED. */
+  int32_t sync_phase;
+  int32_t sync_ranks;
+  int64_t rng_row_offset; /* first global row of this rank's batch: dropout masks are drawn per GLOBAL (row, column), so a
+                             split batch drops the same elements as the whole one */
 } tt_tower_params;
 /* run the tail of a training pass (BN of the last block, output Linear, L2 normalise) as the separate kernels even when
    the fused form applies (last hidden width and d_out <= 64, compute_dtype TT_BF16): for A/B comparison */
@@ -228,6 +243,10 @@ typedef struct tt_tower_acts { /* caller-allocated; kept between forward and bac
   float* rstd[TT_MAX_HIDDEN];
   float* y;   /* [B, d_out] before normalisation */
   float* emb; /* [B, d_out] unit rows */
+  float* bn_sync_local;     /* sync_phase 1 out: [3][hidden[0]] */
+  const float* bn_sync_all; /* sync_phase 2 in:  [sync_ranks][3][hidden[0]] */
+  int64_t bn_sync_stride;   /* floats between two ranks' triples in bn_sync_all (0 = 3 * hidden[0]): lets one all-gather
+                               carry every tower's statistics */
 } tt_tower_acts;
 
 typedef struct tt_tower_grads { /* every buffer is overwritten, not accumulated */
@@ -242,6 +261,9 @@ typedef struct tt_tower_grads { /* every buffer is overwritten, not accumulated 
   void* d_x;                     /* [B, h0 + kcat_e] of params.dx_dtype; columns [h0, ..) feed tt_embed_grad_bwd */
   float* scratch[TT_MAX_HIDDEN]; /* [B, hidden[i]] */
   float* d_y;                    /* [B, d_out] */
+  float* s_sync_local;     /* sync_phase 1 out: [2][hidden[0]] */
+  const float* s_sync_all; /* sync_phase 2 in:  [sync_ranks][2][hidden[0]] */
+  int64_t s_sync_stride;   /* floats between two ranks' pairs in s_sync_all (0 = 2 * hidden[0]) */
 } tt_tower_grads;
 
 /* scratch for either pass (split-K slabs of the weight gradients, column-reduction partials) */

@@ -56,16 +56,18 @@ class TowerParams(C.Structure):
                 ("hidden", i32 * TT_MAX_HIDDEN),
                 ("w_proj", vp), ("b_proj", vp), ("w", _H), ("b", _H), ("bn_w", _H), ("bn_b", _H),
                 ("bn_rm", _H), ("bn_rv", _H), ("bn_nbt", _H), ("w_out", vp), ("b_out", vp), ("compute_dtype", i32),
-                ("x_dtype", i32), ("dx_dtype", i32), ("flags", i32)]
+                ("x_dtype", i32), ("dx_dtype", i32), ("flags", i32),
+                ("sync_phase", i32), ("sync_ranks", i32), ("rng_row_offset", i64)]
 
 
 class TowerActs(C.Structure):
-    _fields_ = [("dense", vp), ("x", vp), ("pre", _H), ("act", _H), ("mean", _H), ("rstd", _H), ("y", vp), ("emb", vp)]
+    _fields_ = [("dense", vp), ("x", vp), ("pre", _H), ("act", _H), ("mean", _H), ("rstd", _H), ("y", vp), ("emb", vp),
+                ("bn_sync_local", vp), ("bn_sync_all", vp), ("bn_sync_stride", i64)]
 
 
 class TowerGrads(C.Structure):
     _fields_ = [("w_proj", vp), ("b_proj", vp), ("w", _H), ("b", _H), ("bn_w", _H), ("bn_b", _H),
-                ("w_out", vp), ("b_out", vp), ("d_x", vp), ("scratch", _H), ("d_y", vp)]
+                ("w_out", vp), ("b_out", vp), ("d_x", vp), ("scratch", _H), ("d_y", vp), ("s_sync_local", vp), ("s_sync_all", vp), ("s_sync_stride", i64)]
 
 
 # name -> (restype, argtypes); every symbol include/twotower.h declares

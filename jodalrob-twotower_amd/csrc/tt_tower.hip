@@ -36,7 +36,10 @@ struct Batch {
 };
 
 // grid (colblocks of 64, nchunks, towers); thread = (column, row-lane of 4)
-struct BnStatArgs { const float* pre; int B, H, rows_per_chunk, nchunks; float* partial; float* mean; float* rstd; float* rm; float* rv; int64_t* nbt; };
+struct BnStatArgs {
+  const float* pre; int B, H, rows_per_chunk, nchunks; float* partial; float* mean; float* rstd; float* rm; float* rv; int64_t* nbt;
+  int64_t pstride = 0;   // floats between chunks when READING partial (0 = 3 * H); chunks are always written densely
+};
 
 __global__ __launch_bounds__(kThreads) void bn_stats_partial_kernel(Batch<BnStatArgs> batch) {
   const BnStatArgs& a = batch.a[blockIdx.z];
@@ -145,6 +148,7 @@ struct ColArgs {
   uint64_t salt;
   int B, H, rows_per_chunk, nchunks;
   float* partial; float* out0; float* out1;
+  int64_t pstride = 0;   // floats between chunks when READING partial (0 = 2 * H)
 };
 
 __global__ __launch_bounds__(kThreads) void colsum_partial_kernel(Batch<ColArgs> batch, bool drop, float p, uint64_t seed0,
@@ -395,10 +399,11 @@ __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArg
     Wf o{0.f, 0.f, 0.f};
     if (c < H) {
       Wf v[kMaxChunks / 4];
+      const int64_t ps = a.pstride ? a.pstride : 3 * H;
 #pragma unroll
       for (int i = 0; i < kMaxChunks / 4; ++i) {
         const int k = rq + 4 * i;
-        const float* q = a.partial + (int64_t)k * 3 * H;
+        const float* q = a.partial + (int64_t)k * ps;
         v[i] = k < a.nchunks ? Wf{q[c], q[H + c], q[2 * H + c]} : Wf{0.f, 0.f, 0.f};
       }
 #pragma unroll
@@ -666,7 +671,9 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_kernel(Batch<TailBwdArg
 // dropout-scaled) d_act, 64 rows per workgroup.  grid (cdiv(B, 64), towers)
 struct TailApplyArgs {
   ColArgs col; BnBwdArgs bn;
-  const float* w_slab; const float* b_slab; int D; float* g_w_out; float* g_b_out;   // [nchunks][D * H], [nchunks][D] -> [D, H], [D]
+  const float* w_slab; const float* b_slab; int D; float* g_w_out; float* g_b_out;   // [slab_chunks][D * H], [slab_chunks][D] -> [D, H], [D]
+  int slab_chunks;      // row chunks of tail_bwd_kernel on THIS rank (col.nchunks counts ranks when the sums come from all ranks)
+  float out_scale;      // BN weight / bias gradients are stored times this (1 / ranks under SyncBN: see twotower.h)
 };
 
 __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<TailApplyArgs> batch) {
@@ -690,7 +697,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<Tail
 #pragma unroll
     for (int i = 0; i < (kMaxChunks + 11) / 12; ++i) {
       const int z = zl + 12 * i;
-      v[i] = (e < total && z < a.nchunks) ? (e < DH ? ta.w_slab[(int64_t)z * DH + e] : ta.b_slab[(int64_t)z * ta.D + (e - DH)]) : 0.f;
+      v[i] = (e < total && z < ta.slab_chunks) ? (e < DH ? ta.w_slab[(int64_t)z * DH + e] : ta.b_slab[(int64_t)z * ta.D + (e - DH)]) : 0.f;
     }
     float sum = 0.f;
 #pragma unroll
@@ -719,10 +726,11 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<Tail
     float s0 = 0.f, s1 = 0.f;
     if (c < H) {
       float v0[kMaxChunks / 4], v1[kMaxChunks / 4];
+      const int64_t ps = a.pstride ? a.pstride : 2 * H;
 #pragma unroll
       for (int i = 0; i < kMaxChunks / 4; ++i) {
         const int k = rq + 4 * i;
-        const float* q = a.partial + (int64_t)k * 2 * H;
+        const float* q = a.partial + (int64_t)k * ps;
         v0[i] = k < a.nchunks ? q[c] : 0.f;
         v1[i] = k < a.nchunks ? q[H + c] : 0.f;
       }
@@ -740,7 +748,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<Tail
     const float t1 = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
     S[0][c] = t0;
     S[1][c] = t1;
-    if (blockIdx.x == 0) { a.out0[c] = t0; a.out1[c] = t1; }
+    if (blockIdx.x == 0) { a.out0[c] = t0 * ta.out_scale; a.out1[c] = t1 * ta.out_scale; }
   } else if (rq == 1 && (int)blockIdx.x < nseg) {
     slab_final(blockIdx.x);
   }
@@ -763,6 +771,62 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<Tail
     __syncthreads();
     if (rq == 1) slab_final(seg);
     __syncthreads();
+  }
+}
+
+// SyncBN phase 1: this rank's chunk statistics merged (bn_stats_finish_kernel's order) into ONE (n, mean, M2) triple per
+// column, and its column sums S1 / S2 into one pair -- what the caller exchanges between the ranks.  grid (1, towers)
+struct LocalArgs { const float* partial; int nchunks, H; float* out; };
+
+__global__ __launch_bounds__(kThreads) void tail_local_stats_kernel(Batch<LocalArgs> batch) {
+  const LocalArgs& a = batch.a[blockIdx.y];
+  const int H = a.H;
+  __shared__ Wf sh[4][64];
+  const int c = threadIdx.x & 63, jl = threadIdx.x >> 6;
+  Wf o{0.f, 0.f, 0.f};
+  if (c < H) {
+    Wf v[kMaxChunks / 4];
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 4; ++i) {
+      const int k = jl + 4 * i;
+      const float* q = a.partial + (int64_t)k * 3 * H;
+      v[i] = k < a.nchunks ? Wf{q[c], q[H + c], q[2 * H + c]} : Wf{0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 4; ++i) o = wf_combine(o, v[i]);
+  }
+  sh[jl][c] = o;
+  __syncthreads();
+  if (jl == 0 && c < H) {
+    o = wf_combine(wf_combine(sh[0][c], sh[1][c]), wf_combine(sh[2][c], sh[3][c]));
+    a.out[c] = o.n; a.out[H + c] = o.mean; a.out[2 * H + c] = o.m2;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void tail_local_colsum_kernel(Batch<LocalArgs> batch) {
+  const LocalArgs& a = batch.a[blockIdx.y];
+  const int H = a.H;
+  __shared__ float sh[2][4][64];
+  const int c = threadIdx.x & 63, jl = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < H) {
+    float v0[kMaxChunks / 4], v1[kMaxChunks / 4];
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 4; ++i) {
+      const int k = jl + 4 * i;
+      const float* q = a.partial + (int64_t)k * 2 * H;
+      v0[i] = k < a.nchunks ? q[c] : 0.f;
+      v1[i] = k < a.nchunks ? q[H + c] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxChunks / 4; ++i) { s0 += v0[i]; s1 += v1[i]; }
+  }
+  sh[0][jl][c] = s0;
+  sh[1][jl][c] = s1;
+  __syncthreads();
+  if (jl == 0 && c < H) {
+    a.out[c] = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+    a.out[H + c] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
   }
 }
 
@@ -869,6 +933,9 @@ int check_batch(int32_t n, const tt_tower_params* const* P, int64_t B, float dro
                  "%s: bf16 x / d_x need compute_dtype TT_BF16", who);
     TT_CHECK_ARG((P[t]->x_dtype == TT_F32 || P[t]->x_dtype == TT_BF16) && (P[t]->dx_dtype == TT_F32 || P[t]->dx_dtype == TT_BF16),
                  "%s: bad x_dtype / dx_dtype", who);
+    TT_CHECK_ARG(P[t]->sync_phase == P[0]->sync_phase && P[t]->sync_phase >= 0 && P[t]->sync_phase <= 2, "%s: bad / mixed sync_phase", who);
+    TT_CHECK_ARG(P[t]->sync_phase == 0 || (P[t]->sync_ranks >= 1 && P[t]->sync_ranks <= kMaxChunks), "%s: sync_ranks=%d not in [1, %d]", who,
+                 P[t]->sync_ranks, kMaxChunks);
     if (B > 0 && (!ws[t] || wsb[t] < tt_tower_workspace_bytes(P[t], B))) {
       tt_set_error("%s: workspace of tower %d: %zu < required %zu", who, t, wsb[t], tt_tower_workspace_bytes(P[t], B));
       return TT_ERR_WORKSPACE;
@@ -908,11 +975,21 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     in[t] = reinterpret_cast<const float*>(A[t]->x);
     in_w[t] = wx;
   }
-  for (int t = 0; t < n; ++t) { nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes; }
-  if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
   const bool drop = train && dropout_p > 0.f;
   const int nh = P[0]->n_hidden;
   const bool fused = tail_fusable(n, P, train);
+  const int phase = P[0]->sync_phase;
+  if (phase != 0) {
+    if (!fused || nh != 1) {
+      tt_set_error("tt_towers_mlp_fwd: sync_phase %d needs the fused tail (training, TT_BF16 operands, one hidden block <= 64 wide, d_out <= 64)", phase);
+      return TT_ERR_UNSUPPORTED;
+    }
+    for (int t = 0; t < n; ++t)
+      TT_CHECK_ARG(phase == 1 ? A[t]->bn_sync_local != nullptr : A[t]->bn_sync_all != nullptr, "tt_towers_mlp_fwd: NULL SyncBN buffer");
+  }
+  for (int t = 0; t < n; ++t) { nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes; }
+  if (phase != 2)
+    if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
   NtDeferred nd[TT_MAX_SIDES];
   for (int i = 0; i < nh; ++i) {
     const bool tail = fused && i == nh - 1;
@@ -928,8 +1005,9 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       const int nchunks = chunks_for(B, H);
       bs.a[t] = BnStatArgs{A[t]->pre[i], (int)B, H, (int)tt_cdiv(B, nchunks), nchunks, ws[t].col, A[t]->mean[i], A[t]->rstd[i],
                            P[t]->bn_rm[i], P[t]->bn_rv[i], P[t]->bn_nbt[i]};
+      // dropout element index = GLOBAL row * H + column: the rank's first row enters through the salt
       ba.a[t] = BnApplyArgs{A[t]->pre[i], B * H, H, A[t]->mean[i], A[t]->rstd[i], P[t]->bn_w[i], P[t]->bn_b[i],
-                            ((uint64_t)(i + 1) << 40) ^ ((uint64_t)t << 52), A[t]->act[i]};
+                            (((uint64_t)(i + 1) << 40) ^ ((uint64_t)t << 52)) + (uint64_t)P[t]->rng_row_offset * (uint64_t)H, A[t]->act[i]};
       hmax = H > hmax ? H : hmax;
       cmax = nchunks > cmax ? nchunks : cmax;
       tmax = B * H > tmax ? B * H : tmax;
@@ -938,17 +1016,31 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes;
       nt[t].defer = tail ? &nd[t] : nullptr;
     }
-    if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
+    if (phase != 2)
+      if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
     if (tail) {
       // slabs (+ bias) -> pre with the chunk statistics in the same pass, then everything up to the unit rows in one kernel
-      if (nd[0].splits > 0) {
-        Batch<HeadArgs> hb{};
-        for (int t = 0; t < n; ++t) hb.a[t] = HeadArgs{nd[t].slabs, nd[t].slab_stride, nd[t].splits, P[t]->b[i], A[t]->pre[i], bs.a[t]};
-        tail_head_kernel<<<dim3((unsigned)cmax, (unsigned)n), kTailThreads, 0, st>>>(hb);
-      } else {
-        bn_stats_partial_kernel<<<dim3(1, (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(bs);
+      if (phase != 2) {
+        if (nd[0].splits > 0) {
+          Batch<HeadArgs> hb{};
+          for (int t = 0; t < n; ++t) hb.a[t] = HeadArgs{nd[t].slabs, nd[t].slab_stride, nd[t].splits, P[t]->b[i], A[t]->pre[i], bs.a[t]};
+          tail_head_kernel<<<dim3((unsigned)cmax, (unsigned)n), kTailThreads, 0, st>>>(hb);
+        } else {
+          bn_stats_partial_kernel<<<dim3(1, (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(bs);
+        }
+        TT_LAUNCH_CHECK();
       }
-      TT_LAUNCH_CHECK();
+      if (phase == 1) {                                 // SyncBN: hand this rank's statistics to the caller and stop
+        Batch<LocalArgs> la{};
+        for (int t = 0; t < n; ++t) la.a[t] = LocalArgs{bs.a[t].partial, bs.a[t].nchunks, bs.a[t].H, A[t]->bn_sync_local};
+        tail_local_stats_kernel<<<dim3(1, (unsigned)n), kThreads, 0, st>>>(la);
+        TT_LAUNCH_CHECK();
+        return TT_OK;
+      }
+      if (phase == 2)                                   // ... and continue with every rank's triple as one "chunk"
+        for (int t = 0; t < n; ++t) {
+          bs.a[t].partial = const_cast<float*>(A[t]->bn_sync_all); bs.a[t].nchunks = P[t]->sync_ranks; bs.a[t].pstride = A[t]->bn_sync_stride;
+        }
       Batch<TailFwdArgs> tf{};
       for (int t = 0; t < n; ++t)
         tf.a[t] = TailFwdArgs{bs.a[t], P[t]->bn_w[i], P[t]->bn_b[i], ba.a[t].salt, A[t]->act[i], P[t]->w_out, P[t]->b_out, P[t]->d_out,
@@ -1012,6 +1104,15 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     na.a[t] = NormArgs{A[t]->y, A[t]->emb, d_emb[t], (int)B, P[t]->d_out, g->d_y};
   }
   const bool fused = tail_fusable(n, P, train);
+  const int phase = P[0]->sync_phase;
+  if (phase != 0) {
+    if (!fused || nh != 1) {
+      tt_set_error("tt_towers_mlp_bwd: sync_phase %d needs the fused tail (training, TT_BF16 operands, one hidden block <= 64 wide, d_out <= 64)", phase);
+      return TT_ERR_UNSUPPORTED;
+    }
+    for (int t = 0; t < n; ++t)
+      TT_CHECK_ARG(G[t] && (phase == 1 ? G[t]->s_sync_local != nullptr : G[t]->s_sync_all != nullptr), "tt_towers_mlp_bwd: NULL SyncBN buffer");
+  }
   if (!fused) {
     l2norm_bwd_kernel<<<dim3((unsigned)tt_cdiv(B, 4), (unsigned)n), kThreads, 0, st>>>(na);
     TT_LAUNCH_CHECK();
@@ -1045,18 +1146,31 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       const int H = P[t]->hidden[i], D = P[t]->d_out;
       TT_CHECK_ARG(g->w[i] && g->b[i] && g->bn_w[i] && g->bn_b[i], "tt_towers_mlp_bwd: NULL gradient buffers of block %d", i);
       const int nchunks = chunks_for(B, H);
-      const uint64_t salt = ((uint64_t)(i + 1) << 40) ^ ((uint64_t)t << 52);
+      const uint64_t salt = (((uint64_t)(i + 1) << 40) ^ ((uint64_t)t << 52)) + (uint64_t)P[t]->rng_row_offset * (uint64_t)H;
       const ColArgs col{nullptr, 0, A[t]->pre[i], A[t]->mean[i], A[t]->rstd[i], salt, (int)B, H, (int)tt_cdiv(B, nchunks), nchunks,
                         ws[t].col, g->bn_b[i], g->bn_w[i]};
       float* w_slab = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(ws[t].tn[nh + 1]) + 255) & ~uintptr_t(255));
       float* b_slab = w_slab + (size_t)nchunks * D * H;
       tb.a[t] = TailBwdArgs{A[t]->y, A[t]->emb, d_emb[t], g->d_y, D, P[t]->w_out, A[t]->act[i], dcur[t], col, w_slab, b_slab};
-      tp.a[t] = TailApplyArgs{col, BnBwdArgs{dcur[t], A[t]->pre[i], B * H, H, 1.f / (float)B, A[t]->mean[i], A[t]->rstd[i], P[t]->bn_w[i],
-                                             g->bn_b[i], g->bn_w[i], salt}, w_slab, b_slab, D, g->w_out, g->b_out};
+      ColArgs colD = col;                               // SyncBN: S1 / S2 of every rank, one "chunk" each, over ranks * B rows
+      const int ranks = phase == 2 ? P[t]->sync_ranks : 1;
+      if (phase == 2) { colD.partial = const_cast<float*>(g->s_sync_all); colD.nchunks = ranks; colD.pstride = g->s_sync_stride; }
+      tp.a[t] = TailApplyArgs{colD, BnBwdArgs{dcur[t], A[t]->pre[i], B * H, H, 1.f / ((float)B * (float)ranks), A[t]->mean[i], A[t]->rstd[i],
+                                              P[t]->bn_w[i], g->bn_b[i], g->bn_w[i], salt},
+                              w_slab, b_slab, D, g->w_out, g->b_out, nchunks, 1.f / (float)ranks};
       cmax = nchunks > cmax ? nchunks : cmax;
     }
-    tail_bwd_kernel<<<dim3((unsigned)cmax, (unsigned)n), kTailThreads, 0, st>>>(tb, drop, dropout_p, seed, seed_dev);
-    TT_LAUNCH_CHECK();
+    if (phase != 2) {
+      tail_bwd_kernel<<<dim3((unsigned)cmax, (unsigned)n), kTailThreads, 0, st>>>(tb, drop, dropout_p, seed, seed_dev);
+      TT_LAUNCH_CHECK();
+    }
+    if (phase == 1) {                                   // SyncBN: hand this rank's column sums to the caller and stop
+      Batch<LocalArgs> la{};
+      for (int t = 0; t < n; ++t) la.a[t] = LocalArgs{tb.a[t].col.partial, tb.a[t].col.nchunks, tb.a[t].col.H, G[t]->s_sync_local};
+      tail_local_colsum_kernel<<<dim3(1, (unsigned)n), kThreads, 0, st>>>(la);
+      TT_LAUNCH_CHECK();
+      return TT_OK;
+    }
     tail_bwd_apply_kernel<<<dim3((unsigned)tt_cdiv(B, 64), (unsigned)n), kTailThreads, 0, st>>>(tp);
     TT_LAUNCH_CHECK();
   } else {
@@ -1068,17 +1182,17 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     Batch<BnBwdArgs> bb{};
     int hmax = 1, cmax = 1;
     int64_t tmax = 1;
-    const uint64_t salt = (uint64_t)(i + 1) << 40;
     for (int t = 0; t < n; ++t) {
       const tt_tower_grads* g = G[t];
       const int H = P[t]->hidden[i];
       TT_CHECK_ARG(g->w[i] && g->b[i] && g->bn_w[i] && g->bn_b[i], "tt_towers_mlp_bwd: NULL gradient buffers of block %d", i);
       const int nchunks = chunks_for(B, H);
+      const uint64_t salt = (((uint64_t)(i + 1) << 40) ^ ((uint64_t)t << 52)) + (uint64_t)P[t]->rng_row_offset * (uint64_t)H;
       // S1 = sum da -> bn bias grad ; S2 = sum da*xhat -> bn weight grad
-      cb.a[t] = ColArgs{dcur[t], H, A[t]->pre[i], A[t]->mean[i], A[t]->rstd[i], salt ^ ((uint64_t)t << 52), (int)B, H, (int)tt_cdiv(B, nchunks), nchunks,
+      cb.a[t] = ColArgs{dcur[t], H, A[t]->pre[i], A[t]->mean[i], A[t]->rstd[i], salt, (int)B, H, (int)tt_cdiv(B, nchunks), nchunks,
                         ws[t].col, g->bn_b[i], g->bn_w[i]};
       bb.a[t] = BnBwdArgs{dcur[t], A[t]->pre[i], B * H, H, 1.f / (float)B, A[t]->mean[i], A[t]->rstd[i], P[t]->bn_w[i], g->bn_b[i],
-                          g->bn_w[i], salt ^ ((uint64_t)t << 52)};
+                          g->bn_w[i], salt};
       hmax = H > hmax ? H : hmax;
       cmax = nchunks > cmax ? nchunks : cmax;
       tmax = B * H > tmax ? B * H : tmax;

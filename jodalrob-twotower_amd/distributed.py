@@ -64,13 +64,17 @@ class ShardedStore(EmbeddingStore):
         mine = global_weight[self.rank::self.world]
         self.weight[:mine.shape[0]].copy_(mine.to(self.weight.device))
 
-    def gather_global(self, group=None) -> torch.Tensor:
-        """all-gather the shards back into the [global_rows, E] table (checkpoint / parity use)."""
+    def gather_global(self, group=None, comm=None) -> torch.Tensor:
+        """all-gather the shards back into the [global_rows, E] table (checkpoint / parity use).  comm: an object with
+        DistComm's all_gather instead of torch.distributed on `group` (tests)."""
         per = (self.global_rows + self.world - 1) // self.world
         pad = torch.zeros((per, self.E), dtype=torch.float32, device=self.weight.device)
         pad[:self.local_rows] = self.weight[:self.local_rows]
-        parts = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(parts, pad, group=group)
+        if comm is not None:
+            parts = list(comm.all_gather(pad).view(self.world, per, self.E))
+        else:
+            parts = [torch.empty_like(pad) for _ in range(self.world)]
+            dist.all_gather(parts, pad, group=group)
         out = torch.empty((per * self.world, self.E), dtype=torch.float32, device=self.weight.device)
         for r, p in enumerate(parts):
             out[r::self.world] = p
@@ -370,18 +374,27 @@ class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
     """TwoTowerTrainTask whose tables are row-wise sharded over the process group."""
 
     def __init__(self, two_tower_model: TwoTowerModel, store: ShardedStore, group=None, backend=None, exchange: str = "exact",
-                 negatives: str = "local", **kw):
+                 negatives: str = "local", sync_bn: bool = False, comm=None, **kw):
         super().__init__(two_tower_model, **kw)
         if negatives not in ("local", "global"):
             raise ValueError(f"negatives must be 'local' or 'global', got {negatives!r}")
         self.negatives = negatives
+        self.sync_bn = bool(sync_bn)
         self.sharded_store = store
         self.embedding_shard = store.shard_param                       # registered => in .parameters()
         if exchange not in ("exact", "padded"):
             raise ValueError(f"exchange must be 'exact' or 'padded', got {exchange!r}")
-        self.exchange = (PaddedRowExchange if exchange == "padded" else RowExchange)(store, group, backend)
+        self.exchange = (PaddedRowExchange if exchange == "padded" else RowExchange)(store, group, backend, comm=comm)
         two_tower_model.notice_tower.exchange = self.exchange
         two_tower_model.company_tower.exchange = self.exchange
+        if self.sync_bn and self.exchange.world > 1:
+            # BatchNorm statistics over the rows of ALL ranks (with negatives="global": the single-process reference at the
+            # global batch); dropout masks are drawn per global row, so give every rank the same torch seed for that
+            for tw in (two_tower_model.notice_tower, two_tower_model.company_tower):
+                if tw.mlp_dtype != "bf16" or len(tw.tower_hidden_dims) != 2 or tw.tower_hidden_dims[1] > 64 or tw.final_embedding_dim > 64:
+                    raise NotImplementedError("sync_bn needs mlp_dtype='bf16', one hidden block of width <= 64 and final_embedding_dim <= 64 "
+                                              "(the fused tower tail is where the pass is cut for the exchange)")
+                tw.sync_comm = self.exchange.comm
         for p in self._dense_parameters():                             # replicas start identical
             dist.broadcast(p.data, src=0, group=group)
         for b in self.buffers():
@@ -422,7 +435,8 @@ class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
     def full_state_dict(self):
         """State dict in the REFERENCE layout (per-key [V_k, E] tables gathered from all ranks)."""
         sd = {k: v for k, v in self.state_dict().items() if k != "embedding_shard"}
-        full = self.sharded_store.gather_global(self.exchange.group)
+        comm = self.exchange.comm
+        full = self.sharded_store.gather_global(self.exchange.group, None if isinstance(comm, DistComm) else comm)
         for name, base, v in self.key_directory():
             sd[name] = full[base:base + v].clone()
         return sd
@@ -441,7 +455,7 @@ def create_distributed_train_task(notice_categorical_keys, company_categorical_k
                                   dropout_rate: float = 0.2, temperature: float = 1.0, loss_type: str = "cross_entropy",
                                   device="cuda:0", embedding_grad: Optional[str] = "sparse", score_dtype=None, mlp_dtype=None,
                                   group=None, backend=None, seed: int = 0, exchange: str = "exact",
-                                  negatives: str = "local") -> DistributedTwoTowerTrainTask:
+                                  negatives: str = "local", sync_bn: bool = False, comm=None) -> DistributedTwoTowerTrainTask:
     """Same arguments as create_two_tower_train_task; requires an initialised process group."""
     if not dist.is_initialized():
         raise RuntimeError("create_distributed_train_task needs torch.distributed.init_process_group first")
@@ -459,6 +473,6 @@ def create_distributed_train_task(notice_categorical_keys, company_categorical_k
     ce.set_row_base(ne.total_rows)
     store = ShardedStore(categorical_embedding_dim, ne.total_rows + ce.total_rows, dist.get_rank(group),
                          dist.get_world_size(group), torch.device(device), embedding_grad or "sparse", seed)
-    return DistributedTwoTowerTrainTask(model, store, group=group, backend=backend, exchange=exchange, negatives=negatives,
+    return DistributedTwoTowerTrainTask(model, store, group=group, backend=backend, exchange=exchange, negatives=negatives, sync_bn=sync_bn, comm=comm,
                                         temperature=temperature,
                                         loss_type=loss_type, score_dtype=score_dtype)

@@ -30,6 +30,19 @@ from .cat_embed import CategoricalEmbedder, EmbeddingStore
 _DEBUG_KEEP = None   # set to a list by debugging tools
 
 
+def _sync_comm(sides):
+    """The communicator for SyncBN if it applies to this pass: every tower asks for it, trains, shares one batch size and
+    dropout setting (the C side then checks the shape conditions of the fused tail), else None."""
+    if not sides:
+        return None
+    comms = [getattr(s.tower, "sync_comm", None) for s in sides]
+    if any(c is None for c in comms) or not all(s.train for s in sides):
+        return None
+    if len({s.B for s in sides}) != 1 or len({s.p_drop for s in sides}) != 1:
+        raise ValueError("SyncBN needs one batch size and one dropout rate for all towers of a pass")
+    return comms[0]
+
+
 def _al(n: int) -> int:
     return (n + 63) // 64 * 64
 
@@ -73,7 +86,9 @@ class BaseTower(nn.Module):
         self.unfused_tail = os.environ.get("TT_TOWER_UNFUSED_TAIL", "0") == "1"
         self.categorical_keys = list(categorical_keys)
         self.exchange = None            # set by the distributed task: sharded-table row exchange
+        self.sync_comm = None           # set by the distributed task (sync_bn=True): BN statistics over all ranks' rows
         self._seed_dev = None           # set by GraphedTrainStep: device word added to the dropout seed
+        self._seed_override = None      # tests: a fixed dropout seed instead of one drawn from torch's CPU generator
         self.device = device
         self.tower_hidden_dims = list(tower_hidden_dims)
         self.final_embedding_dim = final_embedding_dim
@@ -191,7 +206,7 @@ def run_towers(towers: Sequence[BaseTower], inputs: Sequence[Dict]) -> List[torc
 
 
 class _Side:
-    __slots__ = ("tower", "B", "acts", "acts_struct", "buf", "x", "emb", "train", "seed", "p_drop")
+    __slots__ = ("tower", "B", "acts", "acts_struct", "buf", "x", "emb", "train", "seed", "p_drop", "sync_keep")
 
 
 class _TowersFn(torch.autograd.Function):
@@ -219,7 +234,8 @@ class _TowersFn(torch.autograd.Function):
             s = _Side()
             s.tower, s.B, s.train = tw, B, tw.training
             s.p_drop = tw.dropout_rate if tw.training else 0.0
-            s.seed = int(torch.empty((), dtype=torch.int64).random_().item()) if s.p_drop > 0 else 0
+            s.seed = 0 if s.p_drop <= 0 else (tw._seed_override if tw._seed_override is not None else
+                                              int(torch.empty((), dtype=torch.int64).random_().item()))
             # one flat activation buffer: x | (pre_i, act_i)* | (mean_i, rstd_i)* | y
             hid = tw.tower_hidden_dims[1:]
             x_f32 = tw.x_dtype == torch.float32
@@ -274,7 +290,34 @@ class _TowersFn(torch.autograd.Function):
         live = [s for s in sides if s.B]
         fused = len(live) > 1 and len({s.B for s in live}) == 1 and len({s.tower.n_hidden for s in live}) == 1 and \
             len({(s.train, s.p_drop) for s in live}) == 1
-        if fused:           # horizontal fusion: one launch per layer step covers every tower
+        comm = _sync_comm(live)
+        if comm is not None:
+            # SyncBN: the pass stops at the local BN statistics, ONE all-gather carries every tower's (n, mean, M2) triples,
+            # and the second half merges them in rank order (twotower.h: sync_phase)
+            s0 = live[0]
+            widths = [3 * s.tower.tower_hidden_dims[1] for s in live]
+            loc = torch.empty(sum(widths), dtype=torch.float32, device=s0.emb.device)
+            params = [s.tower._params() for s in live]
+            off = 0
+            for s, p, w in zip(live, params, widths):
+                s.acts_struct.bn_sync_local = loc.data_ptr() + 4 * off
+                p.sync_phase, p.sync_ranks, p.rng_row_offset = 1, comm.world, comm.rank * s.B
+                off += w
+            try:
+                ops.towers_fwd(params, [s.acts_struct for s in live], s0.B, s0.train, s0.p_drop, s0.seed, s0.emb.device, s0.tower._seed_dev)
+                allg = comm.all_gather(loc)
+                off = 0
+                for s, p, w in zip(live, params, widths):
+                    s.acts_struct.bn_sync_all, s.acts_struct.bn_sync_stride = allg.data_ptr() + 4 * off, loc.numel()
+                    p.sync_phase = 2
+                    off += w
+                ops.towers_fwd(params, [s.acts_struct for s in live], s0.B, s0.train, s0.p_drop, s0.seed, s0.emb.device, s0.tower._seed_dev)
+            finally:
+                for p in params:
+                    p.sync_phase = 0
+            for s in live:
+                s.seed, s.sync_keep = s0.seed, (loc, allg)
+        elif fused:           # horizontal fusion: one launch per layer step covers every tower
             s0 = live[0]
             ops.towers_fwd([s.tower._params() for s in live], [s.acts_struct for s in live], s0.B, s0.train, s0.p_drop, s0.seed,
                            s0.emb.device, s0.tower._seed_dev)
@@ -370,7 +413,32 @@ class _TowersFn(torch.autograd.Function):
             dxs[id(s)] = d_x[:, tw.tower_hidden_dims[0]:]
         fused = len(prepared) > 1 and len({s.B for s, _, _ in prepared}) == 1 and \
             len({s.tower.n_hidden for s, _, _ in prepared}) == 1 and len({(s.train, s.p_drop, s.seed) for s, _, _ in prepared}) == 1
-        if fused:
+        comm = _sync_comm([s for s, _, _ in prepared])
+        if comm is not None:
+            s0 = prepared[0][0]
+            widths = [2 * s.tower.tower_hidden_dims[1] for s, _, _ in prepared]
+            loc = torch.empty(sum(widths), dtype=torch.float32, device=s0.emb.device)
+            params = [s.tower._params() for s, _, _ in prepared]
+            args = ([s.acts_struct for s, _, _ in prepared], [d for _, d, _ in prepared], [g for _, _, g in prepared], s0.B, s0.train,
+                    s0.p_drop, s0.seed, s0.emb.device, s0.tower._seed_dev)
+            off = 0
+            for (s, _, g), p, w in zip(prepared, params, widths):
+                g.s_sync_local = loc.data_ptr() + 4 * off
+                p.sync_phase, p.sync_ranks, p.rng_row_offset = 1, comm.world, comm.rank * s.B
+                off += w
+            try:
+                ops.towers_bwd(params, *args)
+                allg = comm.all_gather(loc)                         # every rank's (S1, S2), added in rank order
+                off = 0
+                for (s, _, g), p, w in zip(prepared, params, widths):
+                    g.s_sync_all, g.s_sync_stride = allg.data_ptr() + 4 * off, loc.numel()
+                    p.sync_phase = 2
+                    off += w
+                ops.towers_bwd(params, *args)
+            finally:
+                for p in params:
+                    p.sync_phase = 0
+        elif fused:
             s0 = prepared[0][0]
             ops.towers_bwd([s.tower._params() for s, _, _ in prepared], [s.acts_struct for s, _, _ in prepared],
                            [d for _, d, _ in prepared], [g for _, _, g in prepared], s0.B, s0.train, s0.p_drop, s0.seed,

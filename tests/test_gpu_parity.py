@@ -948,6 +948,42 @@ def test_padded_exchange_multi_rank_on_one_gpu(tt, G, x_dtype):
         assert set(np.flatnonzero(np.abs(mine).sum(1) > 0)) <= set(r["uniq"][real].tolist())
 
 
+def test_two_processes_equal_single_process(tt):
+    """SURVEY 8(e)'s parity definition on one GPU: a 2-rank job (two processes sharing the device, collectives through gloo
+    with host staging) with row-wise sharded tables behind the fixed-capacity exchange, global in-batch negatives and SyncBN
+    == the single-process task on the same global batch: loss, dense gradients, BN running statistics, parameters after one
+    Adam step (tests/_dist_world2_worker.py).  (Threads cannot stand in for ranks here: the backward passes of all
+    threads run on autograd's one device thread, so a collective inside backward deadlocks.)"""
+    import os, socket, subprocess, sys
+    from pathlib import Path
+    worker = Path(__file__).resolve().parent / "_dist_world2_worker.py"
+
+    def run_pair(extra_env):
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        env = dict(os.environ, **extra_env)
+        procs = [subprocess.Popen([sys.executable, str(worker), str(r), "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                  text=True, env=env) for r in range(2)]
+        outs = []
+        try:
+            for p in procs:
+                outs.append(p.communicate(timeout=240))
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        return outs
+
+    ctrl = run_pair({"TT_W2_NO_SYNC": "1"})          # negative control: per-rank BN statistics must NOT pass the same checks
+    assert not any("DIST_WORLD2_OK" in o[0] for o in ctrl), "the check does not see the BN statistics"
+    outs = run_pair({})
+    ok = all("DIST_WORLD2_OK" in o[0] for o in outs) and len(outs) == 2
+    if not ok:
+        log = Path(__file__).resolve().parents[1] / "gpurun_out"
+        log.mkdir(exist_ok=True)
+        (log / "dist_world2_worker.log").write_text("\n".join(f"==== rank {i} stdout ====\n{o[0]}\n==== stderr ====\n{o[1]}" for i, o in enumerate(outs)))
+    assert ok, "\n".join(o[1][-1500:] for o in outs)
+
+
 @pytest.mark.parametrize("G,B,D", [(2, 300, 64), (3, 129, 32), (4, 256, 64)])
 def test_global_negatives_equal_single_process(tt, G, B, D):
     """Global in-batch negatives on G virtual ranks == the single-process loss over the concatenated batch of G*B pairs
