@@ -243,6 +243,9 @@ typedef struct tt_tower_acts { /* caller-allocated; kept between forward and bac
   float* rstd[TT_MAX_HIDDEN];
   float* y;   /* [B, d_out] before normalisation */
   float* emb; /* [B, d_out] unit rows */
+  void* emb_packed; /* optional, tt_score_pack_bytes(B, d_out) bytes, 16-byte aligned: on return also holds the score kernels'
+                       bf16 operand images of emb (what tt_score_pack_bf16 would produce) -- written by the fused tail kernel
+                       itself where that applies, by the pack kernel otherwise */
   float* bn_sync_local;     /* sync_phase 1 out: [3][hidden[0]] */
   const float* bn_sync_all; /* sync_phase 2 in:  [sync_ranks][3][hidden[0]] */
   int64_t bn_sync_stride;   /* floats between two ranks' triples in bn_sync_all (0 = 3 * hidden[0]): lets one all-gather

@@ -61,7 +61,7 @@ class TowerParams(C.Structure):
 
 
 class TowerActs(C.Structure):
-    _fields_ = [("dense", vp), ("x", vp), ("pre", _H), ("act", _H), ("mean", _H), ("rstd", _H), ("y", vp), ("emb", vp),
+    _fields_ = [("dense", vp), ("x", vp), ("pre", _H), ("act", _H), ("mean", _H), ("rstd", _H), ("y", vp), ("emb", vp), ("emb_packed", vp),
                 ("bn_sync_local", vp), ("bn_sync_all", vp), ("bn_sync_stride", i64)]
 
 

@@ -373,6 +373,7 @@ struct TailFwdArgs {
   BnStatArgs s;
   const float* g; const float* b; uint64_t salt; float* act;
   const float* w_out; const float* b_out; int D; float* y; float* emb;
+  __bf16* pk_rows; __bf16* pk_frag; int Dp;     // optional: the score kernels' two operand images of emb (tt_score_pack_bf16)
 };
 
 __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed0,
@@ -488,14 +489,37 @@ __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArg
 #pragma unroll
     for (int j = 0; j < 4; ++j) den[j] += __shfl_xor(den[j], o);
   }
+  float e[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = m0 + wave * 4 + j;
     const float d = fmaxf(sqrtf(den[j]), kNormEps);
+    e[j] = 0.f;
     if (r < B && lane < D) {
+      e[j] = v[j] / d;
       f.y[(int64_t)r * D + lane] = v[j];
-      f.emb[(int64_t)r * D + lane] = v[j] / d;
+      f.emb[(int64_t)r * D + lane] = e[j];
     }
+  }
+  if (f.pk_rows && lane < f.Dp) {
+    // the unit rows straight into the score kernels' operand images (layouts: pack_bf16_kernel in tt_score_bf16.hip; padding
+    // rows and columns are written as zeros, this workgroup owns rows m0 .. m0 + 63 of both images):
+    //   rows image  [tile][k-step][half][row in tile][8]  -- element (row, d): chunk ((t * Dp/16 + d/16) * 2 + (d%16)/8) * 32 + row%32
+    //   frag image  [tile][s][h][d][8]                    -- element (row, d): 8 rows of one column; this wave's 4 rows are 4 adjacent slots
+    const int Dp = f.Dp, d = lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = m0 + wave * 4 + j;
+      const int64_t c = (((int64_t)(row >> 5) * (Dp >> 4) + (d >> 4)) * 2 + ((d >> 3) & 1)) * 32 + (row & 31);
+      f.pk_rows[c * 8 + (d & 7)] = (__bf16)e[j];
+    }
+    const int row0 = m0 + wave * 4, rr = row0 & 31, q = rr & 15;
+    const int64_t fi = (((int64_t)(row0 >> 5) * 2 + (rr >> 4)) * 2 + ((q & 7) >> 2)) * Dp + d;
+    using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+    bf16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (__bf16)e[j];
+    *reinterpret_cast<bf16x4*>(f.pk_frag + fi * 8 + (q >> 3) * 4) = o;
   }
 }
 
@@ -1044,7 +1068,15 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       Batch<TailFwdArgs> tf{};
       for (int t = 0; t < n; ++t)
         tf.a[t] = TailFwdArgs{bs.a[t], P[t]->bn_w[i], P[t]->bn_b[i], ba.a[t].salt, A[t]->act[i], P[t]->w_out, P[t]->b_out, P[t]->d_out,
-                              A[t]->y, A[t]->emb};
+                              A[t]->y, A[t]->emb, nullptr, nullptr, 0};
+      for (int t = 0; t < n; ++t)
+        if (A[t]->emb_packed) {
+          const int Dp = P[t]->d_out <= 32 ? 32 : 64;
+          __bf16* base = reinterpret_cast<__bf16*>(A[t]->emb_packed);
+          tf.a[t].pk_rows = base;
+          tf.a[t].pk_frag = base + tt_cdiv(B, 64) * 64 * Dp;
+          tf.a[t].Dp = Dp;
+        }
       tail_fwd_kernel<<<dim3((unsigned)tt_cdiv(B, 64), (unsigned)n), kTailThreads, 0, st>>>(tf, drop, dropout_p, seed, seed_dev);
       TT_LAUNCH_CHECK();
       return TT_OK;
@@ -1078,6 +1110,9 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
   l2norm_fwd_kernel<<<dim3((unsigned)tt_cdiv(B, 4), (unsigned)n), kThreads, 0, st>>>(na);
   TT_LAUNCH_CHECK();
   (void)dmax;
+  for (int t = 0; t < n; ++t)                            // emb_packed is honoured on every path: here by the pack kernel
+    if (A[t]->emb_packed)
+      if (int rc = tt_score_pack_bf16(ctx, A[t]->emb, B, P[t]->d_out, A[t]->emb_packed, stream)) return rc;
   return TT_OK;
 }
 

@@ -87,6 +87,8 @@ class BaseTower(nn.Module):
         self.categorical_keys = list(categorical_keys)
         self.exchange = None            # set by the distributed task: sharded-table row exchange
         self.sync_comm = None           # set by the distributed task (sync_bn=True): BN statistics over all ranks' rows
+        self.pack_for_score = False     # set by the train task (score_dtype='bf16'): also emit the score kernels' operand images
+        self._last_packed = None
         self._seed_dev = None           # set by GraphedTrainStep: device word added to the dropout seed
         self._seed_override = None      # tests: a fixed dropout seed instead of one drawn from torch's CPU generator
         self.device = device
@@ -202,11 +204,15 @@ def run_towers(towers: Sequence[BaseTower], inputs: Sequence[Dict]) -> List[torc
         values = (kjt.to(dev) if hasattr(kjt, "to") else kjt).values()
         flat += [dense, values] + tw.dense_parameters() + tw.categorical_embedder.table_parameters()
     outs = _TowersFn.apply(tuple(towers), *flat)
-    return list(outs) if isinstance(outs, tuple) else [outs]
+    outs = list(outs) if isinstance(outs, tuple) else [outs]
+    for tw, o in zip(towers, outs):                      # hand the packed images to the score step with the rows they belong to
+        if tw._last_packed is not None:
+            o._tt_packed, tw._last_packed = tw._last_packed, None
+    return outs
 
 
 class _Side:
-    __slots__ = ("tower", "B", "acts", "acts_struct", "buf", "x", "emb", "train", "seed", "p_drop", "sync_keep")
+    __slots__ = ("tower", "B", "acts", "acts_struct", "buf", "x", "emb", "train", "seed", "p_drop", "sync_keep", "packed")
 
 
 class _TowersFn(torch.autograd.Function):
@@ -258,6 +264,11 @@ class _TowersFn(torch.autograd.Function):
                 a.mean[i] = base + esz * offs[1 + 2 * nh + 2 * i]
                 a.rstd[i] = base + esz * offs[2 + 2 * nh + 2 * i]
             a.y = base + esz * offs[1 + 4 * nh]
+            s.packed = None
+            if tw.pack_for_score and B:
+                # the score kernels' bf16 operand images of the unit rows, written by the tower pass itself (tt_tower_acts.emb_packed)
+                s.packed = torch.empty(L.load().tt_score_pack_bytes(B, tw.final_embedding_dim), dtype=torch.uint8, device=dev)
+                a.emb_packed = s.packed.data_ptr()
             s.acts, s.acts_struct = (dense,), a
             sides.append(s)
             if K and B:
@@ -348,6 +359,8 @@ class _TowersFn(torch.autograd.Function):
                             plan = ops.dedup_plan(rows, store.rows)
                     plan.keep, plan.stream = rows, (None if inline else ds)   # keep the sort input alive until it has run
                 pl[:] = [store, psides, plan]
+        for s in sides:
+            s.tower._last_packed = s.packed
         ctx.sides, ctx.plans, ctx.spans, ctx.n_flat = sides, plans, spans, len(flat)
         # hand out aliases: keeping the returned objects themselves on ctx would form a reference cycle
         outs = tuple(s.emb.view(s.emb.shape) for s in sides)

@@ -26,12 +26,13 @@ class _ScoreCEFn(torch.autograd.Function):
     score_dtype 'fp32': exact-f32 MFMA path (parity); 'bf16': bf16-operand MFMA fast path."""
 
     @staticmethod
-    def forward(ctx, n, c, inv_t, score_dtype, want_col_rank=True, full_rank=True):
+    def forward(ctx, n, c, inv_t, score_dtype, want_col_rank=True, full_rank=True, packed_n=None, packed_c=None):
         n, c = n.contiguous().float(), c.contiguous().float()
         B, D = n.shape
         shift = abs(inv_t)                                   # unit rows: |s| <= 1/T
         if score_dtype == "bf16":
-            Np, Cp = ops.score_pack2_bf16(n, c)
+            # the towers' fused tail can emit the packed operand images itself (tt_tower_acts.emb_packed): one launch fewer
+            Np, Cp = (packed_n, packed_c) if packed_n is not None and packed_c is not None else ops.score_pack2_bf16(n, c)
             rowsum, colsum, diag, row_rank, col_rank, sumscore = ops.score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank, full_rank)
             if not want_col_rank:
                 col_rank = row_rank                      # placeholder: column top-1 rate is only a first-call diagnostic
@@ -52,7 +53,7 @@ class _ScoreCEFn(torch.autograd.Function):
         n, c, rowsum, colsum = ctx.saved_tensors
         B, D = n.shape
         if d_loss is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         if d_loss.dtype != torch.float32 or not d_loss.is_contiguous():
             d_loss = d_loss.contiguous().float()
         scale = ctx.inv_t / (2.0 * B)
@@ -61,7 +62,7 @@ class _ScoreCEFn(torch.autograd.Function):
         else:
             dN = ops.score_dir_bwd(n, c, ctx.inv_t, ctx.shift, 0, rowsum, colsum, d_loss, scale)
             dC = ops.score_dir_bwd(c, n, ctx.inv_t, ctx.shift, 0, colsum, rowsum, d_loss, scale)
-        return dN, dC, None, None, None, None
+        return dN, dC, None, None, None, None, None, None
 
 
 class _Result(dict):
@@ -111,6 +112,9 @@ class TwoTowerTrainTask(nn.Module):
         self.score_dtype = score_dtype or os.environ.get("TT_SCORE_DTYPE", "fp32")
         if self.score_dtype not in ("fp32", "bf16"):
             raise ValueError(f"score_dtype must be 'fp32' or 'bf16', got {self.score_dtype!r}")
+        if self.score_dtype == "bf16" and os.environ.get("TT_TOWER_PACK", "1") != "0":      # TT_TOWER_PACK=0: separate pack launch (A/B)
+            for tw in (two_tower_model.notice_tower, two_tower_model.company_tower):
+                tw.pack_for_score = True
         self.two_tower_model = two_tower_model
         self.temperature = temperature
         self.loss_type = loss_type
@@ -147,7 +151,10 @@ class TwoTowerTrainTask(nn.Module):
 
     def _score_ce(self, n, c, inv_t, first_call):
         """(loss, out8, row_rank) of the symmetric in-batch-negative softmax-CE (:99-134); the sharded task overrides it."""
-        return _ScoreCEFn.apply(n, c, inv_t, self.score_dtype, first_call, False)
+        pn, pc = getattr(n, "_tt_packed", None), getattr(c, "_tt_packed", None)     # emitted by the towers (towers.run_towers)
+        if self.score_dtype != "bf16" or n.shape != c.shape:
+            pn = pc = None
+        return _ScoreCEFn.apply(n, c, inv_t, self.score_dtype, first_call, False, pn, pc)
 
     def _compute_similarity_matrix(self, notice_embeddings, company_embeddings):                # :99-112
         return self.two_tower_model.compute_similarity(notice_embeddings, company_embeddings, self.temperature)

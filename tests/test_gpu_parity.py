@@ -644,6 +644,39 @@ def test_fused_tower_tail_equals_separate_kernels(tt, manifest, schema_real, mon
         assert np.linalg.norm(gf - g) <= 5e-6 * np.linalg.norm(g) + 1e-12, (k, np.linalg.norm(gf - g), np.linalg.norm(g))
 
 
+@pytest.mark.parametrize("case,B", [("real_schema", 300), ("real_schema", 8192), ("wide_b40", 40), ("deep_temp", 24)])
+def test_tower_emits_packed_score_operands(tt, manifest, schema_real, monkeypatch, case, B):
+    """tt_tower_acts.emb_packed: the operand images the tower pass writes (fused tail kernel, or the pack kernel behind the
+    same field on the other paths) are the images tt_score_pack2_bf16 makes from the unit rows -- the step with and without
+    the separate pack launch (TT_TOWER_PACK=0) agrees bit for bit, ragged last tiles and padded columns included."""
+    cfg = dict(manifest["cases"][case])
+    if case == "real_schema":
+        cfg.update(keys_n=schema_real["notice"]["categorical"], keys_c=schema_real["company"]["categorical"])
+        vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+        shapes = {k: tuple(v) for k, v in manifest["state_dict_keys_real"].items()}
+        meta = GOLD / "real_vocab_metadata.csv"
+    else:
+        vn, vc = cfg["vocab_n"], cfg["vocab_c"]
+        z = np.load(GOLD / f"case_{case}.npz")
+        shapes = {k[6:]: z[k].shape for k in z.files if k.startswith("state.")}
+        meta = None
+    state = init_state_numpy(shapes, 141)
+    b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 142, oob=False)
+    outs = {}
+    for pack in ("0", "1"):
+        monkeypatch.setenv("TT_TOWER_PACK", pack)
+        task = make_task(tt, cfg, meta=meta, mlp_dtype="bf16", score_dtype="bf16")
+        assert task.two_tower_model.notice_tower.pack_for_score == (pack == "1")
+        load_state(task, state)
+        task.train()
+        res = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+        res["loss"].backward()
+        outs[pack] = (res["loss"].item(), float(res["accuracy"]), {n: p.grad.cpu().numpy() for n, p in task.named_parameters()})
+    assert outs["0"][:2] == outs["1"][:2]
+    for k, g in outs["0"][2].items():
+        assert np.array_equal(outs["1"][2][k], g), k
+
+
 def test_copy_multi(tt):
     """tt_copy_multi: several device segments of odd sizes (16-byte body + byte tail) and a pinned-host source."""
     from jodalrob_twotower_amd import ops
