@@ -74,9 +74,9 @@ class BaseTower(nn.Module):
             raise ValueError(f"mlp_dtype must be 'fp32' or 'bf16', got {self.mlp_dtype!r}")
         # bf16 MLP: the tower input x = [projection | embedding rows] lives in bf16 -- bit-identical results (the GEMMs
         # that read x round it to bf16 anyway) at half the bytes: lookup 15.7 -> 9.2 us, step -7 us at B = 8192.
-        # A bf16 d_x (TT_TOWER_IO_DTYPE = dx | both) is implemented but measured 30 us SLOWER per step (2-byte
-        # scattered stores of the data-gradient GEMM, 8-byte gathers in the segmented reduction) and rounds the
-        # per-slot row gradients, so it stays off.
+        # A bf16 d_x (TT_TOWER_IO_DTYPE = dx | both) is implemented but measures no faster (0.354 vs 0.352 ms per step: the
+        # segmented reduction is bound by its dependent trips, not by bytes, and the data-gradient GEMM stores 2-byte
+        # pieces) and rounds the per-slot row gradients, so it stays off.
         io = os.environ.get("TT_TOWER_IO_DTYPE", "x") if self.mlp_dtype == "bf16" else "none"
         if io not in ("none", "x", "dx", "both"):
             raise ValueError(f"TT_TOWER_IO_DTYPE must be none|x|dx|both, got {io!r}")
