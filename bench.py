@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--rows-notice", type=int, default=1_000_000, help="table rows per GPU, notice tower")
     ap.add_argument("--rows-company", type=int, default=1_000_000, help="table rows per GPU, company tower")
     ap.add_argument("--zipf", type=float, default=None, help="Zipf alpha for ids (default uniform)")
+    ap.add_argument("--final-dim", type=int, default=64, help="final_embedding_dim (BASELINE configs[4] uses 256 at --batch 65536)")
     ap.add_argument("--optimizer", choices=["fused_sparse", "fused_dense", "torch_adam"], default="fused_sparse")
     ap.add_argument("--score-dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--mlp-dtype", choices=["bf16", "fp32"], default="bf16")
@@ -99,7 +100,7 @@ def main():
     # weak scaling: every GPU brings its own 1 M + 1 M rows and its own 8192 pairs
     vocab_n = synthetic.scale_vocabs(schema["notice"]["vocab_sizes"], args.rows_notice * world)
     vocab_c = synthetic.scale_vocabs(schema["company"]["vocab_sizes"], args.rows_company * world)
-    E, hidden, D, din_n, din_c = 32, [128, 64], 64, 256, 128
+    E, hidden, D, din_n, din_c = 32, [128, 64], args.final_dim, 256, 128
     B = args.batch
     tmp = tempfile.mkdtemp(prefix="tt_bench_")
     meta = synthetic.write_metadata(Path(tmp) / "metadata.csv", {"notice": dict(zip(keys_n, vocab_n)),
@@ -281,8 +282,9 @@ def main():
                   f"score {args.score_dtype} / mlp {args.mlp_dtype}") + " MFMA operands, f32 accumulate; f32 tables, master weights and activations" +
                  (" (the tower input x, which the GEMMs round to bf16 anyway, is stored bf16)" if x_bf16 else ""),
         "data": "synthetic",
-        "config": {"workload": "configs[1]: 32+6 real keys, 1M-row notice + 1M-row company tables per GPU, batch 8192 per GPU, "
-                               "E=32, towers [128,64], final 64, in-batch negatives, dropout 0.1",
+        "config": {"workload": ("configs[1]: " if (B == 8192 and D == 64 and args.zipf is None) else "variant of configs[1]: ") +
+                               f"32+6 real keys, {sum(vocab_n)}-row notice + {sum(vocab_c)}-row company tables per GPU, batch {B} per GPU, "
+                               f"E=32, towers [128,64], final {D}, in-batch negatives, dropout 0.1",
                    "batch_per_gpu": B, "global_batch": B * world, "rows_notice": sum(vocab_n), "rows_company": sum(vocab_c),
                    "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})", "optimizer": args.optimizer,
                    "score_dtype": args.score_dtype, "mlp_dtype": args.mlp_dtype, "launch": "hip graph replay" if gstep is not None else "eager",
