@@ -352,7 +352,7 @@ def lookup_dispatch_overhead_us(task, pool, dev, profile, iters: int = 48):
     with torch.cuda.graph(g, capture_error_mode=mode):
         keep = [ops.embed_lookup(store.weight, sides, B, want_rows=True) for _ in range(REP) for sides, B in sides_per_batch]
     ev_us = []
-    for rep in range(6):
+    for rep in range(12):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         g.replay()
@@ -370,6 +370,8 @@ def lookup_dispatch_overhead_us(task, pool, dev, profile, iters: int = 48):
     st_us = profile.durations_us()
     if not ev_us or not st_us:
         return None
+    if os.environ.get("TT_BENCH_TRACE"):
+        print(f"[bench] dispatch calibration: replays {['%.2f' % v for v in ev_us]} us/launch, stamps {sum(st_us) / len(st_us):.2f} us", file=sys.stderr)
     ev_us.sort()
     return max(0.0, ev_us[len(ev_us) // 2] - sum(st_us) / len(st_us))      # upper median of the replays: min() under-reports
 
