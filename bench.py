@@ -282,7 +282,8 @@ def main():
                   f"score {args.score_dtype} / mlp {args.mlp_dtype}") + " MFMA operands, f32 accumulate; f32 tables, master weights and activations" +
                  (" (the tower input x, which the GEMMs round to bf16 anyway, is stored bf16)" if x_bf16 else ""),
         "data": "synthetic",
-        "config": {"workload": ("configs[1]: " if (B == 8192 and D == 64 and args.zipf is None) else "variant of configs[1]: ") +
+        "config": {"workload": ("configs[1]: " if (B == 8192 and D == 64 and args.zipf is None and args.rows_notice == 1_000_000 and args.rows_company == 1_000_000)
+                                else "variant of configs[1]: ") +
                                f"32+6 real keys, {sum(vocab_n)}-row notice + {sum(vocab_c)}-row company tables per GPU, batch {B} per GPU, "
                                f"E=32, towers [128,64], final {D}, in-batch negatives, dropout 0.1",
                    "batch_per_gpu": B, "global_batch": B * world, "rows_notice": sum(vocab_n), "rows_company": sum(vocab_c),
