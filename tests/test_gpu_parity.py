@@ -981,6 +981,40 @@ def test_padded_exchange_multi_rank_on_one_gpu(tt, G, x_dtype):
         assert set(np.flatnonzero(np.abs(mine).sum(1) > 0)) <= set(r["uniq"][real].tolist())
 
 
+def test_sync_bn_phases_at_world_one_equal_the_whole_pass(tt, manifest, schema_real):
+    """tt_tower_params.sync_phase 1 + 2 with ONE rank (the all-gather hands back the rank's own statistics) == the uncut
+    pass, bit for bit: unit rows, BN running statistics and every gradient, dropout on."""
+    class Solo:
+        world, rank = 1, 0
+
+        def all_gather(self, t):
+            return t.clone()
+
+    cfg = dict(manifest["cases"]["real_schema"])
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    cfg.update(keys_n=kn, keys_c=kc)
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    shapes = {k: tuple(v) for k, v in manifest["state_dict_keys_real"].items()}
+    state = init_state_numpy(shapes, 151)
+    b = synth_batch_numpy(333, vn, vc, cfg["din_n"], cfg["din_c"], 152, oob=False)
+    outs = []
+    for comm in (None, Solo()):
+        task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", mlp_dtype="bf16", score_dtype="bf16", dropout_rate=0.1)
+        for tw in (task.two_tower_model.notice_tower, task.two_tower_model.company_tower):
+            tw._seed_override, tw.sync_comm = 77, comm
+        load_state(task, state)
+        task.train()
+        res = task(to_batch(tt, b, kn, kc), return_metrics=True)
+        res["loss"].backward()
+        outs.append((res["loss"].item(), {n: p.grad.cpu().numpy() for n, p in task.named_parameters()},
+                     {k: v.cpu().numpy() for k, v in task.state_dict().items() if "running" in k}))
+    assert outs[0][0] == outs[1][0]
+    for k, v in outs[0][2].items():
+        assert np.array_equal(outs[1][2][k], v), k
+    for k, g in outs[0][1].items():
+        assert np.array_equal(outs[1][1][k], g), k
+
+
 def test_two_processes_equal_single_process(tt):
     """SURVEY 8(e)'s parity definition on one GPU: a 2-rank job (two processes sharing the device, collectives through gloo
     with host staging) with row-wise sharded tables behind the fixed-capacity exchange, global in-batch negatives and SyncBN
