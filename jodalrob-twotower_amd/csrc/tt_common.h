@@ -49,11 +49,19 @@ __device__ __forceinline__ float tt_bf2f(uint16_t h) {
 }
 
 // counter-based uniform in [0,1): one value per (seed, element index) -- dropout masks are
-// regenerated in the backward pass instead of being stored.
+// regenerated in the backward pass instead of being stored.  32-bit arithmetic only: a multiply-xorshift
+// finaliser (the "lowbias32" constants) over the low index word xor the seed, the high words folded in by one multiply.  The 64-bit splitmix this
+// replaces cost ~30 quarter-rate v_mul_*_u32 per element -- 3 us of each fused tail kernel at 4 elements per thread.
+__device__ __forceinline__ uint32_t tt_mix32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7feb352dU;
+  x ^= x >> 15;
+  x *= 0x846ca68bU;
+  x ^= x >> 16;
+  return x;
+}
 __device__ __forceinline__ float tt_uniform01(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return static_cast<float>(z >> 40) * (1.0f / 16777216.0f);
+  const uint32_t lo = static_cast<uint32_t>(idx), hi = static_cast<uint32_t>(idx >> 32);
+  const uint32_t h = tt_mix32(lo ^ static_cast<uint32_t>(seed) ^ ((hi ^ static_cast<uint32_t>(seed >> 32)) * 0x9E3779B9U));
+  return static_cast<float>(h >> 8) * (1.0f / 16777216.0f);
 }

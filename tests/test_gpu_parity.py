@@ -677,6 +677,46 @@ def test_tower_emits_packed_score_operands(tt, manifest, schema_real, monkeypatc
         assert np.array_equal(outs["1"][2][k], g), k
 
 
+def test_dropout_mask_statistics(tt, manifest, schema_real):
+    """The counter-based dropout mask (tt_uniform01: 32-bit multiply-xorshift over (seed, global element index)): the kept
+    fraction is 1 - p, kept values are scaled by 1 / (1 - p), the two towers and two seeds drop different elements, and
+    neighbouring elements / rows are uncorrelated."""
+    from jodalrob_twotower_amd import towers as TW
+    cfg = dict(manifest["cases"]["real_schema"])
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    cfg.update(keys_n=kn, keys_c=kc)
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    shapes = {k: tuple(v) for k, v in manifest["state_dict_keys_real"].items()}
+    state = init_state_numpy(shapes, 161)
+    B, p, H = 4096, 0.3, cfg["hidden"][1]
+    b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 162, oob=False)
+    masks = {}
+    for seed in (11, 12):
+        task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", mlp_dtype="bf16", dropout_rate=p)
+        for tw in (task.two_tower_model.notice_tower, task.two_tower_model.company_tower):
+            tw._seed_override = seed
+        load_state(task, state)
+        task.train()
+        TW._DEBUG_KEEP = []
+        try:
+            task(to_batch(tt, b, kn, kc), return_metrics=True)["loss"].backward()
+            torch.cuda.synchronize()
+            for t, k in enumerate(TW._DEBUG_KEEP):           # activation buffer (bf16 x lives elsewhere): pre | act | ...
+                al = (B * H + 63) // 64 * 64
+                masks[(seed, t)] = (k["acts"][al:al + B * H].view(B, H) != 0).cpu().numpy()
+        finally:
+            TW._DEBUG_KEEP = None
+    for m in masks.values():
+        assert abs(m.mean() - (1 - p)) < 0.005
+        assert np.abs(m.mean(0) - (1 - p)).max() < 0.05 and np.abs(m.mean(1) - (1 - p)).max() < 0.3      # per column / per row
+        z = m.astype(np.float64) - m.mean()
+        assert abs((z[:, 1:] * z[:, :-1]).mean()) < 0.003 and abs((z[1:] * z[:-1]).mean()) < 0.003          # neighbours
+    same = lambda a, b: (a == b).mean()
+    indep = (1 - p) ** 2 + p ** 2
+    assert abs(same(masks[(11, 0)], masks[(11, 1)]) - indep) < 0.01        # towers
+    assert abs(same(masks[(11, 0)], masks[(12, 0)]) - indep) < 0.01        # seeds
+
+
 def test_copy_multi(tt):
     """tt_copy_multi: several device segments of odd sizes (16-byte body + byte tail) and a pinned-host source."""
     from jodalrob_twotower_amd import ops
