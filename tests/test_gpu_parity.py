@@ -671,8 +671,12 @@ def test_tower_emits_packed_score_operands(tt, manifest, schema_real, monkeypatc
         task.train()
         res = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
         res["loss"].backward()
-        outs[pack] = (res["loss"].item(), float(res["accuracy"]), {n: p.grad.cpu().numpy() for n, p in task.named_parameters()})
-    assert outs["0"][:2] == outs["1"][:2]
+        grads = {n: p.grad.cpu().numpy() for n, p in task.named_parameters()}
+        task.eval()                                   # eval pass: BN from the running statistics, unfused kernels + the pack kernel
+        with torch.no_grad():
+            ev = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+        outs[pack] = (res["loss"].item(), float(res["accuracy"]), grads, ev["loss"].item())
+    assert outs["0"][:2] == outs["1"][:2] and outs["0"][3] == outs["1"][3]
     for k, g in outs["0"][2].items():
         assert np.array_equal(outs["1"][2][k], g), k
 
