@@ -246,6 +246,7 @@ typedef struct tt_tower_acts { /* caller-allocated; kept between forward and bac
   void* emb_packed; /* optional, tt_score_pack_bytes(B, d_out) bytes, 16-byte aligned: on return also holds the score kernels'
                        bf16 operand images of emb (what tt_score_pack_bf16 would produce) -- written by the fused tail kernel
                        itself where that applies, by the pack kernel otherwise */
+  float emb_pack_scale; /* the images hold bf16(emb_pack_scale * emb) (0 = 1): tt_score_pack_bf16's `scale` */
   float* bn_sync_local;     /* sync_phase 1 out: [3][hidden[0]] */
   const float* bn_sync_all; /* sync_phase 2 in:  [sync_ranks][3][hidden[0]] */
   int64_t bn_sync_stride;   /* floats between two ranks' triples in bn_sync_all (0 = 3 * hidden[0]): lets one all-gather
@@ -341,6 +342,12 @@ typedef struct tt_score_fwd_dir {
   int32_t rank_mode; /* with rank != NULL: 0 or 2 = full rank; 1 = top-1 flag only (rank = 0 if the positive is the
                         row's argmax, first index winning ties, else 1) -- what the training metrics need, at a
                         quarter of the per-element work */
+  float ab_scale;    /* product of the scales the two operand images were packed with (0 = 1).  When it equals
+                        tt_score_unit_scale(inv_t) in EVERY direction of a call, the kernels run their "unit" form: the softmax
+                        term is exp2(acc) -- one VALU op less per score -- and the fixed shift's factor goes onto the finished
+                        sums.  Results (sums, diagonal, ranks, gradients) are scale-free either way. */
+  float* inv_sumexp; /* [Ra] or NULL: the reciprocal tt_score_bwd_bf16 multiplies by (its inv_a / inv_b): with it the backward
+                        kernel takes no reciprocals in its tile loop.  Valid for a backward call with the same ab_scale. */
 } tt_score_fwd_dir;
 typedef struct tt_score_bwd_dir {
   const void* A_packed;
@@ -349,12 +356,19 @@ typedef struct tt_score_bwd_dir {
   const float* sumexp_a; /* [Ra] */
   const float* sumexp_b; /* [Rb], 16-byte aligned */
   float* dA;             /* [Ra, D] f32 */
+  float ab_scale;        /* as in tt_score_fwd_dir */
+  float b_scale;         /* scale of the B image alone (0 = 1): dA is divided by it */
+  const float* inv_a;    /* [Ra] / [Rb] or NULL: tt_score_fwd_dir.inv_sumexp of the A rows' direction and of the B rows' */
+  const float* inv_b;    /* direction (16-byte aligned); NULL = reciprocals of sumexp_a / sumexp_b are taken in the kernel */
 } tt_score_bwd_dir;
 size_t tt_score_pack_bytes(int64_t R, int32_t D);
-int tt_score_pack_bf16(tt_ctx* ctx, const float* X, int64_t R, int32_t D, void* packed, tt_stream stream);
+/* `scale` (0 = 1): the image holds bf16(scale * X).  Packing ONE of the two towers with tt_score_unit_scale(inv_t) =
+ * inv_t * log2(e) folds the softmax's exponent scale into the MFMA (see tt_score_fwd_dir.ab_scale). */
+float tt_score_unit_scale(float inv_t);
+int tt_score_pack_bf16(tt_ctx* ctx, const float* X, int64_t R, int32_t D, float scale, void* packed, tt_stream stream);
 /* two operands in one launch (the notice and company embeddings of a step) */
 int tt_score_pack2_bf16(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0, const float* X1, int64_t R1,
-                        void* packed1, int32_t D, tt_stream stream);
+                        void* packed1, int32_t D, float scale0, float scale1, tt_stream stream);
 int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t,
                       float shift, tt_stream stream);
 int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t,

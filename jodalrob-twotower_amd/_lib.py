@@ -40,12 +40,12 @@ class AdamTensor(C.Structure):
 
 class ScoreFwdDir(C.Structure):
     _fields_ = [("A_packed", vp), ("B_packed", vp), ("Ra", i64), ("Rb", i64), ("diag_offset", i64),
-                ("sumexp", vp), ("diag", vp), ("rank", vp), ("sumscore", vp), ("rank_mode", i32)]
+                ("sumexp", vp), ("diag", vp), ("rank", vp), ("sumscore", vp), ("rank_mode", i32), ("ab_scale", f32), ("inv_sumexp", vp)]
 
 
 class ScoreBwdDir(C.Structure):
     _fields_ = [("A_packed", vp), ("B_packed", vp), ("Ra", i64), ("Rb", i64), ("diag_offset", i64),
-                ("sumexp_a", vp), ("sumexp_b", vp), ("dA", vp)]
+                ("sumexp_a", vp), ("sumexp_b", vp), ("dA", vp), ("ab_scale", f32), ("b_scale", f32), ("inv_a", vp), ("inv_b", vp)]
 
 
 _H = vp * TT_MAX_HIDDEN
@@ -61,7 +61,7 @@ class TowerParams(C.Structure):
 
 
 class TowerActs(C.Structure):
-    _fields_ = [("dense", vp), ("x", vp), ("pre", _H), ("act", _H), ("mean", _H), ("rstd", _H), ("y", vp), ("emb", vp), ("emb_packed", vp),
+    _fields_ = [("dense", vp), ("x", vp), ("pre", _H), ("act", _H), ("mean", _H), ("rstd", _H), ("y", vp), ("emb", vp), ("emb_packed", vp), ("emb_pack_scale", f32),
                 ("bn_sync_local", vp), ("bn_sync_all", vp), ("bn_sync_stride", i64)]
 
 
@@ -103,8 +103,9 @@ SIGNATURES = {
     "tt_score_loss_finish": (C.c_int, [vp, i64, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "tt_score_dir_bwd": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, f32, i64, vp, vp, vp, f32, vp, vp]),
     "tt_score_pack_bytes": (sz, [i64, i32]),
-    "tt_score_pack_bf16": (C.c_int, [vp, vp, i64, i32, vp, vp]),
-    "tt_score_pack2_bf16": (C.c_int, [vp, vp, i64, vp, vp, i64, vp, i32, vp]),
+    "tt_score_unit_scale": (f32, [f32]),
+    "tt_score_pack_bf16": (C.c_int, [vp, vp, i64, i32, f32, vp, vp]),
+    "tt_score_pack2_bf16": (C.c_int, [vp, vp, i64, vp, vp, i64, vp, i32, f32, f32, vp]),
     "tt_score_fwd_bf16": (C.c_int, [vp, C.POINTER(ScoreFwdDir), i32, i32, f32, f32, vp]),
     "tt_score_bwd_bf16": (C.c_int, [vp, C.POINTER(ScoreBwdDir), i32, i32, f32, f32, vp, f32, vp]),
     "tt_score_matrix": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, vp, i64, vp]),

@@ -40,7 +40,7 @@ __device__ __forceinline__ float max3_asm(float a, float b, float c) {
 }
 
 // ---- pack ------------------------------------------------------------------------------------------
-struct PackArgs { const float* X; int64_t R, Rp; __bf16* rows; __bf16* frag; };
+struct PackArgs { const float* X; int64_t R, Rp; __bf16* rows; __bf16* frag; float scale; };
 struct PackBatch { PackArgs a[2]; };
 
 __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBatch batch, int D, int Dp) {
@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBatch batch, int D, 
   const int64_t R = pa.R, Rp = pa.Rp;
   __bf16* __restrict__ rows = pa.rows;
   __bf16* __restrict__ frag = pa.frag;
+  const float sc = pa.scale;
   const int64_t nchunk = Rp * Dp / 8;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < 2 * nchunk; c += stride) {
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBatch batch, int D, 
       const int64_t row = 32 * (q / (Dp / 16)) + ci;
       const int d0 = 16 * ks + 8 * hh;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = (__bf16)((row < R && d0 + j < D) ? X[row * D + d0 + j] : 0.f);
+      for (int j = 0; j < 8; ++j) v[j] = (__bf16)((row < R && d0 + j < D) ? X[row * D + d0 + j] * sc : 0.f);
       *reinterpret_cast<bf16x8*>(rows + c * 8) = v;
     } else {                                            // fragment-ordered image [t][s][h][d][8]
       const int64_t f = c - nchunk;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void pack_bf16_kernel(PackBatch batch, int D, 
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int64_t row = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-        v[j] = (__bf16)((row < R && d < D) ? X[row * D + d] : 0.f);
+        v[j] = (__bf16)((row < R && d < D) ? X[row * D + d] * sc : 0.f);
       }
       *reinterpret_cast<bf16x8*>(frag + f * 8) = v;
     }
@@ -87,10 +88,13 @@ struct DirFwd {
   int32_t* rank;
   float* sumscore;
   int32_t rank_mode;   // 0 none, 1 top-1 flag (rank = 0/1), 2 full rank
+  float c1;            // exponent scale for this direction's products: inv_t * log2(e) / (scale the operand images carry)
+  float unscale;       // product -> s / T
+  float* inv_sumexp;   // optional out: 1 / (the sum as accumulated), the factor the backward kernel multiplies by
 };
 struct FwdArgs {
   DirFwd d[2];
-  float c1, c2, inv_t;
+  float c2, kexp;      // exponent offset (-shift * log2 e); UNIT kernels leave it out of the terms and scale the row sums by 2^c2
 };
 
 struct DirBwd {
@@ -101,10 +105,14 @@ struct DirBwd {
   const float* sumexp_a;
   const float* sumexp_b;
   float* dA;
+  float c1;            // as DirFwd::c1
+  float out_scale;     // scale / (the B image's scale)
+  const float* inv_a;  // optional: DirFwd::inv_sumexp of the A rows / of the B rows (then no reciprocals in the tile loop)
+  const float* inv_b;
 };
 struct BwdArgs {
   DirBwd d[2];
-  float c1, c2, scale;
+  float c2, kexp;
   const float* d_loss;
   int D;
 };
@@ -137,7 +145,11 @@ __device__ __forceinline__ void gemm1(const __bf16* __restrict__ b_rows, int64_t
 }
 
 // ---- forward ---------------------------------------------------------------------------------------
-template <int KS, int AT, int NW>
+// UNIT: every direction's exponent scale is exactly 1 (one operand image was packed times inv_t * log2 e): the softmax
+// term is exp2(acc) with no multiply-add in front -- one VALU op less per score in kernels that are bound by VALU issue --
+// and the constant factor 2^c2 of the fixed shift goes onto the finished row sums (|acc| <= log2(e) / T <= 58 for the
+// supported temperatures: no overflow without the shift).  Rank / diagonal comparisons are scale-free.
+template <int KS, int AT, int NW, bool UNIT>
 __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
   constexpr int ROWS = 32 * AT;
   __shared__ float part_e[NW][ROWS];
@@ -155,6 +167,10 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
   dr.rank = d1 ? args.d[1].rank : args.d[0].rank;
   dr.sumscore = d1 ? args.d[1].sumscore : args.d[0].sumscore;
   dr.rank_mode = d1 ? args.d[1].rank_mode : args.d[0].rank_mode;
+  const float c1 = d1 ? args.d[1].c1 : args.d[0].c1, unscale = d1 ? args.d[1].unscale : args.d[0].unscale;
+  float* const inv_out = d1 ? args.d[1].inv_sumexp : args.d[0].inv_sumexp;
+  const float c2 = args.c2;
+  auto ex = [&](float x) { return UNIT ? __builtin_amdgcn_exp2f(x) : __builtin_amdgcn_exp2f(__builtin_fmaf(x, c1, c2)); };
   const int Ra = (int)(d1 ? args.d[1].Ra : args.d[0].Ra), Rb = (int)(d1 ? args.d[1].Rb : args.d[0].Rb);
   const int off = (int)(d1 ? args.d[1].off : args.d[0].off);
   const int a0 = (int)blockIdx.x * ROWS;
@@ -203,7 +219,7 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
 #pragma unroll
       for (int i = 0; i < AT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) se[i] += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][r], args.c1, args.c2));
+        for (int r = 0; r < 16; ++r) se[i] += ex(acc[i][r]);
       if (want_ss) {
 #pragma unroll
         for (int i = 0; i < AT; ++i)
@@ -243,7 +259,7 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
           const int b = b_lo + rowmap(r, h);
           const float x = acc[i][r];
           const bool valid = b < Rb, bef = valid && b < pos[i], aft = valid && b > pos[i];
-          se[i] += valid ? __builtin_amdgcn_exp2f(__builtin_fmaf(x, args.c1, args.c2)) : 0.f;
+          se[i] += valid ? ex(x) : 0.f;
           ss[i] += valid ? x : 0.f;
           mb[i] = bef ? fmaxf(mb[i], x) : mb[i];
           ma[i] = aft ? fmaxf(ma[i], x) : ma[i];
@@ -291,23 +307,24 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
         e += part_e[w][threadIdx.x]; sc += part_s[w][threadIdx.x]; k += part_c[w][threadIdx.x];
         xb = fmaxf(xb, part_mb[w][threadIdx.x]); xa = fmaxf(xa, part_ma[w][threadIdx.x]);
       }
-      dr.sumexp[a] = e;
+      dr.sumexp[a] = UNIT ? e * args.kexp : e;
+      if (inv_out) inv_out[a] = 1.f / e;
       if (mode == 2) dr.rank[a] = k;
       else if (mode == 1) dr.rank[a] = (xb < dg_s[threadIdx.x] && xa <= dg_s[threadIdx.x]) ? 0 : 1;
-      if (dr.sumscore) dr.sumscore[a] = sc * args.inv_t;
+      if (dr.sumscore) dr.sumscore[a] = sc * unscale;                            // products -> sum_b s_ab / T
     }
   }
   if (wave == 0 && h == 0 && dr.diag) {
 #pragma unroll
     for (int i = 0; i < AT; ++i) {
       const int a = a0 + 32 * i + c;
-      if (a < Ra) dr.diag[a] = dg[i] > -1.0e38f ? dg[i] * args.inv_t : 0.f;
+      if (a < Ra) dr.diag[a] = dg[i] > -1.0e38f ? dg[i] * unscale : 0.f;
     }
   }
 }
 
 // ---- backward --------------------------------------------------------------------------------------
-template <int KS, int AT, int NW, bool PF_B, bool EARLY_BM>
+template <int KS, int AT, int NW, bool PF_B, bool EARLY_BM, bool UNIT>
 __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
   constexpr int Dp = KS * 16, ROWS = 32 * AT, DT = KS / 2;
   __shared__ float red[(NW / 2) * ROWS * Dp];
@@ -319,6 +336,10 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
   dr.sumexp_a = d1 ? args.d[1].sumexp_a : args.d[0].sumexp_a;
   dr.sumexp_b = d1 ? args.d[1].sumexp_b : args.d[0].sumexp_b;
   dr.dA = d1 ? args.d[1].dA : args.d[0].dA;
+  const float c1 = d1 ? args.d[1].c1 : args.d[0].c1, out_scale = d1 ? args.d[1].out_scale : args.d[0].out_scale;
+  const float* const inv_a = d1 ? args.d[1].inv_a : args.d[0].inv_a;
+  const float* const inv_b = d1 ? args.d[1].inv_b : args.d[0].inv_b;
+  const float c2 = args.c2, kx = UNIT ? args.kexp : 1.f;     // without the forward's reciprocals: 1 / raw sum = 2^c2 / stored sum
   const int Ra = (int)(d1 ? args.d[1].Ra : args.d[0].Ra), Rb = (int)(d1 ? args.d[1].Rb : args.d[0].Rb);
   const int off = (int)(d1 ? args.d[1].off : args.d[0].off);
   const int a0 = (int)blockIdx.x * ROWS;
@@ -333,7 +354,7 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
   for (int i = 0; i < AT; ++i) {
     load_bfrag<KS>(dr.a_rows, a0 / 32 + i, c, h, ares[i]);
     const int a = a0 + 32 * i + c;
-    ia[i] = a < Ra ? __builtin_amdgcn_rcpf(dr.sumexp_a[a]) : 0.f;
+    ia[i] = a < Ra ? (inv_a ? inv_a[a] : __builtin_amdgcn_rcpf(dr.sumexp_a[a]) * kx) : 0.f;
     pos[i] = a + off;
   }
   const int posmin = a0 + off, posmax = a0 + ROWS - 1 + off;
@@ -369,17 +390,25 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
     const int b_lo = 32 * t;
     float ib[16];
     if (b_lo + 31 < Rb) {
+      if (inv_b) {                                       // the forward pass left 1 / sum: no reciprocals (quarter rate) per tile
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(dr.sumexp_b + b_lo + 4 * h + 8 * q);
-        ib[4 * q + 0] = __builtin_amdgcn_rcpf(v.x); ib[4 * q + 1] = __builtin_amdgcn_rcpf(v.y);
-        ib[4 * q + 2] = __builtin_amdgcn_rcpf(v.z); ib[4 * q + 3] = __builtin_amdgcn_rcpf(v.w);
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(inv_b + b_lo + 4 * h + 8 * q);
+          ib[4 * q + 0] = v.x; ib[4 * q + 1] = v.y; ib[4 * q + 2] = v.z; ib[4 * q + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(dr.sumexp_b + b_lo + 4 * h + 8 * q);
+          ib[4 * q + 0] = __builtin_amdgcn_rcpf(v.x) * kx; ib[4 * q + 1] = __builtin_amdgcn_rcpf(v.y) * kx;
+          ib[4 * q + 2] = __builtin_amdgcn_rcpf(v.z) * kx; ib[4 * q + 3] = __builtin_amdgcn_rcpf(v.w) * kx;
+        }
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int b = b_lo + rowmap(r, h);
-        ib[r] = b < Rb ? __builtin_amdgcn_rcpf(dr.sumexp_b[b]) : 0.f;
+        ib[r] = b < Rb ? (inv_b ? inv_b[b] : __builtin_amdgcn_rcpf(dr.sumexp_b[b]) * kx) : 0.f;
       }
     }
     const bool band = !(b_lo + 31 < posmin || b_lo > posmax);
@@ -388,7 +417,8 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
     for (int i = 0; i < AT; ++i) {
       float w[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) w[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][r], args.c1, args.c2)) * (ia[i] + ib[r]);
+      for (int r = 0; r < 16; ++r)
+        w[r] = (UNIT ? __builtin_amdgcn_exp2f(acc[i][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][r], c1, c2))) * (ia[i] + ib[r]);
       if (band) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -434,7 +464,7 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
     __syncthreads();
   }
   if (wave == 0) {
-    const float g = args.d_loss[0] * args.scale;
+    const float g = args.d_loss[0] * out_scale;
 #pragma unroll
     for (int i = 0; i < AT; ++i)
 #pragma unroll
@@ -468,8 +498,10 @@ size_t tt_score_pack_bytes(int64_t R, int32_t D) {
   return (size_t)(4 * rup(R > 0 ? R : 1, 64) * padded_d(D));
 }
 
+float tt_score_unit_scale(float inv_t) { return inv_t * kLog2e; }
+
 int tt_score_pack2_bf16(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0, const float* X1, int64_t R1, void* packed1,
-                        int32_t D, tt_stream stream) {
+                        int32_t D, float scale0, float scale1, tt_stream stream) {
   TT_CHECK_ARG(ctx && X0 && packed0, "tt_score_pack_bf16: NULL argument");
   TT_CHECK_ARG(R0 >= 1 && D >= 1 && (X1 == nullptr || (packed1 && R1 >= 1)), "tt_score_pack_bf16: bad shape");
   if (D > 256) {
@@ -484,7 +516,8 @@ int tt_score_pack2_bf16(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0,
   for (int i = 0; i < n; ++i) {
     const int64_t R = i ? R1 : R0, Rp = rup(R, 64);     // a workgroup reads up to 64 consecutive rows of its operand
     __bf16* base = reinterpret_cast<__bf16*>(i ? packed1 : packed0);
-    b.a[i] = PackArgs{i ? X1 : X0, R, Rp, base, base + Rp * Dp};
+    const float sc = i ? scale1 : scale0;
+    b.a[i] = PackArgs{i ? X1 : X0, R, Rp, base, base + Rp * Dp, sc == 0.f ? 1.f : sc};
     const int64_t chunks = 2 * Rp * Dp / 8;
     maxchunks = chunks > maxchunks ? chunks : maxchunks;
   }
@@ -496,8 +529,8 @@ int tt_score_pack2_bf16(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0,
   return TT_OK;
 }
 
-int tt_score_pack_bf16(tt_ctx* ctx, const float* X, int64_t R, int32_t D, void* packed, tt_stream stream) {
-  return tt_score_pack2_bf16(ctx, X, R, packed, nullptr, 0, nullptr, D, stream);
+int tt_score_pack_bf16(tt_ctx* ctx, const float* X, int64_t R, int32_t D, float scale, void* packed, tt_stream stream) {
+  return tt_score_pack2_bf16(ctx, X, R, packed, nullptr, 0, nullptr, D, scale, 1.f, stream);
 }
 
 int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t, float shift,
@@ -510,20 +543,26 @@ int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs,
   }
   FwdArgs a{};
   int64_t maxRa = 0;
+  bool unit = true;
   for (int i = 0; i < 2; ++i) {
     const tt_score_fwd_dir& d = dirs[i < n_dirs ? i : 0];
     TT_CHECK_ARG(d.A_packed && d.B_packed && d.sumexp && d.Ra >= 1 && d.Rb >= 1, "tt_score_fwd_bf16: bad direction %d", i);
+    const float ab = d.ab_scale == 0.f ? 1.f : d.ab_scale;
     a.d[i] = DirFwd{view(d.A_packed, d.Ra, D).rows, view(d.B_packed, d.Rb, D).rows, d.Ra, d.Rb, d.diag_offset, d.sumexp, d.diag, d.rank, d.sumscore,
-                      d.rank ? (d.rank_mode == 1 ? 1 : 2) : 0};
+                      d.rank ? (d.rank_mode == 1 ? 1 : 2) : 0, inv_t * kLog2e / ab, inv_t / ab, d.inv_sumexp};
+    unit = unit && ab == inv_t * kLog2e;                // exactly: the caller got the scale from tt_score_unit_scale(inv_t)
     maxRa = d.Ra > maxRa ? d.Ra : maxRa;
   }
-  a.c1 = inv_t * kLog2e;
   a.c2 = -shift * kLog2e;
-  a.inv_t = inv_t;
+  a.kexp = exp2f(a.c2);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int Dp = padded_d(D);
 #define TT_FWD(KS, AT, NW)                                                                                     \
-  score_fwd_bf16_kernel<KS, AT, NW><<<dim3((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs), NW * 64, 0, st>>>(a)
+  do {                                                                                                         \
+    const dim3 grid((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs);                                      \
+    if (unit) score_fwd_bf16_kernel<KS, AT, NW, true><<<grid, NW * 64, 0, st>>>(a);                            \
+    else score_fwd_bf16_kernel<KS, AT, NW, false><<<grid, NW * 64, 0, st>>>(a);                                \
+  } while (0)
   // D <= 64: 32 rows per wave (AT = 1), 8 waves, 2 workgroups per CU measured best (43.6 us; AT = 2: 48.0, 4 waves: 53.4,
   // 16 waves: 48.7 at B = 8192); TT_SCORE_FWD_VARIANT = 2 selects the 64-row form
   static const int fvar = getenv("TT_SCORE_FWD_VARIANT") ? atoi(getenv("TT_SCORE_FWD_VARIANT")) : 0;
@@ -543,25 +582,33 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
   TT_CHECK_ARG(D >= 1 && D <= 256, "tt_score_bwd_bf16: D=%d not in [1,256]", D);
   BwdArgs a{};
   int64_t maxRa = 0;
+  bool unit = true;
   for (int i = 0; i < 2; ++i) {
     const tt_score_bwd_dir& d = dirs[i < n_dirs ? i : 0];
     TT_CHECK_ARG(d.A_packed && d.B_packed && d.sumexp_a && d.sumexp_b && d.dA && d.Ra >= 1 && d.Rb >= 1,
                  "tt_score_bwd_bf16: bad direction %d", i);
     TT_CHECK_ARG(tt_aligned(d.sumexp_b, 16), "tt_score_bwd_bf16: sumexp_b must be 16-byte aligned");
     const PackedView vb = view(d.B_packed, d.Rb, D);
-    a.d[i] = DirBwd{view(d.A_packed, d.Ra, D).rows, vb.rows, vb.frag, d.Ra, d.Rb, d.diag_offset, d.sumexp_a, d.sumexp_b, d.dA};
+    const float ab = d.ab_scale == 0.f ? 1.f : d.ab_scale, bs = d.b_scale == 0.f ? 1.f : d.b_scale;
+    a.d[i] = DirBwd{view(d.A_packed, d.Ra, D).rows, vb.rows, vb.frag, d.Ra, d.Rb, d.diag_offset, d.sumexp_a, d.sumexp_b, d.dA,
+                      inv_t * kLog2e / ab, scale / bs, d.inv_a, d.inv_b};
+    TT_CHECK_ARG(d.inv_b == nullptr || tt_aligned(d.inv_b, 16), "tt_score_bwd_bf16: inv_b must be 16-byte aligned");
+    unit = unit && ab == inv_t * kLog2e;
     maxRa = d.Ra > maxRa ? d.Ra : maxRa;
   }
-  a.c1 = inv_t * kLog2e;
   a.c2 = -shift * kLog2e;
-  a.scale = scale;
+  a.kexp = exp2f(a.c2);
   a.d_loss = d_loss;
   a.D = D;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int Dp = padded_d(D);
   static const int bvar = getenv("TT_SCORE_BWD_VARIANT") ? atoi(getenv("TT_SCORE_BWD_VARIANT")) : 0;
 #define TT_BWD(KS, AT, NW, PF, EB)                                                                             \
-  score_bwd_bf16_kernel<KS, AT, NW, PF, EB><<<dim3((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs), NW * 64, 0, st>>>(a)
+  do {                                                                                                         \
+    const dim3 grid((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs);                                      \
+    if (unit) score_bwd_bf16_kernel<KS, AT, NW, PF, EB, true><<<grid, NW * 64, 0, st>>>(a);                    \
+    else score_bwd_bf16_kernel<KS, AT, NW, PF, EB, false><<<grid, NW * 64, 0, st>>>(a);                        \
+  } while (0)
   if (Dp == 32) TT_BWD(2, 2, 8, true, true);
   else if (Dp == 64) {
     switch (bvar) {

@@ -373,7 +373,7 @@ struct TailFwdArgs {
   BnStatArgs s;
   const float* g; const float* b; uint64_t salt; float* act;
   const float* w_out; const float* b_out; int D; float* y; float* emb;
-  __bf16* pk_rows; __bf16* pk_frag; int Dp;     // optional: the score kernels' two operand images of emb (tt_score_pack_bf16)
+  __bf16* pk_rows; __bf16* pk_frag; int Dp; float pk_scale;   // optional: the score kernels' two operand images of emb (tt_score_pack_bf16)
 };
 
 __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed0,
@@ -511,14 +511,14 @@ __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArg
     for (int j = 0; j < 4; ++j) {
       const int row = m0 + wave * 4 + j;
       const int64_t c = (((int64_t)(row >> 5) * (Dp >> 4) + (d >> 4)) * 2 + ((d >> 3) & 1)) * 32 + (row & 31);
-      f.pk_rows[c * 8 + (d & 7)] = (__bf16)e[j];
+      f.pk_rows[c * 8 + (d & 7)] = (__bf16)(e[j] * f.pk_scale);
     }
     const int row0 = m0 + wave * 4, rr = row0 & 31, q = rr & 15;
     const int64_t fi = (((int64_t)(row0 >> 5) * 2 + (rr >> 4)) * 2 + ((q & 7) >> 2)) * Dp + d;
     using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
     bf16x4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (__bf16)e[j];
+    for (int j = 0; j < 4; ++j) o[j] = (__bf16)(e[j] * f.pk_scale);
     *reinterpret_cast<bf16x4*>(f.pk_frag + fi * 8 + (q >> 3) * 4) = o;
   }
 }
@@ -1068,7 +1068,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       Batch<TailFwdArgs> tf{};
       for (int t = 0; t < n; ++t)
         tf.a[t] = TailFwdArgs{bs.a[t], P[t]->bn_w[i], P[t]->bn_b[i], ba.a[t].salt, A[t]->act[i], P[t]->w_out, P[t]->b_out, P[t]->d_out,
-                              A[t]->y, A[t]->emb, nullptr, nullptr, 0};
+                              A[t]->y, A[t]->emb, nullptr, nullptr, 0, 1.f};
       for (int t = 0; t < n; ++t)
         if (A[t]->emb_packed) {
           const int Dp = P[t]->d_out <= 32 ? 32 : 64;
@@ -1076,6 +1076,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
           tf.a[t].pk_rows = base;
           tf.a[t].pk_frag = base + tt_cdiv(B, 64) * 64 * Dp;
           tf.a[t].Dp = Dp;
+          tf.a[t].pk_scale = A[t]->emb_pack_scale == 0.f ? 1.f : A[t]->emb_pack_scale;
         }
       tail_fwd_kernel<<<dim3((unsigned)tt_cdiv(B, 64), (unsigned)n), kTailThreads, 0, st>>>(tf, drop, dropout_p, seed, seed_dev);
       TT_LAUNCH_CHECK();
@@ -1112,7 +1113,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
   (void)dmax;
   for (int t = 0; t < n; ++t)                            // emb_packed is honoured on every path: here by the pack kernel
     if (A[t]->emb_packed)
-      if (int rc = tt_score_pack_bf16(ctx, A[t]->emb, B, P[t]->d_out, A[t]->emb_packed, stream)) return rc;
+      if (int rc = tt_score_pack_bf16(ctx, A[t]->emb, B, P[t]->d_out, A[t]->emb_pack_scale, A[t]->emb_packed, stream)) return rc;
   return TT_OK;
 }
 

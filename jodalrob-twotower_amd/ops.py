@@ -370,50 +370,62 @@ def score_dir_bwd(A, Bm, inv_t, shift, diag_offset, sumexp_a, sumexp_b, d_loss, 
     return dA
 
 
-def score_pack_bf16(X):
-    """f32 [R, D] -> packed bf16 operand images (uint8 buffer)."""
+def score_pack_bf16(X, scale: float = 1.0):
+    """f32 [R, D] -> packed bf16 operand images of scale * X (uint8 buffer)."""
     dev, R, D = X.device, X.shape[0], X.shape[1]
     lib = L.load()
     buf = torch.empty(lib.tt_score_pack_bytes(R, D), dtype=torch.uint8, device=dev)
     with _timed("tt_score_pack_bf16"):
-        L.check(lib.tt_score_pack_bf16(L.ctx(dev), L.ptr(X), R, D, L.ptr(buf), L.stream(dev)), "tt_score_pack_bf16")
+        L.check(lib.tt_score_pack_bf16(L.ctx(dev), L.ptr(X), R, D, scale, L.ptr(buf), L.stream(dev)), "tt_score_pack_bf16")
     return buf
 
 
-def score_pack2_bf16(X0, X1):
-    """Both operands of a step in one launch."""
+def score_unit_scale(inv_t: float) -> float:
+    """inv_t * log2(e) exactly as the library computes it: packing ONE tower's operand images with it lets the score
+    kernels drop the exponent's multiply-add (tt_score_fwd_dir.ab_scale)."""
+    return float(L.load().tt_score_unit_scale(inv_t))
+
+
+def score_pack2_bf16(X0, X1, scale0: float = 1.0, scale1: float = 1.0):
+    """Both operands of a step in one launch (images of scale * X)."""
     dev, D = X0.device, X0.shape[1]
     lib = L.load()
     b0 = torch.empty(lib.tt_score_pack_bytes(X0.shape[0], D), dtype=torch.uint8, device=dev)
     b1 = torch.empty(lib.tt_score_pack_bytes(X1.shape[0], D), dtype=torch.uint8, device=dev)
     with _timed("tt_score_pack_bf16"):
         L.check(lib.tt_score_pack2_bf16(L.ctx(dev), L.ptr(X0), X0.shape[0], L.ptr(b0), L.ptr(X1), X1.shape[0], L.ptr(b1), D,
-                                        L.stream(dev)), "tt_score_pack2_bf16")
+                                        scale0, scale1, L.stream(dev)), "tt_score_pack2_bf16")
     return b0, b1
 
 
-def score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank=True, full_rank=True):
-    """Both softmax directions of the square in-batch problem in one launch."""
+def score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank=True, full_rank=True, scale_n: float = 1.0, with_inv: bool = False):
+    """Both softmax directions of the square in-batch problem in one launch.  scale_n: the scale Np was packed with.
+    with_inv: also return (inv_row, inv_col), the reciprocals score_bwd_bf16 can take instead of computing its own."""
     dev = Np.device
     Bp = (B + 3) // 4 * 4                                              # keep every row 16-byte aligned
-    f = torch.empty((4, Bp), dtype=torch.float32, device=dev)         # rowsum, colsum, diag, sumscore
+    f = torch.empty((6, Bp), dtype=torch.float32, device=dev)         # rowsum, colsum, diag, sumscore, 1/rowsum', 1/colsum'
     ranks = torch.empty((2, B), dtype=torch.int32, device=dev)
     arr = (L.ScoreFwdDir * 2)()
     rm = 2 if full_rank else 1
-    arr[0] = L.ScoreFwdDir(L.ptr(Np), L.ptr(Cp), B, B, 0, L.ptr(f[0]), L.ptr(f[2]), L.ptr(ranks[0]), L.ptr(f[3]), rm)
-    arr[1] = L.ScoreFwdDir(L.ptr(Cp), L.ptr(Np), B, B, 0, L.ptr(f[1]), None, L.ptr(ranks[1]) if want_col_rank else None, None, rm)
+    arr[0] = L.ScoreFwdDir(L.ptr(Np), L.ptr(Cp), B, B, 0, L.ptr(f[0]), L.ptr(f[2]), L.ptr(ranks[0]), L.ptr(f[3]), rm, scale_n,
+                           L.ptr(f[4]) if with_inv else None)
+    arr[1] = L.ScoreFwdDir(L.ptr(Cp), L.ptr(Np), B, B, 0, L.ptr(f[1]), None, L.ptr(ranks[1]) if want_col_rank else None, None, rm, scale_n,
+                           L.ptr(f[5]) if with_inv else None)
     with _timed("tt_score_fwd_bf16"):
         L.check(L.load().tt_score_fwd_bf16(L.ctx(dev), arr, 2, D, inv_t, shift, L.stream(dev)), "tt_score_fwd_bf16")
-    return f[0][:B], f[1][:B], f[2][:B], ranks[0], ranks[1], f[3][:B]
+    out = (f[0][:B], f[1][:B], f[2][:B], ranks[0], ranks[1], f[3][:B])
+    return out + ((f[4][:B], f[5][:B]),) if with_inv else out
 
 
-def score_bwd_bf16(Np, Cp, B, D, inv_t, shift, rowsum, colsum, d_loss, scale):
+def score_bwd_bf16(Np, Cp, B, D, inv_t, shift, rowsum, colsum, d_loss, scale, scale_n: float = 1.0, inv=None):
+    """inv: (inv_row, inv_col) from score_fwd_bf16(..., with_inv=True) with the same scale_n (optional)."""
     dev = Np.device
     dN = torch.empty((B, D), dtype=torch.float32, device=dev)
     dC = torch.empty((B, D), dtype=torch.float32, device=dev)
     arr = (L.ScoreBwdDir * 2)()
-    arr[0] = L.ScoreBwdDir(L.ptr(Np), L.ptr(Cp), B, B, 0, L.ptr(rowsum), L.ptr(colsum), L.ptr(dN))
-    arr[1] = L.ScoreBwdDir(L.ptr(Cp), L.ptr(Np), B, B, 0, L.ptr(colsum), L.ptr(rowsum), L.ptr(dC))
+    ir, ic = (L.ptr(inv[0]), L.ptr(inv[1])) if inv is not None else (None, None)
+    arr[0] = L.ScoreBwdDir(L.ptr(Np), L.ptr(Cp), B, B, 0, L.ptr(rowsum), L.ptr(colsum), L.ptr(dN), scale_n, 1.0, ir, ic)   # B = company: unscaled
+    arr[1] = L.ScoreBwdDir(L.ptr(Cp), L.ptr(Np), B, B, 0, L.ptr(colsum), L.ptr(rowsum), L.ptr(dC), scale_n, scale_n, ic, ir)  # B = notice image
     with _timed("tt_score_bwd_bf16"):
         L.check(L.load().tt_score_bwd_bf16(L.ctx(dev), arr, 2, D, inv_t, shift, L.ptr(d_loss), scale, L.stream(dev)),
                 "tt_score_bwd_bf16")

@@ -89,6 +89,7 @@ class BaseTower(nn.Module):
         self.sync_comm = None           # set by the distributed task (sync_bn=True): BN statistics over all ranks' rows
         self.pack_for_score = False     # set by the train task (score_dtype='bf16'): also emit the score kernels' operand images
         self._last_packed = None
+        self.pack_scale = 1.0           # the images hold bf16(pack_scale * emb)
         self._seed_dev = None           # set by GraphedTrainStep: device word added to the dropout seed
         self._seed_override = None      # tests: a fixed dropout seed instead of one drawn from torch's CPU generator
         self.device = device
@@ -268,7 +269,7 @@ class _TowersFn(torch.autograd.Function):
             if tw.pack_for_score and B:
                 # the score kernels' bf16 operand images of the unit rows, written by the tower pass itself (tt_tower_acts.emb_packed)
                 s.packed = torch.empty(L.load().tt_score_pack_bytes(B, tw.final_embedding_dim), dtype=torch.uint8, device=dev)
-                a.emb_packed = s.packed.data_ptr()
+                a.emb_packed, a.emb_pack_scale = s.packed.data_ptr(), float(tw.pack_scale)
             s.acts, s.acts_struct = (dense,), a
             sides.append(s)
             if K and B:
@@ -360,7 +361,7 @@ class _TowersFn(torch.autograd.Function):
                     plan.keep, plan.stream = rows, (None if inline else ds)   # keep the sort input alive until it has run
                 pl[:] = [store, psides, plan]
         for s in sides:
-            s.tower._last_packed = s.packed
+            s.tower._last_packed = None if s.packed is None else (s.packed, float(s.tower.pack_scale))
         ctx.sides, ctx.plans, ctx.spans, ctx.n_flat = sides, plans, spans, len(flat)
         # hand out aliases: keeping the returned objects themselves on ctx would form a reference cycle
         outs = tuple(s.emb.view(s.emb.shape) for s in sides)

@@ -21,22 +21,33 @@ from .two_tower_model import TwoTowerModel, create_two_tower_model
 LAZY_SIM_BATCH = 2048
 
 
+_PRESCALE = __import__("os").environ.get("TT_SCORE_PRESCALE", "1") != "0"      # TT_SCORE_PRESCALE=0: unscaled operand images (A/B)
+
+
 class _ScoreCEFn(torch.autograd.Function):
     """loss = 0.5 * [CE(S, diag) + CE(S^T, diag)],  S = N C^T / T   (:99-134); out8 carries the metrics.
     score_dtype 'fp32': exact-f32 MFMA path (parity); 'bf16': bf16-operand MFMA fast path."""
 
     @staticmethod
-    def forward(ctx, n, c, inv_t, score_dtype, want_col_rank=True, full_rank=True, packed_n=None, packed_c=None):
+    def forward(ctx, n, c, inv_t, score_dtype, want_col_rank=True, full_rank=True, packed_n=None, packed_c=None, scale_n=None):
         n, c = n.contiguous().float(), c.contiguous().float()
         B, D = n.shape
         shift = abs(inv_t)                                   # unit rows: |s| <= 1/T
         if score_dtype == "bf16":
-            # the towers' fused tail can emit the packed operand images itself (tt_tower_acts.emb_packed): one launch fewer
-            Np, Cp = (packed_n, packed_c) if packed_n is not None and packed_c is not None else ops.score_pack2_bf16(n, c)
-            rowsum, colsum, diag, row_rank, col_rank, sumscore = ops.score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank, full_rank)
+            # scale_n: the notice image holds bf16(scale_n * n) -- with scale_n = inv_t * log2(e) the exponent scale of the
+            # softmax rides in the MFMA and the kernels skip a multiply-add per score (results are scale-free).
+            # The towers' fused tail can emit the packed operand images itself (tt_tower_acts.emb_packed): one launch fewer.
+            if packed_n is not None and packed_c is not None:
+                Np, Cp = packed_n, packed_c
+                scale_n = 1.0 if scale_n is None else scale_n
+            else:
+                scale_n = ops.score_unit_scale(inv_t) if (scale_n is None and _PRESCALE) else (scale_n or 1.0)
+                Np, Cp = ops.score_pack2_bf16(n, c, scale_n, 1.0)
+            rowsum, colsum, diag, row_rank, col_rank, sumscore, inv = ops.score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank,
+                                                                                         full_rank, scale_n, with_inv=True)
             if not want_col_rank:
                 col_rank = row_rank                      # placeholder: column top-1 rate is only a first-call diagnostic
-            ctx.packed = (Np, Cp)
+            ctx.packed = (Np, Cp, scale_n, inv)
         else:
             rowsum, diag, row_rank, sumscore = ops.score_dir_fwd(n, c, inv_t, shift, 0, True)
             colsum, _, col_rank, _ = ops.score_dir_fwd(c, n, inv_t, shift, 0, False)
@@ -53,16 +64,17 @@ class _ScoreCEFn(torch.autograd.Function):
         n, c, rowsum, colsum = ctx.saved_tensors
         B, D = n.shape
         if d_loss is None:
-            return None, None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
         if d_loss.dtype != torch.float32 or not d_loss.is_contiguous():
             d_loss = d_loss.contiguous().float()
         scale = ctx.inv_t / (2.0 * B)
         if ctx.packed is not None:
-            dN, dC = ops.score_bwd_bf16(ctx.packed[0], ctx.packed[1], B, D, ctx.inv_t, ctx.shift, rowsum, colsum, d_loss, scale)
+            dN, dC = ops.score_bwd_bf16(ctx.packed[0], ctx.packed[1], B, D, ctx.inv_t, ctx.shift, rowsum, colsum, d_loss, scale,
+                                        ctx.packed[2], ctx.packed[3])
         else:
             dN = ops.score_dir_bwd(n, c, ctx.inv_t, ctx.shift, 0, rowsum, colsum, d_loss, scale)
             dC = ops.score_dir_bwd(c, n, ctx.inv_t, ctx.shift, 0, colsum, rowsum, d_loss, scale)
-        return dN, dC, None, None, None, None, None, None
+        return dN, dC, None, None, None, None, None, None, None
 
 
 class _Result(dict):
@@ -115,6 +127,8 @@ class TwoTowerTrainTask(nn.Module):
         if self.score_dtype == "bf16" and os.environ.get("TT_TOWER_PACK", "1") != "0":      # TT_TOWER_PACK=0: separate pack launch (A/B)
             for tw in (two_tower_model.notice_tower, two_tower_model.company_tower):
                 tw.pack_for_score = True
+            if _PRESCALE:                    # the notice image carries the softmax's exponent scale (see _ScoreCEFn)
+                two_tower_model.notice_tower.pack_scale = ops.score_unit_scale(1.0 / float(temperature))
         self.two_tower_model = two_tower_model
         self.temperature = temperature
         self.loss_type = loss_type
@@ -151,10 +165,10 @@ class TwoTowerTrainTask(nn.Module):
 
     def _score_ce(self, n, c, inv_t, first_call):
         """(loss, out8, row_rank) of the symmetric in-batch-negative softmax-CE (:99-134); the sharded task overrides it."""
-        pn, pc = getattr(n, "_tt_packed", None), getattr(c, "_tt_packed", None)     # emitted by the towers (towers.run_towers)
-        if self.score_dtype != "bf16" or n.shape != c.shape:
-            pn = pc = None
-        return _ScoreCEFn.apply(n, c, inv_t, self.score_dtype, first_call, False, pn, pc)
+        pn, pc = getattr(n, "_tt_packed", None), getattr(c, "_tt_packed", None)     # (buffer, scale) emitted by the towers
+        if self.score_dtype != "bf16" or n.shape != c.shape or pn is None or pc is None or pc[1] != 1.0:
+            return _ScoreCEFn.apply(n, c, inv_t, self.score_dtype, first_call, False)
+        return _ScoreCEFn.apply(n, c, inv_t, self.score_dtype, first_call, False, pn[0], pc[0], pn[1])
 
     def _compute_similarity_matrix(self, notice_embeddings, company_embeddings):                # :99-112
         return self.two_tower_model.compute_similarity(notice_embeddings, company_embeddings, self.temperature)

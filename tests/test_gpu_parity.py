@@ -268,7 +268,10 @@ def test_score_bf16_path_vs_oracle(tt):
         c /= np.linalg.norm(c, axis=1, keepdims=True)
         c[5] = c[3]
         n[7] = n[2]
-        nb = torch.from_numpy(n).bfloat16().float().numpy().astype(np.float64)
+        # the notice image is packed times inv_t * log2(e) (the kernels' unit form): bf16(scale * n) / scale is the operand
+        from jodalrob_twotower_amd.two_tower_train_task import _PRESCALE
+        sn = ops.score_unit_scale(1.0 / T) if _PRESCALE else 1.0
+        nb = (torch.from_numpy(n) * np.float32(sn)).bfloat16().float().numpy().astype(np.float64) / float(np.float32(sn))
         cb = torch.from_numpy(c).bfloat16().float().numpy().astype(np.float64)
         loss, met, S, lse = O.score_ce_fwd(nb, cb, T)
         dN, dC = O.score_ce_bwd(nb, cb, S, lse, T)
@@ -721,6 +724,35 @@ def test_dropout_mask_statistics(tt, manifest, schema_real):
     assert abs(same(masks[(11, 0)], masks[(12, 0)]) - indep) < 0.01        # seeds
 
 
+@pytest.mark.parametrize("B,D,inv_t", [(300, 64, 1.0), (257, 16, 4.0), (1024, 200, 0.5)])
+def test_score_prescaled_operands(tt, B, D, inv_t):
+    """Notice image packed times tt_score_unit_scale(inv_t) (the kernels' unit form: accumulators start at the exponent
+    offset, exp2(acc) with no multiply-add) against unscaled images: every output is scale-free -- sums, diagonal, sum of
+    scores, ranks and both gradients agree to the rounding of bf16(scale * x) vs bf16(x); an arbitrary scale (the general
+    scaled form) likewise."""
+    from jodalrob_twotower_amd import ops
+    g = torch.Generator().manual_seed(B + D)
+    n = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=1).to(DEV)
+    c = torch.nn.functional.normalize(n.cpu() + 0.5 * torch.randn(B, D, generator=g), dim=1).to(DEV)
+    shift, one = abs(inv_t), torch.ones(1, device=DEV)
+    ref = None
+    for scale in (1.0, ops.score_unit_scale(inv_t), 0.37):
+        Np, Cp = ops.score_pack2_bf16(n, c, scale, 1.0)
+        rs, cs, dg, rr, cr, ss, inv = ops.score_fwd_bf16(Np, Cp, B, D, inv_t, shift, True, True, scale, with_inv=True)
+        dN, dC = ops.score_bwd_bf16(Np, Cp, B, D, inv_t, shift, rs, cs, one, inv_t / (2 * B), scale)
+        dN2, dC2 = ops.score_bwd_bf16(Np, Cp, B, D, inv_t, shift, rs, cs, one, inv_t / (2 * B), scale, inv)   # forward's reciprocals
+        for x2, x in ((dN2, dN), (dC2, dC)):         # (1 ulp of the reciprocal can flip the bf16 rounding of a softmax weight)
+            assert float(torch.linalg.norm(x2 - x)) <= 2e-3 * float(torch.linalg.norm(x))
+        out = [x.float().cpu().numpy() for x in (rs, cs, dg, ss, dN, dC)] + [rr.cpu().numpy(), cr.cpu().numpy()]
+        if ref is None:
+            ref = out
+            continue
+        for k, (a, b) in enumerate(zip(out[:6], ref[:6])):
+            assert np.linalg.norm(a - b) <= 6e-3 * np.linalg.norm(b) + 1e-6, (scale, k, np.linalg.norm(a - b), np.linalg.norm(b))
+        for a, b in zip(out[6:], ref[6:]):                                 # ranks move by one where a score sits within bf16
+            assert np.abs(a - b).max() <= max(8, B // 50) and np.abs(a - b).mean() < 1.0      # rounding of the positive's
+
+
 def test_copy_multi(tt):
     """tt_copy_multi: several device segments of odd sizes (16-byte body + byte tail) and a pinned-host source."""
     from jodalrob_twotower_amd import ops
@@ -1108,7 +1140,7 @@ def test_global_negatives_equal_single_process(tt, G, B, D):
     c_all = torch.nn.functional.normalize(n_all.cpu() + 0.7 * torch.randn(G * B, D, generator=g), dim=1).to(DEV)
     inv_t = 2.0
     ns, cs = n_all.clone().requires_grad_(True), c_all.clone().requires_grad_(True)
-    loss_s, out_s, _ = _ScoreCEFn.apply(ns, cs, inv_t, "bf16", True, True)
+    loss_s, out_s, _ = _ScoreCEFn.apply(ns, cs, inv_t, "bf16", True, True, None, None, 1.0)      # unscaled images, as the global form packs them
     loss_s.backward()
     shared = {"slots": [None] * G, "bar": threading.Barrier(G)}
     res, errors = [None] * G, []

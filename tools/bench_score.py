@@ -14,6 +14,7 @@ ap.add_argument("--dim", type=int, default=64)
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--no-col-rank", action="store_true")
 ap.add_argument("--top1", action="store_true")
+ap.add_argument("--prescale", action="store_true", help="pack the notice image times inv_t*log2(e): the kernels' unit form")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 B, D = a.batch, a.dim
@@ -24,11 +25,12 @@ t = {"pack": [], "fwd": [], "bwd": []}
 for i in range(a.iters + 5):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     ev[0].record()
-    Np, Cp = ops.score_pack_bf16(n), ops.score_pack_bf16(c)
+    sn = ops.score_unit_scale(1.0) if a.prescale else 1.0
+    Np, Cp = ops.score_pack_bf16(n, sn), ops.score_pack_bf16(c)
     ev[1].record()
-    rs, cs, dg, rr, cr, ss = ops.score_fwd_bf16(Np, Cp, B, D, 1.0, 1.0, not a.no_col_rank, not a.top1)
+    rs, cs, dg, rr, cr, ss, inv = ops.score_fwd_bf16(Np, Cp, B, D, 1.0, 1.0, not a.no_col_rank, not a.top1, sn, with_inv=True)
     ev[2].record()
-    dN, dC = ops.score_bwd_bf16(Np, Cp, B, D, 1.0, 1.0, rs, cs, one, 1.0 / (2 * B))
+    dN, dC = ops.score_bwd_bf16(Np, Cp, B, D, 1.0, 1.0, rs, cs, one, 1.0 / (2 * B), sn, inv if a.prescale else None)
     ev[3].record()
     if i >= 5:
         torch.cuda.synchronize()
