@@ -267,16 +267,24 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
         }
     }
   };
-  bf16x8 bnext[KS];
-  if (wave < nT) load_bfrag<KS>(dr.b_rows, wave, c, h, bnext);
-  for (int t = wave; t < nT; t += NW) {
-    f32x16 acc[AT];
-    bf16x8 bcur[KS];
+  // operand prefetch PFD tiles ahead (a ring of register buffers, the loop unrolled over it so no buffer is copied): a tile
+  // is ~150 ns of work for a wave, an L2 hit several times that -- one tile of lookahead left the waves waiting on loads
+  constexpr int PFD = KS <= 4 ? 3 : (KS <= 8 ? 2 : 1);
+  bf16x8 bq[PFD][KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bcur[s] = bnext[s];
-    if (t + NW < nT) load_bfrag<KS>(dr.b_rows, t + NW, c, h, bnext);      // next tile's operand under this tile's work
-    mfma1<KS, AT>(bcur, ares, acc);
-    epilogue(acc, t);
+  for (int p = 0; p < PFD; ++p)
+    if (wave + p * NW < nT) load_bfrag<KS>(dr.b_rows, wave + p * NW, c, h, bq[p]);
+  for (int t0 = wave; t0 < nT; t0 += PFD * NW) {
+#pragma unroll
+    for (int p = 0; p < PFD; ++p) {
+      const int t = t0 + p * NW;
+      if (t < nT) {                                                         // wave-uniform
+        f32x16 acc[AT];
+        mfma1<KS, AT>(bq[p], ares, acc);
+        if (t + PFD * NW < nT) load_bfrag<KS>(dr.b_rows, t + PFD * NW, c, h, bq[p]);    // refill behind the MFMAs that read it
+        epilogue(acc, t);
+      }
+    }
   }
   __shared__ float part_mb[NW][ROWS], part_ma[NW][ROWS];
 #pragma unroll
