@@ -211,10 +211,15 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
   const bool want_ss = dr.sumscore != nullptr;
   // (a two-accumulator variant that issues tile t+NW's MFMAs before the epilogue of tile t measured SLOWER:
   //  199 VGPRs, 72-78 us vs 63-65 us -- kept single-buffered)
+  // tile classes by index alone (two scalar compares per tile; deriving them from row positions cost ~30 SALU instructions
+  // per tile): t < t_before: full tiles entirely before the workgroup's positives; t_after <= t < n_full: entirely after
+  const int n_full = Rb / 32;
+  const int t_before = min(posmin > 0 ? posmin / 32 : 0, n_full);
+  const int t_after = posmax >= 0 ? posmax / 32 + 1 : 0;
   auto epilogue = [&](const f32x16 (&acc)[AT], int t) {
-    const int b_lo = 32 * t, b_hi = 32 * t + 31;
-    const bool full_tile = b_hi < Rb;
-    const bool before = full_tile && b_hi < posmin, after = full_tile && b_lo > posmax;
+    const int b_lo = 32 * t;
+    const bool before = t < t_before, after = t >= t_after && t < n_full;
+    const bool full_tile = t < n_full;
     if (before || after) {
 #pragma unroll
       for (int i = 0; i < AT; ++i)
@@ -251,7 +256,40 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
             for (int r = 0; r < 16; ++r) cnt[i] += acc[i][r] > dg[i] ? 1 : 0;
         }
       }
-    } else {                      // tiles touching the diagonal band or the ragged end: per-element care
+    } else if (full_tile) {       // the tile(s) holding the positives: every b is a row, only before / after is per lane.
+      // Selects, no per-element branches: one wave of every workgroup meets this tile, and the general form below (exec-mask
+      // branches around every element, ~600 VALU instructions against 56 for a plain tile) made that wave the straggler.
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) se[i] += ex(acc[i][r]);
+      if (want_ss) {
+#pragma unroll
+        for (int i = 0; i < AT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ss[i] += acc[i][r];
+      }
+#pragma unroll
+      for (int i = 0; i < AT; ++i) {
+        const int q = pos[i] - b_lo - 4 * h;              // b < pos  <=>  (r & 3) + 8 * (r >> 2) < q
+        if (mode == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2);
+            const float x = acc[i][r];
+            mb[i] = fmaxf(mb[i], k < q ? x : kNegBig);
+            ma[i] = fmaxf(ma[i], k > q ? x : kNegBig);
+          }
+        } else if (mode == 2) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = (r & 3) + 8 * (r >> 2);
+            const float x = acc[i][r];
+            cnt[i] += ((k < q && x >= dg[i]) || (k > q && x > dg[i])) ? 1 : 0;
+          }
+        }
+      }
+    } else {                      // the ragged last tile (Rb not a multiple of 32): per-element care
 #pragma unroll
       for (int i = 0; i < AT; ++i)
 #pragma unroll
