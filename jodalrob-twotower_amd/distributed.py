@@ -273,6 +273,7 @@ class PaddedRowExchange(RowExchange):
         self.C, self.slack = capacity, slack
         self._overflow = None
         self.wire_bf16 = __import__("os").environ.get("TT_DIST_WIRE_F32", "0") != "1"      # TT_DIST_WIRE_F32=1: f32 rows on the wire (A/B)
+        self.grad_wire_bf16 = __import__("os").environ.get("TT_DIST_GRAD_WIRE_BF16", "0") == "1"
 
     def local_rows_of(self, g: int) -> int:
         R = self.store.global_rows
@@ -324,7 +325,10 @@ class PaddedRowExchange(RowExchange):
     def backward(self, state, srcs, B: int):
         be = self.backend
         grad_u = be.reduce_local(state["plan"], srcs, B, self.E)                 # one row per distinct row (+ a zero row)
-        d_rows = self._a2a_equal(be.gather_rows(grad_u, state["send_u"]))        # to the owners, pads carry zeros
+        # opt-in (TT_DIST_GRAD_WIRE_BF16=1 / grad_wire_bf16): the per-rank row sums travel as bf16 and are added in f32 by
+        # their owner -- half the bytes of the step's largest message, at 2^-9 relative rounding per contribution
+        wire = torch.bfloat16 if (self.grad_wire_bf16 and self.E % 8 == 0) else torch.float32
+        d_rows = self._a2a_equal(be.gather_rows(grad_u, state["send_u"], wire))  # to the owners, pads carry zeros
         be.owner_accumulate(self.store, state["owner_plan"], d_rows, self.world)
 
 
