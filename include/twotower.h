@@ -137,10 +137,12 @@ typedef struct tt_grad_src {
 } tt_grad_src;
 
 size_t tt_embed_grad_workspace_bytes(int64_t M, int32_t E);
+/* counters: NULL, or 3 int32 words of device memory that are ZERO on entry and that the caller keeps (per stream) between
+ * calls: the last kernel of the reduction leaves them zero again, so no zeroing launch precedes the reduction. */
 int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int64_t B, int32_t E,
                       const int32_t* sorted_src, const int32_t* seg_offsets,
                       const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t mode,
-                      float* out, void* workspace, size_t workspace_bytes, tt_stream stream);
+                      float* out, int32_t* counters, void* workspace, size_t workspace_bytes, tt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Adam -- replaces torch.optim.Adam(lr, betas=(0.9,0.999), eps=1e-8, weight_decay coupled)

@@ -84,7 +84,7 @@ SIGNATURES = {
     "tt_dedup_keyed_workspace_bytes": (sz, [i64, i32]),
     "tt_dedup_plan_keyed": (C.c_int, [vp, vp, C.POINTER(i32), i32, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_embed_grad_workspace_bytes": (sz, [i64, i32]),
-    "tt_embed_grad_bwd": (C.c_int, [vp, C.POINTER(GradSrc), i32, i64, i32, vp, vp, vp, vp, i64, i32, vp, vp, sz, vp]),
+    "tt_embed_grad_bwd": (C.c_int, [vp, C.POINTER(GradSrc), i32, i64, i32, vp, vp, vp, vp, i64, i32, vp, vp, vp, sz, vp]),
     "tt_adam_hparams": (None, [i64, f32, f32, f32, f32, f32, C.POINTER(f32 * 6)]),
     "tt_adam_dense_step": (C.c_int, [vp, vp, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp, vp]),
     "tt_adam_multi_step": (C.c_int, [vp, C.POINTER(AdamTensor), i32, i64, f32, f32, f32, f32, f32, vp, vp]),

@@ -36,6 +36,16 @@ class EmbeddingStore:
         self.sparse_grad = None                         # sparse mode: (DedupPlan, grad_rows [M, E])
         self.members: List["CategoricalEmbedder"] = []
         self.version = 0
+        self._grad_counters = None                      # 4 int32 words the gradient reduction keeps zero between calls
+
+    def grad_counters(self) -> Optional[torch.Tensor]:
+        """Allocated on first use OUTSIDE a graph capture (a zero-fill inside one would become a memset node: DESIGN.md section 6);
+        while capturing without them, the reduction falls back to its own zeroing launch."""
+        if self._grad_counters is None or self._grad_counters.device != self.device:
+            if self.device.type != "cuda" or torch.cuda.is_current_stream_capturing():
+                return None
+            self._grad_counters = torch.zeros(4, dtype=torch.int32, device=self.device)
+        return self._grad_counters
 
     @property
     def rows(self) -> int:
@@ -95,7 +105,7 @@ class EmbeddingStore:
         """srcs: [(d_out view [B, K*E], K)] in slot order of `plan`."""
         if self.grad_mode == "sparse":
             grad_rows = torch.empty((max(plan.M, 1), self.E), dtype=torch.float32, device=self.device)
-            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_SPARSE, grad_rows, short_segments)
+            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_SPARSE, grad_rows, short_segments, self.grad_counters())
             self.sparse_grad = (plan, grad_rows)
             return
         params = self.optim_parameters()
@@ -104,10 +114,10 @@ class EmbeddingStore:
             self.grad = torch.empty_like(self.weight)
         if fresh:
             self.grad.zero_()                            # reference semantics: dense [V_k, E] grads
-            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_DENSE_SET, self.grad)
+            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_DENSE_SET, self.grad, counters=self.grad_counters())
             self.bind_grads()
         else:
-            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_DENSE_ACC, self.grad)
+            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_DENSE_ACC, self.grad, counters=self.grad_counters())
 
 
 class _Table(nn.Module):

@@ -929,6 +929,7 @@ __global__ __launch_bounds__(kThreads) void seg_reduce_kernel(SideSet a, const i
 template <int VEC, int DT, int LGT>
 __global__ __launch_bounds__(kThreads) void seg_chunk_kernel(SideSet a, const int32_t* __restrict__ sorted_src, GradWs ws, uint32_t LG) {
   const uint32_t nchunks = (uint32_t)ws.counters[0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) ws.counters[2] = ws.counters[1];      // snapshot for seg_long_finish_kernel
   const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t lig = gthread % LG;
   const uint32_t ngroups = gridDim.x * blockDim.x / LG;
@@ -951,7 +952,11 @@ __global__ __launch_bounds__(kThreads) void seg_long_finish_kernel(int32_t E, ui
                                                                   const int32_t* __restrict__ unique_rows, int32_t mode,
                                                                   float* __restrict__ out, GradWs ws, uint32_t LG) {
   __shared__ float part[kFinishMaxFloats];
-  const uint32_t nlong = (uint32_t)ws.counters[1];
+  // counters[2] = the long-row count as seg_chunk_kernel saw it: nobody reads the live words [0] / [1] any more, so one
+  // thread zeroes them here for the next call -- a caller that keeps the words between calls needs no zeroing launch
+  // (a "last workgroup done" atomic instead cost 35 us: 2048 same-address atomics with return serialise at ~17 ns each)
+  const uint32_t nlong = (uint32_t)ws.counters[2];
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ws.counters[0] = 0; ws.counters[1] = 0; }
   const uint32_t grp = threadIdx.x / LG, lig = threadIdx.x % LG, ngrp = blockDim.x / LG;
   for (uint32_t li = blockIdx.x; li < nlong; li += gridDim.x) {
     const int32_t u = ws.long_row[li], base = ws.long_base[li];
@@ -1369,7 +1374,7 @@ inline GradLayout grad_layout(char* base, int64_t M, int32_t E) {
   g.max_chunks = M / kLongSeg + g.max_long + 1;
   size_t o = 0;
   auto take = [&](size_t n) { char* p = base ? base + o : nullptr; o += align256(n); return p; };
-  g.ws.counters = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 2));
+  g.ws.counters = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * 3));     // chunks allocated, long rows, snapshot of the long-row count
   g.ws.long_row = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (size_t)g.max_long));
   g.ws.long_base = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (size_t)g.max_long));
   g.ws.chunk_lo = reinterpret_cast<int32_t*>(take(sizeof(int32_t) * (size_t)g.max_chunks));
@@ -1610,7 +1615,7 @@ size_t tt_embed_grad_workspace_bytes(int64_t M, int32_t E) { return grad_layout(
 
 int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int64_t B, int32_t E, const int32_t* sorted_src,
                       const int32_t* seg_offsets, const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t mode,
-                      float* out, void* workspace, size_t workspace_bytes, tt_stream stream) {
+                      float* out, int32_t* counters, void* workspace, size_t workspace_bytes, tt_stream stream) {
   TT_CHECK_ARG(ctx && srcs && out, "tt_embed_grad_bwd: NULL argument");
   TT_CHECK_ARG(n_srcs >= 1 && n_srcs <= TT_MAX_SIDES, "tt_embed_grad_bwd: n_srcs=%d", n_srcs);
   // TT_GRAD_SHORT_SEGMENTS: every segment is summed by its own lane group whatever its length -- the right choice (and
@@ -1648,7 +1653,9 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   const int dt = srcs[0].dtype;
   GradLayout gl = grad_layout(reinterpret_cast<char*>(workspace), M, E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!all_short) {
+  if (counters) {
+    gl.ws.counters = counters;      // caller-kept, zero on entry: the finish kernel re-zeroes them (one launch fewer per step)
+  } else if (!all_short) {
     zero_words_kernel<<<1, 64, 0, st>>>(gl.ws.counters, 2);    // (a kernel, not a memset node: see graph notes in DESIGN.md)
     TT_LAUNCH_CHECK();
   }

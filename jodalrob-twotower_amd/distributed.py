@@ -171,10 +171,10 @@ class HipBackend:
         order); the pad value `local_rows` groups into one (last) row that is left out of the plan's row count"""
         return ops.dedup_plan_runs(recv_ids, G, recv_ids.numel() // G, local_rows)
 
-    def reduce_local(self, plan, srcs, B: int, E: int) -> torch.Tensor:
+    def reduce_local(self, plan, srcs, B: int, E: int, counters=None) -> torch.Tensor:
         """[M, E]: row u = summed gradient of plan row u (unused bucket entries carry u = -1: gather_rows gives them zeros)"""
         out = torch.empty((max(plan.M, 1), E), dtype=torch.float32, device=plan.unique_rows.device)
-        ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_SPARSE, out)
+        ops.embed_grad(plan, srcs, B, E, ops.TT_GRAD_SPARSE, out, counters=counters)
         return out
 
 
@@ -324,7 +324,7 @@ class PaddedRowExchange(RowExchange):
 
     def backward(self, state, srcs, B: int):
         be = self.backend
-        grad_u = be.reduce_local(state["plan"], srcs, B, self.E)                 # one row per distinct row (+ a zero row)
+        grad_u = be.reduce_local(state["plan"], srcs, B, self.E, self.store.grad_counters())      # one row per distinct row (+ a zero row)
         # opt-in (TT_DIST_GRAD_WIRE_BF16=1 / grad_wire_bf16): the per-rank row sums travel as bf16 and are added in f32 by
         # their owner -- half the bytes of the step's largest message, at 2^-9 relative rounding per contribution
         wire = torch.bfloat16 if (self.grad_wire_bf16 and self.E % 8 == 0) else torch.float32

@@ -196,9 +196,11 @@ def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int) -> Dedup
     return plan
 
 
-def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int, out: torch.Tensor, short_segments: bool = False):
+def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int, out: torch.Tensor, short_segments: bool = False,
+               counters: Optional[torch.Tensor] = None):
     """srcs: [(d_out 2-D view [B, K*E], K)].  short_segments: the caller knows no row has many contributions (skips the
-    chunk passes; results do not depend on it)."""
+    chunk passes; results do not depend on it).  counters: >= 3 int32 words the caller keeps ZERO between calls (allocated
+    once, outside any graph capture): the reduction re-zeroes them itself and needs no zeroing launch in front."""
     if short_segments:
         mode |= L.TT_GRAD_SHORT_SEGMENTS
     dev = out.device
@@ -211,8 +213,8 @@ def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int
     ws = L.workspace(dev, nb)
     with _timed("tt_embed_grad_bwd"):
         L.check(lib.tt_embed_grad_bwd(L.ctx(dev), arr, len(srcs), B, E, L.ptr(plan.sorted_src), L.ptr(plan.seg_offsets),
-                                      L.ptr(plan.unique_rows), L.ptr(plan.n_unique), plan.M, mode, L.ptr(out), L.ptr(ws),
-                                      ws.numel(), L.stream(dev)), "tt_embed_grad_bwd")
+                                      L.ptr(plan.unique_rows), L.ptr(plan.n_unique), plan.M, mode, L.ptr(out),
+                                      L.ptr(counters), L.ptr(ws), ws.numel(), L.stream(dev)), "tt_embed_grad_bwd")
 
 
 # ---------------------------------------------------------------------------------------------- Adam

@@ -100,7 +100,7 @@ class CheckerBackend:
         assert bool((runs[:, 1:] >= runs[:, :-1]).all()), "every received bucket must be ascending (the owner merges runs)"
         return recv_ids.clone()
 
-    def reduce_local(self, plan, srcs, B, E):
+    def reduce_local(self, plan, srcs, B, E, counters=None):
         flat = torch.cat([d.reshape(B * K, E) for d, K in srcs])
         out = torch.zeros((max(plan.M, 1), E))
         for u in range(int(plan.n_unique)):
