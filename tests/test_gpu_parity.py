@@ -753,6 +753,39 @@ def test_score_prescaled_operands(tt, B, D, inv_t):
             assert np.abs(a - b).max() <= max(8, B // 50) and np.abs(a - b).mean() < 1.0      # rounding of the positive's
 
 
+@pytest.mark.parametrize("B,H,D,drop", [(65, 33, 17, 0.1), (127, 64, 64, 0.0), (4097, 40, 33, 0.1), (64, 63, 1, 0.0), (2, 8, 8, 0.0),
+                                        (8191, 24, 48, 0.2)])
+def test_fused_tower_tail_odd_shapes(tt, manifest, monkeypatch, B, H, D, drop):
+    """Fused tail against the separate kernels on shapes off the tile grid: widths that are not multiples of 8 or 32, ragged
+    last row blocks and chunks, a single output column, two rows -- loss bit-identical, gradients to rounding."""
+    cfg = dict(manifest["cases"]["wide_b40"])
+    cfg.update(hidden=[32, H], D=D)
+    outs = {}
+    state = None
+    b = synth_batch_numpy(B, cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 171, oob=True)
+    for unfused in ("1", "0"):
+        monkeypatch.setenv("TT_TOWER_UNFUSED_TAIL", unfused)
+        task = make_task(tt, cfg, mlp_dtype="bf16", score_dtype="bf16", dropout_rate=drop)
+        if state is None:
+            state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 172)
+        for tw in (task.two_tower_model.notice_tower, task.two_tower_model.company_tower):
+            tw._seed_override = 5
+        load_state(task, state)
+        task.train()
+        res = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+        res["loss"].backward()
+        outs[unfused] = (res["loss"].item(), {n: p.grad.cpu().numpy() for n, p in task.named_parameters()},
+                         {k: v.cpu().numpy() for k, v in task.state_dict().items() if "running" in k})
+    assert outs["0"][0] == outs["1"][0] and np.isfinite(outs["0"][0])
+    for k, v in outs["1"][2].items():
+        assert np.array_equal(outs["0"][2][k], v), k
+    for k, g in outs["1"][1].items():
+        gf = outs["0"][1][k]
+        assert np.isfinite(gf).all(), k
+        tol = 2e-5 if B >= 32 else 2e-4            # (BatchNorm over two rows: the backward terms cancel to rounding noise)
+        assert np.linalg.norm(gf - g) <= tol * np.linalg.norm(g) + 1e-10, (k, np.linalg.norm(gf - g), np.linalg.norm(g))
+
+
 def test_copy_multi(tt):
     """tt_copy_multi: several device segments of odd sizes (16-byte body + byte tail) and a pinned-host source."""
     from jodalrob_twotower_amd import ops
