@@ -289,6 +289,10 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "rows_notice": sum(vocab_n), "rows_company": sum(vocab_c),
                    "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})", "optimizer": args.optimizer,
                    "score_dtype": args.score_dtype, "mlp_dtype": args.mlp_dtype, "launch": "hip graph replay" if gstep is not None else "eager",
+                   **({} if dist is None or not hasattr(task.exchange, "C") else
+                      {"exchange_capacity_rows_per_peer": task.exchange.C,
+                       "exchange_bytes_per_rank_fwd": world * task.exchange.C * E * (2 if (x_bf16 and task.exchange.wire_bf16) else 4),
+                       "exchange_bytes_per_rank_bwd": world * task.exchange.C * E * (2 if task.exchange.grad_wire_bf16 else 4)}),
                    "parallelism": ("single GPU" if dist is None else f"row-wise sharded tables x{world} (dedup-first fixed-capacity all-to-all" +
                                    (", RCCL inside the graph" if gstep is not None else "") + ") + data parallel towers" +
                                    (f", {args.negatives} in-batch negatives" + (", SyncBN" if args.sync_bn else "")))},
