@@ -412,7 +412,9 @@ int tt_batch_gather(tt_ctx* ctx, const int64_t* entity, int64_t B, const float* 
  * FIXED-CAPACITY buckets, so no size ever travels to the host and the whole exchange can sit inside a captured graph:
  *   send_ids [G, C] int32  local row index at owner g, in plan order; unused entries = pad_id[g]
  *   send_u   [G, C] int32  plan index u of each entry; unused entries = pad_u (caller: index of an all-zero row)
- *   pos_u    [M]    int32  g*C + position of plan row u (0 for rows that did not fit)
+ *   pos_u    [M]    int32  g*C + position of plan row u; G*C for rows that did not fit -- the caller keeps row G*C of the
+ *                          buffer the exchanged rows are placed from all-zero, so an overflowing step (which it must
+ *                          reject: overflow[0]) never feeds a tower another row's embedding
  *   counts   [G]    int32  entries wanted per owner; overflow[0] is set to 1 when any count exceeds C (sticky: never
  *                          cleared here, the caller owns the flag)
  * tt_route_expand: idx_slot[slot] = pos_u[u] for every slot of plan row u (int64: ids of the placing lookup).

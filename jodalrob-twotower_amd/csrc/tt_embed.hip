@@ -705,6 +705,12 @@ struct GradWs {
 __global__ void zero_words_kernel(int32_t* __restrict__ p, int n) {
   if ((int)threadIdx.x < n) p[threadIdx.x] = 0;
 }
+// two single words at unrelated addresses (an empty plan's n_unique and seg_offsets[0]) in ONE launch -- never a pair of
+// hipMemsetAsync calls: captured into a graph, two memset nodes are the pattern that faulted on replay
+__global__ void zero_two_words_kernel(int32_t* __restrict__ a, int32_t* __restrict__ b) {
+  if (threadIdx.x == 0) a[0] = 0;
+  if (threadIdx.x == 1) b[0] = 0;
+}
 
 template <int VEC>
 struct Acc {
@@ -1284,8 +1290,8 @@ __global__ __launch_bounds__(kThreads) void route_scatter_kernel(const int32_t* 
         send_u[(size_t)g * C + pos] = (int32_t)u;
         pos_u[u] = (int32_t)(g * C + pos);
       } else {
-        pos_u[u] = 0;                                   // did not fit: flagged by route_scan_kernel
-      }
+        pos_u[u] = (int32_t)(G * C);                    // did not fit (flagged by route_scan_kernel): the row AFTER the buckets,
+      }                                                 // which the caller keeps all-zero -- never another row's embedding
     }
   }
 }
@@ -1502,8 +1508,8 @@ int tt_dedup_plan(tt_ctx* ctx, const int32_t* rows, int64_t M, int64_t table_row
   TT_CHECK_ARG(table_rows >= 1 && table_rows <= INT32_MAX, "tt_dedup_plan: table_rows=%lld out of range", (long long)table_rows);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (M == 0) {
-    TT_HIP(hipMemsetAsync(n_unique, 0, sizeof(int32_t), st));
-    TT_HIP(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), st));
+    zero_two_words_kernel<<<1, 64, 0, st>>>(n_unique, seg_offsets);
+    TT_LAUNCH_CHECK();
     return TT_OK;
   }
   TT_CHECK_ARG(rows && workspace, "tt_dedup_plan: NULL rows/workspace");
@@ -1592,8 +1598,8 @@ int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K,
   TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_dedup_plan_keyed: too many slots");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (n_keys == 0) {
-    TT_HIP(hipMemsetAsync(n_unique, 0, sizeof(int32_t), st));
-    TT_HIP(hipMemsetAsync(seg_offsets, 0, sizeof(int32_t), st));
+    zero_two_words_kernel<<<1, 64, 0, st>>>(n_unique, seg_offsets);
+    TT_LAUNCH_CHECK();
     return TT_OK;
   }
   if (workspace_bytes < tt_dedup_keyed_workspace_bytes(slots, n_keys)) {

@@ -88,7 +88,7 @@ def create_unified_bid_dataloaders(db_engine, schema: TorchRecSchema, batch_size
         idx[i] = (n2i[tuple(nk)], c2i[str(ck)])
     rng = np.random.default_rng(shuffle_seed)
     perm = rng.permutation(len(idx))
-    n_test = int(round(len(idx) * test_split)) if test_split > 0 else 0
+    n_test = int(len(idx) * test_split) if test_split > 0 else 0      # floor, as the reference (:207)
     test_idx, train_idx = idx[perm[:n_test]], idx[perm[n_test:]]
     ns = DeviceFeatureStore(stores["notice"], schema.notice.categorical, device)
     cs = DeviceFeatureStore(stores["company"], schema.company.categorical, device)

@@ -46,11 +46,11 @@ class ShardedStore(EmbeddingStore):
         super().__init__(E, device, grad_mode)
         self.global_rows, self.rank, self.world = global_rows, rank, world
         self.local_rows = (global_rows - rank + world - 1) // world if global_rows > rank else 0
-        g = torch.Generator(device="cpu")
+        # nn.Embedding init N(0,1), drawn where the shard lives (a 12.5 M-row shard of the 100 M-row tables is 1.6 GB: the
+        # host generator would take tens of seconds per rank); a stream per (seed, rank)
+        g = torch.Generator(device=self.device)
         g.manual_seed(seed * 1000003 + rank)
-        w = torch.empty((max(self.local_rows, 1), E), dtype=torch.float32)
-        w.normal_(generator=g)                                   # nn.Embedding init N(0,1)
-        self.weight = w.to(self.device)
+        self.weight = torch.empty((max(self.local_rows, 1), E), dtype=torch.float32, device=self.device).normal_(generator=g)
         self.shard_param = nn.Parameter(self.weight)             # what optimisers / checkpoints see
 
     def optim_parameters(self):
@@ -147,11 +147,14 @@ class HipBackend:
         store.accumulate_grad(plan, [(d_rows, 1)], d_rows.shape[0], short_segments=0 < max_per_row <= 64)
 
     # ---- steps of the fixed-capacity exchange (PaddedRowExchange) --------------------------------------------
-    def local_plan(self, rows: torch.Tensor, side_K: Sequence[int], B: int):
-        """duplicate-row plan of this rank's slots over the GLOBAL row space"""
+    def local_plan(self, rows: torch.Tensor, side_K: Sequence[int], B: int, table_rows: int = 0):
+        """duplicate-row plan of this rank's slots over the GLOBAL row space (table_rows = its size: sets the sort's digit
+        count; nothing is read back from the device)"""
         if 0 < B <= ops.KEYED_MAX_B:
             return ops.dedup_plan_keyed(rows, list(side_K), B)
-        return ops.dedup_plan(rows, int(rows.max().item()) + 1)
+        if table_rows <= 0:
+            raise ValueError("local_plan: table_rows (the global row count) is required above the keyed plan's batch limit")
+        return ops.dedup_plan(rows, table_rows)
 
     def route_bucket(self, plan, G: int, C: int, pad_id: Sequence[int], pad_u: int, overflow: torch.Tensor):
         return ops.route_bucket(plan, G, C, pad_id, pad_u, overflow)
@@ -187,8 +190,8 @@ class DistComm:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
 
-    def all_to_all_equal(self, send: torch.Tensor) -> torch.Tensor:
-        out = torch.empty_like(send)
+    def all_to_all_equal(self, send: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        out = torch.empty_like(send) if out is None else out
         dist.all_to_all_single(out, send.contiguous(), group=self.group)
         return out
 
@@ -204,6 +207,40 @@ class DistComm:
 
     def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+
+class HostStagedComm:
+    """DistComm's interface over a gloo group with the device tensors staged through the host -- for REHEARSALS in which
+    several ranks share one GPU (RCCL refuses two ranks on one device): every kernel of the step is the product path,
+    only the wire is not xGMI.  Eager only (a host round trip cannot be captured)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def all_to_all_equal(self, send):
+        s = send.detach().cpu().contiguous()
+        out = torch.empty_like(s)
+        dist.all_to_all_single(out, s, group=self.group)
+        return out.to(send.device)
+
+    def all_reduce_max(self, t):
+        c = t.detach().cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.MAX, group=self.group)
+        t.copy_(c)
+        return t
+
+    def all_gather(self, t):
+        c = t.detach().cpu().contiguous()
+        outs = [torch.empty_like(c) for _ in range(self.world)]
+        dist.all_gather(outs, c, group=self.group)
+        return torch.cat(outs).to(t.device)
+
+    def all_reduce_sum(self, t):
+        c = t.detach().cpu()
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+        t.copy_(c)
         return t
 
 
@@ -254,6 +291,13 @@ class RowExchange:
             self.comm.all_reduce_sum(g)
 
 
+class ExchangeOverflowError(RuntimeError):
+    """A batch needed more than the calibrated capacity of a (source, owner) bucket of the fixed-capacity exchange: the rows
+    that did not fit were fed to the towers as zero rows and their gradients were not sent.  The steps since the last clean
+    check are invalid: restore a checkpoint (or accept the few perturbed rows), call `reset_capacity()` -- the next forward
+    re-calibrates -- and re-capture the graph if one is in use."""
+
+
 class PaddedRowExchange(RowExchange):
     """The same routing with (1) the duplicate-row plan BEFORE the exchange -- a rank sends each distinct row once:
     65 k instead of 311 k entries at B = 8192 on the real schema, and a hot row no longer floods one owner -- and
@@ -261,9 +305,12 @@ class PaddedRowExchange(RowExchange):
     training step -- collectives included -- can be captured into ONE graph and replayed.
 
     Capacity C (entries per (source, owner) pair, identical on all ranks) is calibrated on the first forward (one
-    host sync): 1.25 x the largest bucket any rank needs, rounded up to 256.  A later batch that needs more sets a
-    device-side flag (`overflowed()`); its over-capacity rows were not exchanged, so the caller must re-calibrate
-    (`reset_capacity()`) and redo the step -- bench.py checks the flag after the timed region."""
+    host sync): 1.25 x the largest bucket any rank needs, rounded up to 256.  A later batch that needs more sets a sticky
+    device-side flag.  Its over-capacity rows are NOT exchanged: the towers see zero rows for them (never another row's
+    embedding) and their gradients are dropped, so such a step must be rejected.  The product path does that itself:
+    every eager forward and every `GraphedTrainStep.step()` calls `poll_overflow()`, which reads the flag through an
+    asynchronous device-to-host copy (no stall; the answer is at most `poll_lag` steps old) and raises
+    `ExchangeOverflowError`; `check_overflow()` is the synchronous form (epoch end, checkpoint, `GraphedTrainStep.close()`)."""
 
     def __init__(self, store: ShardedStore, group=None, backend=None, capacity: Optional[int] = None, slack: float = 1.25, comm=None):
         super().__init__(store, group, backend, comm)
@@ -272,6 +319,9 @@ class PaddedRowExchange(RowExchange):
                              "row-sparse Adam; a dense gradient buffer has no row for them)")
         self.C, self.slack = capacity, slack
         self._overflow = None
+        self._place_buf = None           # [G * C + 1, E] rows as received; the LAST row stays zero (target of rows that did not fit)
+        self._flag_host, self._flag_event, self._flag_pending = None, None, False
+        self.poll_lag = 2                # steps a raised overflow may lag behind the step that caused it
         self.wire_bf16 = __import__("os").environ.get("TT_DIST_WIRE_F32", "0") != "1"      # TT_DIST_WIRE_F32=1: f32 rows on the wire (A/B)
         self.grad_wire_bf16 = __import__("os").environ.get("TT_DIST_GRAD_WIRE_BF16", "0") == "1"
 
@@ -281,16 +331,57 @@ class PaddedRowExchange(RowExchange):
 
     def reset_capacity(self):
         self.C = None
+        self._flag_pending = False
         if self._overflow is not None:
             self._overflow.zero_()
 
     def overflowed(self) -> bool:
+        """synchronous read of the sticky flag"""
         return self._overflow is not None and bool(self._overflow.item())
 
-    def _a2a_equal(self, send: torch.Tensor) -> torch.Tensor:
+    def check_overflow(self):
+        if self.overflowed():
+            raise ExchangeOverflowError(f"fixed-capacity exchange: a bucket needed more than C = {self.C} rows (rank {self.rank})")
+
+    def poll_overflow(self):
+        """Non-blocking check: looks at the answer of the PREVIOUS poll's device-to-host copy if it has landed, then
+        queues the next copy behind the work issued so far.  Never called while a stream is capturing."""
+        if self._overflow is None or self._overflow.device.type != "cuda":
+            return self.check_overflow()
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self._flag_host is None:
+            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._flag_event = torch.cuda.Event()
+        if self._flag_pending and self._flag_event.query():
+            self._flag_pending = False
+            if int(self._flag_host[0]) != 0:
+                raise ExchangeOverflowError(f"fixed-capacity exchange: a bucket needed more than C = {self.C} rows (rank {self.rank}) "
+                                            f"within the last {self.poll_lag} steps")
+        if not self._flag_pending:
+            self._flag_host.copy_(self._overflow, non_blocking=True)
+            self._flag_event.record()
+            self._flag_pending = True
+
+    def _a2a_equal(self, send: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if self.world == 1 and __import__("os").environ.get("TT_DIST_FAKE_A2A"):     # fault hunting only
-            return send.clone()
-        return self.comm.all_to_all_equal(send)
+            return send.clone() if out is None else out.copy_(send)
+        if out is None:
+            return self.comm.all_to_all_equal(send)
+        if isinstance(self.comm, DistComm):
+            return self.comm.all_to_all_equal(send, out)
+        return out.copy_(self.comm.all_to_all_equal(send))      # test communicators hand back a fresh tensor
+
+    def _rows_buffer(self, like: torch.Tensor) -> torch.Tensor:
+        """[G * C + 1, E] in the wire dtype: the received rows land in the first G * C rows every step, row G * C is
+        zeroed once and never written -- tt_route_bucket points every row that did not fit at it."""
+        n = self.world * self.C + 1
+        b = self._place_buf
+        if b is None or b.shape[0] != n or b.dtype != like.dtype or b.device != like.device:
+            if like.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("PaddedRowExchange: run one eager forward before capturing (the receive buffer is allocated there)")
+            b = self._place_buf = torch.zeros((n, self.E), dtype=like.dtype, device=like.device)
+        return b
 
     def _calibrate(self, plan, dev):
         G = self.world
@@ -304,7 +395,7 @@ class PaddedRowExchange(RowExchange):
     def forward(self, sides: Sequence[ops.LookupSide], B: int, want_grad: bool):
         G, be, E = self.world, self.backend, self.E
         rows = be.global_rows(sides, B, E, self.store.global_rows)               # int32 [M], slot order
-        plan = be.local_plan(rows, [s.K for s in sides], B)
+        plan = be.local_plan(rows, [s.K for s in sides], B, self.store.global_rows)
         if self.C is None:
             self._calibrate(plan, rows.device)
         pads = [self.local_rows_of(g) for g in range(G)]
@@ -316,8 +407,9 @@ class PaddedRowExchange(RowExchange):
         # placed -- the same bits in x, half the bytes on the wire
         wire = torch.bfloat16 if all(s.out.dtype == torch.bfloat16 for s in sides) and E % 8 == 0 and self.wire_bf16 else torch.float32
         pooled_local = be.gather_rows(self.store.weight, recv_ids, wire)         # pads clamp to the last row (unused)
-        got = self._a2a_equal(pooled_local)                                      # [G*C, E] in my send order
-        be.place_rows(got, be.route_expand(plan, pos_u), sides, B)
+        buf = self._rows_buffer(pooled_local)
+        self._a2a_equal(pooled_local, buf[:G * self.C])                          # [G*C, E] in my send order (+ the zero row)
+        be.place_rows(buf, be.route_expand(plan, pos_u), sides, B)
         if not want_grad:
             return None
         return {"plan": plan, "send_u": send_u, "owner_plan": be.owner_plan(recv_ids, self.store.local_rows, G), "padded": True}
@@ -377,9 +469,11 @@ class _GlobalScoreCEFn(torch.autograd.Function):
 class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
     """TwoTowerTrainTask whose tables are row-wise sharded over the process group."""
 
-    def __init__(self, two_tower_model: TwoTowerModel, store: ShardedStore, group=None, backend=None, exchange: str = "exact",
+    def __init__(self, two_tower_model: TwoTowerModel, store: ShardedStore, group=None, backend=None, exchange: Optional[str] = None,
                  negatives: str = "local", sync_bn: bool = False, comm=None, **kw):
         super().__init__(two_tower_model, **kw)
+        if exchange is None:             # the fixed-capacity exchange wherever it applies (row-sparse table gradients)
+            exchange = "padded" if store.grad_mode == "sparse" else "exact"
         if negatives not in ("local", "global"):
             raise ValueError(f"negatives must be 'local' or 'global', got {negatives!r}")
         self.negatives = negatives
@@ -404,6 +498,11 @@ class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
         for b in self.buffers():
             if b.is_floating_point():
                 dist.broadcast(b, src=0, group=group)
+
+    def forward(self, batch, return_metrics: bool = False):
+        if hasattr(self.exchange, "poll_overflow"):
+            self.exchange.poll_overflow()          # rejects a step whose rows did not fit the buckets (non-blocking, <= poll_lag steps late)
+        return super().forward(batch, return_metrics)
 
     def _score_ce(self, n, c, inv_t, first_call):
         if self.negatives == "global" and self.exchange.world > 1:
@@ -458,9 +557,12 @@ def create_distributed_train_task(notice_categorical_keys, company_categorical_k
                                   company_dense_input_dim: int = 128, tower_hidden_dims=None, final_embedding_dim: int = 128,
                                   dropout_rate: float = 0.2, temperature: float = 1.0, loss_type: str = "cross_entropy",
                                   device="cuda:0", embedding_grad: Optional[str] = "sparse", score_dtype=None, mlp_dtype=None,
-                                  group=None, backend=None, seed: int = 0, exchange: str = "exact",
+                                  group=None, backend=None, seed: int = 0, exchange: Optional[str] = None,
                                   negatives: str = "local", sync_bn: bool = False, comm=None) -> DistributedTwoTowerTrainTask:
-    """Same arguments as create_two_tower_train_task; requires an initialised process group."""
+    """Same arguments as create_two_tower_train_task; requires an initialised process group.
+    exchange: None = "padded" (dedup-first fixed-capacity all-to-alls, every step of the routing inside the .so, capturable)
+    with row-sparse table gradients, "exact" with dense ones.  "exact" (RowExchange: exact bucket sizes, one host sync
+    and a few ATen index ops per step, eager only) is the simple implementation the padded one is tested against."""
     if not dist.is_initialized():
         raise RuntimeError("create_distributed_train_task needs torch.distributed.init_process_group first")
     if tower_hidden_dims is None:

@@ -48,9 +48,12 @@ class TwoTowerEvaluator:
     @torch.no_grad()
     def evaluate_single_batch(self, model, batch: Dict, verbose: bool = True) -> Dict[str, float]:  # :123-155
         model.eval()
-        res = model(batch, return_metrics=True)
+        if hasattr(model, "forward_with_ranks"):                       # one pass through the towers serves loss, metrics and ranks
+            res, ranks = model.forward_with_ranks(batch)
+        else:
+            res = model(batch, return_metrics=True)
+            ranks = self._ranks(res["similarity_matrix"])
         basic = {k: (v.item() if torch.is_tensor(v) and v.numel() == 1 else v) for k, v in dict.items(res) if k != "similarity_matrix"}
-        ranks = model.diagonal_ranks(batch) if hasattr(model, "diagonal_ranks") else self._ranks(res["similarity_matrix"])
         out = self.metrics_from_ranks(ranks, basic)
         if verbose:
             print(f"[eval] loss {out['loss']:.4f} acc {out['accuracy']:.4f} R@5 {out['recall@5']:.4f} "

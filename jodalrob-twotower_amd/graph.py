@@ -147,4 +147,26 @@ class GraphedTrainStep:
         self.graph.replay()
         self._steps_done += 1
         self.opt.advance_steps(1)
+        ex = getattr(self.task, "exchange", None)
+        if ex is not None and hasattr(ex, "poll_overflow"):
+            ex.poll_overflow()                                  # sharded tables: a bucket overflow rejects the step (non-blocking)
         return self.result
+
+    def close(self):
+        """Final (synchronous) overflow check, then drop the captured graph and its private pool.  With a process group
+        alive this must happen BEFORE `destroy_process_group()`: the graph's nodes reference the communicator's buffers
+        and streams, and tearing the communicator down first aborts inside RCCL."""
+        dev = self._dev.device
+        torch.cuda.synchronize(dev)
+        ex = getattr(self.task, "exchange", None)
+        try:
+            if ex is not None and hasattr(ex, "check_overflow"):
+                ex.check_overflow()
+        finally:
+            self.result = None
+            if self.graph is not None:
+                self.graph.reset()
+                self.graph = None
+            import gc
+            gc.collect()
+            torch.cuda.synchronize(dev)

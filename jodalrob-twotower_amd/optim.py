@@ -183,8 +183,21 @@ class FusedAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        # re-point the table parameters' moments at store-level buffers
+        # re-point the table parameters' moments at store-level buffers (the kernels update those; self.state holds views)
         for store in self._stores:
+            shard = getattr(store, "shard_param", None)
+            if shard is not None:
+                # row-wise sharded store: ONE parameter = this rank's rows, its moments are the store-level buffers themselves
+                old = dict(self.state[shard]) if shard in self.state and "exp_avg" in self.state[shard] else None
+                self._store_state.pop(id(store), None)
+                if old is None:
+                    continue
+                st = self._state_of(store)                     # fresh zero buffers, aliased into self.state[shard]
+                st["m"].copy_(old["exp_avg"].to(st["m"].device))
+                st["v"].copy_(old["exp_avg_sq"].to(st["v"].device))
+                st["step"] = int(float(old["step"]))
+                self.state[shard]["step"] = torch.tensor(float(st["step"]))
+                continue
             loaded = {}
             for emb in store.members:
                 for k in emb.keys:

@@ -163,6 +163,23 @@ class TwoTowerTrainTask(nn.Module):
             res._materialise()
         return res
 
+    def forward_with_ranks(self, batch):
+        """(result dict as forward(batch, return_metrics=True), 0-based rank of each positive in its row) from ONE pass
+        through the towers -- what the evaluator needs per batch (src/evaluation/evaluator.py:123-155 calls the model once
+        and ranks its similarity matrix).  Ranks come from the exact-f32 score sweep, as diagonal_ranks()."""
+        with torch.no_grad():
+            n, c = self.two_tower_model(batch["notice"], batch["company"])
+            if n.size(0) != c.size(0):
+                raise ValueError(f"Notice와 Company 배치 크기가 다릅니다: {n.size(0)} vs {c.size(0)}")
+            inv_t = 1.0 / float(self.temperature)
+            loss, out8, _ = self._score_ce(n, c, inv_t, False)
+            _, _, rank, _ = ops.score_dir_fwd(n.contiguous(), c.contiguous(), inv_t, abs(inv_t), 0, False)
+            n_det, c_det = n.detach(), c.detach()
+            res = _Result({"loss": loss, "accuracy": out8[1], "positive_similarity_mean": out8[2],
+                           "negative_similarity_mean": out8[3], "similarity_gap": out8[4]},
+                          sim_thunk=lambda: ops.score_matrix(n_det, c_det, inv_t))
+            return res, rank
+
     def _score_ce(self, n, c, inv_t, first_call):
         """(loss, out8, row_rank) of the symmetric in-batch-negative softmax-CE (:99-134); the sharded task overrides it."""
         pn, pc = getattr(n, "_tt_packed", None), getattr(c, "_tt_packed", None)     # (buffer, scale) emitted by the towers

@@ -18,6 +18,25 @@ import numpy as np
 BN_EPS = 1e-5          # nn.BatchNorm1d default (src/towers/tower/base_tower.py:91)
 BN_MOMENTUM = 0.1
 NORM_EPS = 1e-12       # F.normalize default eps (base_tower.py:145)
+LOG2E = 1.4426950408889634
+
+
+# ------------------------------------------------------------------------------------------------
+# operand rounding of the MEASURED mode (mlp_dtype="bf16", score_dtype="bf16"): the HIP kernels keep f32
+# tensors and f32 accumulation but feed the matrix cores bf16 operands.  Passing `q=q_bf16` to the
+# functions below rounds exactly those operands (and nothing else) in the restatement, so the f64 oracle
+# and the kernels then differ by f32 accumulation order only.  q=None is the reference's arithmetic.
+# ------------------------------------------------------------------------------------------------
+def q_bf16(a):
+    """round-to-nearest-even to bfloat16 (through f32, as the kernels do), returned in a's float dtype"""
+    a = np.asarray(a)
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    return r.astype(a.dtype if a.dtype.kind == "f" else np.float32)
+
+
+def _ident(a):
+    return a
 
 
 # ------------------------------------------------------------------------------------------------
@@ -85,27 +104,30 @@ def tower_layout(state: dict, prefix: str, keys):
     return i, 4 * i
 
 
-def tower_fwd(state: dict, prefix: str, keys, vocab_sizes, dense, values, train: bool, dtype=np.float32):
+def tower_fwd(state: dict, prefix: str, keys, vocab_sizes, dense, values, train: bool, dtype=np.float32, q=None):
     """BaseTower.forward.  Returns (emb [B,D], cache, bn_updates).
     x = cat[dense W0^T + b0 | embed concat]          base_tower.py:133-139
     per hidden block: BN(ReLU(x W^T + b)) (dropout p=0 / eval: identity)   base_tower.py:88-93
     y = h W_f^T + b_f ; y / max(||y||, 1e-12)        base_tower.py:97,145
+    q: operand rounding of the bf16 mode (q_bf16) -- every Linear's two operands, and the stored tower input x.
     """
     f = lambda a: np.asarray(a, dtype=dtype)
+    q = q or _ident
     ids = unpack_clamp_ids(values, vocab_sizes)
-    tables = [f(state[f"{prefix}categorical_embedder.embeddings.{k}.weight"]) for k in keys]
+    # (rows are gathered before the dtype conversion: a 1 M-row table is never copied whole)
+    rows = [f(np.asarray(state[f"{prefix}categorical_embedder.embeddings.{k}.weight"])[ids[:, i]]) for i, k in enumerate(keys)]
     W0, b0 = f(state[prefix + "dense_projection.weight"]), f(state[prefix + "dense_projection.bias"])
     dense = f(dense)
-    x = np.concatenate([dense @ W0.T + b0, embed_lookup(tables, ids)], axis=1)
+    x = q(np.concatenate([q(dense) @ q(W0).T + b0] + rows, axis=1))
     nblk, fin = tower_layout(state, prefix, keys)
-    cache = {"ids": ids, "dense": dense, "x": x, "blocks": [], "E": tables[0].shape[1] if tables else 0,
-             "H0": W0.shape[0]}
+    cache = {"ids": ids, "dense": dense, "x": x, "blocks": [], "E": rows[0].shape[1] if rows else 0,
+             "H0": W0.shape[0], "q": q}
     bn_updates = {}
     h = x
     for i in range(nblk):
         W, b = f(state[f"{prefix}mlp.{4 * i}.weight"]), f(state[f"{prefix}mlp.{4 * i}.bias"])
         g, be = f(state[f"{prefix}mlp.{4 * i + 2}.weight"]), f(state[f"{prefix}mlp.{4 * i + 2}.bias"])
-        pre = h @ W.T + b
+        pre = q(h) @ q(W).T + b
         a = np.maximum(pre, 0)
         if train:
             mean = a.mean(axis=0)
@@ -124,7 +146,7 @@ def tower_fwd(state: dict, prefix: str, keys, vocab_sizes, dense, values, train:
         cache["blocks"].append({"inp": h, "W": W, "pre": pre, "xhat": xhat, "rstd": rstd, "g": g})
         h = out
     Wf, bf = f(state[f"{prefix}mlp.{fin}.weight"]), f(state[f"{prefix}mlp.{fin}.bias"])
-    y = h @ Wf.T + bf
+    y = q(h) @ q(Wf).T + bf
     nrm = np.sqrt((y * y).sum(axis=1, keepdims=True))
     den = np.maximum(nrm, dtype(NORM_EPS))
     emb = y / den
@@ -132,18 +154,21 @@ def tower_fwd(state: dict, prefix: str, keys, vocab_sizes, dense, values, train:
     return emb, cache, bn_updates
 
 
-def tower_bwd(cache: dict, d_emb: np.ndarray, prefix: str, keys, vocab_sizes):
-    """Backward of tower_fwd (train-mode BN, dropout p=0).  Returns {state_dict key: grad}."""
+def tower_bwd(cache: dict, d_emb: np.ndarray, prefix: str, keys, vocab_sizes, table_grads: str = "dense"):
+    """Backward of tower_fwd (train-mode BN, dropout p=0).  Returns {state_dict key: grad}.
+    table_grads: "dense" = the reference's dense [V_k, E] arrays; "none" = skip them (the caller takes the
+    slot gradients `_d_concat` and forms the sparse-unique rows itself: 1 M-row tables)."""
     grads = {}
+    q = cache.get("q") or _ident
     emb, den, nrm = cache["emb"], cache["den"], cache["nrm"]
     # y/max(||y||,eps): for ||y||>eps  dy = (d - emb*(emb.d))/||y|| ; else dy = d/eps
     dot = (emb * d_emb).sum(axis=1, keepdims=True)
     dy = np.where(nrm > NORM_EPS, (d_emb - emb * dot) / den, d_emb / den)
     nblk = len(cache["blocks"])
     fin = 4 * nblk
-    grads[f"{prefix}mlp.{fin}.weight"] = dy.T @ cache["h_last"]
+    grads[f"{prefix}mlp.{fin}.weight"] = q(dy).T @ q(cache["h_last"])
     grads[f"{prefix}mlp.{fin}.bias"] = dy.sum(axis=0)
-    dh = dy @ cache["Wf"]
+    dh = q(dy) @ q(cache["Wf"])
     for i in reversed(range(nblk)):
         blk = cache["blocks"][i]
         xhat, rstd, g = blk["xhat"], blk["rstd"], blk["g"]
@@ -155,15 +180,16 @@ def tower_bwd(cache: dict, d_emb: np.ndarray, prefix: str, keys, vocab_sizes):
         else:
             da = dh * g * rstd
         dpre = da * (blk["pre"] > 0)
-        grads[f"{prefix}mlp.{4 * i}.weight"] = dpre.T @ blk["inp"]
+        grads[f"{prefix}mlp.{4 * i}.weight"] = q(dpre).T @ q(blk["inp"])
         grads[f"{prefix}mlp.{4 * i}.bias"] = dpre.sum(axis=0)
-        dh = dpre @ blk["W"]
+        dh = q(dpre) @ q(blk["W"])
     H0, E = cache["H0"], cache["E"]
     dproj, dcat = dh[:, :H0], dh[:, H0:]
-    grads[prefix + "dense_projection.weight"] = dproj.T @ cache["dense"]
+    grads[prefix + "dense_projection.weight"] = q(dproj).T @ q(cache["dense"])
     grads[prefix + "dense_projection.bias"] = dproj.sum(axis=0)
-    for k, g in zip(keys, embed_grad_dense(dcat, cache["ids"], vocab_sizes, E)):
-        grads[f"{prefix}categorical_embedder.embeddings.{k}.weight"] = g
+    if table_grads == "dense":
+        for k, g in zip(keys, embed_grad_dense(dcat, cache["ids"], vocab_sizes, E)):
+            grads[f"{prefix}categorical_embedder.embeddings.{k}.weight"] = g
     grads["_d_concat"] = dcat
     return grads
 
@@ -193,13 +219,27 @@ def score_ce_fwd(N, C, temperature=1.0):
                   "similarity_gap": pos - neg}, S, (lse_r, lse_c)
 
 
-def score_ce_bwd(N, C, S, lse, temperature=1.0, dloss=1.0):
-    """dS = (softmax_rows + softmax_cols - 2I)/(2B) ; dN = dS C / T ; dC = dS^T N / T."""
+def score_ce_bwd(N, C, S, lse, temperature=1.0, dloss=1.0, q=None):
+    """dS = (softmax_rows + softmax_cols - 2I)/(2B) ; dN = dS C / T ; dC = dS^T N / T.
+    q: the bf16 score kernels round the weight matrix (softmax_rows + softmax_cols - 2I) once more before the
+    gradient products (it is the second MFMA's operand)."""
     B = S.shape[0]
-    dS = (np.exp(S - lse[0][:, None]) + np.exp(S - lse[1][None, :]) - 2 * np.eye(B, dtype=S.dtype)) * (dloss / (2 * B))
+    W = np.exp(S - lse[0][:, None])
+    W += np.exp(S - lse[1][None, :])
+    W[np.arange(B), np.arange(B)] -= 2
+    if q is not None:
+        W = q(W)
+    W *= dloss / (2 * B)
     if temperature != 1.0:
-        dS = dS / S.dtype.type(temperature)
-    return dS @ C, dS.T @ N
+        W /= S.dtype.type(temperature)
+    return W @ C, W.T @ N
+
+
+def score_operands_bf16(N, C, temperature=1.0):
+    """The operand images of the bf16 score kernels: the notice rows are packed times 1/T * log2(e) (the softmax's
+    exponent scale rides in the MFMA: tt_score_unit_scale), so the operand is bf16(scale * n) / scale."""
+    sn = float(np.float32(np.float32(1.0 / temperature) * np.float32(LOG2E)))
+    return q_bf16(np.asarray(N) * N.dtype.type(sn)) / N.dtype.type(sn), q_bf16(C)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -209,23 +249,30 @@ NT, CT = "two_tower_model.notice_tower.", "two_tower_model.company_tower."
 
 
 def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, train=True, backward=True,
-              dtype=np.float32):
+              dtype=np.float32, rounding=None, table_grads="dense", keep_sim=True):
     """One forward (+backward) of the task.  batch: dict with notice_ids/company_ids [B,K] (or flat
     values) and notice_dense/company_dense.  Returns dict(loss, metrics, sim, notice_emb, company_emb,
-    grads{state key: array}, bn_updates)."""
+    grads{state key: array}, bn_updates).
+    rounding="bf16": the operand rounding of the measured mode (mlp_dtype = score_dtype = "bf16"), see q_bf16."""
+    q = q_bf16 if rounding == "bf16" else None
+    if rounding not in (None, "bf16"):
+        raise ValueError(f"rounding must be None or 'bf16', got {rounding!r}")
     vals_n = np.asarray(batch["notice_ids"]).reshape(-1)
     vals_c = np.asarray(batch["company_ids"]).reshape(-1)
     if batch["notice_dense"].shape[0] != batch["company_dense"].shape[0]:
         raise ValueError("notice/company batch size mismatch")          # two_tower_train_task.py:64-67
-    ne, cn, bn_n = tower_fwd(state, NT, keys_n, vocab_n, batch["notice_dense"], vals_n, train, dtype)
-    ce, cc, bn_c = tower_fwd(state, CT, keys_c, vocab_c, batch["company_dense"], vals_c, train, dtype)
-    loss, metrics, S, lse = score_ce_fwd(ne, ce, temperature)
-    out = {"loss": loss, **metrics, "sim": S, "notice_emb": ne, "company_emb": ce, "bn_updates": {**bn_n, **bn_c}}
+    ne, cn, bn_n = tower_fwd(state, NT, keys_n, vocab_n, batch["notice_dense"], vals_n, train, dtype, q)
+    ce, cc, bn_c = tower_fwd(state, CT, keys_c, vocab_c, batch["company_dense"], vals_c, train, dtype, q)
+    sn, sc = score_operands_bf16(ne, ce, temperature) if q is not None else (ne, ce)
+    loss, metrics, S, lse = score_ce_fwd(sn, sc, temperature)
+    out = {"loss": loss, **metrics, "sim": S if keep_sim else None, "notice_emb": ne, "company_emb": ce,
+           "bn_updates": {**bn_n, **bn_c}}
     if backward:
-        dN, dC = score_ce_bwd(ne, ce, S, lse, temperature)
-        g = tower_bwd(cn, dN, NT, keys_n, vocab_n)
+        dN, dC = score_ce_bwd(sn, sc, S, lse, temperature, q=q)
+        del S
+        g = tower_bwd(cn, dN, NT, keys_n, vocab_n, table_grads)
         out["d_concat_notice"] = g.pop("_d_concat")
-        g2 = tower_bwd(cc, dC, CT, keys_c, vocab_c)
+        g2 = tower_bwd(cc, dC, CT, keys_c, vocab_c, table_grads)
         out["d_concat_company"] = g2.pop("_d_concat")
         out["grads"] = {**g, **g2}
         out["ids_notice"], out["ids_company"] = cn["ids"], cc["ids"]

@@ -2,7 +2,11 @@
 
 exact-size exchange (eager) == fixed-capacity exchange (eager) == fixed-capacity exchange captured as ONE graph with the RCCL
 all-to-alls / all-reduce inside, over a warm-up step + 4 steps with different batches (bf16 and fp32 MLP): same losses, final
-state equal to 1e-6.  Prints DIST_WORLD1_OK and leaves with os._exit (no communicator teardown)."""
+state equal to 1e-6; a sharded run resumed from (full_state_dict, FusedAdam.state_dict()) continues bit for bit.
+Teardown is the ordinary one, in the order a graph with RCCL nodes needs: GraphedTrainStep.close() (drops the graph and its
+pool) -> tasks / optimisers released -> synchronize -> destroy_process_group() -> normal interpreter exit (rc 0).
+`--eager-collective`: additionally issue an eager RCCL all-reduce on the SAME communicator between replays of the graph that
+contains RCCL collectives (the pattern a checkpoint all-gather inside a training loop produces)."""
 import json
 import os
 import sys
@@ -56,10 +60,15 @@ def main():
             t.train()
             o = FusedAdam.for_task(t, lr=1e-2, weight_decay=1e-5)
             losses = []
+            gs = None
             if mode == "padded-graph":
                 gs = GraphedTrainStep(t, o, batches[0], warmup=1)       # the eager warm-up step calibrates the bucket capacity
                 for bt in batches:
                     losses.append(gs.step(bt)["loss"].item())
+                    if "--eager-collective" in sys.argv:
+                        probe = torch.full((1024,), 3.0, device=DEV)
+                        dist.all_reduce(probe)                          # eager, same communicator, between two replays
+                        assert float(probe.sum().item()) == 3.0 * 1024
             else:
                 o.zero_grad(); t(batches[0], return_metrics=True)["loss"].backward(); o.step()     # the same warm-up step
                 for bt in batches:
@@ -71,11 +80,63 @@ def main():
             if mode != "exact":
                 assert not t.exchange.overflowed()
             finals[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in t.full_state_dict().items()})
+            if gs is not None:
+                gs.close()                                              # graph + pool go before the communicator does
+            del gs, o, t
         for mode in ("padded", "padded-graph"):
             assert finals[mode][0] == finals["exact"][0], (mlp, mode, finals[mode][0], finals["exact"][0])
             for k, v in finals["exact"][1].items():
                 np.testing.assert_allclose(finals[mode][1][k], v, rtol=1e-6, atol=1e-7, err_msg=f"{mlp}:{mode}:{k}")
+    resume_check(cfg, batches)
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
     print("DIST_WORLD1_OK", flush=True)
+
+
+def resume_check(cfg, batches):
+    """save -> load -> step on the sharded path: model through full_state_dict / load_full_state_dict, optimiser through
+    FusedAdam.state_dict / load_state_dict (the shard's Adam moments and step count must survive: ADVICE round 1)."""
+    import copy
+
+    def make():
+        t = create_distributed_train_task(
+            cfg["keys_n"], cfg["keys_c"], metadata_path=str(GOLD / "synthetic_metadata.csv"), categorical_embedding_dim=cfg["E"],
+            notice_dense_input_dim=cfg["din_n"], company_dense_input_dim=cfg["din_c"], tower_hidden_dims=list(cfg["hidden"]),
+            final_embedding_dim=cfg["D"], dropout_rate=0.0, temperature=cfg["T"], device=DEV, embedding_grad="sparse", mlp_dtype="bf16")
+        t.train()
+        return t, FusedAdam.for_task(t, lr=1e-2, weight_decay=1e-5)
+
+    def run(t, o, bs):
+        out = []
+        for bt in bs:
+            o.zero_grad()
+            r = t(bt, return_metrics=True)
+            r["loss"].backward()
+            o.step()
+            out.append(r["loss"].item())
+        return out
+
+    ta, oa = make()
+    shapes = {k: tuple(v.shape) for k, v in ta.full_state_dict().items()}
+    ta.load_full_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in init_state_numpy(shapes, 778).items()})
+    run(ta, oa, batches[:2])
+    snap_model = {k: v.detach().clone() for k, v in ta.full_state_dict().items()}
+    snap_opt = copy.deepcopy(oa.state_dict())
+    la = run(ta, oa, batches[2:])
+    tb, ob = make()
+    tb.load_full_state_dict(snap_model)
+    ob.load_state_dict(snap_opt)
+    shard_state = ob.state[tb.embedding_shard]
+    assert float(shard_state["step"]) == 2.0 and shard_state["exp_avg"].abs().sum().item() > 0      # moments arrived
+    assert shard_state["exp_avg"].data_ptr() == ob._store_state[id(tb.sharded_store)]["m"].data_ptr()   # and alias the kernels' buffers
+    lb = run(tb, ob, batches[2:])
+    assert la == lb, (la, lb)
+    fa, fb = ta.full_state_dict(), tb.full_state_dict()
+    for k in fa:
+        assert torch.equal(fa[k], fb[k]), k
+    assert torch.equal(oa.state[ta.embedding_shard]["exp_avg_sq"], ob.state[tb.embedding_shard]["exp_avg_sq"])
 
 
 if __name__ == "__main__":
@@ -87,4 +148,3 @@ if __name__ == "__main__":
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(1)
     sys.stdout.flush()
-    os._exit(0)

@@ -19,43 +19,12 @@ ROOT = Path(__file__).resolve().parents[1]
 for p in (ROOT, ROOT / "tests", ROOT / "oracle"):
     sys.path.insert(0, str(p))
 import jodalrob_twotower_amd as tt  # noqa: E402
-from jodalrob_twotower_amd.distributed import create_distributed_train_task  # noqa: E402
+from jodalrob_twotower_amd.distributed import HostStagedComm, create_distributed_train_task  # noqa: E402
 from jodalrob_twotower_amd.optim import FusedAdam  # noqa: E402
 from params_init import init_state_numpy, synth_batch_numpy  # noqa: E402
 
 DEV = "cuda:0"
 GOLD = ROOT / "tests" / "golden"
-
-
-class HostStagedComm:
-    """DistComm's interface over gloo, device tensors staged through the host."""
-
-    def __init__(self):
-        self.world, self.rank = dist.get_world_size(), dist.get_rank()
-
-    def all_to_all_equal(self, send):
-        s = send.detach().cpu().contiguous()
-        out = torch.empty_like(s)
-        dist.all_to_all_single(out, s)
-        return out.to(send.device)
-
-    def all_reduce_max(self, t):
-        c = t.detach().cpu()
-        dist.all_reduce(c, op=dist.ReduceOp.MAX)
-        t.copy_(c)
-        return t
-
-    def all_gather(self, t):
-        c = t.detach().cpu().contiguous()
-        outs = [torch.empty_like(c) for _ in range(self.world)]
-        dist.all_gather(outs, c)
-        return torch.cat(outs).to(t.device)
-
-    def all_reduce_sum(self, t):
-        c = t.detach().cpu()
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        t.copy_(c)
-        return t
 
 
 def main():

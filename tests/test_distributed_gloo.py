@@ -52,7 +52,7 @@ class CheckerBackend:
         self.dense_grad = g[:-1]
 
     # ---- fixed-capacity exchange (PaddedRowExchange): same contracts as HipBackend's steps, plain numpy ----
-    def local_plan(self, rows, side_K, B):
+    def local_plan(self, rows, side_K, B, table_rows=0):
         from types import SimpleNamespace
         r = rows.numpy()
         order = np.argsort(r, kind="stable").astype(np.int32)
@@ -71,7 +71,7 @@ class CheckerBackend:
         U = int(plan.n_unique)
         send_ids = np.repeat(np.asarray(pad_id, np.int32), C)
         send_u = np.full(G * C, pad_u, np.int32)
-        pos_u = np.zeros(plan.M, np.int32)
+        pos_u = np.full(plan.M, G * C, np.int32)            # rows that do not fit point at the zero row behind the buckets
         counts = np.zeros(G, np.int32)
         for u in range(U):
             row = int(plan.unique_rows[u]); g = row % G
@@ -173,10 +173,32 @@ def _worker(rank, world, port, q, kind="exact"):
         np.testing.assert_allclose(be.dense_grad.numpy()[:mine.shape[0]], mine, rtol=1e-5, atol=1e-6)
         if kind == "padded":
             assert not ex.overflowed() and ex.C >= 256
-            # a capacity that is too small must be flagged, never silently wrong-and-quiet
+            # a capacity that is too small must be flagged AND rejected by the product path, never silently wrong-and-quiet:
+            # the rows that did not fit reach the towers as ZERO rows (not as some other row's embedding), the sticky flag
+            # is set, and both the polling check (every forward / replay) and the synchronous one raise
+            from jodalrob_twotower_amd.distributed import ExchangeOverflowError
             ex2 = PaddedRowExchange(store, backend=be, capacity=1)
+            for o in outs:
+                o.fill_(7.0)
             ex2.forward(sides, B, False)
             assert ex2.overflowed()
+            n_zero = 0
+            for out, (_, e) in zip(outs, exp):
+                got = out.numpy().reshape(-1, E)
+                want = e.reshape(-1, E)
+                fit = (got == want).all(axis=1)
+                assert ((got[~fit] == 0).all())             # every row that is not the right one is all-zero
+                n_zero += int((~fit).sum())
+            assert n_zero > 0
+            with pytest.raises(ExchangeOverflowError):
+                ex2.poll_overflow()
+            with pytest.raises(ExchangeOverflowError):
+                ex2.check_overflow()
+            ex2.reset_capacity()
+            ex2.forward(sides, B, False)                    # re-calibrated: clean again
+            ex2.check_overflow()
+            for out, (_, e) in zip(outs, exp):
+                assert np.array_equal(out.numpy(), e)
         # dense-gradient reduction = SUM over ranks (the towers pre-scale by 1/world)
         g = [torch.full((5,), float(rank + 1))]
         ex.all_reduce_dense(g)

@@ -431,18 +431,19 @@ def test_distributed_world1_matches_single_gpu(tt, manifest):
 
 def test_padded_exchange_graph_world1_subprocess(tt):
     """Fixed-capacity exchange == exact-size exchange, eagerly and as ONE captured graph with the RCCL collectives inside
-    (world 1).  Runs in its own process: a process group that has been captured into a graph does not always tear down
-    cleanly (destroy_process_group aborted now and then when it shared a process with other tests), and the worker leaves
-    with os._exit after printing its verdict."""
+    (world 1); a sharded run resumed from its checkpoint (model + FusedAdam state) continues bit for bit.  Runs in its own
+    process so that it owns its process group from init to the ORDINARY teardown: GraphedTrainStep.close() -> objects released
+    -> destroy_process_group() -> normal interpreter exit; the return code must be 0 (no os._exit escape)."""
     import subprocess, sys
     from pathlib import Path
     worker = Path(__file__).resolve().parent / "_dist_world1_worker.py"
     r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=300)
-    if "DIST_WORLD1_OK" not in r.stdout:
+    if "DIST_WORLD1_OK" not in r.stdout or r.returncode != 0:
         log = Path(__file__).resolve().parents[1] / "gpurun_out"
         log.mkdir(exist_ok=True)
         (log / "dist_world1_worker.log").write_text(r.stdout + "\n==== stderr ====\n" + r.stderr)
     assert "DIST_WORLD1_OK" in r.stdout, [ln for ln in r.stderr.splitlines() if "rror" in ln or "what()" in ln][-8:]
+    assert r.returncode == 0, (r.returncode, r.stderr.splitlines()[-8:])
 
 
 def test_fused_adam_matches_oracle(tt, manifest):
@@ -1210,3 +1211,93 @@ def test_global_negatives_equal_single_process(tt, G, B, D):
     acc = np.mean([float(x[3][1]) for x in res])
     np.testing.assert_allclose(acc, float(out_s[1]), rtol=1e-6)                     # row top-1 rate over the global batch
     np.testing.assert_allclose(np.mean([float(x[3][3]) for x in res]), float(out_s[3]), rtol=1e-4, atol=1e-6)   # negative mean
+
+
+# ------------------------------------------------------------------------------- the MEASURED mode, pinned directly
+def _rel(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return float(np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-300))
+
+
+# Per-tensor bounds of the bf16 step against the f64 oracle fed the SAME bf16-rounded operands (oracle_np.task_step(
+# rounding="bf16")): what is left is f32 accumulation order, the hardware exp2 / reciprocal, and the rare element whose
+# f32 value sits on the other side of a bf16 rounding boundary than the f64 one (each such flip is a 2^-8 relative change
+# of ONE operand element, so max-abs bounds are looser than norm-wise ones).  DESIGN.md section 4 quotes this table.
+BF16_STEP_BOUNDS = {
+    "loss_rtol": 2e-6,                 # |loss - ref| / ref
+    "emb_norm": 2e-5, "emb_maxabs": 3e-4,          # unit rows [B, D]
+    "metric_atol": 2e-6,               # positive / negative similarity means, gap
+    "dense_grad_matrix_norm": 2e-3,    # Linear weights  (norm-wise, per tensor)
+    "dense_grad_vector_norm": 4e-3,    # biases, BN scale / shift: column sums over the batch whose terms largely cancel
+    "row_grad_norm": 2e-3,             # sparse table gradient rows (all touched rows, norm-wise); row SET bit-exact
+}
+
+
+@pytest.mark.parametrize("rows_per_tower,B,T", [(1_000_000, 8192, 1.0), (None, 1000, 0.5)])
+def test_bf16_step_vs_rounded_oracle(tt, schema_real, tmp_path, rows_per_tower, B, T):
+    """ONE step of exactly bench.py's task (real 32 + 6 key schema, vocabularies scaled to 1 M + 1 M rows, B = 8192, E = 32,
+    towers [128, 64] -> 64, mlp_dtype = score_dtype = "bf16", embedding_grad = "sparse"; dropout 0 so that the oracle needs
+    no mask) against the f64 oracle with the kernels' operand rounding: loss, both towers' embeddings, the metrics, every
+    dense gradient and the sparse row gradients, each with its own stated bound.  Second case: the real (unscaled)
+    vocabularies at a ragged batch and T = 0.5."""
+    from jodalrob_twotower_amd import synthetic
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    if rows_per_tower:
+        vn, vc = synthetic.scale_vocabs(vn, rows_per_tower), synthetic.scale_vocabs(vc, rows_per_tower)
+    meta = synthetic.write_metadata(tmp_path / "m.csv", {"notice": dict(zip(kn, vn)), "company": dict(zip(kc, vc))})
+    torch.manual_seed(1234)
+    task = tt.create_two_tower_train_task(kn, kc, metadata_path=str(meta), categorical_embedding_dim=32, notice_dense_input_dim=256,
+                                          company_dense_input_dim=128, tower_hidden_dims=[128, 64], final_embedding_dim=64,
+                                          dropout_rate=0.0, temperature=T, device=DEV, embedding_grad="sparse", score_dtype="bf16",
+                                          mlp_dtype="bf16")
+    task.train()
+    task._pair_check_done = True
+    # weights away from the init's symmetric spots: BN scale / shift and biases random, so their gradients are exercised
+    with torch.no_grad():
+        g = torch.Generator(device=DEV).manual_seed(77)
+        for n_, p in task.named_parameters():
+            if p.ndim == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g, device=DEV))
+    state = {k: v.detach().cpu().numpy() for k, v in task.state_dict().items()}
+    batch = synthetic.make_batch(B, vn, vc, kn, kc, 256, 128, torch.device(DEV), seed=1234)
+    res = task(batch, return_metrics=True)
+    res["loss"].backward()
+    torch.cuda.synchronize()
+    store = task.two_tower_model.embedding_store
+    store = store() if callable(store) else store
+    plan, grad_rows = store.sparse_grad
+    U = int(plan.n_unique.item())
+    got_rows, got_grad = plan.unique_rows[:U].cpu().numpy().astype(np.int64), grad_rows[:U].cpu().numpy()
+    with torch.no_grad():
+        ne, ce = task.two_tower_model(batch["notice"], batch["company"])
+
+    b = {"notice_ids": batch["notice"]["kjt"].values().cpu().numpy().reshape(B, len(kn)),
+         "company_ids": batch["company"]["kjt"].values().cpu().numpy().reshape(B, len(kc)),
+         "notice_dense": batch["notice"]["dense"].cpu().numpy(), "company_dense": batch["company"]["dense"].cpu().numpy()}
+    ref = O.task_step(state, b, kn, kc, vn, vc, T, True, dtype=np.float64, rounding="bf16", table_grads="none", keep_sim=False)
+    bd = BF16_STEP_BOUNDS
+    report = {"loss": abs(res["loss"].item() - ref["loss"]) / ref["loss"]}
+    assert report["loss"] <= bd["loss_rtol"], report
+    for name, got, want in (("notice_emb", ne, ref["notice_emb"]), ("company_emb", ce, ref["company_emb"])):
+        got = got.cpu().numpy()
+        report[name] = (_rel(got, want), float(np.abs(got - want).max()))
+        assert report[name][0] <= bd["emb_norm"] and report[name][1] <= bd["emb_maxabs"], report
+    for k in ("positive_similarity_mean", "negative_similarity_mean", "similarity_gap"):
+        assert abs(res[k].item() - float(ref[k])) <= bd["metric_atol"] + 1e-4 * abs(float(ref[k])), (k, res[k].item(), ref[k])
+    assert abs(res["accuracy"].item() - float(ref["accuracy"])) <= 2.0 / B
+    for n_, p in task.named_parameters():
+        if "categorical_embedder" in n_:
+            continue
+        r = _rel(p.grad.cpu().numpy(), ref["grads"][n_])
+        report[n_] = r
+        assert r <= (bd["dense_grad_matrix_norm"] if p.ndim > 1 else bd["dense_grad_vector_norm"]), (n_, r)
+    # sparse row gradients over the fused row space (notice keys, then company keys): same row set, bounded values
+    offs_n = np.cumsum([0] + list(vn[:-1]))
+    offs_c = sum(vn) + np.cumsum([0] + list(vc[:-1]))
+    rn, gn = O.embed_grad_sparse(ref["d_concat_notice"], ref["ids_notice"], offs_n, 32)
+    rc, gc = O.embed_grad_sparse(ref["d_concat_company"], ref["ids_company"], offs_c, 32)
+    assert np.array_equal(got_rows, np.concatenate([rn, rc]))                       # touched-row set: bit-exact
+    report["row_grads"] = _rel(got_grad, np.concatenate([gn, gc]))
+    assert report["row_grads"] <= bd["row_grad_norm"], report
+    print("\n[bf16 step vs rounded oracle]", json.dumps({k: (v if not isinstance(v, tuple) else list(v)) for k, v in report.items()}))

@@ -123,3 +123,63 @@ def test_ctypes_structs_match_c_layout(tmp_path):
     mine = [ctypes.sizeof(c) for c in (_lib.EmbedSide, _lib.GradSrc, _lib.AdamTensor, _lib.TowerParams, _lib.TowerActs,
                                        _lib.TowerGrads, _lib.ScoreFwdDir, _lib.ScoreBwdDir)]
     assert sizes == mine
+
+
+def test_fused_adam_load_state_dict_keeps_sharded_moments():
+    """FusedAdam.load_state_dict on a row-wise sharded store: the shard's exp_avg / exp_avg_sq / step survive the round trip
+    and self.state[shard] aliases the store-level buffers the kernels update (they used to be dropped and
+    re-created as zeros with step 0 on the next step)."""
+    import torch
+    from jodalrob_twotower_amd.distributed import ShardedStore
+    from jodalrob_twotower_amd.optim import FusedAdam
+
+    def make():
+        store = ShardedStore(4, 37, 1, 3, "cpu", "sparse", seed=5)
+        w = torch.nn.Parameter(torch.ones(3, 2))
+        return store, w, FusedAdam([w, store.shard_param], lr=1e-3, stores=[store])
+
+    store, w, opt = make()
+    st = opt._state_of(store)
+    st["m"].copy_(torch.arange(st["m"].numel(), dtype=torch.float32).view_as(st["m"]))
+    st["v"].fill_(0.25)
+    st["step"] = 7
+    opt.state[store.shard_param]["step"] = torch.tensor(7.0)
+    opt.state[w] = {"step": torch.tensor(7.0), "exp_avg": torch.full((3, 2), 2.0), "exp_avg_sq": torch.full((3, 2), 3.0)}
+    sd = opt.state_dict()
+    store2, w2, opt2 = make()
+    opt2.load_state_dict(sd)
+    st2 = opt2._store_state[id(store2)]
+    assert st2["step"] == 7 and torch.equal(st2["m"], st["m"]) and torch.equal(st2["v"], st["v"])
+    sh = opt2.state[store2.shard_param]
+    assert float(sh["step"]) == 7.0 and sh["exp_avg"].data_ptr() == st2["m"].data_ptr() and sh["exp_avg_sq"].data_ptr() == st2["v"].data_ptr()
+    assert opt2._state_of(store2) is st2                      # the next step keeps using the loaded buffers
+    assert torch.equal(opt2.state[w2]["exp_avg"], torch.full((3, 2), 2.0))
+
+
+def test_bench_self_launch_plumbing():
+    """`python bench.py --gpus N` with no launcher around it starts its own N rank processes (before anything touches a GPU),
+    hands each RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, and only rank 0 writes to stdout: ONE JSON line.  TT_BENCH_LAUNCH_ONLY
+    stops each rank right after the argument / environment plumbing (no GPU here)."""
+    import json as _json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TT_BENCH_LAUNCH_ONLY"] = "1"
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "3", "--steps", "5", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                              # rank 0 only
+    info = _json.loads(lines[0])
+    assert info["RANK"] == "0" and info["WORLD_SIZE"] == "3" and info["MASTER_ADDR"] == "127.0.0.1" and info["gpus"] == 3
+    others = [_json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith("{") and "launch_only" in ln]
+    assert sorted(o["RANK"] for o in others) == ["1", "2"] and all(o["MASTER_PORT"] == info["MASTER_PORT"] for o in others)
+    # under an external launcher (WORLD_SIZE already set) it does not spawn again
+    env2 = dict(env, WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r2 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=60)
+    assert r2.returncode == 0 and _json.loads(r2.stdout.strip())["RANK"] == "1"
+    # a failing rank fails the launch
+    r3 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--no-such-flag"], env=env, capture_output=True, text=True, timeout=60)
+    assert r3.returncode != 0

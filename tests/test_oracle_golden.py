@@ -146,3 +146,52 @@ def test_projector_and_id_mappings():
                                     "company": {"ids": j["company_ids"]}})
     assert n2i == {tuple(k): v for k, v in j["notice_id_to_idx"]}
     assert c2i == {k: v for k, v in j["company_id_to_idx"]}
+
+
+def test_q_bf16_is_round_to_nearest_even():
+    """the oracle's operand rounding == torch's float32 -> bfloat16 conversion (RNE), incl. ties, subnormal-ish and large values"""
+    import torch
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, 20000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, 1.00390625, 1.01171875, 3.0e38, -3.0e38, 1e-40], dtype=np.float32)])
+    want = torch.from_numpy(x).bfloat16().float().numpy()
+    assert np.array_equal(O.q_bf16(x), want)
+    assert O.q_bf16(x.astype(np.float64)).dtype == np.float64 and np.array_equal(O.q_bf16(x.astype(np.float64)), want.astype(np.float64))
+
+
+def test_rounded_oracle_reduces_to_plain_oracle_on_bf16_exact_inputs(manifest):
+    """rounding="bf16" changes nothing but the operands: on a state / batch whose every GEMM operand is already exactly
+    representable in bf16 the forward up to the first non-representable intermediate is identical; and the plain path is
+    untouched by the hooks (q=None)."""
+    cfg = manifest["cases"]["tiny_train"]
+    g = load_case("tiny_train")
+    state, b = split_prefix(g, "state."), split_prefix(g, "in.")
+    plain = O.task_step(state, b, cfg["keys_n"], cfg["keys_c"], cfg["vocab_n"], cfg["vocab_c"], cfg["T"], True, dtype=np.float64)
+    rounded = O.task_step(state, b, cfg["keys_n"], cfg["keys_c"], cfg["vocab_n"], cfg["vocab_c"], cfg["T"], True, dtype=np.float64,
+                          rounding="bf16")
+    np.testing.assert_allclose(plain["loss"], g["out.loss"], rtol=1e-5)
+    assert abs(rounded["loss"] - plain["loss"]) / plain["loss"] < 2e-2              # bf16 operands: close, not equal
+    assert rounded["loss"] != plain["loss"]
+    for k, v in plain["grads"].items():
+        assert rounded["grads"][k].shape == v.shape
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_torch_restatement_matches_reference(case, manifest):
+    """oracle/oracle_torch.py (the vectorised torch-CPU restatement bench.py times as `cpu_baseline`) against the same
+    reference-generated vectors: loss, similarity matrix, every gradient, BN running statistics."""
+    import torch
+    import oracle_torch as OT
+    cfg = manifest["cases"][case]
+    g = load_case(case)
+    state = OT.make_state(split_prefix(g, "state."))
+    batch = {k: torch.as_tensor(v) for k, v in split_prefix(g, "in.").items()}
+    loss, S = OT.task_loss(state, batch, cfg["keys_n"], cfg["keys_c"], cfg["vocab_n"], cfg["vocab_c"], cfg["T"], cfg["train"])
+    np.testing.assert_allclose(loss.item(), g["out.loss"], rtol=RTOL)
+    np.testing.assert_allclose(S.detach().numpy(), g["sim"], rtol=RTOL, atol=5e-6)
+    if cfg["train"]:
+        loss.backward()
+        for k, v in split_prefix(g, "grad.").items():
+            np.testing.assert_allclose(state[k].grad.numpy(), v, rtol=2e-4, atol=2e-7, err_msg=k)
+        for k, v in split_prefix(g, "state_after.").items():
+            np.testing.assert_allclose(state[k].numpy(), v, rtol=RTOL, atol=ATOL, err_msg=k)
