@@ -5,8 +5,9 @@ all-to-alls / all-reduce inside, over a warm-up step + 4 steps with different ba
 state equal to 1e-6; a sharded run resumed from (full_state_dict, FusedAdam.state_dict()) continues bit for bit.
 Teardown is the ordinary one, in the order a graph with RCCL nodes needs: GraphedTrainStep.close() (drops the graph and its
 pool) -> tasks / optimisers released -> synchronize -> destroy_process_group() -> normal interpreter exit (rc 0).
-`--eager-collective`: additionally issue an eager RCCL all-reduce on the SAME communicator between replays of the graph that
-contains RCCL collectives (the pattern a checkpoint all-gather inside a training loop produces)."""
+Between the replays of the graph that contains RCCL collectives it issues an EAGER RCCL all-reduce on the SAME communicator
+(the pattern a checkpoint all-gather inside a training loop produces; round 1 suspected this of faulting the GPU -- it was
+the memset-node bug of DESIGN.md section 7, fixed since)."""
 import json
 import os
 import sys
@@ -65,10 +66,9 @@ def main():
                 gs = GraphedTrainStep(t, o, batches[0], warmup=1)       # the eager warm-up step calibrates the bucket capacity
                 for bt in batches:
                     losses.append(gs.step(bt)["loss"].item())
-                    if "--eager-collective" in sys.argv:
-                        probe = torch.full((1024,), 3.0, device=DEV)
-                        dist.all_reduce(probe)                          # eager, same communicator, between two replays
-                        assert float(probe.sum().item()) == 3.0 * 1024
+                    probe = torch.full((1024,), 3.0, device=DEV)
+                    dist.all_reduce(probe)                              # eager, same communicator, between two replays
+                    assert float(probe.sum().item()) == 3.0 * 1024
             else:
                 o.zero_grad(); t(batches[0], return_metrics=True)["loss"].backward(); o.step()     # the same warm-up step
                 for bt in batches:
