@@ -375,6 +375,20 @@ int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs,
                       float shift, tt_stream stream);
 int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t,
                       float shift, const float* d_loss, float scale, tt_stream stream);
+/* Single-pass symmetric forward of the SQUARE training problem (B notice rows against the B company rows of the same
+ * pairs; replaces two_tower_train_task.py:99-179's mm + two cross-entropies + metrics): every 32 x 32 tile of S is computed
+ * once and feeds both softmax directions.  Inputs: the two packed operand images (tt_score_pack_bf16 / the tower pass);
+ * ab_scale as tt_score_fwd_dir.ab_scale.  Outputs, all [B]: rowsum / colsum (shifted exp-sums, as tt_score_fwd_bf16's
+ * sumexp of the two directions), inv_row / inv_col (tt_score_fwd_dir.inv_sumexp of the two directions: what
+ * tt_score_bwd_bf16 takes as inv_a / inv_b), diag (s_ii / T), row_rank (want_rank != 0: 0 where the positive is the row's
+ * first maximum, else 1); out8 / loss_out as tt_score_loss_finish (out8[5], the column-direction top-1 rate, is 0 here).
+ * Three launches (sweep, per-row finish, scalar finish), every sum in a fixed order: bitwise reproducible.
+ * workspace: tt_score_fwd_sym_workspace_bytes(B, D) bytes. */
+size_t tt_score_fwd_sym_workspace_bytes(int64_t B, int32_t D);
+int tt_score_fwd_sym_bf16(tt_ctx* ctx, const void* N_packed, const void* C_packed, int64_t B, int32_t D, float inv_t,
+                          float shift, float ab_scale, int32_t want_rank, float* rowsum, float* colsum, float* inv_row,
+                          float* inv_col, float* diag, int32_t* row_rank, float* out8, float* loss_out, void* workspace,
+                          size_t workspace_bytes, tt_stream stream);
 /* dense score matrix S[Ra, Rb] = A Bm^T * inv_t (result["similarity_matrix"], predict_batch
  * "all_similarities": two_tower_train_task.py:94, :206) */
 int tt_score_matrix(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D,

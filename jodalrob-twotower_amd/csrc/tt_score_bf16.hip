@@ -14,30 +14,13 @@
 //     of the first product, and [tile][k-step][half][d][8] whose 16-B chunks are exactly the B operand of
 //     the second product in the k-permutation the accumulator registers impose.
 //   * partial results of the NW waves are combined through LDS in a fixed tree order.
-#include "tt_common.h"
+#include "tt_score_bf16.h"
 
 #include <stdlib.h>
 
 namespace {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr float kNegBig = -3.0e38f;
-
-__host__ __device__ inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
-inline int padded_d(int D) { return D <= 32 ? 32 : (D <= 64 ? 64 : (D <= 128 ? 128 : 256)); }
-
-__device__ __forceinline__ int rowmap(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
-
-// single-instruction 3-input max (plain fmaxf on MFMA results makes hipcc insert canonicalising v_max first)
-__device__ __forceinline__ float max3_asm(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-  return r;
-}
+using namespace ttscore;
 
 // ---- pack ------------------------------------------------------------------------------------------
 struct PackArgs { const float* X; int64_t R, Rp; __bf16* rows; __bf16* frag; float scale; };
@@ -116,13 +99,6 @@ struct BwdArgs {
   const float* d_loss;
   int D;
 };
-
-template <int KS>
-__device__ __forceinline__ void load_bfrag(const __bf16* __restrict__ b_rows, int64_t t, int c, int h, bf16x8 (&bf)[KS]) {
-  const __bf16* p = b_rows + ((t * KS * 2 + h) * 32 + c) * 8;      // a wave-instruction reads 1 KB contiguous
-#pragma unroll
-  for (int s = 0; s < KS; ++s) bf[s] = *reinterpret_cast<const bf16x8*>(p + s * 512);
-}
 
 template <int KS, int AT>
 __device__ __forceinline__ void mfma1(const bf16x8 (&bf)[KS], const bf16x8 (&ares)[AT][KS], f32x16 (&acc)[AT]) {
@@ -522,17 +498,6 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
           if (a < Ra && dd < args.D) dr.dA[(int64_t)a * args.D + dd] = dacc[i][d][r] * g;
         }
   }
-}
-
-struct PackedView {
-  const __bf16* rows;
-  const __bf16* frag;
-};
-inline PackedView view(const void* packed, int64_t R, int D) {
-  const int64_t Rp = rup(R, 64);
-  const int Dp = padded_d(D);
-  const __bf16* base = reinterpret_cast<const __bf16*>(packed);
-  return PackedView{base, base + Rp * Dp};
 }
 
 }  // namespace

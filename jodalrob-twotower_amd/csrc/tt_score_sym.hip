@@ -1,0 +1,489 @@
+// Single-pass symmetric forward of the in-batch-negative score + softmax-CE (two_tower_train_task.py:99-179) on the square
+// training problem: S = N C^T is swept ONCE; every 32x32 tile feeds both softmax directions.
+//
+// The two-direction kernel of tt_score_bf16.hip computes every tile (MFMA + exp2) twice, once per direction, because a
+// 32x32 MFMA result holds one index on the lanes and the other in the registers: sums over the register index are
+// in-lane adds, sums over the lane index are cross-lane reductions (80 DPP steps per tile).  Here a wave keeps ONE tile J
+// of company rows b as its resident operand and sweeps a chunk of notice tiles I; X[b = register][a = lane]:
+//   * column direction (per b, sum over a): 16 per-lane accumulators that live across the whole sweep -- the cross-lane
+//     reduction happens once per sweep, not once per tile;
+//   * row direction (per a, sum over b): the in-lane sum over the 16 registers is the tile's partial for 32 rows a; it goes
+//     to a wave-private LDS slot (one ds_write per tile).  After the sweep the workgroup adds the slots of its 8 waves
+//     (8 tiles J) in wave order and writes ONE partial per (J-group, a) to a slab [n_groups][B].
+// A second launch (finish1, B/256 workgroups) adds the slab rows in a fixed order, forms the per-row terms of the loss and
+// the metrics, and leaves rowsum / colsum / their reciprocals for the backward kernel; finish2 (one workgroup) adds the
+// workgroups' partial sums.  Every sum has a fixed order: results are bitwise reproducible.
+//
+// Top-1 accuracy: per (J, a) the tile's maximum goes to a "before the positive" or "after the positive" slot (ties before
+// the positive beat it, ties after do not -- torch.argmax takes the first maximum); the diagonal tile splits per element.
+// sum of all scores (negative_similarity_mean): sum_ab n_a . c_b = (sum_a n_a) . (sum_b c_b) -- finish1 adds the operand
+// images' columns instead of the kernel adding 67 M products.
+#include "tt_score_bf16.h"
+
+#include <stdlib.h>
+
+namespace {
+
+using namespace ttscore;
+
+constexpr int kSymWaves = 8;           // tiles J per workgroup
+constexpr int kSymThreads = kSymWaves * 64;
+
+// x[lane] + x[lane ^ 32] in every lane: v_permlane32_swap exchanges the upper half of one register with the lower half of the
+// other -- on two copies of x that leaves {lo, lo} and {hi, hi}.  A VALU op: no LDS round trip as __shfl_xor(x, 32) (ds_bpermute)
+// (inline asm: through __builtin_amdgcn_permlane32_swap hipcc 7.2 drops the second result and adds r[0] to itself.  The
+//  s_nop covers the VALU-write -> permlane-read wait states the compiler would have inserted for its own instruction)
+__device__ __forceinline__ void half_swap(float x, float& lo, float& hi) {
+  unsigned a = __builtin_bit_cast(unsigned, x), b = a;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  lo = __builtin_bit_cast(float, a);
+  hi = __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float half_sum(float x) {
+  float p, q;
+  half_swap(x, p, q);
+  return p + q;
+}
+__device__ __forceinline__ float half_max(float x) {
+  float p, q;
+  half_swap(x, p, q);
+  return fmaxf(p, q);
+}
+
+struct SymArgs {
+  const __bf16* a_rows;                // notice image (rows image), may carry the exponent scale
+  const __bf16* b_rows;                // company image
+  int R, nT, NI;                       // rows, 32-row tiles, notice tiles per workgroup
+  int64_t Rp;                          // slab row stride (floats)
+  float c1, c2;                        // non-unit form: exp2(acc * c1 + c2)
+  float* rs; float* mb; float* ma;     // [n_groups][Rp]: exp-sum / max before / max after the positive, per (J group, a)
+  float* cs;                           // [n_chunks][Rp]: exp-sum per (a chunk, b)
+  float* diag_raw;                     // [R] the positives' products, as the MFMA delivers them
+  int want_rank;
+};
+
+// Notice tiles are staged through LDS once per WORKGROUP (all 8 waves sweep the same tiles I): read straight from L2 by
+// every wave, the operand stream was 4 KB per 32 x 32 tile -- 268 MB per launch at B = 8192, D = 64 -- and the kernel ran at
+// the L2's ~11 TB/s, not at its VALU rate.  A stage = TS tiles (8 KB; 16 KB at D = 256) in the images' own fragment order, so
+// the copy is verbatim (16 bytes per thread) and a wave's ds_read_b128 of a fragment is 1 KB contiguous: conflict-free.
+// Double buffered, one barrier per stage; the next stage's global loads are in flight while this one is computed.
+template <int KS>
+struct SymStage {
+  static constexpr int TS = KS <= 2 ? 4 : (KS <= 4 ? 2 : 1);               // tiles per stage
+  static constexpr int kBytes = TS * KS * 1024;
+  static constexpr int LPT = kBytes / (kSymThreads * 16);                   // 16-byte loads per thread per stage
+  static_assert(LPT >= 1 && LPT * kSymThreads * 16 == kBytes, "stage must be whole 16-byte loads");
+};
+
+template <int KS, bool UNIT>
+__global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
+  using ST = SymStage<KS>;
+  constexpr int TS = ST::TS, LPT = ST::LPT;
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [3][8 waves][NI * 32] slots | 2 stage buffers
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int NI = g.NI, nT = g.nT, R = g.R;
+  const int slots = NI * 32;
+  float* s_sum = lds + (0 * kSymWaves + wave) * slots;
+  float* s_mb = lds + (1 * kSymWaves + wave) * slots;
+  float* s_ma = lds + (2 * kSymWaves + wave) * slots;
+  char* stage = reinterpret_cast<char*>(lds + 3 * kSymWaves * slots);
+  const int J = (int)blockIdx.x * kSymWaves + wave;        // this wave's company tile
+  const int I0 = (int)blockIdx.y * NI, I1 = min(I0 + NI, nT);
+  const bool active = J < nT;
+  for (int i = lane; i < slots; i += 64) { s_sum[i] = 0.f; s_mb[i] = kNegBig; s_ma[i] = kNegBig; }
+  const float c1 = g.c1, c2 = g.c2;
+  auto ex = [&](float x) { return UNIT ? __builtin_amdgcn_exp2f(x) : __builtin_amdgcn_exp2f(__builtin_fmaf(x, c1, c2)); };
+  float colacc[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) colacc[r] = 0.f;
+  bf16x8 bres[KS];
+  load_bfrag<KS>(g.b_rows, active ? J : 0, c, h, bres);
+  const int n_full = R / 32;                               // tiles below n_full hold 32 valid rows
+  const bool jfull = active && J < n_full;
+  float dg_keep = kNegBig;                                 // the positives of tile J (met once per wave, if J is in this chunk)
+  // stage loader: thread t copies bytes [16 t, 16 t + 16) (+ 8 KB per further load) of the stage's tiles; tiles past the
+  // image's end are clamped to its last tile (their results are never used)
+  const int nst = (I1 - I0 + TS - 1) / TS;
+  uint4 sreg[LPT];
+  auto stage_load = [&](int st) {
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) {
+      const int off = (q * kSymThreads + (int)threadIdx.x) * 16;           // byte offset inside the stage
+      const int tl = off / (KS * 1024);                                    // tile of the stage this chunk belongs to
+      const int tile = min(I0 + st * TS + tl, nT - 1);
+      sreg[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g.a_rows) + (int64_t)tile * (KS * 1024) + (off - tl * KS * 1024));
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < LPT; ++q)
+      *reinterpret_cast<uint4*>(stage + buf * ST::kBytes + (q * kSymThreads + (int)threadIdx.x) * 16) = sreg[q];
+  };
+  stage_load(0);
+  for (int st = 0; st < nst; ++st) {
+    stage_store(st & 1);
+    stage_load(min(st + 1, nst - 1));                      // unconditional: the compiler's vmcnt waits stay exact
+    __syncthreads();
+    if (active) {
+      const char* sb = stage + (st & 1) * ST::kBytes;
+#pragma unroll
+      for (int tl = 0; tl < TS; ++tl) {
+        const int I = I0 + st * TS + tl;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(sb + (((tl * KS + s) * 2 + h) * 32 + c) * 16);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bres[s], af, acc, 0, 0, 0);
+        }
+        const int il = (I - I0) * 32 + c;
+        if (I < I1 && I != J && I < n_full && jfull) {     // plain tile: 32 x 32 valid scores, all on one side of the positives
+          float e[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) e[r] = ex(acc[r]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) colacc[r] += e[r];
+          float t0 = (e[0] + e[1]) + (e[2] + e[3]), t1 = (e[4] + e[5]) + (e[6] + e[7]);
+          float t2 = (e[8] + e[9]) + (e[10] + e[11]), t3 = (e[12] + e[13]) + (e[14] + e[15]);
+          const float rsum = half_sum((t0 + t1) + (t2 + t3));
+          if (g.want_rank) {
+            float m = max3_asm(acc[0], acc[1], acc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) m = max3_asm(m, acc[r], acc[r + 1]);
+            m = half_max(fmaxf(m, acc[15]));
+            if (h == 0) (J < I ? s_mb : s_ma)[il] = m;     // every b of tile J lies before (J < I) / after the positive of every a of tile I
+          }
+          if (h == 0) s_sum[il] = rsum;
+        } else if (I < I1) {                               // the diagonal tile and the ragged last tiles: per element
+          const int a = 32 * I + c;
+          float rsum = 0.f, xb = kNegBig, xa = kNegBig, dg = kNegBig;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int b = 32 * J + rowmap(r, h);
+            const float x = acc[r];
+            const bool valid = b < R && a < R;
+            const float e = valid ? ex(x) : 0.f;
+            colacc[r] += e;
+            rsum += e;
+            xb = (valid && b < a) ? fmaxf(xb, x) : xb;
+            xa = (valid && b > a) ? fmaxf(xa, x) : xa;
+            dg = (b == a) ? x : dg;
+          }
+          rsum = half_sum(rsum);
+          xb = half_max(xb);
+          xa = half_max(xa);
+          dg = half_max(dg);
+          if (h == 0) { s_sum[il] = rsum; s_mb[il] = xb; s_ma[il] = xa; }
+          if (I == J) dg_keep = dg;                        // taken from the MFMA result itself, so ties compare bit for bit
+        }
+      }
+    }
+  }
+  if (active) {
+    if (J >= I0 && J < I1 && h == 0 && 32 * J + c < R) g.diag_raw[32 * J + c] = dg_keep;
+    // column direction: one cross-lane reduction per sweep (fixed butterfly order), lanes c == 0 hold the 32 sums
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) colacc[r] += __shfl_xor(colacc[r], o);
+    if (c == 0) {
+      float* dst = g.cs + (int64_t)blockIdx.y * g.Rp + 32 * J;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[rowmap(r, h)] = colacc[r];      // (rows beyond R: slab padding, never read)
+    }
+  }
+  __syncthreads();
+  // row direction: the 8 waves' slots in wave order -> one partial per (J group, a)
+  for (int i = threadIdx.x; i < slots; i += kSymThreads) {
+    const int a = I0 * 32 + i;                              // < Rp by construction (sym_layout)
+    float s = 0.f, xb = kNegBig, xa = kNegBig;
+#pragma unroll
+    for (int w = 0; w < kSymWaves; ++w) {
+      s += lds[(0 * kSymWaves + w) * slots + i];
+      xb = fmaxf(xb, lds[(1 * kSymWaves + w) * slots + i]);
+      xa = fmaxf(xa, lds[(2 * kSymWaves + w) * slots + i]);
+    }
+    const int64_t o = (int64_t)blockIdx.x * g.Rp + a;
+    g.rs[o] = s;
+    if (g.want_rank) { g.mb[o] = xb; g.ma[o] = xa; }
+  }
+}
+
+// ---- finish1: slabs -> per-row sums, reciprocals, top-1 flags; per-workgroup partial sums of the loss terms; column sums
+// of both operand images (for the sum of all scores).  64 rows per workgroup: wave q adds the slab rows g = q, q + 4, ...
+// (independent loads, 8 in flight), the four partial results are combined in wave order.
+constexpr int kFinRows = 64;
+struct Fin1Args {
+  const float* rs; const float* mb; const float* ma; const float* cs; const float* diag_raw;
+  int n_groups, n_chunks, R, KS;
+  int64_t Rp;
+  float kexp, unscale, shift;
+  int unit, want_rank;
+  float* rowsum; float* colsum; float* inv_row; float* inv_col; float* diag; int32_t* row_rank;
+  const __bf16* a_rows; const __bf16* b_rows;
+  float* part;                         // [n_wg][4 + 2 * Dp]: l, hits, dsum, (pad), U[Dp], V[Dp]
+};
+
+__device__ __forceinline__ float slab_sum4(const float* __restrict__ slab, int64_t Rp, int n, int q, int i) {
+  float s = 0.f;
+  for (int g0 = q; g0 < n; g0 += 32) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = g0 + 4 * k < n ? slab[(int64_t)(g0 + 4 * k) * Rp + i] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k];
+  }
+  return s;
+}
+__device__ __forceinline__ float slab_max4(const float* __restrict__ slab, int64_t Rp, int n, int q, int i) {
+  float s = kNegBig;
+  for (int g0 = q; g0 < n; g0 += 32) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = g0 + 4 * k < n ? slab[(int64_t)(g0 + 4 * k) * Rp + i] : kNegBig;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s = fmaxf(s, v[k]);
+  }
+  return s;
+}
+
+__global__ __launch_bounds__(256) void score_sym_finish1_kernel(Fin1Args f) {
+  const int t = threadIdx.x, lane = t & 63, q = t >> 6;
+  const int i = blockIdx.x * kFinRows + lane;              // slab rows are padded: i < Rp always
+  const int Dp = f.KS * 16, stride = 4 + 2 * Dp;
+  float* part = f.part + (int64_t)blockIdx.x * stride;
+  __shared__ float red[4][4][kFinRows];                    // [quantity][wave][row]
+  red[0][q][lane] = slab_sum4(f.rs, f.Rp, f.n_groups, q, i);
+  red[1][q][lane] = slab_sum4(f.cs, f.Rp, f.n_chunks, q, i);
+  if (f.want_rank) {
+    red[2][q][lane] = slab_max4(f.mb, f.Rp, f.n_groups, q, i);
+    red[3][q][lane] = slab_max4(f.ma, f.Rp, f.n_groups, q, i);
+  }
+  // column sums of the images over this workgroup's 2 tiles: chunk id = (k-step * 2 + half) * 32 + row, 16 bytes each
+  __shared__ float cols[2][256];
+  const int chunks = f.KS * 64;                            // per tile
+  for (int img = 0; img < 2; ++img) {
+    const __bf16* base = img ? f.b_rows : f.a_rows;
+    for (int ch0 = 0; ch0 < chunks; ch0 += 256) {
+      const int ch = ch0 + t;
+      float acc8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
+      if (ch < chunks) {
+#pragma unroll
+        for (int qq = 0; qq < kFinRows / 32; ++qq) {
+          const int64_t tile = (int64_t)blockIdx.x * (kFinRows / 32) + qq;
+          if (tile * 32 < f.R) {                           // (rows beyond R inside a tile are zero in the image)
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(base + (tile * chunks + ch) * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc8[j] += (float)vv[j];
+          }
+        }
+      }
+      // the 32 threads of a (k-step, half) group hold the 32 rows: butterfly over the low 5 lane bits
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc8[j] += __shfl_xor(acc8[j], o);
+      if (ch < chunks && (t & 31) == 0) {
+        const int dbase = (ch >> 5) * 8;                   // (k-step * 2 + half) * 8 = first column of the chunk
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cols[img][dbase + j] = acc8[j];
+      }
+    }
+  }
+  __syncthreads();
+  float l = 0.f, hit = 0.f, dsum = 0.f;
+  if (q == 0) {
+    if (i < f.R) {
+      const float rsum = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
+      const float csum = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
+      const float draw = f.diag_raw[i], d = draw * f.unscale;
+      f.inv_row[i] = 1.f / rsum;
+      f.inv_col[i] = 1.f / csum;
+      const float rs_shifted = f.unit ? rsum * f.kexp : rsum, cs_shifted = f.unit ? csum * f.kexp : csum;
+      f.rowsum[i] = rs_shifted;
+      f.colsum[i] = cs_shifted;
+      f.diag[i] = d;
+      l = (logf(rs_shifted) + f.shift - d) + (logf(cs_shifted) + f.shift - d);
+      dsum = d;
+      if (f.want_rank) {
+        const float xb = fmaxf(fmaxf(red[2][0][lane], red[2][1][lane]), fmaxf(red[2][2][lane], red[2][3][lane]));
+        const float xa = fmaxf(fmaxf(red[3][0][lane], red[3][1][lane]), fmaxf(red[3][2][lane], red[3][3][lane]));
+        const int rk = (xb < draw && xa <= draw) ? 0 : 1;
+        f.row_rank[i] = rk;
+        hit = rk == 0 ? 1.f : 0.f;
+      }
+    }
+    float v[3] = {l, hit, dsum};                           // butterfly inside the one wave that holds the rows
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v[j] += __shfl_xor(v[j], o);
+    if (lane == 0) { part[0] = v[0]; part[1] = v[1]; part[2] = v[2]; part[3] = 0.f; }
+  }
+  for (int d = t; d < 2 * Dp; d += 256) part[4 + d] = cols[d / Dp][d % Dp];
+}
+
+// finish2: one workgroup adds the partial records in a fixed order (thread (j, q): records q, q + 4, ... of entry j, the four
+// partial sums in order); loss and metrics (out8 as tt_score_loss_finish)
+__global__ __launch_bounds__(1024) void score_sym_finish2_kernel(const float* __restrict__ part, int n_wg, int Dp, float fb, float unscale,
+                                                                float* __restrict__ out, float* __restrict__ loss_out) {
+  __shared__ float red[4][4 + 2 * 256];
+  __shared__ float prod[256];
+  const int t = threadIdx.x, q = t >> 8, j0 = t & 255, stride = 4 + 2 * Dp;
+  for (int j = j0; j < stride; j += 256) {
+    float s = 0.f;
+    for (int w0 = q; w0 < n_wg; w0 += 32) {
+      float v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = w0 + 4 * k < n_wg ? part[(int64_t)(w0 + 4 * k) * stride + j] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    red[q][j] = s;
+  }
+  __syncthreads();
+  if (t < 256) {
+    float p = 0.f;
+    if (t < Dp) {
+      const float u = (red[0][4 + t] + red[1][4 + t]) + (red[2][4 + t] + red[3][4 + t]);
+      const float v = (red[0][4 + Dp + t] + red[1][4 + Dp + t]) + (red[2][4 + Dp + t] + red[3][4 + Dp + t]);
+      p = u * v;
+    }
+    prod[t] = p;
+  }
+  __syncthreads();
+  if (t < 64) {
+    float p = (prod[t] + prod[t + 64]) + (prod[t + 128] + prod[t + 192]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+    if (t == 0) {
+      const float tot = p * unscale;                       // sum of all s_ab / T = (sum_a n_a) . (sum_b c_b) / T
+      const float l = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+      const float hit = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+      const float dsum = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
+      const float pos = dsum / fb;
+      const float neg = (tot - dsum) / (fb * fb - fb);     // mean over the off-diagonal (nan for B == 1, as torch)
+      out[0] = 0.5f * l / fb;
+      out[1] = hit / fb;
+      out[2] = pos;
+      out[3] = neg;
+      out[4] = pos - neg;
+      out[5] = 0.f;                                        // column-direction top-1 rate: first-call diagnostic only (two-direction kernel)
+      out[6] = tot;
+      out[7] = 0.f;
+      if (loss_out) loss_out[0] = out[0];
+    }
+  }
+}
+
+struct SymLayout {
+  int nT, NI, n_groups, n_chunks, n_wg, Dp;
+  int64_t Rp;
+  size_t off_rs, off_mb, off_ma, off_cs, off_diag, off_part, bytes;
+};
+
+inline SymLayout sym_layout(const tt_ctx* ctx, int64_t R, int D) {
+  SymLayout L;
+  L.Dp = padded_d(D);
+  L.nT = (int)tt_cdiv(R, 32);
+  L.n_groups = (int)tt_cdiv(L.nT, kSymWaves);
+  // notice tiles per workgroup: enough workgroups for ~2 per CU, at least 4 tiles per sweep, at most 32 (LDS: 3 * 8 * NI * 128 B)
+  static const int ni_env = getenv("TT_SCORE_SYM_NI") ? atoi(getenv("TT_SCORE_SYM_NI")) : 0;
+  int ni = ni_env > 0 ? ni_env : (int)tt_cdiv((int64_t)L.nT * L.n_groups, 2 * (ctx ? ctx->num_cus : 256));
+  ni = ni < 4 ? 4 : (ni > 16 ? 16 : ni);                  // 16 tiles: 48 KB of LDS slots per workgroup
+  ni = (ni + 3) / 4 * 4;                                  // whole stages (a stage is 1, 2 or 4 tiles)
+  L.NI = ni;
+  L.n_chunks = (int)tt_cdiv(L.nT, ni);
+  L.n_wg = (int)tt_cdiv(R, kFinRows);
+  L.Rp = rup((int64_t)L.n_chunks * ni * 32, 256);          // slab rows cover every slot a workgroup writes (>= R)
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t at = o; o += (n + 255) & ~size_t(255); return at; };
+  L.off_rs = take(sizeof(float) * L.n_groups * L.Rp);
+  L.off_mb = take(sizeof(float) * L.n_groups * L.Rp);
+  L.off_ma = take(sizeof(float) * L.n_groups * L.Rp);
+  L.off_cs = take(sizeof(float) * L.n_chunks * L.Rp);
+  L.off_diag = take(sizeof(float) * L.Rp);
+  L.off_part = take(sizeof(float) * L.n_wg * (4 + 2 * L.Dp));
+  L.bytes = o + 256;
+  return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tt_score_fwd_sym_workspace_bytes(int64_t B, int32_t D) {
+  if (B < 1 || D < 1 || D > 256) return 0;
+  tt_ctx fake{};
+  fake.num_cus = 256;
+  return sym_layout(&fake, B, D).bytes;
+}
+
+int tt_score_fwd_sym_bf16(tt_ctx* ctx, const void* N_packed, const void* C_packed, int64_t B, int32_t D, float inv_t, float shift,
+                          float ab_scale, int32_t want_rank, float* rowsum, float* colsum, float* inv_row, float* inv_col,
+                          float* diag, int32_t* row_rank, float* out8, float* loss_out, void* workspace, size_t workspace_bytes,
+                          tt_stream stream) {
+  TT_CHECK_ARG(ctx && N_packed && C_packed && rowsum && colsum && inv_row && inv_col && diag && out8 && workspace,
+               "tt_score_fwd_sym_bf16: NULL argument");
+  TT_CHECK_ARG(!want_rank || row_rank, "tt_score_fwd_sym_bf16: want_rank needs row_rank");
+  TT_CHECK_ARG(B >= 1 && B < ((int64_t)1 << 30) && D >= 1 && D <= 256, "tt_score_fwd_sym_bf16: bad shape B=%lld D=%d", (long long)B, D);
+  if (2.f * fabsf(inv_t) > 80.f) {
+    tt_set_error("tt_score_fwd_sym_bf16: 1/temperature = %g: fixed-shift softmax needs 2/T <= 80", inv_t);
+    return TT_ERR_UNSUPPORTED;
+  }
+  tt_ctx sized = *ctx;
+  sized.num_cus = 256;                                     // the layout must not depend on the device: it sizes the workspace
+  const SymLayout L = sym_layout(&sized, B, D);
+  if (workspace_bytes < L.bytes) {
+    tt_set_error("tt_score_fwd_sym_bf16: workspace %zu < required %zu", workspace_bytes, L.bytes);
+    return TT_ERR_WORKSPACE;
+  }
+  char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
+  const float ab = ab_scale == 0.f ? 1.f : ab_scale;
+  const bool unit = ab == inv_t * kLog2e;                  // exactly: the caller got the scale from tt_score_unit_scale(inv_t)
+  SymArgs g{};
+  g.a_rows = view(N_packed, B, D).rows;
+  g.b_rows = view(C_packed, B, D).rows;
+  g.R = (int)B; g.nT = L.nT; g.NI = L.NI; g.Rp = L.Rp;
+  g.c1 = inv_t * kLog2e / ab;
+  g.c2 = -shift * kLog2e;
+  g.rs = reinterpret_cast<float*>(ws + L.off_rs);
+  g.mb = reinterpret_cast<float*>(ws + L.off_mb);
+  g.ma = reinterpret_cast<float*>(ws + L.off_ma);
+  g.cs = reinterpret_cast<float*>(ws + L.off_cs);
+  g.diag_raw = reinterpret_cast<float*>(ws + L.off_diag);
+  g.want_rank = want_rank ? 1 : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)L.n_groups, (unsigned)L.n_chunks);
+  const size_t slot_bytes = sizeof(float) * 3 * kSymWaves * L.NI * 32;
+#define TT_SYM(KS)                                                                                                      \
+  do {                                                                                                                  \
+    const size_t lds = slot_bytes + 2 * SymStage<KS>::kBytes;                                                           \
+    if (unit) score_fwd_sym_kernel<KS, true><<<grid, kSymThreads, lds, st>>>(g);                                        \
+    else score_fwd_sym_kernel<KS, false><<<grid, kSymThreads, lds, st>>>(g);                                            \
+  } while (0)
+  if (L.Dp == 32) TT_SYM(2);
+  else if (L.Dp == 64) TT_SYM(4);
+  else if (L.Dp == 128) TT_SYM(8);
+  else TT_SYM(16);
+#undef TT_SYM
+  TT_LAUNCH_CHECK();
+  Fin1Args f{};
+  f.rs = g.rs; f.mb = g.mb; f.ma = g.ma; f.cs = g.cs; f.diag_raw = g.diag_raw;
+  f.n_groups = L.n_groups; f.n_chunks = L.n_chunks; f.R = (int)B; f.KS = L.Dp / 16; f.Rp = L.Rp;
+  f.kexp = exp2f(g.c2); f.unscale = inv_t / ab; f.shift = shift; f.unit = unit ? 1 : 0; f.want_rank = g.want_rank;
+  f.rowsum = rowsum; f.colsum = colsum; f.inv_row = inv_row; f.inv_col = inv_col; f.diag = diag; f.row_rank = row_rank;
+  f.a_rows = g.a_rows; f.b_rows = g.b_rows;
+  f.part = reinterpret_cast<float*>(ws + L.off_part);
+  score_sym_finish1_kernel<<<(unsigned)L.n_wg, 256, 0, st>>>(f);
+  TT_LAUNCH_CHECK();
+  score_sym_finish2_kernel<<<1, 1024, 0, st>>>(f.part, L.n_wg, L.Dp, (float)B, f.unscale, out8, loss_out);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+}  // extern "C"

@@ -419,6 +419,24 @@ def score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank=True, full_rank=Tru
     return out + ((f[4][:B], f[5][:B]),) if with_inv else out
 
 
+def score_fwd_sym(Np, Cp, B, D, inv_t, shift, scale_n: float = 1.0, want_rank: bool = True):
+    """Single-pass symmetric forward of the square problem (tt_score_fwd_sym_bf16): returns (rowsum, colsum, diag, row_rank,
+    (inv_row, inv_col), out8, loss) -- loss its own 0-dim tensor so that autograd sees a plain output."""
+    dev = Np.device
+    Bp = (B + 3) // 4 * 4                                              # keep every row 16-byte aligned
+    f = torch.empty((5, Bp), dtype=torch.float32, device=dev)         # rowsum, colsum, diag, 1/rowsum', 1/colsum'
+    rank = torch.empty(B, dtype=torch.int32, device=dev)
+    out8 = torch.empty(8, dtype=torch.float32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    lib = L.load()
+    ws = L.workspace(dev, lib.tt_score_fwd_sym_workspace_bytes(B, D))
+    with _timed("tt_score_fwd_sym_bf16"):
+        L.check(lib.tt_score_fwd_sym_bf16(L.ctx(dev), L.ptr(Np), L.ptr(Cp), B, D, inv_t, shift, scale_n, int(want_rank), L.ptr(f[0]), L.ptr(f[1]),
+                                          L.ptr(f[3]), L.ptr(f[4]), L.ptr(f[2]), L.ptr(rank), L.ptr(out8), L.ptr(loss), L.ptr(ws), ws.numel(),
+                                          L.stream(dev)), "tt_score_fwd_sym_bf16")
+    return f[0][:B], f[1][:B], f[2][:B], rank, (f[3][:B], f[4][:B]), out8, loss
+
+
 def score_bwd_bf16(Np, Cp, B, D, inv_t, shift, rowsum, colsum, d_loss, scale, scale_n: float = 1.0, inv=None):
     """inv: (inv_row, inv_col) from score_fwd_bf16(..., with_inv=True) with the same scale_n (optional)."""
     dev = Np.device

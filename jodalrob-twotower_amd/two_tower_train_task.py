@@ -22,6 +22,7 @@ LAZY_SIM_BATCH = 2048
 
 
 _PRESCALE = __import__("os").environ.get("TT_SCORE_PRESCALE", "1") != "0"      # TT_SCORE_PRESCALE=0: unscaled operand images (A/B)
+_SYM_FWD = __import__("os").environ.get("TT_SCORE_SYM_FWD", "1") != "0"        # TT_SCORE_SYM_FWD=0: the two-direction forward kernel (A/B)
 
 
 class _ScoreCEFn(torch.autograd.Function):
@@ -43,6 +44,15 @@ class _ScoreCEFn(torch.autograd.Function):
             else:
                 scale_n = ops.score_unit_scale(inv_t) if (scale_n is None and _PRESCALE) else (scale_n or 1.0)
                 Np, Cp = ops.score_pack2_bf16(n, c, scale_n, 1.0)
+            if not want_col_rank and not full_rank and _SYM_FWD:
+                # steady state of training: ONE sweep of the B x B tiles serves both softmax directions (tt_score_fwd_sym_bf16)
+                rowsum, colsum, diag, row_rank, inv, out8, loss = ops.score_fwd_sym(Np, Cp, B, D, inv_t, shift, scale_n, True)
+                ctx.packed = (Np, Cp, scale_n, inv)
+                ctx.save_for_backward(n, c, rowsum, colsum)
+                ctx.inv_t, ctx.shift = inv_t, shift
+                ctx.mark_non_differentiable(out8, row_rank)
+                ctx.set_materialize_grads(False)
+                return loss, out8, row_rank
             rowsum, colsum, diag, row_rank, col_rank, sumscore, inv = ops.score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank,
                                                                                          full_rank, scale_n, with_inv=True)
             if not want_col_rank:

@@ -1308,3 +1308,53 @@ def test_bf16_step_vs_rounded_oracle(tt, schema_real, tmp_path, rows_per_tower, 
             assert report[n_] <= (bd["dense_grad_matrix_norm"] if p.ndim > 1 else bd["dense_grad_vector_norm"]), (n_, report[n_])
     assert rows_equal                                                               # touched-row set: bit-exact
     assert report["row_grads"] <= bd["row_grad_norm"], report["row_grads"]
+
+
+@pytest.mark.parametrize("B,D,T", [(300, 64, 1.0), (129, 16, 0.5), (64, 6, 0.25), (1000, 128, 1.0), (257, 200, 2.0), (2048, 64, 1.0), (70, 32, 1.0),
+                                   (8192, 64, 1.0), (33, 64, 1.0), (1, 8, 1.0), (4100, 64, 0.5)])
+@pytest.mark.parametrize("prescale", [True, False])
+def test_score_sym_forward(tt, B, D, T, prescale):
+    """tt_score_fwd_sym_bf16 (every tile of S computed ONCE for both softmax directions) against (a) the two-direction kernel
+    on the same packed operands -- exp-sums 1e-5, the diagonal and the top-1 flags bit for bit -- and (b) the f64 oracle fed
+    the same bf16-rounded operands: loss 2e-6, metrics; twice the same bits."""
+    from jodalrob_twotower_amd import ops
+    rng = np.random.default_rng(B * 7 + D)
+    n = rng.standard_normal((B, D)).astype(np.float32)
+    c = (0.6 * n + rng.standard_normal((B, D))).astype(np.float32)              # correlated: some positives ARE the row maximum
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    if B > 8:
+        c[5] = c[3]                                                              # exact ties: duplicated company rows
+        n[7] = n[2]
+    inv_t = 1.0 / T
+    sn = ops.score_unit_scale(inv_t) if prescale else 1.0
+    tn, tc = torch.from_numpy(n).to(DEV), torch.from_numpy(c).to(DEV)
+    Np, Cp = ops.score_pack2_bf16(tn, tc, sn, 1.0)
+    rs, cs, dg, rk, (ir, ic), out8, loss = ops.score_fwd_sym(Np, Cp, B, D, inv_t, abs(inv_t), sn, True)
+    old = ops.score_fwd_bf16(Np, Cp, B, D, inv_t, abs(inv_t), True, False, sn, with_inv=True)
+    o_out8, o_loss = ops.score_loss_finish(B, abs(inv_t), *old[:6])
+    torch.testing.assert_close(rs, old[0], rtol=1e-5, atol=0)
+    torch.testing.assert_close(cs, old[1], rtol=1e-5, atol=0)
+    assert torch.equal(dg, old[2])                                               # the positives: the same MFMA results
+    assert torch.equal(rk, old[3])                                               # top-1 flags incl. the tie rules
+    torch.testing.assert_close(ir, old[6][0], rtol=1e-5, atol=0)
+    torch.testing.assert_close(ic, old[6][1], rtol=1e-5, atol=0)
+    np.testing.assert_allclose(loss.item(), o_loss.item(), rtol=2e-6, atol=2e-7)
+    for k in (1, 2):
+        assert out8[k].item() == pytest.approx(o_out8[k].item(), rel=1e-6, abs=1e-7)
+    if B > 1:
+        np.testing.assert_allclose(out8[3].item(), o_out8[3].item(), rtol=2e-3, atol=2e-6)      # sum of scores: (sum n).(sum c) vs 67 M adds
+    # the oracle on the same rounded operands
+    nb = (torch.from_numpy(n) * np.float32(sn)).bfloat16().float().numpy().astype(np.float64) / float(np.float32(sn))
+    cb = torch.from_numpy(c).bfloat16().float().numpy().astype(np.float64)
+    ref_loss, met, S, lse = O.score_ce_fwd(nb, cb, T)
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=2e-6, atol=2e-7)
+    np.testing.assert_allclose(out8[2].item(), met["positive_similarity_mean"], rtol=1e-4, atol=1e-6)
+    if B > 1:
+        np.testing.assert_allclose(out8[3].item(), met["negative_similarity_mean"], rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(rs.cpu().numpy(), np.exp(S - abs(inv_t)).sum(1), rtol=2e-5)
+    np.testing.assert_allclose(cs.cpu().numpy(), np.exp(S - abs(inv_t)).sum(0), rtol=2e-5)
+    # bitwise reproducible
+    again = ops.score_fwd_sym(Np, Cp, B, D, inv_t, abs(inv_t), sn, True)
+    assert torch.equal(again[0], rs) and torch.equal(again[1], cs) and again[6].item() == loss.item()
+    assert torch.equal(again[5].nan_to_num(nan=-7.0), out8.nan_to_num(nan=-7.0))            # (B = 1: the off-diagonal mean is nan, as torch)

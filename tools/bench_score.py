@@ -15,6 +15,7 @@ ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--no-col-rank", action="store_true")
 ap.add_argument("--top1", action="store_true")
 ap.add_argument("--prescale", action="store_true", help="pack the notice image times inv_t*log2(e): the kernels' unit form")
+ap.add_argument("--sym", action="store_true", help="single-pass symmetric forward (tt_score_fwd_sym_bf16) instead of the two-direction kernel")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 B, D = a.batch, a.dim
@@ -28,7 +29,11 @@ for i in range(a.iters + 5):
     sn = ops.score_unit_scale(1.0) if a.prescale else 1.0
     Np, Cp = ops.score_pack_bf16(n, sn), ops.score_pack_bf16(c)
     ev[1].record()
-    rs, cs, dg, rr, cr, ss, inv = ops.score_fwd_bf16(Np, Cp, B, D, 1.0, 1.0, not a.no_col_rank, not a.top1, sn, with_inv=True)
+    if a.sym:
+        rs, cs, dg, rr, inv, out8, loss = ops.score_fwd_sym(Np, Cp, B, D, 1.0, 1.0, sn, True)
+    else:
+        rs, cs, dg, rr, cr, ss, inv = ops.score_fwd_bf16(Np, Cp, B, D, 1.0, 1.0, not a.no_col_rank, not a.top1, sn, with_inv=True)
+        out8, loss = ops.score_loss_finish(B, 1.0, rs, cs, dg, rr, rr, ss)
     ev[2].record()
     dN, dC = ops.score_bwd_bf16(Np, Cp, B, D, 1.0, 1.0, rs, cs, one, 1.0 / (2 * B), sn, inv if a.prescale else None)
     ev[3].record()
