@@ -360,6 +360,8 @@ typedef struct tt_score_bwd_dir {
   float* dA;             /* [Ra, D] f32 */
   float ab_scale;        /* as in tt_score_fwd_dir */
   float b_scale;         /* scale of the B image alone (0 = 1): dA is divided by it */
+  /* sumexp_b and inv_b are read a whole 32-row tile at a time: [round_up(Rb, 32)] readable floats, the entries past Rb
+     finite (and non-zero in sumexp_b); 16-byte aligned */
   const float* inv_a;    /* [Ra] / [Rb] or NULL: tt_score_fwd_dir.inv_sumexp of the A rows' direction and of the B rows' */
   const float* inv_b;    /* direction (16-byte aligned); NULL = reciprocals of sumexp_a / sumexp_b are taken in the kernel */
 } tt_score_bwd_dir;
@@ -378,7 +380,8 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
 /* Single-pass symmetric forward of the SQUARE training problem (B notice rows against the B company rows of the same
  * pairs; replaces two_tower_train_task.py:99-179's mm + two cross-entropies + metrics): every 32 x 32 tile of S is computed
  * once and feeds both softmax directions.  Inputs: the two packed operand images (tt_score_pack_bf16 / the tower pass);
- * ab_scale as tt_score_fwd_dir.ab_scale.  Outputs, all [B]: rowsum / colsum (shifted exp-sums, as tt_score_fwd_bf16's
+ * ab_scale as tt_score_fwd_dir.ab_scale.  Outputs: rowsum / colsum / inv_row / inv_col are [round_up(B, 64)] (the entries past B
+ * are written too -- 1 and 0 -- so that they can go straight into tt_score_bwd_bf16), diag and row_rank [B]: rowsum / colsum (shifted exp-sums, as tt_score_fwd_bf16's
  * sumexp of the two directions), inv_row / inv_col (tt_score_fwd_dir.inv_sumexp of the two directions: what
  * tt_score_bwd_bf16 takes as inv_a / inv_b), diag (s_ii / T), row_rank (want_rank != 0: 0 where the positive is the row's
  * first maximum, else 1); out8 / loss_out as tt_score_loss_finish (out8[5], the column-direction top-1 rate, is 0 here).

@@ -346,7 +346,35 @@ __global__ __launch_bounds__(NW * 64) void score_fwd_bf16_kernel(FwdArgs args) {
 }
 
 // ---- backward --------------------------------------------------------------------------------------
-template <int KS, int AT, int NW, bool PF_B, bool EARLY_BM, bool UNIT>
+// One tile's worth of streamed operands: the b tile's fragments for the first product, its fragment-ordered image for the
+// second, and the 16 softmax reciprocals (or exp-sums) of its rows this lane half needs.
+template <int KS>
+struct BwdTile {
+  bf16x8 b[KS];
+  bf16x8 bm[2][KS / 2];
+  float4 iv[4];
+};
+
+template <int KS>
+__device__ __forceinline__ void bwd_tile_load(BwdTile<KS>& T, const __bf16* __restrict__ b_rows, const __bf16* __restrict__ b_frag,
+                                              const float* __restrict__ ivsrc, int t, int c, int h) {
+  constexpr int Dp = KS * 16, DT = KS / 2;
+  load_bfrag<KS>(b_rows, t, c, h, T.b);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+      T.bm[s][d] = *reinterpret_cast<const bf16x8*>(b_frag + (((((int64_t)t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
+#pragma unroll
+  for (int q = 0; q < 4; ++q) T.iv[q] = *reinterpret_cast<const float4*>(ivsrc + 32 * t + 4 * h + 8 * q);
+}
+
+// Structure of the tile loop: TWO operand buffers, the loop unrolled over them, every load issued unconditionally (past the
+// wave's last tile: that tile again) and in a fixed order.  The first version prefetched under `if (t + NW < nT)` and loaded
+// the reciprocals inside the tile body: hipcc then cannot count the loads in flight and drained them all (s_waitcnt
+// vmcnt(0)) twice per tile -- the prefetch never overlapped anything and the kernel ran at a third of its issue rate.
+// The per-row reciprocal arrays must be readable up to a multiple of 32 rows (tt_score_bwd_dir).
+template <int KS, int AT, int NW, bool UNIT>
 __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
   constexpr int Dp = KS * 16, ROWS = 32 * AT, DT = KS / 2;
   __shared__ float red[(NW / 2) * ROWS * Dp];
@@ -387,79 +415,62 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
     for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dacc[i][d][r] = 0.f;
-  bf16x8 bnext[PF_B ? KS : 1];
-  if (PF_B && wave < nT) load_bfrag<KS>(dr.b_rows, wave, c, h, reinterpret_cast<bf16x8(&)[KS]>(bnext));
-  for (int t = wave; t < nT; t += NW) {
-    f32x16 acc[AT];
-    bf16x8 bcur[KS];
-    if (PF_B) {
-#pragma unroll
-      for (int s = 0; s < KS; ++s) bcur[s] = bnext[PF_B ? s : 0];
-      if (t + NW < nT) load_bfrag<KS>(dr.b_rows, t + NW, c, h, reinterpret_cast<bf16x8(&)[KS]>(bnext));
-    } else {
-      load_bfrag<KS>(dr.b_rows, t, c, h, bcur);
-    }
-    // operands of the second product: optionally issued now, consumed after the first product + softmax weights
-    bf16x8 bm[2][DT];
-    if (EARLY_BM) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int d = 0; d < DT; ++d)
-          bm[s][d] = *reinterpret_cast<const bf16x8*>(dr.b_frag + (((((int64_t)t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
-    }
-    mfma1<KS, AT>(bcur, ares, acc);
+  const bool have_inv = inv_b != nullptr;                      // wave-uniform
+  const float* const ivsrc = have_inv ? inv_b : dr.sumexp_b;
+  const int tlast = nT - 1;
+  auto compute = [&](const BwdTile<KS>& T, int t) {
     const int b_lo = 32 * t;
     float ib[16];
-    if (b_lo + 31 < Rb) {
-      if (inv_b) {                                       // the forward pass left 1 / sum: no reciprocals (quarter rate) per tile
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = *reinterpret_cast<const float4*>(inv_b + b_lo + 4 * h + 8 * q);
-          ib[4 * q + 0] = v.x; ib[4 * q + 1] = v.y; ib[4 * q + 2] = v.z; ib[4 * q + 3] = v.w;
-        }
-      } else {
+    for (int q = 0; q < 4; ++q) { ib[4 * q] = T.iv[q].x; ib[4 * q + 1] = T.iv[q].y; ib[4 * q + 2] = T.iv[q].z; ib[4 * q + 3] = T.iv[q].w; }
+    if (!have_inv) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 v = *reinterpret_cast<const float4*>(dr.sumexp_b + b_lo + 4 * h + 8 * q);
-          ib[4 * q + 0] = __builtin_amdgcn_rcpf(v.x) * kx; ib[4 * q + 1] = __builtin_amdgcn_rcpf(v.y) * kx;
-          ib[4 * q + 2] = __builtin_amdgcn_rcpf(v.z) * kx; ib[4 * q + 3] = __builtin_amdgcn_rcpf(v.w) * kx;
-        }
-      }
-    } else {
+      for (int r = 0; r < 16; ++r) ib[r] = __builtin_amdgcn_rcpf(ib[r]) * kx;
+    }
+    if (b_lo + 31 >= Rb) {                                     // the ragged last tile: rows past the end weigh nothing
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int b = b_lo + rowmap(r, h);
-        ib[r] = b < Rb ? (inv_b ? inv_b[b] : __builtin_amdgcn_rcpf(dr.sumexp_b[b]) * kx) : 0.f;
-      }
+      for (int r = 0; r < 16; ++r) ib[r] = b_lo + rowmap(r, h) < Rb ? ib[r] : 0.f;
     }
     const bool band = !(b_lo + 31 < posmin || b_lo > posmax);
-    bf16x8 wf[AT][2];
 #pragma unroll
     for (int i = 0; i < AT; ++i) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T.b[s], ares[i][s], acc, 0, 0, 0);
       float w[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        w[r] = (UNIT ? __builtin_amdgcn_exp2f(acc[i][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][r], c1, c2))) * (ia[i] + ib[r]);
+        w[r] = (UNIT ? __builtin_amdgcn_exp2f(acc[r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], c1, c2))) * (ia[i] + ib[r]);
+      if (b_lo + 31 >= Rb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = b_lo + rowmap(r, h) < Rb ? w[r] : 0.f;
+      }
       if (band) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (b_lo + rowmap(r, h) == pos[i]) w[r] -= 2.f;
       }
+      bf16x8 wf[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wf[i][s][j] = (__bf16)w[8 * s + j];
+        for (int j = 0; j < 8; ++j) wf[s][j] = (__bf16)w[8 * s + j];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) dacc[i][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], T.bm[s][d], dacc[i][d], 0, 0, 0);
     }
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int d = 0; d < DT; ++d) {
-        if (!EARLY_BM)
-          bm[s][d] = *reinterpret_cast<const bf16x8*>(dr.b_frag + (((((int64_t)t * 2 + s) * 2 + h) * Dp + 32 * d + c) * 8));
-#pragma unroll
-        for (int i = 0; i < AT; ++i) dacc[i][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i][s], bm[s][d], dacc[i][d], 0, 0, 0);
-      }
+  };
+  BwdTile<KS> T0, T1;
+  bwd_tile_load<KS>(T0, dr.b_rows, dr.b_frag, ivsrc, min(wave, tlast), c, h);
+  __builtin_amdgcn_sched_barrier(0);                           // (issue order pinned: see the forward kernels)
+  for (int t = wave; t < nT; t += 2 * NW) {
+    bwd_tile_load<KS>(T1, dr.b_rows, dr.b_frag, ivsrc, min(t + NW, tlast), c, h);
+    compute(T0, t);
+    bwd_tile_load<KS>(T0, dr.b_rows, dr.b_frag, ivsrc, min(t + 2 * NW, tlast), c, h);
+    if (t + NW < nT) compute(T1, t + NW);
   }
   // fixed-order tree over the NW waves: upper half writes, lower half adds
 #pragma unroll
@@ -614,26 +625,18 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int Dp = padded_d(D);
   static const int bvar = getenv("TT_SCORE_BWD_VARIANT") ? atoi(getenv("TT_SCORE_BWD_VARIANT")) : 0;
-#define TT_BWD(KS, AT, NW, PF, EB)                                                                             \
+#define TT_BWD(KS, AT, NW)                                                                                     \
   do {                                                                                                         \
     const dim3 grid((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs);                                      \
-    if (unit) score_bwd_bf16_kernel<KS, AT, NW, PF, EB, true><<<grid, NW * 64, 0, st>>>(a);                    \
-    else score_bwd_bf16_kernel<KS, AT, NW, PF, EB, false><<<grid, NW * 64, 0, st>>>(a);                        \
+    if (unit) score_bwd_bf16_kernel<KS, AT, NW, true><<<grid, NW * 64, 0, st>>>(a);                            \
+    else score_bwd_bf16_kernel<KS, AT, NW, false><<<grid, NW * 64, 0, st>>>(a);                                \
   } while (0)
-  if (Dp == 32) TT_BWD(2, 2, 8, true, true);
+  if (Dp == 32) TT_BWD(2, 2, 8);
   else if (Dp == 64) {
-    switch (bvar) {
-      case 1: TT_BWD(4, 2, 8, false, false); break;
-      case 2: TT_BWD(4, 2, 8, false, true); break;
-      case 3: TT_BWD(4, 1, 8, true, true); break;
-      case 4: TT_BWD(4, 1, 8, false, true); break;
-      case 5: TT_BWD(4, 1, 8, false, false); break;
-      case 6: TT_BWD(4, 2, 8, true, false); break;
-      case 7: TT_BWD(4, 2, 8, false, true); break;
-      default: TT_BWD(4, 2, 8, true, true); break;       // both operand prefetches: 56.6 us vs 57.8 (0), 65.7 (1), 61.7 (6), no spills
-    }
-  } else if (Dp == 128) TT_BWD(8, 1, 8, false, true);
-  else TT_BWD(16, 1, 4, false, true);
+    if (bvar == 1) TT_BWD(4, 1, 8);
+    else TT_BWD(4, 2, 8);
+  } else if (Dp == 128) TT_BWD(8, 1, 8);
+  else TT_BWD(16, 1, 4);
 #undef TT_BWD
   TT_LAUNCH_CHECK();
   return TT_OK;

@@ -316,6 +316,9 @@ __global__ __launch_bounds__(256) void score_sym_finish1_kernel(Fin1Args f) {
         f.row_rank[i] = rk;
         hit = rk == 0 ? 1.f : 0.f;
       }
+    } else {
+      // rows past the end, up to this workgroup's 64: tt_score_bwd_bf16 reads the reciprocals a whole 32-row tile at a time
+      f.inv_row[i] = 0.f; f.inv_col[i] = 0.f; f.rowsum[i] = 1.f; f.colsum[i] = 1.f;
     }
     float v[3] = {l, hit, dsum};                           // butterfly inside the one wave that holds the rows
 #pragma unroll

@@ -404,8 +404,8 @@ def score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank=True, full_rank=Tru
     """Both softmax directions of the square in-batch problem in one launch.  scale_n: the scale Np was packed with.
     with_inv: also return (inv_row, inv_col), the reciprocals score_bwd_bf16 can take instead of computing its own."""
     dev = Np.device
-    Bp = (B + 3) // 4 * 4                                              # keep every row 16-byte aligned
-    f = torch.empty((6, Bp), dtype=torch.float32, device=dev)         # rowsum, colsum, diag, sumscore, 1/rowsum', 1/colsum'
+    Bp = (B + 63) // 64 * 64                                           # tt_score_bwd_bf16 reads its per-row arrays a 32-row tile at a time
+    f = (torch.empty if B == Bp else torch.ones)((6, Bp), dtype=torch.float32, device=dev)    # rowsum, colsum, diag, sumscore, 1/rowsum', 1/colsum'
     ranks = torch.empty((2, B), dtype=torch.int32, device=dev)
     arr = (L.ScoreFwdDir * 2)()
     rm = 2 if full_rank else 1
@@ -423,7 +423,7 @@ def score_fwd_sym(Np, Cp, B, D, inv_t, shift, scale_n: float = 1.0, want_rank: b
     """Single-pass symmetric forward of the square problem (tt_score_fwd_sym_bf16): returns (rowsum, colsum, diag, row_rank,
     (inv_row, inv_col), out8, loss) -- loss its own 0-dim tensor so that autograd sees a plain output."""
     dev = Np.device
-    Bp = (B + 3) // 4 * 4                                              # keep every row 16-byte aligned
+    Bp = (B + 63) // 64 * 64                                           # the kernel fills the entries past B (read by tt_score_bwd_bf16)
     f = torch.empty((5, Bp), dtype=torch.float32, device=dev)         # rowsum, colsum, diag, 1/rowsum', 1/colsum'
     rank = torch.empty(B, dtype=torch.int32, device=dev)
     out8 = torch.empty(8, dtype=torch.float32, device=dev)
@@ -469,10 +469,21 @@ def score_fwd_bf16_rect(Ap0, Bp0, Ap1, Bp1, Ra, Rb, off, D, inv_t, shift, full_r
     return f[0][:Ra], f[1][:Ra], f[2][:Ra], ranks[0], ranks[1], f[3][:Ra]
 
 
+def _tile_padded(t: torch.Tensor) -> torch.Tensor:
+    """per-row float array readable a whole 32-row tile at a time (tt_score_bwd_dir): ragged sizes get a padded copy"""
+    n = t.numel()
+    if n % 32 == 0 and t.is_contiguous():
+        return t
+    out = torch.ones((n + 31) // 32 * 32, dtype=t.dtype, device=t.device)
+    out[:n] = t
+    return out
+
+
 def score_bwd_bf16_rect(Ap0, Bp0, Ap1, Bp1, Ra, Rb, off, D, inv_t, shift, sa0, sb0, sa1, sb1, d_loss, scale):
     """dA0 [Ra, D], dA1 [Ra, D]: sa* = sum-exp of the A rows (this direction), sb* = sum-exp of the B rows in the OTHER
     direction (all Rb of them: gathered from their owners)."""
     dev = Ap0.device
+    sb0, sb1 = _tile_padded(sb0), _tile_padded(sb1)
     d0 = torch.empty((Ra, D), dtype=torch.float32, device=dev)
     d1 = torch.empty((Ra, D), dtype=torch.float32, device=dev)
     arr = (L.ScoreBwdDir * 2)()
