@@ -105,20 +105,23 @@ __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
   // stage loader: thread t copies bytes [16 t, 16 t + 16) (+ 8 KB per further load) of the stage's tiles; tiles past the
   // image's end are clamped to its last tile (their results are never used)
   const int nst = (I1 - I0 + TS - 1) / TS;
-  uint4 sreg[LPT];
+  // (two named registers, not an array behind the lambdas: at LPT = 2 hipcc kept the array in scratch memory and every stage
+  //  paid a store, a reload and a full vmcnt(0) drain -- two thirds of the D = 256 kernel's wave time was that wait)
+  static_assert(LPT <= 2, "stage loader holds at most two 16-byte pieces per thread");
+  uint4 sreg0 = make_uint4(0, 0, 0, 0), sreg1 = make_uint4(0, 0, 0, 0);
+  auto stage_addr = [&](int st, int q) -> const uint4* {
+    const int off = (q * kSymThreads + (int)threadIdx.x) * 16;             // byte offset inside the stage
+    const int tl = off / (KS * 1024);                                      // tile of the stage this piece belongs to
+    const int tile = min(I0 + st * TS + tl, nT - 1);
+    return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g.a_rows) + (int64_t)tile * (KS * 1024) + (off - tl * KS * 1024));
+  };
   auto stage_load = [&](int st) {
-#pragma unroll
-    for (int q = 0; q < LPT; ++q) {
-      const int off = (q * kSymThreads + (int)threadIdx.x) * 16;           // byte offset inside the stage
-      const int tl = off / (KS * 1024);                                    // tile of the stage this chunk belongs to
-      const int tile = min(I0 + st * TS + tl, nT - 1);
-      sreg[q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g.a_rows) + (int64_t)tile * (KS * 1024) + (off - tl * KS * 1024));
-    }
+    sreg0 = *stage_addr(st, 0);
+    if (LPT > 1) sreg1 = *stage_addr(st, 1);
   };
   auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < LPT; ++q)
-      *reinterpret_cast<uint4*>(stage + buf * ST::kBytes + (q * kSymThreads + (int)threadIdx.x) * 16) = sreg[q];
+    *reinterpret_cast<uint4*>(stage + buf * ST::kBytes + (int)threadIdx.x * 16) = sreg0;
+    if (LPT > 1) *reinterpret_cast<uint4*>(stage + buf * ST::kBytes + (kSymThreads + (int)threadIdx.x) * 16) = sreg1;
   };
   stage_load(0);
   for (int st = 0; st < nst; ++st) {
@@ -130,14 +133,17 @@ __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
 #pragma unroll
       for (int tl = 0; tl < TS; ++tl) {
         const int I = I0 + st * TS + tl;
+        // the tile's fragments in one burst of LDS reads (left to itself hipcc reads two, waits, issues two MFMAs, reads two
+        // ...: at D = 256 every second MFMA then pays a full LDS round trip), the MFMA chain behind counted lgkmcnt waits
+        bf16x8 af[KS];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(sb + (((tl * KS + s) * 2 + h) * 32 + c) * 16);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const bf16x8 af = *reinterpret_cast<const bf16x8*>(sb + (((tl * KS + s) * 2 + h) * 32 + c) * 16);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bres[s], af, acc, 0, 0, 0);
-        }
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bres[s], af[s], acc, 0, 0, 0);
         const int il = (I - I0) * 32 + c;
         if (I < I1 && I != J && I < n_full && jfull) {     // plain tile: 32 x 32 valid scores, all on one side of the positives
           float e[16];
