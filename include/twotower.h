@@ -392,6 +392,24 @@ int tt_score_fwd_sym_bf16(tt_ctx* ctx, const void* N_packed, const void* C_packe
                           float shift, float ab_scale, int32_t want_rank, float* rowsum, float* colsum, float* inv_row,
                           float* inv_col, float* diag, int32_t* row_rank, float* out8, float* loss_out, void* workspace,
                           size_t workspace_bytes, tt_stream stream);
+/* fp8 (OCP e4m3) form of the score kernels -- BASELINE.json configs[4] (final_embedding_dim 256, batch 65536): the S products
+ * run on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 MFMA rate), f32 accumulate; softmax, loss and the gradient
+ * products (softmax weights x bf16 operand images) as on the bf16 path.  Per-tensor scale: the images hold
+ * fp8(64 * scale * x), the factor 2^6 leaves again through the instruction's block scales, so ab_scale / b_scale mean what
+ * they mean in the bf16 calls.  tt_score_pack2_fp8 writes, per operand, the fp8 rows image followed by the bf16
+ * fragment image (tt_score_pack_fp8_bytes(R, D) bytes, 16-byte aligned).  tt_score_fwd_sym_fp8 = tt_score_fwd_sym_bf16
+ * on such operands (same workspace); tt_score_bwd_fp8 = tt_score_bwd_bf16 on such operands (always the workgroup-staged
+ * form).  Tolerance: tests/test_gpu_parity.py::test_score_fp8_vs_rounded_oracle (the f64 oracle fed the same e4m3-rounded
+ * operands). */
+size_t tt_score_pack_fp8_bytes(int64_t R, int32_t D);
+int tt_score_pack2_fp8(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0, const float* X1, int64_t R1,
+                       void* packed1, int32_t D, float scale0, float scale1, tt_stream stream);
+int tt_score_fwd_sym_fp8(tt_ctx* ctx, const void* N_packed, const void* C_packed, int64_t B, int32_t D, float inv_t,
+                         float shift, float ab_scale, int32_t want_rank, float* rowsum, float* colsum, float* inv_row,
+                         float* inv_col, float* diag, int32_t* row_rank, float* out8, float* loss_out, void* workspace,
+                         size_t workspace_bytes, tt_stream stream);
+int tt_score_bwd_fp8(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t,
+                     float shift, const float* d_loss, float scale, tt_stream stream);
 /* dense score matrix S[Ra, Rb] = A Bm^T * inv_t (result["similarity_matrix"], predict_batch
  * "all_similarities": two_tower_train_task.py:94, :206) */
 int tt_score_matrix(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D,

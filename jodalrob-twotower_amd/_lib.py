@@ -108,6 +108,10 @@ SIGNATURES = {
     "tt_score_pack2_bf16": (C.c_int, [vp, vp, i64, vp, vp, i64, vp, i32, f32, f32, vp]),
     "tt_score_fwd_bf16": (C.c_int, [vp, C.POINTER(ScoreFwdDir), i32, i32, f32, f32, vp]),
     "tt_score_bwd_bf16": (C.c_int, [vp, C.POINTER(ScoreBwdDir), i32, i32, f32, f32, vp, f32, vp]),
+    "tt_score_pack_fp8_bytes": (sz, [i64, i32]),
+    "tt_score_pack2_fp8": (C.c_int, [vp, vp, i64, vp, vp, i64, vp, i32, f32, f32, vp]),
+    "tt_score_fwd_sym_fp8": (C.c_int, [vp, vp, vp, i64, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "tt_score_bwd_fp8": (C.c_int, [vp, C.POINTER(ScoreBwdDir), i32, i32, f32, f32, vp, f32, vp]),
     "tt_score_fwd_sym_workspace_bytes": (sz, [i64, i32]),
     "tt_score_fwd_sym_bf16": (C.c_int, [vp, vp, vp, i64, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "tt_score_matrix": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, vp, i64, vp]),

@@ -511,6 +511,258 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
   }
 }
 
+// ---- backward, large-batch form ---------------------------------------------------------------------
+// When there are enough rows a for every SIMD to own its own (Ra / 64 x directions >= ~1024), nothing has to be split along b:
+// a workgroup is 4 waves, ONE per SIMD with the whole 512-register file (amdgpu_waves_per_eu(1, 1)), each wave owns two
+// 32-row tiles of a -- A fragments (2 x KS) and the dA accumulators (2 x Dp / 32 tiles of 16 registers: 256 at D = 256) stay
+// in registers for the whole sweep -- and ALL four waves stream the same b tiles, staged ONCE per workgroup through LDS
+// (rows image + fragment image + the 32 reciprocals of a tile: 32 KB at D = 256, double buffered).  The b-split form above
+// reads those 32 KB once per WAVE: 268 GB of L2 traffic at B = 65536, D = 256, which is what bounded it (15 TB/s at 23 %
+// MFMA busy); here it is 34 GB.  No cross-wave reduction at the end: a wave's rows are its own.
+// Inside a wave the two a tiles give the matrix pipe independent work while the VALU forms the softmax weights: S(0) S(1)
+// | E(0) beside S(1) | dA(0) | E(1) beside dA(0) | dA(1).
+// FP8: the S products take fp8 operands (rows images in the layout of tt_score_bf16.h, K = 64 per MFMA at twice the bf16 rate,
+// half the A-fragment registers and half the staged bytes); the second products stay bf16.
+template <int KS, bool UNIT, bool FP8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void score_bwd_rows_kernel(BwdArgs args) {
+  constexpr int AT = 2, NWV = 4, DT = KS / 2, Dp = KS * 16, K64 = FP8 ? KS / 4 : 1;
+  constexpr int kRowsB = FP8 ? KS * 512 : KS * 1024, kFragB = KS * 1024, kIvB = 256, kStageB = kRowsB + kFragB + kIvB;
+  constexpr int kPieces = (kRowsB + kFragB) / 16, kPPT = (kPieces + 255) / 256;   // 16-byte pieces per thread per stage (last one ragged)
+  static_assert(!FP8 || KS % 4 == 0, "fp8 operands come in K = 64 steps");
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const bool d1 = blockIdx.y != 0;
+  DirBwd dr;
+  dr.a_rows = d1 ? args.d[1].a_rows : args.d[0].a_rows;
+  dr.b_rows = d1 ? args.d[1].b_rows : args.d[0].b_rows;
+  dr.b_frag = d1 ? args.d[1].b_frag : args.d[0].b_frag;
+  dr.sumexp_a = d1 ? args.d[1].sumexp_a : args.d[0].sumexp_a;
+  dr.sumexp_b = d1 ? args.d[1].sumexp_b : args.d[0].sumexp_b;
+  dr.dA = d1 ? args.d[1].dA : args.d[0].dA;
+  const float c1 = d1 ? args.d[1].c1 : args.d[0].c1, out_scale = d1 ? args.d[1].out_scale : args.d[0].out_scale;
+  const float* const inv_a = d1 ? args.d[1].inv_a : args.d[0].inv_a;
+  const float* const inv_b = d1 ? args.d[1].inv_b : args.d[0].inv_b;
+  const float c2 = args.c2, kx = UNIT ? args.kexp : 1.f;
+  const int Ra = (int)(d1 ? args.d[1].Ra : args.d[0].Ra), Rb = (int)(d1 ? args.d[1].Rb : args.d[0].Rb);
+  const int off = (int)(d1 ? args.d[1].off : args.d[0].off);
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nT = (Rb + 31) / 32, nTa_img = (int)(rup(Ra, 64) / 32);
+  const int at0 = ((int)blockIdx.x * NWV + wave) * AT;                      // this wave's first a tile
+  if ((int)blockIdx.x * NWV * AT * 32 >= Ra) return;                        // (whole workgroup)
+  bf16x8 ares[AT][FP8 ? 1 : KS];
+  i32x8 ares8[AT][K64];
+  float ia[AT];
+  int pos[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+    if (FP8) load_f8frag<K64>(reinterpret_cast<const char*>(dr.a_rows), min(at0 + i, nTa_img - 1), c, h, ares8[i]);
+    else load_bfrag<(FP8 ? 1 : KS)>(dr.a_rows, min(at0 + i, nTa_img - 1), c, h, ares[i]);
+    const int a = 32 * (at0 + i) + c;
+    ia[i] = a < Ra ? (inv_a ? inv_a[a] : __builtin_amdgcn_rcpf(dr.sumexp_a[a]) * kx) : 0.f;
+    pos[i] = a + off;
+  }
+  const int posmin = 32 * at0 + off, posmax = 32 * (at0 + AT) - 1 + off;
+  f32x16 dacc[AT][DT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i)
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc[i][d][r] = 0.f;
+  const bool have_inv = inv_b != nullptr;
+  const float* const ivsrc = have_inv ? inv_b : dr.sumexp_b;
+  // stage loader: pieces p = tid + 256 q of the tile's [rows image | fragment image]; both images are contiguous per tile.
+  // ONE load site inside the loop (iteration -1 only loads), plain unrolled loops over the register array: behind lambdas or
+  // a macro hipcc kept the array in scratch memory (a store, a reload and a vmcnt(0) drain per stage)
+  // The copy runs in TWO halves so that only kPPT / 2 pieces are live in registers at a time (at D = 256 the A fragments
+  // alone are 128 registers): half 0 (the rows image's share) is loaded while the previous tile's second product runs and
+  // stored before this tile's barrier; half 1 is loaded before the S products and stored behind them.  Named registers, one
+  // load site each: behind lambdas / arrays hipcc kept them in scratch memory (a store, a reload and a vmcnt(0) drain per stage).
+  constexpr int kHalf = (kPPT + 1) / 2;                    // half 0: pieces [0, kHalf), half 1: [kHalf, kPPT) (a piece index past kPieces is skipped)
+  static_assert(kHalf >= 1 && kHalf <= 4, "stage loader: at most eight pieces per thread");
+  uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
+  float4 ivreg = make_float4(0.f, 0.f, 0.f, 0.f);
+#define TT_PIECE_SRC(q, tn)                                                                                                      \
+  ((tid + 256 * (q)) < kRowsB / 16 ? reinterpret_cast<const char*>(dr.b_rows) + (int64_t)(tn) * kRowsB + (tid + 256 * (q)) * 16  \
+                                   : reinterpret_cast<const char*>(dr.b_frag) + (int64_t)(tn) * kFragB + ((tid + 256 * (q)) - kRowsB / 16) * 16)
+#define TT_PIECE_OK(j, q0) (kHalf > (j) && (q0) + (j) < kPPT && (((q0) + (j) + 1) * 256 <= kPieces || tid + 256 * ((q0) + (j)) < kPieces))
+#define TT_PIECE_ST(j, var, q0) if (TT_PIECE_OK(j, q0)) *reinterpret_cast<uint4*>(base + (tid + 256 * ((q0) + (j))) * 16) = var
+#define TT_PIECE_LD(j, var, q0, tn) if (TT_PIECE_OK(j, q0)) var = *reinterpret_cast<const uint4*>(TT_PIECE_SRC((q0) + (j), tn))
+#define TT_HALF_LOAD(q0, tn) do { TT_PIECE_LD(0, p0, q0, tn); TT_PIECE_LD(1, p1, q0, tn); TT_PIECE_LD(2, p2, q0, tn); TT_PIECE_LD(3, p3, q0, tn); } while (0)
+#define TT_HALF_STORE(q0, buf)                                                                        \
+  do {                                                                                                \
+    char* base = lds_raw + (buf) * kStageB;                                                           \
+    TT_PIECE_ST(0, p0, q0); TT_PIECE_ST(1, p1, q0); TT_PIECE_ST(2, p2, q0); TT_PIECE_ST(3, p3, q0);   \
+  } while (0)
+  // prologue: tile 0 completely into buffer 0, then half 0 of tile 1 into registers
+  TT_HALF_LOAD(0, 0);
+  TT_HALF_STORE(0, 0);
+  TT_HALF_LOAD(kHalf, 0);
+  if (tid < 8) ivreg = *reinterpret_cast<const float4*>(ivsrc + 4 * tid);
+  TT_HALF_STORE(kHalf, 0);
+  if (tid < 8) *reinterpret_cast<float4*>(lds_raw + kRowsB + kFragB + tid * 16) = ivreg;
+  TT_HALF_LOAD(0, min(1, nT - 1));
+  for (int t = 0; t < nT; ++t) {
+    const int tn = min(t + 1, nT - 1), nb = (t + 1) & 1;
+    __syncthreads();                                       // buffer t & 1 complete; buffer nb no longer read by anyone
+    TT_HALF_STORE(0, nb);                                  // half 0 of tile t + 1 (loaded during the previous tile)
+    TT_HALF_LOAD(kHalf, tn);                               // half 1 of tile t + 1: in flight during the S products
+    if (tid < 8) ivreg = *reinterpret_cast<const float4*>(ivsrc + 32 * tn + 4 * tid);
+    const char* rb = lds_raw + (t & 1) * kStageB;
+    const char* fb = rb + kRowsB;
+    const float* ivp = reinterpret_cast<const float*>(fb + kFragB);
+    const int b_lo = 32 * t;
+    // S tiles of both a tiles: the b fragments are read once, four at a time
+    f32x16 acc[AT];
+#pragma unroll
+    for (int i = 0; i < AT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    if (FP8) {
+#pragma unroll
+      for (int s0 = 0; s0 < K64; s0 += 2) {
+        i32x8 bf8[2];
+#pragma unroll
+        for (int j = 0; j < 2 && s0 + j < K64; ++j) {
+          const char* q = rb + ((s0 + j) * 4 + h) * 512 + c * 16;
+          const i32x4 lo = *reinterpret_cast<const i32x4*>(q);
+          const i32x4 hi = *reinterpret_cast<const i32x4*>(q + 1024);
+          bf8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < 2 && s0 + j < K64; ++j)
+#pragma unroll
+          for (int i = 0; i < AT; ++i) acc[i] = mfma_f8(bf8[j], ares8[i][s0 + j], acc[i]);
+      }
+    } else {
+#pragma unroll
+      for (int s0 = 0; s0 < (FP8 ? 1 : KS); s0 += 4) {
+        bf16x8 bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(rb + (((s0 + j) * 2 + h) * 32 + c) * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < AT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], ares[i][FP8 ? 0 : s0 + j], acc[i], 0, 0, 0);
+      }
+    }
+    TT_HALF_STORE(kHalf, nb);                              // half 1 of tile t + 1 has had the S products' time to land
+    if (tid < 8) *reinterpret_cast<float4*>(lds_raw + nb * kStageB + kRowsB + kFragB + tid * 16) = ivreg;
+    TT_HALF_LOAD(0, min(t + 2, nT - 1));                   // half 0 of tile t + 2: in flight during the second products
+    float ib[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(ivp + 4 * h + 8 * q);
+      ib[4 * q] = v.x; ib[4 * q + 1] = v.y; ib[4 * q + 2] = v.z; ib[4 * q + 3] = v.w;
+    }
+    if (!have_inv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ib[r] = __builtin_amdgcn_rcpf(ib[r]) * kx;
+    }
+    const bool ragged = b_lo + 31 >= Rb;
+    if (ragged) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ib[r] = b_lo + rowmap(r, h) < Rb ? ib[r] : 0.f;
+    }
+    const bool band = !(b_lo + 31 < posmin || b_lo > posmax);
+#pragma unroll
+    for (int i = 0; i < AT; ++i) {
+      float w[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        w[r] = (UNIT ? __builtin_amdgcn_exp2f(acc[i][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][r], c1, c2))) * (ia[i] + ib[r]);
+      if (ragged) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = b_lo + rowmap(r, h) < Rb ? w[r] : 0.f;
+      }
+      if (band) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (b_lo + rowmap(r, h) == pos[i]) w[r] -= 2.f;
+      }
+      bf16x8 wf[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[s][j] = (__bf16)w[8 * s + j];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int d0 = 0; d0 < DT; d0 += 4) {
+          bf16x8 bm[4];
+#pragma unroll
+          for (int j = 0; j < 4 && d0 + j < DT; ++j)
+            bm[j] = *reinterpret_cast<const bf16x8*>(fb + (((s * 2 + h) * Dp + 32 * (d0 + j) + c) * 16));
+#pragma unroll
+          for (int j = 0; j < 4 && d0 + j < DT; ++j)
+            dacc[i][d0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], bm[j], dacc[i][d0 + j], 0, 0, 0);
+        }
+    }
+  }
+  const float g = args.d_loss[0] * out_scale;
+#pragma unroll
+  for (int i = 0; i < AT; ++i)
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int a = 32 * (at0 + i) + rowmap(r, h);
+        const int dd = 32 * d + c;
+        if (a < Ra && dd < args.D) dr.dA[(int64_t)a * args.D + dd] = dacc[i][d][r] * g;
+      }
+}
+#undef TT_PIECE_SRC
+#undef TT_PIECE_OK
+#undef TT_PIECE_ST
+#undef TT_PIECE_LD
+#undef TT_HALF_LOAD
+#undef TT_HALF_STORE
+
+// ---- fp8 pack: [fp8 rows image | bf16 fragment image] (tt_score_bf16.h) -------------------------------------
+__global__ __launch_bounds__(256) void pack_fp8_kernel(PackBatch batch, int D, int Dp) {
+  const PackArgs& pa = batch.a[blockIdx.y];
+  const float* __restrict__ X = pa.X;
+  const int64_t R = pa.R, Rp = pa.Rp;
+  char* __restrict__ rows8 = reinterpret_cast<char*>(pa.rows);
+  __bf16* __restrict__ frag = pa.frag;
+  const float sc = pa.scale;
+  const int64_t n8 = Rp * Dp / 16, nfr = Rp * Dp / 8;      // 16-byte chunks of the two images
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int cpt = Dp * 2;                                   // fp8 chunks per 32-row tile
+  for (int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ci < n8 + nfr; ci += stride) {
+    if (ci < n8) {
+      const int64_t t = ci / cpt;
+      const int w = (int)(ci - t * cpt), row_in = w & 31, g5 = w >> 5;
+      const int d0 = 64 * (g5 >> 2) + 32 * (g5 & 1) + 16 * ((g5 >> 1) & 1);
+      const int64_t row = 32 * t + row_in;
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = (row < R && d0 + j < D) ? X[row * D + d0 + j] * sc * kFp8Up : 0.f;
+      i32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int u = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q], v[4 * q + 1], 0, false);
+        u = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * q + 2], v[4 * q + 3], u, true);
+        o[q] = u;
+      }
+      *reinterpret_cast<i32x4*>(rows8 + ci * 16) = o;
+    } else {                                               // fragment-ordered bf16 image [t][s][h][d][8], as pack_bf16_kernel
+      const int64_t f = ci - n8;
+      const int d = (int)(f % Dp);
+      const int64_t rest = f / Dp;
+      const int h = (int)(rest & 1), s = (int)((rest >> 1) & 1);
+      const int64_t t = rest >> 2;
+      bf16x8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t row = 32 * t + 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+        v[j] = (__bf16)((row < R && d < D) ? X[row * D + d] * sc : 0.f);
+      }
+      *reinterpret_cast<bf16x8*>(frag + f * 8) = v;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -631,6 +883,28 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
     if (unit) score_bwd_bf16_kernel<KS, AT, NW, true><<<grid, NW * 64, 0, st>>>(a);                            \
     else score_bwd_bf16_kernel<KS, AT, NW, false><<<grid, NW * 64, 0, st>>>(a);                                \
   } while (0)
+  // enough rows for every SIMD to own 64 of them: the workgroup-staged form (no split along b, operands shared through LDS)
+  const int rows_min = getenv("TT_SCORE_BWD_ROWS_MIN") ? atoi(getenv("TT_SCORE_BWD_ROWS_MIN")) : 32768;   // (read per call: tests switch forms)
+  if (maxRa >= rows_min && Dp >= 64) {
+#define TT_BWD_ROWS(KS)                                                                                        \
+  do {                                                                                                         \
+    const dim3 grid((unsigned)tt_cdiv(maxRa, 256), (unsigned)n_dirs);                                          \
+    const size_t lds = 2 * (size_t)(KS * 2048 + 256);                                                          \
+    if (unit) {                                                                                                \
+      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      score_bwd_rows_kernel<KS, true, false><<<grid, 256, lds, st>>>(a);                                       \
+    } else {                                                                                                   \
+      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      score_bwd_rows_kernel<KS, false, false><<<grid, 256, lds, st>>>(a);                                      \
+    }                                                                                                          \
+  } while (0)
+    if (Dp == 64) TT_BWD_ROWS(4);
+    else if (Dp == 128) TT_BWD_ROWS(8);
+    else TT_BWD_ROWS(16);
+#undef TT_BWD_ROWS
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+  }
   if (Dp == 32) TT_BWD(2, 2, 8);
   else if (Dp == 64) {
     if (bvar == 1) TT_BWD(4, 1, 8);
@@ -638,6 +912,80 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
   } else if (Dp == 128) TT_BWD(8, 1, 8);
   else TT_BWD(16, 1, 4);
 #undef TT_BWD
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+size_t tt_score_pack_fp8_bytes(int64_t R, int32_t D) {
+  if (R < 0 || D < 1 || D > 256) return 0;
+  return (size_t)(3 * rup(R > 0 ? R : 1, 64) * padded_d8(D));
+}
+
+int tt_score_pack2_fp8(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0, const float* X1, int64_t R1, void* packed1,
+                       int32_t D, float scale0, float scale1, tt_stream stream) {
+  TT_CHECK_ARG(ctx && X0 && packed0, "tt_score_pack2_fp8: NULL argument");
+  TT_CHECK_ARG(R0 >= 1 && D >= 1 && D <= 256 && (X1 == nullptr || (packed1 && R1 >= 1)), "tt_score_pack2_fp8: bad shape");
+  TT_CHECK_ARG(tt_aligned(packed0, 16) && tt_aligned(packed1, 16), "tt_score_pack2_fp8: packed buffers must be 16-byte aligned");
+  const int Dp = padded_d8(D);
+  PackBatch b{};
+  const int n = X1 ? 2 : 1;
+  int64_t maxchunks = 1;
+  for (int i = 0; i < n; ++i) {
+    const int64_t R = i ? R1 : R0, Rp = rup(R, 64);
+    char* base = reinterpret_cast<char*>(i ? packed1 : packed0);
+    const float sc = i ? scale1 : scale0;
+    b.a[i] = PackArgs{i ? X1 : X0, R, Rp, reinterpret_cast<__bf16*>(base), reinterpret_cast<__bf16*>(base + Rp * Dp), sc == 0.f ? 1.f : sc};
+    const int64_t chunks = Rp * Dp / 16 + Rp * Dp / 8;
+    maxchunks = chunks > maxchunks ? chunks : maxchunks;
+  }
+  int64_t grid = tt_cdiv(maxchunks, 256);
+  const int64_t cap = (int64_t)ctx->num_cus * 4;
+  if (grid > cap) grid = cap;
+  pack_fp8_kernel<<<dim3((unsigned)grid, (unsigned)n), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(b, D, Dp);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_score_bwd_fp8(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t, float shift,
+                     const float* d_loss, float scale, tt_stream stream) {
+  TT_CHECK_ARG(ctx && dirs && d_loss && (n_dirs == 1 || n_dirs == 2), "tt_score_bwd_fp8: need 1 or 2 directions");
+  TT_CHECK_ARG(D >= 1 && D <= 256, "tt_score_bwd_fp8: D=%d not in [1,256]", D);
+  BwdArgs a{};
+  int64_t maxRa = 0;
+  bool unit = true;
+  for (int i = 0; i < 2; ++i) {
+    const tt_score_bwd_dir& d = dirs[i < n_dirs ? i : 0];
+    TT_CHECK_ARG(d.A_packed && d.B_packed && d.sumexp_a && d.sumexp_b && d.dA && d.Ra >= 1 && d.Rb >= 1, "tt_score_bwd_fp8: bad direction %d", i);
+    TT_CHECK_ARG(tt_aligned(d.sumexp_b, 16) && (d.inv_b == nullptr || tt_aligned(d.inv_b, 16)), "tt_score_bwd_fp8: per-row arrays must be 16-byte aligned");
+    const PackedView8 va = view8(d.A_packed, d.Ra, D), vb = view8(d.B_packed, d.Rb, D);
+    const float ab = d.ab_scale == 0.f ? 1.f : d.ab_scale, bs = d.b_scale == 0.f ? 1.f : d.b_scale;
+    a.d[i] = DirBwd{reinterpret_cast<const __bf16*>(va.rows8), reinterpret_cast<const __bf16*>(vb.rows8), vb.frag, d.Ra, d.Rb, d.diag_offset,
+                    d.sumexp_a, d.sumexp_b, d.dA, inv_t * kLog2e / ab, scale / bs, d.inv_a, d.inv_b};
+    unit = unit && ab == inv_t * kLog2e;
+    maxRa = d.Ra > maxRa ? d.Ra : maxRa;
+  }
+  a.c2 = -shift * kLog2e;
+  a.kexp = exp2f(a.c2);
+  a.d_loss = d_loss;
+  a.D = D;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int Dp = padded_d8(D);
+#define TT_BWD8(KS)                                                                                            \
+  do {                                                                                                         \
+    const dim3 grid((unsigned)tt_cdiv(maxRa, 256), (unsigned)n_dirs);                                          \
+    const size_t lds = 2 * (size_t)(KS * 512 + KS * 1024 + 256);                                               \
+    if (unit) {                                                                                                \
+      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      score_bwd_rows_kernel<KS, true, true><<<grid, 256, lds, st>>>(a);                                        \
+    } else {                                                                                                   \
+      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      score_bwd_rows_kernel<KS, false, true><<<grid, 256, lds, st>>>(a);                                       \
+    }                                                                                                          \
+  } while (0)
+  if (Dp == 64) TT_BWD8(4);
+  else if (Dp == 128) TT_BWD8(8);
+  else TT_BWD8(16);
+#undef TT_BWD8
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

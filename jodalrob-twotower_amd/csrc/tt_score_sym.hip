@@ -51,8 +51,8 @@ __device__ __forceinline__ float half_max(float x) {
 }
 
 struct SymArgs {
-  const __bf16* a_rows;                // notice image (rows image), may carry the exponent scale
-  const __bf16* b_rows;                // company image
+  const void* a_rows;                  // notice image (rows image: bf16, or fp8 for the FP8 kernels), may carry the exponent scale
+  const void* b_rows;                  // company image
   int R, nT, NI;                       // rows, 32-row tiles, notice tiles per workgroup
   int64_t Rp;                          // slab row stride (floats)
   float c1, c2;                        // non-unit form: exp2(acc * c1 + c2)
@@ -67,18 +67,20 @@ struct SymArgs {
 // the L2's ~11 TB/s, not at its VALU rate.  A stage = TS tiles (8 KB; 16 KB at D = 256) in the images' own fragment order, so
 // the copy is verbatim (16 bytes per thread) and a wave's ds_read_b128 of a fragment is 1 KB contiguous: conflict-free.
 // Double buffered, one barrier per stage; the next stage's global loads are in flight while this one is computed.
-template <int KS>
+template <int KS, bool FP8>
 struct SymStage {
-  static constexpr int TS = KS <= 2 ? 4 : (KS <= 4 ? 2 : 1);               // tiles per stage
-  static constexpr int kBytes = TS * KS * 1024;
+  static constexpr int kTileB = FP8 ? KS * 512 : KS * 1024;                 // bytes of one 32-row tile of the rows image
+  static constexpr int TS = kTileB <= 2048 ? 4 : (kTileB <= 4096 ? 2 : 1); // tiles per stage
+  static constexpr int kBytes = TS * kTileB;
   static constexpr int LPT = kBytes / (kSymThreads * 16);                   // 16-byte loads per thread per stage
   static_assert(LPT >= 1 && LPT * kSymThreads * 16 == kBytes, "stage must be whole 16-byte loads");
 };
 
-template <int KS, bool UNIT>
+template <int KS, bool UNIT, bool FP8>
 __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
-  using ST = SymStage<KS>;
-  constexpr int TS = ST::TS, LPT = ST::LPT;
+  using ST = SymStage<KS, FP8>;
+  constexpr int TS = ST::TS, LPT = ST::LPT, kTileB = ST::kTileB, K64 = FP8 ? KS / 4 : 1;
+  static_assert(!FP8 || KS % 4 == 0, "fp8 operands come in K = 64 steps");
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [3][8 waves][NI * 32] slots | 2 stage buffers
   const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -97,8 +99,10 @@ __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
   float colacc[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) colacc[r] = 0.f;
-  bf16x8 bres[KS];
-  load_bfrag<KS>(g.b_rows, active ? J : 0, c, h, bres);
+  bf16x8 bres[FP8 ? 1 : KS];
+  i32x8 bres8[K64];
+  if (FP8) load_f8frag<K64>(reinterpret_cast<const char*>(g.b_rows), active ? J : 0, c, h, bres8);
+  else load_bfrag<(FP8 ? 1 : KS)>(reinterpret_cast<const __bf16*>(g.b_rows), active ? J : 0, c, h, bres);
   const int n_full = R / 32;                               // tiles below n_full hold 32 valid rows
   const bool jfull = active && J < n_full;
   float dg_keep = kNegBig;                                 // the positives of tile J (met once per wave, if J is in this chunk)
@@ -111,9 +115,9 @@ __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
   uint4 sreg0 = make_uint4(0, 0, 0, 0), sreg1 = make_uint4(0, 0, 0, 0);
   auto stage_addr = [&](int st, int q) -> const uint4* {
     const int off = (q * kSymThreads + (int)threadIdx.x) * 16;             // byte offset inside the stage
-    const int tl = off / (KS * 1024);                                      // tile of the stage this piece belongs to
+    const int tl = off / kTileB;                                           // tile of the stage this piece belongs to
     const int tile = min(I0 + st * TS + tl, nT - 1);
-    return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g.a_rows) + (int64_t)tile * (KS * 1024) + (off - tl * KS * 1024));
+    return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g.a_rows) + (int64_t)tile * kTileB + (off - tl * kTileB));
   };
   auto stage_load = [&](int st) {
     sreg0 = *stage_addr(st, 0);
@@ -135,15 +139,23 @@ __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
         const int I = I0 + st * TS + tl;
         // the tile's fragments in one burst of LDS reads (left to itself hipcc reads two, waits, issues two MFMAs, reads two
         // ...: at D = 256 every second MFMA then pays a full LDS round trip), the MFMA chain behind counted lgkmcnt waits
-        bf16x8 af[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) af[s] = *reinterpret_cast<const bf16x8*>(sb + (((tl * KS + s) * 2 + h) * 32 + c) * 16);
-        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (FP8) {
+          i32x8 af8[K64];
+          load_f8frag<K64>(sb, tl, c, h, af8);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bres[s], af[s], acc, 0, 0, 0);
+          for (int s = 0; s < K64; ++s) acc = mfma_f8(bres8[s], af8[s], acc);
+        } else {
+          bf16x8 af[FP8 ? 1 : KS];
+#pragma unroll
+          for (int s = 0; s < (FP8 ? 1 : KS); ++s) af[s] = *reinterpret_cast<const bf16x8*>(sb + (((tl * KS + s) * 2 + h) * 32 + c) * 16);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s = 0; s < (FP8 ? 1 : KS); ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bres[s], af[s], acc, 0, 0, 0);
+        }
         const int il = (I - I0) * 32 + c;
         if (I < I1 && I != J && I < n_full && jfull) {     // plain tile: 32 x 32 valid scores, all on one side of the positives
           float e[16];
@@ -228,7 +240,8 @@ struct Fin1Args {
   float kexp, unscale, shift;
   int unit, want_rank;
   float* rowsum; float* colsum; float* inv_row; float* inv_col; float* diag; int32_t* row_rank;
-  const __bf16* a_rows; const __bf16* b_rows;
+  const void* a_rows; const void* b_rows;
+  int fp8;                             // the rows images hold fp8 (tt_score_bf16.h) instead of bf16
   float* part;                         // [n_wg][4 + 2 * Dp]: l, hits, dsum, (pad), U[Dp], V[Dp]
 };
 
@@ -267,36 +280,77 @@ __global__ __launch_bounds__(256) void score_sym_finish1_kernel(Fin1Args f) {
     red[2][q][lane] = slab_max4(f.mb, f.Rp, f.n_groups, q, i);
     red[3][q][lane] = slab_max4(f.ma, f.Rp, f.n_groups, q, i);
   }
-  // column sums of the images over this workgroup's 2 tiles: chunk id = (k-step * 2 + half) * 32 + row, 16 bytes each
+  // column sums of the images over this workgroup's 2 tiles.  bf16: chunk id = (k-step * 2 + half) * 32 + row, 8 values of
+  // columns 16 ks + 8 half + j.  fp8: chunk id = ((k64-step * 2 + part) * 2 + half) * 32 + row, 16 values of columns
+  // 64 s + 32 half + 16 part + j (as stored: the factor 64 is taken out again below).
   __shared__ float cols[2][256];
-  const int chunks = f.KS * 64;                            // per tile
-  for (int img = 0; img < 2; ++img) {
-    const __bf16* base = img ? f.b_rows : f.a_rows;
-    for (int ch0 = 0; ch0 < chunks; ch0 += 256) {
-      const int ch = ch0 + t;
-      float acc8[8];
+  if (!f.fp8) {
+    const int chunks = f.KS * 64;                          // per tile
+    for (int img = 0; img < 2; ++img) {
+      const __bf16* base = reinterpret_cast<const __bf16*>(img ? f.b_rows : f.a_rows);
+      for (int ch0 = 0; ch0 < chunks; ch0 += 256) {
+        const int ch = ch0 + t;
+        float acc8[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
-      if (ch < chunks) {
+        for (int j = 0; j < 8; ++j) acc8[j] = 0.f;
+        if (ch < chunks) {
 #pragma unroll
-        for (int qq = 0; qq < kFinRows / 32; ++qq) {
-          const int64_t tile = (int64_t)blockIdx.x * (kFinRows / 32) + qq;
-          if (tile * 32 < f.R) {                           // (rows beyond R inside a tile are zero in the image)
-            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(base + (tile * chunks + ch) * 8);
+          for (int qq = 0; qq < kFinRows / 32; ++qq) {
+            const int64_t tile = (int64_t)blockIdx.x * (kFinRows / 32) + qq;
+            if (tile * 32 < f.R) {                         // (rows beyond R inside a tile are zero in the image)
+              const bf16x8 vv = *reinterpret_cast<const bf16x8*>(base + (tile * chunks + ch) * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc8[j] += (float)vv[j];
+              for (int j = 0; j < 8; ++j) acc8[j] += (float)vv[j];
+            }
           }
         }
+        // the 32 threads of a (k-step, half) group hold the 32 rows: butterfly over the low 5 lane bits
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc8[j] += __shfl_xor(acc8[j], o);
+        if (ch < chunks && (t & 31) == 0) {
+          const int dbase = (ch >> 5) * 8;                 // (k-step * 2 + half) * 8 = first column of the chunk
+#pragma unroll
+          for (int j = 0; j < 8; ++j) cols[img][dbase + j] = acc8[j];
+        }
       }
-      // the 32 threads of a (k-step, half) group hold the 32 rows: butterfly over the low 5 lane bits
+    }
+  } else {
+    const int chunks = f.KS * 32;                          // 16-byte chunks per tile: Dp * 32 / 16
+    for (int img = 0; img < 2; ++img) {
+      const char* base = reinterpret_cast<const char*>(img ? f.b_rows : f.a_rows);
+      for (int ch0 = 0; ch0 < chunks; ch0 += 256) {
+        const int ch = ch0 + t;
+        float acc16[16];
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1)
+        for (int j = 0; j < 16; ++j) acc16[j] = 0.f;
+        if (ch < chunks) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc8[j] += __shfl_xor(acc8[j], o);
-      if (ch < chunks && (t & 31) == 0) {
-        const int dbase = (ch >> 5) * 8;                   // (k-step * 2 + half) * 8 = first column of the chunk
+          for (int qq = 0; qq < kFinRows / 32; ++qq) {
+            const int64_t tile = (int64_t)blockIdx.x * (kFinRows / 32) + qq;
+            if (tile * 32 < f.R) {
+              const i32x4 vv = *reinterpret_cast<const i32x4*>(base + (tile * chunks + ch) * 16);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) cols[img][dbase + j] = acc8[j];
+              for (int w4 = 0; w4 < 4; ++w4) {
+                acc16[4 * w4 + 0] += __builtin_amdgcn_cvt_f32_fp8(vv[w4], 0);
+                acc16[4 * w4 + 1] += __builtin_amdgcn_cvt_f32_fp8(vv[w4], 1);
+                acc16[4 * w4 + 2] += __builtin_amdgcn_cvt_f32_fp8(vv[w4], 2);
+                acc16[4 * w4 + 3] += __builtin_amdgcn_cvt_f32_fp8(vv[w4], 3);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc16[j] += __shfl_xor(acc16[j], o);
+        if (ch < chunks && (t & 31) == 0) {
+          const int g5 = ch >> 5;                          // (s * 2 + part) * 2 + half
+          const int dbase = 64 * (g5 >> 2) + 32 * (g5 & 1) + 16 * ((g5 >> 1) & 1);
+#pragma unroll
+          for (int j = 0; j < 16; ++j) cols[img][dbase + j] = acc16[j] * (1.f / kFp8Up);
+        }
       }
     }
   }
@@ -416,12 +470,82 @@ inline SymLayout sym_layout(const tt_ctx* ctx, int64_t R, int D) {
   L.off_ma = take(sizeof(float) * L.n_groups * L.Rp);
   L.off_cs = take(sizeof(float) * L.n_chunks * L.Rp);
   L.off_diag = take(sizeof(float) * L.Rp);
-  L.off_part = take(sizeof(float) * L.n_wg * (4 + 2 * L.Dp));
+  L.off_part = take(sizeof(float) * L.n_wg * (4 + 2 * 256));   // (sized for the widest record: fp8 operands pad D up to 64)
   L.bytes = o + 256;
   return L;
 }
 
 }  // namespace
+
+static int sym_forward(tt_ctx* ctx, const void* N_packed, const void* C_packed, int64_t B, int32_t D, float inv_t, float shift,
+                       float ab_scale, int32_t want_rank, float* rowsum, float* colsum, float* inv_row, float* inv_col, float* diag,
+                       int32_t* row_rank, float* out8, float* loss_out, void* workspace, size_t workspace_bytes, tt_stream stream,
+                       bool fp8, const char* who) {
+  TT_CHECK_ARG(ctx && N_packed && C_packed && rowsum && colsum && inv_row && inv_col && diag && out8 && workspace, "%s: NULL argument", who);
+  TT_CHECK_ARG(!want_rank || row_rank, "%s: want_rank needs row_rank", who);
+  TT_CHECK_ARG(B >= 1 && B < ((int64_t)1 << 30) && D >= 1 && D <= 256, "%s: bad shape B=%lld D=%d", who, (long long)B, D);
+  if (2.f * fabsf(inv_t) > 80.f) {
+    tt_set_error("%s: 1/temperature = %g: fixed-shift softmax needs 2/T <= 80", who, inv_t);
+    return TT_ERR_UNSUPPORTED;
+  }
+  tt_ctx sized = *ctx;
+  sized.num_cus = 256;                                     // the layout must not depend on the device: it sizes the workspace
+  SymLayout L = sym_layout(&sized, B, D);
+  if (fp8) L.Dp = padded_d8(D);                            // (the part record is sized for 256 columns: sym_layout)
+  if (workspace_bytes < L.bytes) {
+    tt_set_error("%s: workspace %zu < required %zu", who, workspace_bytes, L.bytes);
+    return TT_ERR_WORKSPACE;
+  }
+  char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
+  const float ab = ab_scale == 0.f ? 1.f : ab_scale;
+  const bool unit = ab == inv_t * kLog2e;                  // exactly: the caller got the scale from tt_score_unit_scale(inv_t)
+  SymArgs g{};
+  g.a_rows = fp8 ? static_cast<const void*>(view8(N_packed, B, D).rows8) : static_cast<const void*>(view(N_packed, B, D).rows);
+  g.b_rows = fp8 ? static_cast<const void*>(view8(C_packed, B, D).rows8) : static_cast<const void*>(view(C_packed, B, D).rows);
+  g.R = (int)B; g.nT = L.nT; g.NI = L.NI; g.Rp = L.Rp;
+  g.c1 = inv_t * kLog2e / ab;
+  g.c2 = -shift * kLog2e;
+  g.rs = reinterpret_cast<float*>(ws + L.off_rs);
+  g.mb = reinterpret_cast<float*>(ws + L.off_mb);
+  g.ma = reinterpret_cast<float*>(ws + L.off_ma);
+  g.cs = reinterpret_cast<float*>(ws + L.off_cs);
+  g.diag_raw = reinterpret_cast<float*>(ws + L.off_diag);
+  g.want_rank = want_rank ? 1 : 0;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const dim3 grid((unsigned)L.n_groups, (unsigned)L.n_chunks);
+  const size_t slot_bytes = sizeof(float) * 3 * kSymWaves * L.NI * 32;
+#define TT_SYM(KS, F8)                                                                                                  \
+  do {                                                                                                                  \
+    const size_t lds = slot_bytes + 2 * SymStage<KS, F8>::kBytes;                                                       \
+    if (unit) score_fwd_sym_kernel<KS, true, F8><<<grid, kSymThreads, lds, st>>>(g);                                    \
+    else score_fwd_sym_kernel<KS, false, F8><<<grid, kSymThreads, lds, st>>>(g);                                        \
+  } while (0)
+  if (fp8) {
+    if (L.Dp == 64) TT_SYM(4, true);
+    else if (L.Dp == 128) TT_SYM(8, true);
+    else TT_SYM(16, true);
+  } else {
+    if (L.Dp == 32) TT_SYM(2, false);
+    else if (L.Dp == 64) TT_SYM(4, false);
+    else if (L.Dp == 128) TT_SYM(8, false);
+    else TT_SYM(16, false);
+  }
+#undef TT_SYM
+  TT_LAUNCH_CHECK();
+  Fin1Args f{};
+  f.rs = g.rs; f.mb = g.mb; f.ma = g.ma; f.cs = g.cs; f.diag_raw = g.diag_raw;
+  f.n_groups = L.n_groups; f.n_chunks = L.n_chunks; f.R = (int)B; f.KS = L.Dp / 16; f.Rp = L.Rp;
+  f.kexp = exp2f(g.c2); f.unscale = inv_t / ab; f.shift = shift; f.unit = unit ? 1 : 0; f.want_rank = g.want_rank;
+  f.rowsum = rowsum; f.colsum = colsum; f.inv_row = inv_row; f.inv_col = inv_col; f.diag = diag; f.row_rank = row_rank;
+  f.a_rows = g.a_rows; f.b_rows = g.b_rows;
+  f.fp8 = fp8 ? 1 : 0;
+  f.part = reinterpret_cast<float*>(ws + L.off_part);
+  score_sym_finish1_kernel<<<(unsigned)L.n_wg, 256, 0, st>>>(f);
+  TT_LAUNCH_CHECK();
+  score_sym_finish2_kernel<<<1, 1024, 0, st>>>(f.part, L.n_wg, L.Dp, (float)B, f.unscale, out8, loss_out);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
 
 extern "C" {
 
@@ -436,63 +560,16 @@ int tt_score_fwd_sym_bf16(tt_ctx* ctx, const void* N_packed, const void* C_packe
                           float ab_scale, int32_t want_rank, float* rowsum, float* colsum, float* inv_row, float* inv_col,
                           float* diag, int32_t* row_rank, float* out8, float* loss_out, void* workspace, size_t workspace_bytes,
                           tt_stream stream) {
-  TT_CHECK_ARG(ctx && N_packed && C_packed && rowsum && colsum && inv_row && inv_col && diag && out8 && workspace,
-               "tt_score_fwd_sym_bf16: NULL argument");
-  TT_CHECK_ARG(!want_rank || row_rank, "tt_score_fwd_sym_bf16: want_rank needs row_rank");
-  TT_CHECK_ARG(B >= 1 && B < ((int64_t)1 << 30) && D >= 1 && D <= 256, "tt_score_fwd_sym_bf16: bad shape B=%lld D=%d", (long long)B, D);
-  if (2.f * fabsf(inv_t) > 80.f) {
-    tt_set_error("tt_score_fwd_sym_bf16: 1/temperature = %g: fixed-shift softmax needs 2/T <= 80", inv_t);
-    return TT_ERR_UNSUPPORTED;
-  }
-  tt_ctx sized = *ctx;
-  sized.num_cus = 256;                                     // the layout must not depend on the device: it sizes the workspace
-  const SymLayout L = sym_layout(&sized, B, D);
-  if (workspace_bytes < L.bytes) {
-    tt_set_error("tt_score_fwd_sym_bf16: workspace %zu < required %zu", workspace_bytes, L.bytes);
-    return TT_ERR_WORKSPACE;
-  }
-  char* ws = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(workspace) + 255) & ~uintptr_t(255));
-  const float ab = ab_scale == 0.f ? 1.f : ab_scale;
-  const bool unit = ab == inv_t * kLog2e;                  // exactly: the caller got the scale from tt_score_unit_scale(inv_t)
-  SymArgs g{};
-  g.a_rows = view(N_packed, B, D).rows;
-  g.b_rows = view(C_packed, B, D).rows;
-  g.R = (int)B; g.nT = L.nT; g.NI = L.NI; g.Rp = L.Rp;
-  g.c1 = inv_t * kLog2e / ab;
-  g.c2 = -shift * kLog2e;
-  g.rs = reinterpret_cast<float*>(ws + L.off_rs);
-  g.mb = reinterpret_cast<float*>(ws + L.off_mb);
-  g.ma = reinterpret_cast<float*>(ws + L.off_ma);
-  g.cs = reinterpret_cast<float*>(ws + L.off_cs);
-  g.diag_raw = reinterpret_cast<float*>(ws + L.off_diag);
-  g.want_rank = want_rank ? 1 : 0;
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)L.n_groups, (unsigned)L.n_chunks);
-  const size_t slot_bytes = sizeof(float) * 3 * kSymWaves * L.NI * 32;
-#define TT_SYM(KS)                                                                                                      \
-  do {                                                                                                                  \
-    const size_t lds = slot_bytes + 2 * SymStage<KS>::kBytes;                                                           \
-    if (unit) score_fwd_sym_kernel<KS, true><<<grid, kSymThreads, lds, st>>>(g);                                        \
-    else score_fwd_sym_kernel<KS, false><<<grid, kSymThreads, lds, st>>>(g);                                            \
-  } while (0)
-  if (L.Dp == 32) TT_SYM(2);
-  else if (L.Dp == 64) TT_SYM(4);
-  else if (L.Dp == 128) TT_SYM(8);
-  else TT_SYM(16);
-#undef TT_SYM
-  TT_LAUNCH_CHECK();
-  Fin1Args f{};
-  f.rs = g.rs; f.mb = g.mb; f.ma = g.ma; f.cs = g.cs; f.diag_raw = g.diag_raw;
-  f.n_groups = L.n_groups; f.n_chunks = L.n_chunks; f.R = (int)B; f.KS = L.Dp / 16; f.Rp = L.Rp;
-  f.kexp = exp2f(g.c2); f.unscale = inv_t / ab; f.shift = shift; f.unit = unit ? 1 : 0; f.want_rank = g.want_rank;
-  f.rowsum = rowsum; f.colsum = colsum; f.inv_row = inv_row; f.inv_col = inv_col; f.diag = diag; f.row_rank = row_rank;
-  f.a_rows = g.a_rows; f.b_rows = g.b_rows;
-  f.part = reinterpret_cast<float*>(ws + L.off_part);
-  score_sym_finish1_kernel<<<(unsigned)L.n_wg, 256, 0, st>>>(f);
-  TT_LAUNCH_CHECK();
-  score_sym_finish2_kernel<<<1, 1024, 0, st>>>(f.part, L.n_wg, L.Dp, (float)B, f.unscale, out8, loss_out);
-  TT_LAUNCH_CHECK();
-  return TT_OK;
+  return sym_forward(ctx, N_packed, C_packed, B, D, inv_t, shift, ab_scale, want_rank, rowsum, colsum, inv_row, inv_col, diag, row_rank,
+                     out8, loss_out, workspace, workspace_bytes, stream, false, "tt_score_fwd_sym_bf16");
+}
+
+int tt_score_fwd_sym_fp8(tt_ctx* ctx, const void* N_packed, const void* C_packed, int64_t B, int32_t D, float inv_t, float shift,
+                         float ab_scale, int32_t want_rank, float* rowsum, float* colsum, float* inv_row, float* inv_col,
+                         float* diag, int32_t* row_rank, float* out8, float* loss_out, void* workspace, size_t workspace_bytes,
+                         tt_stream stream) {
+  return sym_forward(ctx, N_packed, C_packed, B, D, inv_t, shift, ab_scale, want_rank, rowsum, colsum, inv_row, inv_col, diag, row_rank,
+                     out8, loss_out, workspace, workspace_bytes, stream, true, "tt_score_fwd_sym_fp8");
 }
 
 }  // extern "C"

@@ -419,8 +419,20 @@ def score_fwd_bf16(Np, Cp, B, D, inv_t, shift, want_col_rank=True, full_rank=Tru
     return out + ((f[4][:B], f[5][:B]),) if with_inv else out
 
 
-def score_fwd_sym(Np, Cp, B, D, inv_t, shift, scale_n: float = 1.0, want_rank: bool = True):
-    """Single-pass symmetric forward of the square problem (tt_score_fwd_sym_bf16): returns (rowsum, colsum, diag, row_rank,
+def score_pack2_fp8(X0, X1, scale0: float = 1.0, scale1: float = 1.0):
+    """Both operands of a step as [fp8 rows image | bf16 fragment image] (tt_score_pack2_fp8)."""
+    dev, D = X0.device, X0.shape[1]
+    lib = L.load()
+    b0 = torch.empty(lib.tt_score_pack_fp8_bytes(X0.shape[0], D), dtype=torch.uint8, device=dev)
+    b1 = torch.empty(lib.tt_score_pack_fp8_bytes(X1.shape[0], D), dtype=torch.uint8, device=dev)
+    with _timed("tt_score_pack2_fp8"):
+        L.check(lib.tt_score_pack2_fp8(L.ctx(dev), L.ptr(X0), X0.shape[0], L.ptr(b0), L.ptr(X1), X1.shape[0], L.ptr(b1), D,
+                                       scale0, scale1, L.stream(dev)), "tt_score_pack2_fp8")
+    return b0, b1
+
+
+def score_fwd_sym(Np, Cp, B, D, inv_t, shift, scale_n: float = 1.0, want_rank: bool = True, fp8: bool = False):
+    """Single-pass symmetric forward of the square problem (tt_score_fwd_sym_bf16 / _fp8): returns (rowsum, colsum, diag, row_rank,
     (inv_row, inv_col), out8, loss) -- loss its own 0-dim tensor so that autograd sees a plain output."""
     dev = Np.device
     Bp = (B + 63) // 64 * 64                                           # the kernel fills the entries past B (read by tt_score_bwd_bf16)
@@ -430,15 +442,17 @@ def score_fwd_sym(Np, Cp, B, D, inv_t, shift, scale_n: float = 1.0, want_rank: b
     loss = torch.empty((), dtype=torch.float32, device=dev)
     lib = L.load()
     ws = L.workspace(dev, lib.tt_score_fwd_sym_workspace_bytes(B, D))
-    with _timed("tt_score_fwd_sym_bf16"):
-        L.check(lib.tt_score_fwd_sym_bf16(L.ctx(dev), L.ptr(Np), L.ptr(Cp), B, D, inv_t, shift, scale_n, int(want_rank), L.ptr(f[0]), L.ptr(f[1]),
+    fn, name = (lib.tt_score_fwd_sym_fp8, "tt_score_fwd_sym_fp8") if fp8 else (lib.tt_score_fwd_sym_bf16, "tt_score_fwd_sym_bf16")
+    with _timed(name):
+        L.check(fn(L.ctx(dev), L.ptr(Np), L.ptr(Cp), B, D, inv_t, shift, scale_n, int(want_rank), L.ptr(f[0]), L.ptr(f[1]),
                                           L.ptr(f[3]), L.ptr(f[4]), L.ptr(f[2]), L.ptr(rank), L.ptr(out8), L.ptr(loss), L.ptr(ws), ws.numel(),
-                                          L.stream(dev)), "tt_score_fwd_sym_bf16")
+                                          L.stream(dev)), name)
     return f[0][:B], f[1][:B], f[2][:B], rank, (f[3][:B], f[4][:B]), out8, loss
 
 
-def score_bwd_bf16(Np, Cp, B, D, inv_t, shift, rowsum, colsum, d_loss, scale, scale_n: float = 1.0, inv=None):
-    """inv: (inv_row, inv_col) from score_fwd_bf16(..., with_inv=True) with the same scale_n (optional)."""
+def score_bwd_bf16(Np, Cp, B, D, inv_t, shift, rowsum, colsum, d_loss, scale, scale_n: float = 1.0, inv=None, fp8: bool = False):
+    """inv: (inv_row, inv_col) from score_fwd_bf16(..., with_inv=True) with the same scale_n (optional).
+    fp8: the operands are tt_score_pack2_fp8 buffers (tt_score_bwd_fp8)."""
     dev = Np.device
     dN = torch.empty((B, D), dtype=torch.float32, device=dev)
     dC = torch.empty((B, D), dtype=torch.float32, device=dev)
@@ -446,9 +460,9 @@ def score_bwd_bf16(Np, Cp, B, D, inv_t, shift, rowsum, colsum, d_loss, scale, sc
     ir, ic = (L.ptr(inv[0]), L.ptr(inv[1])) if inv is not None else (None, None)
     arr[0] = L.ScoreBwdDir(L.ptr(Np), L.ptr(Cp), B, B, 0, L.ptr(rowsum), L.ptr(colsum), L.ptr(dN), scale_n, 1.0, ir, ic)   # B = company: unscaled
     arr[1] = L.ScoreBwdDir(L.ptr(Cp), L.ptr(Np), B, B, 0, L.ptr(colsum), L.ptr(rowsum), L.ptr(dC), scale_n, scale_n, ic, ir)  # B = notice image
-    with _timed("tt_score_bwd_bf16"):
-        L.check(L.load().tt_score_bwd_bf16(L.ctx(dev), arr, 2, D, inv_t, shift, L.ptr(d_loss), scale, L.stream(dev)),
-                "tt_score_bwd_bf16")
+    fn, name = (L.load().tt_score_bwd_fp8, "tt_score_bwd_fp8") if fp8 else (L.load().tt_score_bwd_bf16, "tt_score_bwd_bf16")
+    with _timed(name):
+        L.check(fn(L.ctx(dev), arr, 2, D, inv_t, shift, L.ptr(d_loss), scale, L.stream(dev)), name)
     return dN, dC
 
 

@@ -34,6 +34,20 @@ class _ScoreCEFn(torch.autograd.Function):
         n, c = n.contiguous().float(), c.contiguous().float()
         B, D = n.shape
         shift = abs(inv_t)                                   # unit rows: |s| <= 1/T
+        if score_dtype == "fp8":
+            # e4m3 operands for the S products (v_mfma_scale_f32_32x32x64_f8f6f4: twice the bf16 MFMA rate), everything else as
+            # the bf16 path; always the single-pass forward and the workgroup-staged backward (BASELINE configs[4])
+            scale_n = ops.score_unit_scale(inv_t)
+            Np, Cp = ops.score_pack2_fp8(n, c, scale_n, 1.0)
+            rowsum, colsum, diag, row_rank, inv, out8, loss = ops.score_fwd_sym(Np, Cp, B, D, inv_t, shift, scale_n, True, fp8=True)
+            ctx.packed = (Np, Cp, scale_n, inv)
+            ctx.fp8 = True
+            ctx.save_for_backward(n, c, rowsum, colsum)
+            ctx.inv_t, ctx.shift = inv_t, shift
+            ctx.mark_non_differentiable(out8, row_rank)
+            ctx.set_materialize_grads(False)
+            return loss, out8, row_rank
+        ctx.fp8 = False
         if score_dtype == "bf16":
             # scale_n: the notice image holds bf16(scale_n * n) -- with scale_n = inv_t * log2(e) the exponent scale of the
             # softmax rides in the MFMA and the kernels skip a multiply-add per score (results are scale-free).
@@ -80,7 +94,7 @@ class _ScoreCEFn(torch.autograd.Function):
         scale = ctx.inv_t / (2.0 * B)
         if ctx.packed is not None:
             dN, dC = ops.score_bwd_bf16(ctx.packed[0], ctx.packed[1], B, D, ctx.inv_t, ctx.shift, rowsum, colsum, d_loss, scale,
-                                        ctx.packed[2], ctx.packed[3])
+                                        ctx.packed[2], ctx.packed[3], fp8=ctx.fp8)
         else:
             dN = ops.score_dir_bwd(n, c, ctx.inv_t, ctx.shift, 0, rowsum, colsum, d_loss, scale)
             dC = ops.score_dir_bwd(c, n, ctx.inv_t, ctx.shift, 0, colsum, rowsum, d_loss, scale)
@@ -132,8 +146,8 @@ class TwoTowerTrainTask(nn.Module):
         super().__init__()
         import os
         self.score_dtype = score_dtype or os.environ.get("TT_SCORE_DTYPE", "fp32")
-        if self.score_dtype not in ("fp32", "bf16"):
-            raise ValueError(f"score_dtype must be 'fp32' or 'bf16', got {self.score_dtype!r}")
+        if self.score_dtype not in ("fp32", "bf16", "fp8"):
+            raise ValueError(f"score_dtype must be 'fp32', 'bf16' or 'fp8', got {self.score_dtype!r}")
         if self.score_dtype == "bf16" and os.environ.get("TT_TOWER_PACK", "1") != "0":      # TT_TOWER_PACK=0: separate pack launch (A/B)
             for tw in (two_tower_model.notice_tower, two_tower_model.company_tower):
                 tw.pack_for_score = True

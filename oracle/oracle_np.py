@@ -35,6 +35,20 @@ def q_bf16(a):
     return r.astype(a.dtype if a.dtype.kind == "f" else np.float32)
 
 
+def q_e4m3(a):
+    """round-to-nearest-even to OCP fp8 e4m3fn (3 mantissa bits, exponent bias 7, subnormals down to 2^-9, largest finite
+    448: saturating), returned in a's float dtype -- the operand rounding of the fp8 score kernels (score_dtype="fp8")"""
+    a = np.asarray(a)
+    x = np.asarray(a, dtype=np.float64)
+    ax = np.abs(x)
+    e = np.floor(np.log2(np.maximum(ax, 2.0 ** -20)))
+    e = np.maximum(e, -6.0)                                  # below the smallest normal 2^-6 the step stays 2^-9
+    step = 2.0 ** (e - 3)
+    q = np.round(ax / step) * step                           # numpy rounds half to even
+    q = np.minimum(q, 448.0)
+    return (np.sign(x) * q).astype(a.dtype if a.dtype.kind == "f" else np.float32)
+
+
 def _ident(a):
     return a
 
@@ -219,10 +233,13 @@ def score_ce_fwd(N, C, temperature=1.0):
                   "similarity_gap": pos - neg}, S, (lse_r, lse_c)
 
 
-def score_ce_bwd(N, C, S, lse, temperature=1.0, dloss=1.0, q=None):
+def score_ce_bwd(N, C, S, lse, temperature=1.0, dloss=1.0, q=None, prod_operands=None):
     """dS = (softmax_rows + softmax_cols - 2I)/(2B) ; dN = dS C / T ; dC = dS^T N / T.
     q: the bf16 score kernels round the weight matrix (softmax_rows + softmax_cols - 2I) once more before the
-    gradient products (it is the second MFMA's operand)."""
+    gradient products (it is the second MFMA's operand).  prod_operands = (N', C'): the operands of the two gradient
+    products when they differ from those S was formed from (fp8 score kernels: S from e4m3 operands, products from bf16 ones)."""
+    if prod_operands is not None:
+        N, C = prod_operands
     B = S.shape[0]
     W = np.exp(S - lse[0][:, None])
     W += np.exp(S - lse[1][None, :])
@@ -233,6 +250,15 @@ def score_ce_bwd(N, C, S, lse, temperature=1.0, dloss=1.0, q=None):
     if temperature != 1.0:
         W /= S.dtype.type(temperature)
     return W @ C, W.T @ N
+
+
+def score_operands_fp8(N, C, temperature=1.0):
+    """The S-product operands of the fp8 score kernels: fp8(64 * scale * x) / (64 * scale), scale = 1/T * log2(e) on the
+    notice side and 1 on the company side (tt_score_pack2_fp8); the products are formed through f32 first, as the pack kernel does."""
+    sn = np.float32(np.float32(1.0 / temperature) * np.float32(LOG2E))
+    n32 = np.asarray(N, dtype=np.float32) * sn * np.float32(64.0)
+    c32 = np.asarray(C, dtype=np.float32) * np.float32(64.0)
+    return (q_e4m3(n32).astype(N.dtype) / N.dtype.type(float(sn) * 64.0), q_e4m3(c32).astype(C.dtype) / C.dtype.type(64.0))
 
 
 def score_operands_bf16(N, C, temperature=1.0):

@@ -1358,3 +1358,91 @@ def test_score_sym_forward(tt, B, D, T, prescale):
     again = ops.score_fwd_sym(Np, Cp, B, D, inv_t, abs(inv_t), sn, True)
     assert torch.equal(again[0], rs) and torch.equal(again[1], cs) and again[6].item() == loss.item()
     assert torch.equal(again[5].nan_to_num(nan=-7.0), out8.nan_to_num(nan=-7.0))            # (B = 1: the off-diagonal mean is nan, as torch)
+
+
+@pytest.mark.parametrize("B,D,T", [(300, 64, 1.0), (1000, 128, 1.0), (257, 200, 2.0), (2048, 64, 0.5), (70, 256, 1.0), (513, 256, 1.0)])
+def test_score_backward_large_batch_form(tt, monkeypatch, B, D, T):
+    """The workgroup-staged backward kernel (waves own rows a, every b tile staged once through LDS: the form used from
+    32768 rows up) against the b-split form on the same operands -- the two sum over b in different orders: 2e-5 norm-wise
+    -- and against the f64 oracle with the kernels' rounding (operands and softmax weights in bf16): 3e-4 norm-wise."""
+    from jodalrob_twotower_amd import ops
+    rng = np.random.default_rng(B + D)
+    n = rng.standard_normal((B, D)).astype(np.float32)
+    c = (0.5 * n + rng.standard_normal((B, D))).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    inv_t = 1.0 / T
+    sn = ops.score_unit_scale(inv_t)
+    tn, tc = torch.from_numpy(n).to(DEV), torch.from_numpy(c).to(DEV)
+    Np, Cp = ops.score_pack2_bf16(tn, tc, sn, 1.0)
+    rs, cs, dg, rk, inv, out8, loss = ops.score_fwd_sym(Np, Cp, B, D, inv_t, abs(inv_t), sn, True)
+    one = torch.ones(1, device=DEV)
+    scale = inv_t / (2.0 * B)
+    monkeypatch.setenv("TT_SCORE_BWD_ROWS_MIN", "1000000000")
+    dN0, dC0 = ops.score_bwd_bf16(Np, Cp, B, D, inv_t, abs(inv_t), rs, cs, one, scale, sn, inv)
+    monkeypatch.setenv("TT_SCORE_BWD_ROWS_MIN", "1")
+    dN1, dC1 = ops.score_bwd_bf16(Np, Cp, B, D, inv_t, abs(inv_t), rs, cs, one, scale, sn, inv)
+    dN2, dC2 = ops.score_bwd_bf16(Np, Cp, B, D, inv_t, abs(inv_t), rs, cs, one, scale, sn, None)     # reciprocals taken in the kernel
+    for a, b in ((dN1, dN0), (dC1, dC0), (dN2, dN0), (dC2, dC0)):
+        assert _rel(a.cpu().numpy(), b.cpu().numpy()) <= 2e-5
+    nb, cb = O.score_operands_bf16(n.astype(np.float64), c.astype(np.float64), T)
+    ref_loss, met, S, lse = O.score_ce_fwd(nb, cb, T)
+    rN, rC = O.score_ce_bwd(nb, cb, S, lse, T, q=O.q_bf16)
+    assert _rel(dN1.cpu().numpy(), rN) <= 3e-4 and _rel(dC1.cpu().numpy(), rC) <= 3e-4
+    assert torch.equal(ops.score_bwd_bf16(Np, Cp, B, D, inv_t, abs(inv_t), rs, cs, one, scale, sn, inv)[0], dN1)      # reproducible
+
+
+def _unpack_fp8_rows(buf, R, D):
+    """[R, Dp] float32 view of the fp8 rows image (tt_score_bf16.h): [tile][k64][part][half][row][16 bytes]"""
+    Rp, Dp = (R + 63) // 64 * 64, (64 if D <= 64 else (128 if D <= 128 else 256))
+    raw = buf[:Rp * Dp].view(torch.float8_e4m3fn).float().cpu().numpy().reshape(Rp // 32, Dp // 64, 2, 2, 32, 16)
+    # axes: tile, s, part, half, row, byte  ->  row = 32 tile + row ; col = 64 s + 32 half + 16 part + byte
+    out = raw.transpose(0, 4, 1, 3, 2, 5).reshape(Rp, Dp)
+    return out[:R]
+
+
+@pytest.mark.parametrize("B,D,T", [(300, 64, 1.0), (513, 256, 1.0), (1000, 128, 0.5), (70, 200, 2.0), (2048, 256, 1.0)])
+def test_score_fp8_vs_rounded_oracle(tt, B, D, T):
+    """score_dtype="fp8" (BASELINE configs[4]: e4m3 operands on the block-scaled MFMA for the S products, bf16 for the
+    gradient products): (a) the packed fp8 image == torch's float8_e4m3fn conversion of 64 * scale * x, element for
+    element; (b) loss / exp-sums / metrics against the f64 oracle fed the SAME e4m3-rounded operands: loss 2e-6, sums
+    2e-5; (c) gradients against the oracle with the kernels' rounding (bf16 softmax weights, bf16 product operands): 3e-4
+    norm-wise; (d) against the unrounded f64 oracle: what e4m3 operands cost -- loss within 2e-3, gradients within 8e-2."""
+    from jodalrob_twotower_amd import ops
+    from jodalrob_twotower_amd.two_tower_train_task import _ScoreCEFn
+    rng = np.random.default_rng(B * 3 + D)
+    n = rng.standard_normal((B, D)).astype(np.float32)
+    c = (0.5 * n + rng.standard_normal((B, D))).astype(np.float32)
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    c /= np.linalg.norm(c, axis=1, keepdims=True)
+    inv_t = 1.0 / T
+    sn = ops.score_unit_scale(inv_t)
+    tn, tc = torch.from_numpy(n).to(DEV), torch.from_numpy(c).to(DEV)
+    Np, Cp = ops.score_pack2_fp8(tn, tc, sn, 1.0)
+    want_n = (torch.from_numpy(n) * np.float32(sn) * 64.0).to(torch.float8_e4m3fn).float().numpy()
+    want_c = (torch.from_numpy(c) * 64.0).to(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(_unpack_fp8_rows(Np, B, D)[:, :D], want_n) and np.array_equal(_unpack_fp8_rows(Cp, B, D)[:, :D], want_c)
+    n8, c8 = O.score_operands_fp8(n.astype(np.float64), c.astype(np.float64), T)
+    np.testing.assert_allclose(n8 * float(np.float32(sn)) * 64.0, want_n.astype(np.float64), rtol=1e-12, atol=0)     # the oracle's operands ARE the packed ones
+    ref_loss, met, S, lse = O.score_ce_fwd(n8, c8, T)
+    rs, cs, dg, rk, inv, out8, loss = ops.score_fwd_sym(Np, Cp, B, D, inv_t, abs(inv_t), sn, True, fp8=True)
+    np.testing.assert_allclose(loss.item(), ref_loss, rtol=2e-6)
+    np.testing.assert_allclose(rs.cpu().numpy(), np.exp(S - abs(inv_t)).sum(1), rtol=2e-5)
+    np.testing.assert_allclose(cs.cpu().numpy(), np.exp(S - abs(inv_t)).sum(0), rtol=2e-5)
+    np.testing.assert_allclose(dg.cpu().numpy(), np.diagonal(S), rtol=1e-4, atol=2e-6)      # f32 accumulation of D products
+    assert abs(out8[1].item() - float(met["accuracy"])) <= 2.0 / B
+    np.testing.assert_allclose(out8[2].item(), met["positive_similarity_mean"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(out8[3].item(), met["negative_similarity_mean"], rtol=2e-3, atol=2e-6)
+    # gradients through the autograd node the task uses
+    a, b = tn.clone().requires_grad_(True), tc.clone().requires_grad_(True)
+    l2, _, _ = _ScoreCEFn.apply(a, b, inv_t, "fp8", False, False)
+    assert l2.item() == loss.item()
+    l2.backward()
+    nb, cb = O.score_operands_bf16(n.astype(np.float64), c.astype(np.float64), T)
+    rN, rC = O.score_ce_bwd(n8, c8, S, lse, T, q=O.q_bf16, prod_operands=(nb, cb))
+    assert _rel(a.grad.cpu().numpy(), rN) <= 3e-4 and _rel(b.grad.cpu().numpy(), rC) <= 3e-4
+    # what the format costs, against the unrounded oracle
+    f_loss, _, fS, flse = O.score_ce_fwd(n.astype(np.float64), c.astype(np.float64), T)
+    fN, fC = O.score_ce_bwd(n.astype(np.float64), c.astype(np.float64), fS, flse, T)
+    np.testing.assert_allclose(loss.item(), f_loss, rtol=2e-3)
+    assert _rel(a.grad.cpu().numpy(), fN) <= 8e-2 and _rel(b.grad.cpu().numpy(), fC) <= 8e-2

@@ -195,3 +195,16 @@ def test_torch_restatement_matches_reference(case, manifest):
             np.testing.assert_allclose(state[k].grad.numpy(), v, rtol=2e-4, atol=2e-7, err_msg=k)
         for k, v in split_prefix(g, "state_after.").items():
             np.testing.assert_allclose(state[k].numpy(), v, rtol=RTOL, atol=ATOL, err_msg=k)
+
+
+def test_q_e4m3_is_ocp_fp8_rounding():
+    """the oracle's fp8 operand rounding == torch's float32 -> float8_e4m3fn conversion (RNE, subnormals) on values inside the
+    format's range (the score operands are <= 64 * 1.4427 * 80 in magnitude only at extreme temperatures; unit rows: <= 93)"""
+    import torch
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32) * np.float32(2.0) ** rng.integers(-12, 8, 20000).astype(np.float32),
+                        np.array([0.0, 2.0 ** -9, 2.0 ** -10, 1.5 * 2.0 ** -9, 0.0625, 1.0, 1.0625, 1.125, 1.1875, 240.0, 448.0, -448.0, 3.0e-4],
+                                 dtype=np.float32)])
+    x = x[np.abs(x) <= 448.0]
+    want = torch.from_numpy(x).to(torch.float8_e4m3fn).float().numpy()
+    assert np.array_equal(O.q_e4m3(x), want)
