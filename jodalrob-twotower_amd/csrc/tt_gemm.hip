@@ -4,6 +4,8 @@
 // operand reads are conflict-free ds_read_b32 (lanes 0-31 -> k, lanes 32-63 -> k+1).
 #include "tt_gemm.h"
 
+#include <stdlib.h>
+
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, PAD = 4, THREADS = 256;
@@ -338,7 +340,8 @@ inline bool vec_ok(const float* p, int64_t ld, bool bf16_elems = false) {
 
 inline int tn_splits(int64_t M, int64_t N, int64_t R) {
   const int64_t tiles = tt_cdiv(M, BM) * tt_cdiv(N, BN);
-  int64_t s = 1024 / (tiles > 0 ? tiles : 1);       // ~4 workgroups per CU: the loops are load-latency bound
+  static const int64_t target = getenv("TT_GEMM_TN_WGS") ? atoll(getenv("TT_GEMM_TN_WGS")) : 1024;
+  int64_t s = target / (tiles > 0 ? tiles : 1);     // ~4 workgroups per CU: the loops are load-latency bound
   int64_t maxs = tt_cdiv(R, 128);
   if (maxs > 64) maxs = 64;
   if (s > maxs) s = maxs;
@@ -375,7 +378,8 @@ static int launch_gemm(hipStream_t st, const GemmBatch& b, int n, int zsplits, b
 
 static int nt_splits(int64_t tiles_all, int64_t K) {
   if (tiles_all >= 512) return 1;                     // two workgroups per CU already: a slab pass (~7 us) costs more than it buys
-  int64_t sp = 1024 / (tiles_all > 0 ? tiles_all : 1);
+  static const int64_t target = getenv("TT_GEMM_NT_WGS") ? atoll(getenv("TT_GEMM_NT_WGS")) : 1024;
+  int64_t sp = target / (tiles_all > 0 ? tiles_all : 1);
   const int64_t maxs = K / 128;                       // at least 128 of K per split
   if (sp > maxs) sp = maxs;
   if (sp > 16) sp = 16;

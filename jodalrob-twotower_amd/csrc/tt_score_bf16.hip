@@ -523,11 +523,13 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
 // | E(0) beside S(1) | dA(0) | E(1) beside dA(0) | dA(1).
 // FP8: the S products take fp8 operands (rows images in the layout of tt_score_bf16.h, K = 64 per MFMA at twice the bf16 rate,
 // half the A-fragment registers and half the staged bytes); the second products stay bf16.
-template <int KS, bool UNIT, bool FP8>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void score_bwd_rows_kernel(BwdArgs args) {
-  constexpr int AT = 2, NWV = 4, DT = KS / 2, Dp = KS * 16, K64 = FP8 ? KS / 4 : 1;
+// AT = 2, NWV = 4: one wave per SIMD with the whole register file; AT = 1, NWV = 8: two waves per SIMD (256 registers each:
+// the hardware then runs one wave's softmax weights beside the other's MFMAs).
+template <int KS, bool UNIT, bool FP8, int AT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void score_bwd_rows_kernel(BwdArgs args) {
+  constexpr int NTH = NWV * 64, DT = KS / 2, Dp = KS * 16, K64 = FP8 ? KS / 4 : 1;
   constexpr int kRowsB = FP8 ? KS * 512 : KS * 1024, kFragB = KS * 1024, kIvB = 256, kStageB = kRowsB + kFragB + kIvB;
-  constexpr int kPieces = (kRowsB + kFragB) / 16, kPPT = (kPieces + 255) / 256;   // 16-byte pieces per thread per stage (last one ragged)
+  constexpr int kPieces = (kRowsB + kFragB) / 16, kPPT = (kPieces + NTH - 1) / NTH;   // 16-byte pieces per thread per stage (last one ragged)
   static_assert(!FP8 || KS % 4 == 0, "fp8 operands come in K = 64 steps");
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   const bool d1 = blockIdx.y != 0;
@@ -583,10 +585,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
   float4 ivreg = make_float4(0.f, 0.f, 0.f, 0.f);
 #define TT_PIECE_SRC(q, tn)                                                                                                      \
-  ((tid + 256 * (q)) < kRowsB / 16 ? reinterpret_cast<const char*>(dr.b_rows) + (int64_t)(tn) * kRowsB + (tid + 256 * (q)) * 16  \
-                                   : reinterpret_cast<const char*>(dr.b_frag) + (int64_t)(tn) * kFragB + ((tid + 256 * (q)) - kRowsB / 16) * 16)
-#define TT_PIECE_OK(j, q0) (kHalf > (j) && (q0) + (j) < kPPT && (((q0) + (j) + 1) * 256 <= kPieces || tid + 256 * ((q0) + (j)) < kPieces))
-#define TT_PIECE_ST(j, var, q0) if (TT_PIECE_OK(j, q0)) *reinterpret_cast<uint4*>(base + (tid + 256 * ((q0) + (j))) * 16) = var
+  ((tid + NTH * (q)) < kRowsB / 16 ? reinterpret_cast<const char*>(dr.b_rows) + (int64_t)(tn) * kRowsB + (tid + NTH * (q)) * 16  \
+                                   : reinterpret_cast<const char*>(dr.b_frag) + (int64_t)(tn) * kFragB + ((tid + NTH * (q)) - kRowsB / 16) * 16)
+#define TT_PIECE_OK(j, q0) (kHalf > (j) && (q0) + (j) < kPPT && (((q0) + (j) + 1) * NTH <= kPieces || tid + NTH * ((q0) + (j)) < kPieces))
+#define TT_PIECE_ST(j, var, q0) if (TT_PIECE_OK(j, q0)) *reinterpret_cast<uint4*>(base + (tid + NTH * ((q0) + (j))) * 16) = var
 #define TT_PIECE_LD(j, var, q0, tn) if (TT_PIECE_OK(j, q0)) var = *reinterpret_cast<const uint4*>(TT_PIECE_SRC((q0) + (j), tn))
 #define TT_HALF_LOAD(q0, tn) do { TT_PIECE_LD(0, p0, q0, tn); TT_PIECE_LD(1, p1, q0, tn); TT_PIECE_LD(2, p2, q0, tn); TT_PIECE_LD(3, p3, q0, tn); } while (0)
 #define TT_HALF_STORE(q0, buf)                                                                        \
@@ -685,18 +687,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) wf[s][j] = (__bf16)w[8 * s + j];
+      // second product, software-pipelined over batches of (up to) four fragment reads: batch k + 1 is in flight while
+      // batch k's MFMAs issue -- with one wave per SIMD nobody else covers an LDS round trip
+      constexpr int NBATCH = 2 * ((DT + 3) / 4);
+      bf16x8 bmq[2][4];
+      auto bm_read = [&](int k, bf16x8 (&dst)[4]) {
+        const int s = k / ((DT + 3) / 4), d0 = 4 * (k % ((DT + 3) / 4));
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+        for (int j = 0; j < 4; ++j)
+          if (d0 + j < DT) dst[j] = *reinterpret_cast<const bf16x8*>(fb + (((s * 2 + h) * Dp + 32 * (d0 + j) + c) * 16));
+      };
+      bm_read(0, bmq[0]);
 #pragma unroll
-        for (int d0 = 0; d0 < DT; d0 += 4) {
-          bf16x8 bm[4];
+      for (int k = 0; k < NBATCH; ++k) {
+        if (k + 1 < NBATCH) bm_read(k + 1, bmq[(k + 1) & 1]);
+        const int s = k / ((DT + 3) / 4), d0 = 4 * (k % ((DT + 3) / 4));
 #pragma unroll
-          for (int j = 0; j < 4 && d0 + j < DT; ++j)
-            bm[j] = *reinterpret_cast<const bf16x8*>(fb + (((s * 2 + h) * Dp + 32 * (d0 + j) + c) * 16));
-#pragma unroll
-          for (int j = 0; j < 4 && d0 + j < DT; ++j)
-            dacc[i][d0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], bm[j], dacc[i][d0 + j], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j)
+          if (d0 + j < DT) dacc[i][d0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], bmq[k & 1][j], dacc[i][d0 + j], 0, 0, 0);
+      }
     }
   }
   const float g = args.d_loss[0] * out_scale;
@@ -891,11 +900,11 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
     const dim3 grid((unsigned)tt_cdiv(maxRa, 256), (unsigned)n_dirs);                                          \
     const size_t lds = 2 * (size_t)(KS * 2048 + 256);                                                          \
     if (unit) {                                                                                                \
-      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      score_bwd_rows_kernel<KS, true, false><<<grid, 256, lds, st>>>(a);                                       \
+      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, true, false, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      score_bwd_rows_kernel<KS, true, false, 2, 4><<<grid, 256, lds, st>>>(a);                                       \
     } else {                                                                                                   \
-      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      score_bwd_rows_kernel<KS, false, false><<<grid, 256, lds, st>>>(a);                                      \
+      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, false, false, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      score_bwd_rows_kernel<KS, false, false, 2, 4><<<grid, 256, lds, st>>>(a);                                      \
     }                                                                                                          \
   } while (0)
     if (Dp == 64) TT_BWD_ROWS(4);
@@ -970,21 +979,25 @@ int tt_score_bwd_fp8(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, 
   a.D = D;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int Dp = padded_d8(D);
-#define TT_BWD8(KS)                                                                                            \
+  // D = 256: two waves per SIMD, one a tile each (the 128 accumulator registers of a 32 x 256 block leave room for nothing
+  // more); narrower: one wave per SIMD with two a tiles.  TT_SCORE_BWD8_FORM = 1 | 2 forces a form (A/B runs).
+  const int form = getenv("TT_SCORE_BWD8_FORM") ? atoi(getenv("TT_SCORE_BWD8_FORM")) : 0;
+#define TT_BWD8(KS, AT_, NWV_)                                                                                 \
   do {                                                                                                         \
-    const dim3 grid((unsigned)tt_cdiv(maxRa, 256), (unsigned)n_dirs);                                          \
+    const dim3 grid((unsigned)tt_cdiv(maxRa, 32 * AT_ * NWV_), (unsigned)n_dirs);                              \
     const size_t lds = 2 * (size_t)(KS * 512 + KS * 1024 + 256);                                               \
     if (unit) {                                                                                                \
-      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      score_bwd_rows_kernel<KS, true, true><<<grid, 256, lds, st>>>(a);                                        \
+      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, true, true, AT_, NWV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      score_bwd_rows_kernel<KS, true, true, AT_, NWV_><<<grid, NWV_ * 64, lds, st>>>(a);                       \
     } else {                                                                                                   \
-      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      score_bwd_rows_kernel<KS, false, true><<<grid, 256, lds, st>>>(a);                                       \
+      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, false, true, AT_, NWV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      score_bwd_rows_kernel<KS, false, true, AT_, NWV_><<<grid, NWV_ * 64, lds, st>>>(a);                      \
     }                                                                                                          \
   } while (0)
-  if (Dp == 64) TT_BWD8(4);
-  else if (Dp == 128) TT_BWD8(8);
-  else TT_BWD8(16);
+  if (Dp == 64) TT_BWD8(4, 2, 4);
+  else if (Dp == 128) TT_BWD8(8, 2, 4);
+  else if (form == 1) TT_BWD8(16, 2, 4);
+  else TT_BWD8(16, 1, 8);
 #undef TT_BWD8
   TT_LAUNCH_CHECK();
   return TT_OK;
