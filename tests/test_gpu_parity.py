@@ -1446,3 +1446,142 @@ def test_score_fp8_vs_rounded_oracle(tt, B, D, T):
     fN, fC = O.score_ce_bwd(n.astype(np.float64), c.astype(np.float64), fS, flse, T)
     np.testing.assert_allclose(loss.item(), f_loss, rtol=2e-3)
     assert _rel(a.grad.cpu().numpy(), fN) <= 8e-2 and _rel(b.grad.cpu().numpy(), fC) <= 8e-2
+
+
+# ------------------------------------------------------------------ BASELINE configs[2] / [3] / [4] at their own sizes
+def _config_task(tt, schema_real, tmp_path, rows_n, rows_c, sharded, **kw):
+    from jodalrob_twotower_amd import synthetic
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    vn = synthetic.scale_vocabs(schema_real["notice"]["vocab_sizes"], rows_n)
+    vc = synthetic.scale_vocabs(schema_real["company"]["vocab_sizes"], rows_c)
+    meta = synthetic.write_metadata(tmp_path / "m.csv", {"notice": dict(zip(kn, vn)), "company": dict(zip(kc, vc))})
+    common = dict(metadata_path=str(meta), categorical_embedding_dim=32, notice_dense_input_dim=256, company_dense_input_dim=128,
+                  tower_hidden_dims=[128, 64], dropout_rate=0.0, temperature=1.0, device=DEV, embedding_grad="sparse", mlp_dtype="bf16", **kw)
+    if sharded:
+        from jodalrob_twotower_amd.distributed import create_distributed_train_task
+        task = create_distributed_train_task(kn, kc, **common)
+    else:
+        task = tt.create_two_tower_train_task(kn, kc, **common)
+    task.train()
+    task._pair_check_done = True
+    return task, (kn, kc, vn, vc)
+
+
+@pytest.mark.parametrize("zipf", [None, 1.2])
+def test_configs2_3_sharded_100m_rows(tt, schema_real, tmp_path, zipf):
+    """BASELINE configs[2] (100 M notice + 10 M company rows, row-wise sharded tables behind the fixed-capacity exchange, RCCL)
+    and configs[3] (the same with Zipf(1.2) ids) at their OWN table sizes on the one GPU of the box (world 1: every kernel and
+    collective of the sharded step runs, RCCL moves the data to itself; 42 GB with the Adam moments), through
+    size-independent properties: the ids really range over the 100 M rows, no bucket overflows, the loss of a random
+    initialisation is ln(B), two passes give the same bits (loss, touched rows, row gradients), Zipf ids touch far fewer
+    distinct rows than slots, and one optimiser step moves exactly the touched rows of the shard.  (Equality with the
+    unsharded single-GPU step: test_configs2_sharded_equals_unsharded_10m_rows, at sizes where both tasks fit side by side.)"""
+    import os
+    import torch.distributed as dist
+    from jodalrob_twotower_amd import synthetic
+    from jodalrob_twotower_amd.optim import FusedAdam
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29537")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        B = 8192
+        torch.manual_seed(3)
+        dtask, (kn, kc, vn, vc) = _config_task(tt, schema_real, tmp_path, 100_000_000, 10_000_000, True, final_embedding_dim=64, score_dtype="bf16")
+        batch = synthetic.make_batch(B, vn, vc, kn, kc, 256, 128, torch.device(DEV), seed=41, zipf_alpha=zipf)
+        assert int(batch["notice"]["kjt"].values().max()) > 10_000_000        # ids over the whole 100 M-row key
+        opt = FusedAdam.for_task(dtask, lr=1e-3)
+        runs = []
+        for rep in range(2):
+            opt.zero_grad()
+            r = dtask(batch, return_metrics=True)
+            r["loss"].backward()
+            dtask.exchange.check_overflow()
+            plan, grad_rows = dtask.sharded_store.sparse_grad
+            U = int(plan.n_unique.item())
+            runs.append((r["loss"].item(), plan.unique_rows[:U].clone(), grad_rows[:U].clone()))
+        assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+        assert 8.0 < runs[0][0] < 10.0                            # ln(8192) = 9.01 at random init
+        U = runs[0][1].numel()
+        if zipf is None:
+            assert U > 0.7 * B * 21                               # 17 of the 38 keys are binary; the others rarely repeat in 100 M rows
+        else:
+            assert U < 0.6 * B * 38                               # hot ids: far fewer distinct rows than slots
+        before = dtask.embedding_shard.detach().clone()
+        opt.step()
+        torch.cuda.synchronize()
+        changed = (dtask.embedding_shard.detach() != before).any(dim=1).nonzero().flatten().int()
+        rows = runs[1][1]
+        assert torch.equal(changed, rows[rows < dtask.sharded_store.local_rows].int())      # exactly the touched rows moved
+        del before, dtask, opt
+        torch.cuda.empty_cache()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_configs2_sharded_equals_unsharded_10m_rows(tt, schema_real, tmp_path):
+    """the sharded step (world 1, padded exchange) == the single-GPU step on the same 10 M + 1 M-row tables and batch:
+    loss bit for bit, touched rows and their gradients bit for bit (the sizes at which both tasks and a table copy fit
+    comfortably; configs[2]'s own 100 M + 10 M rows are covered by test_configs2_3_sharded_100m_rows)."""
+    import os
+    import torch.distributed as dist
+    from jodalrob_twotower_amd import synthetic
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29538")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        B = 8192
+        torch.manual_seed(5)
+        stask, (kn, kc, vn, vc) = _config_task(tt, schema_real, tmp_path, 10_000_000, 1_000_000, False, final_embedding_dim=64, score_dtype="bf16")
+        dtask, _ = _config_task(tt, schema_real, tmp_path, 10_000_000, 1_000_000, True, final_embedding_dim=64, score_dtype="bf16")
+        dtask.load_full_state_dict(stask.state_dict())
+        batch = synthetic.make_batch(B, vn, vc, kn, kc, 256, 128, torch.device(DEV), seed=43, zipf_alpha=1.2)
+        rs = stask(batch, return_metrics=True); rs["loss"].backward()
+        rd = dtask(batch, return_metrics=True); rd["loss"].backward()
+        dtask.exchange.check_overflow()
+        assert rs["loss"].item() == rd["loss"].item()
+        ps, gs = stask.two_tower_model.embedding_store.sparse_grad
+        pd, gd = dtask.sharded_store.sparse_grad
+        Us, Ud = int(ps.n_unique.item()), int(pd.n_unique.item())
+        assert Us == Ud and torch.equal(ps.unique_rows[:Us], pd.unique_rows[:Ud]) and torch.equal(gs[:Us], gd[:Ud])
+        for (n1, p1), (n2, p2) in zip(stask.named_parameters(), [(n, p) for n, p in dtask.named_parameters() if n != "embedding_shard"]):
+            if "categorical_embedder" not in n1:
+                assert torch.equal(p1.grad, p2.grad), n1
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("score_dtype", ["fp8", "bf16"])
+def test_configs4_full_size_properties(tt, score_dtype):
+    """BASELINE configs[4] at its own size (final_embedding_dim 256, batch 65536; fp8 and bf16 score kernels) through
+    size-independent properties: the loss of random unit rows is ln(B) to the operands' precision, swapping the towers leaves
+    the loss untouched and swaps the gradients, every row of dN is orthogonal to nothing in particular but the gradient of
+    a shifted loss... (linearity:) scaling d_loss scales the gradients exactly, and the step is bitwise reproducible."""
+    from jodalrob_twotower_amd.two_tower_train_task import _ScoreCEFn
+    B, D = 65536, 256
+    g = torch.Generator(device=DEV).manual_seed(9)
+    n = torch.nn.functional.normalize(torch.randn((B, D), generator=g, device=DEV), dim=1)
+    c = torch.nn.functional.normalize(torch.randn((B, D), generator=g, device=DEV), dim=1)
+
+    def run(a, b, seed_grad=1.0):
+        a, b = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        loss, out8, _ = _ScoreCEFn.apply(a, b, 1.0, score_dtype, False, False)
+        loss.backward(torch.full((), seed_grad, device=DEV))
+        return loss.item(), a.grad, b.grad, out8
+
+    l1, dn1, dc1, o1 = run(n, c)
+    assert abs(l1 - np.log(B)) < 2e-2                              # scores of random unit rows in 256-d: |s| ~ 1/16
+    l2, dn2, dc2, _ = run(n, c)
+    assert l1 == l2 and torch.equal(dn1, dn2) and torch.equal(dc1, dc2)          # reproducible
+    _, dn3, dc3, _ = run(n, c, 2.0)
+    assert torch.equal(dn3, 2.0 * dn1) and torch.equal(dc3, 2.0 * dc1)           # linear in the incoming gradient (a power of two: exact)
+    if score_dtype == "bf16":
+        # swapping the towers: the same loss, the gradients swap (bf16: both images carry... only the notice one is scaled, so
+        # the swap changes roundings: compare at the operands' precision)
+        l4, dn4, dc4, _ = run(c, n)
+        assert abs(l4 - l1) < 1e-4 * l1
+        assert float((dn4 - dc1).norm() / dc1.norm()) < 2e-2 and float((dc4 - dn1).norm() / dn1.norm()) < 2e-2
+    # the gradient of the loss w.r.t. a unit row is a combination of the other tower's rows: finite, no row exactly zero
+    assert bool(torch.isfinite(dn1).all()) and bool(torch.isfinite(dc1).all()) and float(dn1.abs().sum(1).min()) > 0.0
+    assert 0.0 <= o1[1].item() <= 1.0 and abs(o1[2].item()) < 0.01 and abs(o1[3].item()) < 1e-3
