@@ -225,7 +225,8 @@ typedef struct tt_tower_params {
    *                 order with Chan's formula) / grads.s_sync_all [sync_ranks][2][H] (added in rank order); BN normalises
    *                 over sync_ranks * B rows, and the BN weight / bias gradients -- identical on every rank -- are stored
    *                 divided by sync_ranks so that the caller's SUM over ranks of the dense gradients leaves them right.
-   * Phases 1 / 2 need the fused tail (training, TT_BF16 operands, ONE hidden block of width <= 64, d_out <= 64);
+   * Phases 1 / 2 need a training pass over towers with exactly ONE hidden block (any width, either compute_dtype: the
+   * reference's [128, 64] -> 64 on the fused tail kernels, scripts/train.py's [512, 256] -> 128 on the separate ones);
    * anything else returns TT_ERR_UNSUPPORTED. */
   int32_t sync_phase;
   int32_t sync_ranks;

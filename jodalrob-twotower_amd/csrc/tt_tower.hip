@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void bn_stats_finish_kernel(Batch<BnStatA
 #pragma unroll
     for (int i = 0; i < kMaxChunks / 4; ++i) {
       const int k = jl + 4 * i;
-      const float* p = a.partial + (int64_t)k * 3 * H;
+      const float* p = a.partial + (int64_t)k * (a.pstride ? a.pstride : 3 * H);
       v[i] = k < a.nchunks ? Wf{p[c], p[H + c], p[2 * H + c]} : Wf{0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -149,6 +149,8 @@ struct ColArgs {
   int B, H, rows_per_chunk, nchunks;
   float* partial; float* out0; float* out1;
   int64_t pstride = 0;   // floats between chunks when READING partial (0 = 2 * H)
+  float out_scale = 1.f; // colsum_finish_kernel: S1 / S2 are stored times this (1 / ranks under SyncBN); the raw sums go to sums_raw
+  float* sums_raw = nullptr;   // optional [2 * H]: the unscaled S1 | S2 for bn_bwd_apply_kernel
 };
 
 __global__ __launch_bounds__(kThreads) void colsum_partial_kernel(Batch<ColArgs> batch, bool drop, float p, uint64_t seed0,
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(kThreads) void colsum_finish_kernel(Batch<ColArgs> 
 #pragma unroll
     for (int i = 0; i < kMaxChunks / 4; ++i) {
       const int k = jl + 4 * i;
-      const float* q = a.partial + (int64_t)k * 2 * H;
+      const float* q = a.partial + (int64_t)k * (a.pstride ? a.pstride : 2 * H);
       v0[i] = k < a.nchunks ? q[c] : 0.f;
       v1[i] = k < a.nchunks ? q[H + c] : 0.f;
     }
@@ -204,8 +206,11 @@ __global__ __launch_bounds__(kThreads) void colsum_finish_kernel(Batch<ColArgs> 
   sh[1][jl][threadIdx.x & 63] = s1;
   __syncthreads();
   if (jl != 0 || c >= H) return;
-  a.out0[c] = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
-  a.out1[c] = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+  const float t0 = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
+  const float t1 = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
+  a.out0[c] = t0 * a.out_scale;
+  a.out1[c] = t1 * a.out_scale;
+  if (a.sums_raw) { a.sums_raw[c] = t0; a.sums_raw[H + c] = t1; }
 }
 
 // BN backward apply, in place on the gradient buffer:  d_act -> d_pre
@@ -805,8 +810,9 @@ struct LocalArgs { const float* partial; int nchunks, H; float* out; };
 __global__ __launch_bounds__(kThreads) void tail_local_stats_kernel(Batch<LocalArgs> batch) {
   const LocalArgs& a = batch.a[blockIdx.y];
   const int H = a.H;
+  if ((int)blockIdx.x * 64 >= H) return;
   __shared__ Wf sh[4][64];
-  const int c = threadIdx.x & 63, jl = threadIdx.x >> 6;
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, jl = threadIdx.x >> 6;
   Wf o{0.f, 0.f, 0.f};
   if (c < H) {
     Wf v[kMaxChunks / 4];
@@ -819,10 +825,10 @@ __global__ __launch_bounds__(kThreads) void tail_local_stats_kernel(Batch<LocalA
 #pragma unroll
     for (int i = 0; i < kMaxChunks / 4; ++i) o = wf_combine(o, v[i]);
   }
-  sh[jl][c] = o;
+  sh[jl][cl] = o;
   __syncthreads();
   if (jl == 0 && c < H) {
-    o = wf_combine(wf_combine(sh[0][c], sh[1][c]), wf_combine(sh[2][c], sh[3][c]));
+    o = wf_combine(wf_combine(sh[0][cl], sh[1][cl]), wf_combine(sh[2][cl], sh[3][cl]));
     a.out[c] = o.n; a.out[H + c] = o.mean; a.out[2 * H + c] = o.m2;
   }
 }
@@ -830,8 +836,9 @@ __global__ __launch_bounds__(kThreads) void tail_local_stats_kernel(Batch<LocalA
 __global__ __launch_bounds__(kThreads) void tail_local_colsum_kernel(Batch<LocalArgs> batch) {
   const LocalArgs& a = batch.a[blockIdx.y];
   const int H = a.H;
+  if ((int)blockIdx.x * 64 >= H) return;
   __shared__ float sh[2][4][64];
-  const int c = threadIdx.x & 63, jl = threadIdx.x >> 6;
+  const int cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, jl = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f;
   if (c < H) {
     float v0[kMaxChunks / 4], v1[kMaxChunks / 4];
@@ -845,12 +852,12 @@ __global__ __launch_bounds__(kThreads) void tail_local_colsum_kernel(Batch<Local
 #pragma unroll
     for (int i = 0; i < kMaxChunks / 4; ++i) { s0 += v0[i]; s1 += v1[i]; }
   }
-  sh[0][jl][c] = s0;
-  sh[1][jl][c] = s1;
+  sh[0][jl][cl] = s0;
+  sh[1][jl][cl] = s1;
   __syncthreads();
   if (jl == 0 && c < H) {
-    a.out[c] = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
-    a.out[H + c] = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+    a.out[c] = (sh[0][0][cl] + sh[0][1][cl]) + (sh[0][2][cl] + sh[0][3][cl]);
+    a.out[H + c] = (sh[1][0][cl] + sh[1][1][cl]) + (sh[1][2][cl] + sh[1][3][cl]);
   }
 }
 
@@ -1004,8 +1011,8 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
   const bool fused = tail_fusable(n, P, train);
   const int phase = P[0]->sync_phase;
   if (phase != 0) {
-    if (!fused || nh != 1) {
-      tt_set_error("tt_towers_mlp_fwd: sync_phase %d needs the fused tail (training, TT_BF16 operands, one hidden block <= 64 wide, d_out <= 64)", phase);
+    if (nh != 1 || !train) {
+      tt_set_error("tt_towers_mlp_fwd: sync_phase %d needs a training pass over towers with exactly one hidden block (the pass is cut at its BatchNorm)", phase);
       return TT_ERR_UNSUPPORTED;
     }
     for (int t = 0; t < n; ++t)
@@ -1057,7 +1064,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       if (phase == 1) {                                 // SyncBN: hand this rank's statistics to the caller and stop
         Batch<LocalArgs> la{};
         for (int t = 0; t < n; ++t) la.a[t] = LocalArgs{bs.a[t].partial, bs.a[t].nchunks, bs.a[t].H, A[t]->bn_sync_local};
-        tail_local_stats_kernel<<<dim3(1, (unsigned)n), kThreads, 0, st>>>(la);
+        tail_local_stats_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)n), kThreads, 0, st>>>(la);
         TT_LAUNCH_CHECK();
         return TT_OK;
       }
@@ -1083,8 +1090,21 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       return TT_OK;
     }
     if (train) {
-      bn_stats_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(bs);
-      TT_LAUNCH_CHECK();
+      if (phase != 2) {
+        bn_stats_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(bs);
+        TT_LAUNCH_CHECK();
+      }
+      if (phase == 1) {                                 // SyncBN on the separate kernels (any width): hand this rank's statistics out and stop
+        Batch<LocalArgs> la{};
+        for (int t = 0; t < n; ++t) la.a[t] = LocalArgs{bs.a[t].partial, bs.a[t].nchunks, bs.a[t].H, A[t]->bn_sync_local};
+        tail_local_stats_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)n), kThreads, 0, st>>>(la);
+        TT_LAUNCH_CHECK();
+        return TT_OK;
+      }
+      if (phase == 2)                                   // ... and continue with every rank's triple as one "chunk"
+        for (int t = 0; t < n; ++t) {
+          bs.a[t].partial = const_cast<float*>(A[t]->bn_sync_all); bs.a[t].nchunks = P[t]->sync_ranks; bs.a[t].pstride = A[t]->bn_sync_stride;
+        }
       bn_stats_finish_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)n), kThreads, 0, st>>>(bs);
       TT_LAUNCH_CHECK();
     } else {
@@ -1142,14 +1162,14 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
   const bool fused = tail_fusable(n, P, train);
   const int phase = P[0]->sync_phase;
   if (phase != 0) {
-    if (!fused || nh != 1) {
-      tt_set_error("tt_towers_mlp_bwd: sync_phase %d needs the fused tail (training, TT_BF16 operands, one hidden block <= 64 wide, d_out <= 64)", phase);
+    if (nh != 1 || !train) {
+      tt_set_error("tt_towers_mlp_bwd: sync_phase %d needs a training pass over towers with exactly one hidden block (the pass is cut at its BatchNorm)", phase);
       return TT_ERR_UNSUPPORTED;
     }
     for (int t = 0; t < n; ++t)
       TT_CHECK_ARG(G[t] && (phase == 1 ? G[t]->s_sync_local != nullptr : G[t]->s_sync_all != nullptr), "tt_towers_mlp_bwd: NULL SyncBN buffer");
   }
-  if (!fused) {
+  if (!fused && phase != 2) {
     l2norm_bwd_kernel<<<dim3((unsigned)tt_cdiv(B, 4), (unsigned)n), kThreads, 0, st>>>(na);
     TT_LAUNCH_CHECK();
   }
@@ -1203,13 +1223,13 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     if (phase == 1) {                                   // SyncBN: hand this rank's column sums to the caller and stop
       Batch<LocalArgs> la{};
       for (int t = 0; t < n; ++t) la.a[t] = LocalArgs{tb.a[t].col.partial, tb.a[t].col.nchunks, tb.a[t].col.H, G[t]->s_sync_local};
-      tail_local_colsum_kernel<<<dim3(1, (unsigned)n), kThreads, 0, st>>>(la);
+      tail_local_colsum_kernel<<<dim3(1, (unsigned)n), kThreads, 0, st>>>(la);                  // (fused tail: H <= 64)
       TT_LAUNCH_CHECK();
       return TT_OK;
     }
     tail_bwd_apply_kernel<<<dim3((unsigned)tt_cdiv(B, 64), (unsigned)n), kTailThreads, 0, st>>>(tp);
     TT_LAUNCH_CHECK();
-  } else {
+  } else if (phase != 2) {
     if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;
     if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
   }
@@ -1234,8 +1254,26 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       tmax = B * H > tmax ? B * H : tmax;
     }
     if (!(fused && i == nh - 1)) {
-      colsum_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(cb, drop, dropout_p, seed, seed_dev);
-      TT_LAUNCH_CHECK();
+      if (phase != 2) {
+        colsum_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(cb, drop, dropout_p, seed, seed_dev);
+        TT_LAUNCH_CHECK();
+      }
+      if (phase == 1) {                                 // SyncBN on the separate kernels: hand this rank's column sums out and stop
+        if (int rc = tt_gemm_tn_flush(st, pend.p)) return rc;     // (the output layer's weight-gradient slabs)
+        Batch<LocalArgs> la{};
+        for (int t = 0; t < n; ++t) la.a[t] = LocalArgs{cb.a[t].partial, cb.a[t].nchunks, cb.a[t].H, G[t]->s_sync_local};
+        tail_local_colsum_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)n), kThreads, 0, st>>>(la);
+        TT_LAUNCH_CHECK();
+        return TT_OK;
+      }
+      if (phase == 2)                                   // S1 / S2 of every rank, one "chunk" each, over ranks * B rows
+        for (int t = 0; t < n; ++t) {
+          const int ranks = P[t]->sync_ranks, H = P[t]->hidden[i];
+          float* raw = ws[t].col + 2 * (size_t)hmax * kMaxChunks;         // (the third third of the column workspace is free here)
+          cb.a[t].partial = const_cast<float*>(G[t]->s_sync_all); cb.a[t].nchunks = ranks; cb.a[t].pstride = G[t]->s_sync_stride;
+          cb.a[t].out_scale = 1.f / (float)ranks; cb.a[t].sums_raw = raw;
+          bb.a[t].invB = 1.f / ((float)B * (float)ranks); bb.a[t].S1 = raw; bb.a[t].S2 = raw + H;
+        }
       colsum_finish_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)n), kThreads, 0, st>>>(cb);
       TT_LAUNCH_CHECK();
       bn_bwd_apply_kernel<<<dim3((unsigned)ew_grid(ctx, tmax, n), (unsigned)n), kThreads, 0, st>>>(bb, train != 0, drop, dropout_p, seed, seed_dev);

@@ -489,9 +489,9 @@ class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
             # BatchNorm statistics over the rows of ALL ranks (with negatives="global": the single-process reference at the
             # global batch); dropout masks are drawn per global row, so give every rank the same torch seed for that
             for tw in (two_tower_model.notice_tower, two_tower_model.company_tower):
-                if tw.mlp_dtype != "bf16" or len(tw.tower_hidden_dims) != 2 or tw.tower_hidden_dims[1] > 64 or tw.final_embedding_dim > 64:
-                    raise NotImplementedError("sync_bn needs mlp_dtype='bf16', one hidden block of width <= 64 and final_embedding_dim <= 64 "
-                                              "(the fused tower tail is where the pass is cut for the exchange)")
+                if len(tw.tower_hidden_dims) != 2:
+                    raise NotImplementedError("sync_bn needs towers with exactly one hidden block (tower_hidden_dims of length 2, as the "
+                                              "reference's [512, 256] and [128, 64]): the pass is cut at that block's BatchNorm")
                 tw.sync_comm = self.exchange.comm
         for p in self._dense_parameters():                             # replicas start identical
             dist.broadcast(p.data, src=0, group=group)

@@ -32,6 +32,8 @@ def main():
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = dict(json.load(open(GOLD / "manifest.json"))["cases"]["wide_b40"])        # towers [32, 24] -> 16, E = 16
+    if os.environ.get("TT_W2_WIDE") == "1":                  # wider than the fused tail takes: the separate kernels' SyncBN cut
+        cfg["hidden"], cfg["D"] = [48, 80], 72
     Bl, drop = 96, 0.1
     B = world * Bl
     b = synth_batch_numpy(B, cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 881, oob=True)

@@ -1098,9 +1098,12 @@ def test_padded_exchange_multi_rank_on_one_gpu(tt, G, x_dtype, grad_bf16):
         assert set(np.flatnonzero(np.abs(mine).sum(1) > 0)) <= set(r["uniq"][real].tolist())
 
 
-def test_sync_bn_phases_at_world_one_equal_the_whole_pass(tt, manifest, schema_real):
+@pytest.mark.parametrize("hidden,D,mlp", [([128, 64], 64, "bf16"), ([512, 256], 128, "bf16"), ([96, 200], 70, "fp32")])
+def test_sync_bn_phases_at_world_one_equal_the_whole_pass(tt, manifest, schema_real, hidden, D, mlp):
     """tt_tower_params.sync_phase 1 + 2 with ONE rank (the all-gather hands back the rank's own statistics) == the uncut
-    pass, bit for bit: unit rows, BN running statistics and every gradient, dropout on."""
+    pass, bit for bit: unit rows, BN running statistics and every gradient, dropout on.  [128, 64] -> 64 takes the fused
+    tail kernels; scripts/train.py's own [512, 256] -> 128 (/root/reference/scripts/train.py:106-107) and an odd fp32 shape
+    take the separate kernels, cut at the same place."""
     class Solo:
         world, rank = 1, 0
 
@@ -1109,16 +1112,16 @@ def test_sync_bn_phases_at_world_one_equal_the_whole_pass(tt, manifest, schema_r
 
     cfg = dict(manifest["cases"]["real_schema"])
     kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
-    cfg.update(keys_n=kn, keys_c=kc)
+    cfg.update(keys_n=kn, keys_c=kc, hidden=hidden, D=D)
     vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
-    shapes = {k: tuple(v) for k, v in manifest["state_dict_keys_real"].items()}
-    state = init_state_numpy(shapes, 151)
     b = synth_batch_numpy(333, vn, vc, cfg["din_n"], cfg["din_c"], 152, oob=False)
-    outs = []
+    outs, state = [], None
     for comm in (None, Solo()):
-        task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", mlp_dtype="bf16", score_dtype="bf16", dropout_rate=0.1)
+        task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", mlp_dtype=mlp, score_dtype="bf16", dropout_rate=0.1)
         for tw in (task.two_tower_model.notice_tower, task.two_tower_model.company_tower):
             tw._seed_override, tw.sync_comm = 77, comm
+        if state is None:
+            state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 151)
         load_state(task, state)
         task.train()
         res = task(to_batch(tt, b, kn, kc), return_metrics=True)
@@ -1159,6 +1162,8 @@ def test_two_processes_equal_single_process(tt):
 
     ctrl = run_pair({"TT_W2_NO_SYNC": "1"})          # negative control: per-rank BN statistics must NOT pass the same checks
     assert not any("DIST_WORLD2_OK" in o[0] for o in ctrl), "the check does not see the BN statistics"
+    wide = run_pair({"TT_W2_WIDE": "1"})               # towers [48, 80] -> 72: SyncBN on the separate (unfused) kernels
+    assert all("DIST_WORLD2_OK" in o[0] for o in wide) and len(wide) == 2, "\n".join(o[1][-1500:] for o in wide)
     outs = run_pair({})
     ok = all("DIST_WORLD2_OK" in o[0] for o in outs) and len(outs) == 2
     if not ok:
