@@ -54,6 +54,7 @@ def parse(argv=None):
     ap.add_argument("--rows-company", type=int, default=None, help="table rows, company tower (default 1 M at N = 1; 10 M over all GPUs at N > 1)")
     ap.add_argument("--zipf", type=float, default=None, help="Zipf alpha for ids (default uniform; 1.2 = configs[3])")
     ap.add_argument("--final-dim", type=int, default=64, help="final_embedding_dim (BASELINE configs[4] uses 256 at --batch 65536)")
+    ap.add_argument("--hidden", default="128,64", help="tower_hidden_dims (BASELINE configs: 128,64; the reference driver scripts/train.py:106-107 trains 512,256 with --final-dim 128)")
     ap.add_argument("--optimizer", choices=["fused_sparse", "fused_dense", "torch_adam"], default="fused_sparse")
     ap.add_argument("--score-dtype", choices=["bf16", "fp32", "fp8"], default="bf16")
     ap.add_argument("--mlp-dtype", choices=["bf16", "fp32"], default="bf16")
@@ -129,7 +130,7 @@ class Leg:
         self.keys_n, self.keys_c = schema["notice"]["categorical"], schema["company"]["categorical"]
         self.vocab_n = synthetic.scale_vocabs(schema["notice"]["vocab_sizes"], rows_n)
         self.vocab_c = synthetic.scale_vocabs(schema["company"]["vocab_sizes"], rows_c)
-        self.E, self.hidden, self.D, self.din_n, self.din_c = 32, [128, 64], args.final_dim, 256, 128
+        self.E, self.hidden, self.D, self.din_n, self.din_c = 32, [int(h) for h in args.hidden.split(",")], args.final_dim, 256, 128
         tmp = tempfile.mkdtemp(prefix="tt_bench_")
         meta = synthetic.write_metadata(Path(tmp) / "metadata.csv", {"notice": dict(zip(self.keys_n, self.vocab_n)),
                                                                      "company": dict(zip(self.keys_c, self.vocab_c))})
@@ -412,10 +413,10 @@ def bench_single(args, ctx, sharded):
     B = args.batch
     leg = Leg(args, ctx, B, rows_n, rows_c, sharded, negatives=args.negatives or "local", sync_bn=args.sync_bn)
     leg.run()
-    is_c1 = B == 8192 and args.final_dim == 64 and args.zipf is None and rows_n == 1_000_000 and rows_c == 1_000_000 and args.score_dtype == "bf16"
+    is_c1 = B == 8192 and args.final_dim == 64 and args.hidden == "128,64" and args.zipf is None and rows_n == 1_000_000 and rows_c == 1_000_000 and args.score_dtype == "bf16"
     out = base_line(args, leg, 1, "weak", B)
     out["config"] = config_of(args, leg, 1, ctx, B, ("configs[1]: " if is_c1 else "variant of configs[1]: ") +
-                              f"32+6 real keys, {rows_n}-row notice + {rows_c}-row company tables, batch {B}, E=32, towers [128,64], "
+                              f"32+6 real keys, {rows_n}-row notice + {rows_c}-row company tables, batch {B}, E=32, towers [{args.hidden}], "
                               f"final {args.final_dim}, in-batch negatives, dropout 0.1")
     out["roofline"] = roofline_of(args, leg, 1)
     out["final_loss"] = leg.loss
@@ -455,7 +456,7 @@ def bench_multi(args, ctx):
         raise SystemExit(f"--batch {Bg} must be a multiple of the {world} ranks")
     cname = "configs[3]" if args.zipf is not None else "configs[2]"
     desc = (f"32+6 real keys, {rows_n}-row notice + {rows_c}-row company tables sharded row-wise over {world} GPUs (row r on GPU r mod {world}), "
-            f"E=32, towers [128,64], final {args.final_dim}, dropout 0.1")
+            f"E=32, towers [{args.hidden}], final {args.final_dim}, dropout 0.1")
     out, results = None, {}
     if "strong" in legs:
         # the BASELINE metric: the batch-8192 job split over N GPUs -- global in-batch negatives + SyncBN make it the

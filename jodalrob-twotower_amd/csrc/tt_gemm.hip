@@ -340,8 +340,11 @@ inline bool vec_ok(const float* p, int64_t ld, bool bf16_elems = false) {
 
 inline int tn_splits(int64_t M, int64_t N, int64_t R) {
   const int64_t tiles = tt_cdiv(M, BM) * tt_cdiv(N, BN);
-  static const int64_t target = getenv("TT_GEMM_TN_WGS") ? atoll(getenv("TT_GEMM_TN_WGS")) : 1024;
-  int64_t s = target / (tiles > 0 ? tiles : 1);     // ~4 workgroups per CU: the loops are load-latency bound
+  // ~2 workgroups per CU (TT_GEMM_TN_WGS: A/B runs).  More splits shorten each workgroup's batch range but every split
+  // writes a 64 x 64 f32 slab: at 1024 workgroups the slabs of the block weight gradient (16.5 MB) were as large as its
+  // operands; 512 measured 5 us per step faster than 1024, 384 and 256 slower again
+  static const int64_t target = getenv("TT_GEMM_TN_WGS") ? atoll(getenv("TT_GEMM_TN_WGS")) : 512;
+  int64_t s = target / (tiles > 0 ? tiles : 1);
   int64_t maxs = tt_cdiv(R, 128);
   if (maxs > 64) maxs = 64;
   if (s > maxs) s = maxs;
