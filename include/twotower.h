@@ -75,14 +75,14 @@ typedef struct tt_embed_side {
   int32_t out_dtype; /* TT_F32 (bit-exact row copy) or TT_BF16 (round-to-nearest-even) */
 } tt_embed_side;
 
-/* Measurement hook: a ring of per-launch device-clock stamps for the lookup kernel, usable inside a
- * captured graph (where HIP events cannot bracket one kernel) and without any host synchronisation.
- * `ring_dev` = 2 + 2*n_slots + 2*4096 uint64 words of device memory, zero-initialised by the caller:
- *   [0] launch counter, [1] reserved, then n_slots pairs {start, end} -- pair i (mod n_slots) belongs to
- *   launch number i: start = min over the kernel's workgroups of their first instruction, end = max over
- *   workgroups of the time all their stores have completed; the tail is per-workgroup scratch.
- *   100 MHz clock: (end - start) * 10 ns = duration.  While the hook is on, every lookup launch is followed by
- *   a one-workgroup reduction kernel that fills the pair.  ring_dev == NULL switches the hook off. */
+/* Measurement hook: per-launch device-clock stamps of the lookup kernel, usable inside a captured graph (where
+ * HIP events cannot bracket one kernel), without host synchronisation and WITHOUT an extra launch.
+ * `ring_dev` = 4096 + n_slots * 4096 * 2 uint64 words of device memory, zero-initialised by the caller:
+ *   [b], b < 4096: launch counter of workgroup b (each workgroup keeps its own: [0] = launches so far);
+ *   then n_slots blocks of 4096 pairs {start, end}: block (n mod n_slots), pair b = workgroup b in launch n --
+ *   start = its first instruction, end = all its stores have completed (0, 0 = workgroup not in the grid).
+ *   Kernel duration of launch n = (max end - min start over the block) * 10 ns (100 MHz clock); the caller reduces.
+ *   ring_dev == NULL switches the hook off. */
 int tt_embed_lookup_set_profile(tt_ctx* ctx, uint64_t* ring_dev, int32_t n_slots);
 int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E,
                         const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_out,
@@ -236,6 +236,7 @@ typedef struct tt_tower_params {
 /* run the tail of a training pass (BN of the last block, output Linear, L2 normalise) as the separate kernels even when
    the fused form applies (last hidden width and d_out <= 64, compute_dtype TT_BF16): for A/B comparison */
 #define TT_TOWER_UNFUSED_TAIL 1
+#define TT_TOWER_UNFUSED_FRONT 2 /* keep projection GEMM, block GEMM and slab/statistics pass as separate launches */
 
 typedef struct tt_tower_acts { /* caller-allocated; kept between forward and backward */
   const float* dense;          /* [B, din] */

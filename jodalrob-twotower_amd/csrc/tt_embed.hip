@@ -127,9 +127,14 @@ template <int C, int SPW, int MODE>   // SPW slots per wave pass; MODE 0: nt sto
 __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const float* __restrict__ table,
                                                               int32_t* __restrict__ rows_out,
                                                               unsigned long long* __restrict__ ring, int ring_slots) {
-  // measurement only: per-workgroup start/end stamps (plain stores; reduced by lookup_profile_reduce_kernel)
-  unsigned long long* wg_stamps = ring ? ring + 2 + 2 * ring_slots + 2 * blockIdx.x : nullptr;
-  if (wg_stamps && blockIdx.x < kProfileMaxWg && threadIdx.x == 0) wg_stamps[0] = __builtin_amdgcn_s_memrealtime();
+  // measurement only: per-workgroup start/end stamps.  Workgroup b keeps its OWN launch counter (ring[b]) and writes the pair
+  // of launch n into slot n % ring_slots of its column: no cross-workgroup traffic, no extra launch; the host reduces afterwards
+  const bool stamp = ring && blockIdx.x < kProfileMaxWg && threadIdx.x == 0;
+  unsigned long long t_start = 0, n_launch = 0;
+  if (stamp) {
+    t_start = __builtin_amdgcn_s_memrealtime();
+    n_launch = ring[blockIdx.x];
+  }
   __shared__ SlotRec recs[kThreads / 64][SPW];
   __shared__ int dts[kThreads / 64][SPW];
   constexpr int RPI = 64 / C;                       // rows per wave-instruction
@@ -204,36 +209,15 @@ __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const 
     }
     __builtin_amdgcn_wave_barrier();
   }
-  if (wg_stamps) {                                       // measurement only: wait for this workgroup's stores
+  if (ring) {                                            // measurement only: wait for this workgroup's stores
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    if (blockIdx.x < kProfileMaxWg && threadIdx.x == 0) wg_stamps[1] = __builtin_amdgcn_s_memrealtime();
-  }
-}
-
-// one workgroup: min start / max end over the lookup's workgroups -> slot of this launch; bump the counter
-__global__ __launch_bounds__(kThreads) void lookup_profile_reduce_kernel(unsigned long long* __restrict__ ring, int ring_slots, int nwg) {
-  __shared__ unsigned long long smin[kThreads], smax[kThreads];
-  const unsigned long long* wg = ring + 2 + 2 * ring_slots;
-  unsigned long long lo = ~0ull, hi = 0ull;
-  for (int i = threadIdx.x; i < nwg; i += kThreads) {
-    lo = wg[2 * i] < lo ? wg[2 * i] : lo;
-    hi = wg[2 * i + 1] > hi ? wg[2 * i + 1] : hi;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const unsigned long long l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
-    lo = l2 < lo ? l2 : lo;
-    hi = h2 > hi ? h2 : hi;
-  }
-  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int i = 1; i < kThreads / 64; ++i) { lo = smin[i] < lo ? smin[i] : lo; hi = smax[i] > hi ? smax[i] : hi; }
-    const unsigned long long n = ring[0];
-    ring[2 + 2 * (n % (unsigned long long)ring_slots)] = lo;
-    ring[3 + 2 * (n % (unsigned long long)ring_slots)] = hi;
-    ring[0] = n + 1;
+    if (stamp) {
+      unsigned long long* pair = ring + kProfileMaxWg + ((n_launch % (unsigned long long)ring_slots) * kProfileMaxWg + blockIdx.x) * 2;
+      pair[0] = t_start;
+      pair[1] = __builtin_amdgcn_s_memrealtime();
+      ring[blockIdx.x] = n_launch + 1;
+    }
   }
 }
 
@@ -1485,11 +1469,6 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
 #undef TT_LK
 #undef TT_LK2
     TT_LAUNCH_CHECK();
-    if (ctx->lookup_stamps) {
-      lookup_profile_reduce_kernel<<<1, kThreads, 0, st>>>(ctx->lookup_stamps, ctx->lookup_stamp_slots,
-                                                           grid < kProfileMaxWg ? grid : kProfileMaxWg);
-      TT_LAUNCH_CHECK();
-    }
     return TT_OK;
   }
   const int grid = grid_for(ctx, tt_cdiv(slots * C, U));

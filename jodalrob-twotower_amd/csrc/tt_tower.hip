@@ -372,6 +372,236 @@ __global__ __launch_bounds__(kTailThreads) void tail_head_kernel(Batch<HeadArgs>
   }
 }
 
+// (A') the whole front of a one-block tower in ONE launch: dense projection (x[:, 0:h0] = dense . W_proj^T + b_proj, stored
+// bf16), the block's Linear over x = [projection | looked-up rows] and the chunk BN statistics of relu(pre) -- the
+// projection GEMM, the split-K block GEMM and tail_head_kernel above (3 dependent launches, 12.6 + 12.6 + 9.4 us at
+// B = 8192: 77 MB of traffic of which 34 MB are split-K slabs written and read back).  One 512-thread workgroup per
+// 64-row block (the BN chunks).  Operands go through LDS in 128-wide k stages: every thread loads 16-byte pieces of whole
+// rows (coalesced: a fragment-shaped load straight from global memory -- one row per lane -- was tried first and ran at a
+// quarter of the texture-address rate, 50 us), rounds f32 to bf16 on the way in, and the loads run THREE stages ahead of
+// the MFMAs in registers -- all unconditional (pieces past the end read a dummy address and are zeroed), so the compiler
+// can count them.  The block GEMM's first stages are requested before the projection is computed.  K is split over the
+// waves of the block GEMM (4 tiles x 2 k-halves; the projection's 8 tiles take a wave each), the partial tiles are added
+// through LDS in a fixed order: reproducible, but not bit-identical to the split-K GEMM path.  The projection tile goes to x AND stays in
+// LDS as the block GEMM's operand for k < h0.
+// Needs: din <= 256, din and h0 + K E multiples of 64, h0 a multiple of 32 and <= 128, H <= 64.  grid (nchunks, towers)
+struct FrontArgs {
+  const float* dense; int64_t ld_dense; int din;
+  const float* w_proj; const float* b_proj; int h0;
+  uint16_t* x; int64_t ldx; int kx;
+  const float* w; const float* bias; float* pre;
+  BnStatArgs s;
+};
+constexpr int kFS = 136;                                         // bf16 elements per LDS row of a 128-wide k stage
+constexpr int kFrontThreads = 512;                               // 8 waves at up to 256 registers: three stages of loads in flight
+constexpr int kFrontA = 64 * kFS * 2, kFrontB = 128 * kFS * 2;   // bytes of one A / B stage buffer
+constexpr int kFrontLds = 2 * kFrontA + 2 * kFrontB + kFrontA + 4 * 64 * 12;
+
+using tl_bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+__device__ __forceinline__ void front_put4(__bf16* dst, const float4& v, bool live) {
+  tl_bf16x4 o;
+  o[0] = (__bf16)(live ? v.x : 0.f); o[1] = (__bf16)(live ? v.y : 0.f);
+  o[2] = (__bf16)(live ? v.z : 0.f); o[3] = (__bf16)(live ? v.w : 0.f);
+  *reinterpret_cast<tl_bf16x4*>(dst) = o;
+}
+
+// uniform base + 32-bit byte offset: the global_load "saddr" form, one VGPR of address per load instead of two
+template <typename T>
+__device__ __forceinline__ T front_ld(const void* base, uint32_t off) {
+  return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + off);
+}
+
+__global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontArgs> batch) {
+  const FrontArgs& f = batch.a[blockIdx.y];
+  const BnStatArgs& a = f.s;
+  const int H = a.H, B = a.B, h0 = f.h0, din = f.din, kx = f.kx;
+  if ((int)blockIdx.x >= a.nchunks) return;
+  extern __shared__ __attribute__((aligned(16))) char front_smem[];
+  __bf16* bufA = reinterpret_cast<__bf16*>(front_smem);                              // [2][64][kFS]
+  __bf16* bufB = reinterpret_cast<__bf16*>(front_smem + 2 * kFrontA);                // [2][128][kFS]
+  __bf16* Pt = reinterpret_cast<__bf16*>(front_smem + 2 * kFrontA + 2 * kFrontB);    // [64][kFS] projection tile
+  Wf (*sh)[64] = reinterpret_cast<Wf (*)[64]>(front_smem + 3 * kFrontA + 2 * kFrontB);
+  float* part = reinterpret_cast<float*>(bufB);                                      // partial tiles (after the MFMAs): 32 KB
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int c = t & 63, rq = t >> 6;
+  const int r0 = blockIdx.x * a.rows_per_chunk, r1 = min(B, r0 + a.rows_per_chunk);
+  const float bias = (f.bias && c < H) ? f.bias[c] : 0.f;
+  // piece of an f32 stage: row (t >> 5) + 16 pass, k = 4 (t & 31); piece of a bf16 stage: row (t >> 4) + 32 pass, k = 8 (t & 15)
+  const int frow = t >> 5, fk = 4 * (t & 31), xrow = t >> 4, xk = 8 * (t & 15);
+  const int ns2 = 3 * ((kx + 383) / 384);                       // block stages, padded to the unroll of 3 (pad stages are zeros)
+  const int pn = (wave >> 1) * 32 + li;                         // this lane's projection column
+  const float bp = pn < h0 ? f.b_proj[pn] : 0.f;
+  float x0 = 0.f, s = 0.f, q = 0.f, cnt = 0.f;
+  for (int b0 = r0; b0 < r1; b0 += 64) {
+    // ---- everything that can be requested now: the projection's two stages, the block GEMM's first three ----
+    float4 pa[2][4], pb[2][8];
+    uint32_t oa[4], ob[8];                                  // byte offsets of this thread's rows (k = fk)
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) oa[ps] = (uint32_t)(min(b0 + frow + 16 * ps, B - 1) * (int)f.ld_dense + fk) * 4u;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) ob[ps] = (uint32_t)(min(frow + 16 * ps, h0 - 1) * din + fk) * 4u;
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      const bool live = 128 * st + fk < din;
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) pa[st][ps] = front_ld<float4>(f.dense, live ? oa[ps] + 512u * st : 0u);
+#pragma unroll
+      for (int ps = 0; ps < 8; ++ps) pb[st][ps] = front_ld<float4>(f.w_proj, live ? ob[ps] + 512u * st : 0u);
+    }
+    uint4 qa[3][2];
+    float4 qb[3][4];
+    uint32_t ox[2], ow[4];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) ox[ps] = (uint32_t)(min(b0 + xrow + 32 * ps, B - 1) * (int)f.ldx + xk) * 2u;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) ow[ps] = (uint32_t)(min(frow + 16 * ps, H - 1) * kx + fk) * 4u;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int ka = 128 * u + xk, kb = 128 * u + fk;
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) qa[u][ps] = front_ld<uint4>(f.x, (ka >= h0 && ka < kx) ? ox[ps] + 256u * u : 0u);
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) qb[u][ps] = front_ld<float4>(f.w, kb < kx ? ow[ps] + 512u * u : 0u);
+    }
+    __builtin_amdgcn_sched_barrier(0);                      // 36 loads in flight before the first one is waited for
+    // ---- projection: wave = tile (rt, ct) of the 64 x h0 block, whole K ----
+    {
+      const int rt = wave & 1, ct = wave >> 1;
+      tl_f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const bool live = 128 * st + fk < din;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) front_put4(bufA + st * 64 * kFS + (frow + 16 * ps) * kFS + fk, pa[st][ps], live);
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) front_put4(bufB + st * 128 * kFS + (frow + 16 * ps) * kFS + fk, pb[st][ps], live);
+      }
+      {                                                     // third block stage, into the registers the projection just freed
+        const int ka = 256 + xk, kb = 256 + fk;
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) qa[2][ps] = front_ld<uint4>(f.x, (ka >= h0 && ka < kx) ? ox[ps] + 512u : 0u);
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) qb[2][ps] = front_ld<float4>(f.w, kb < kx ? ow[ps] + 1024u : 0u);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        const __bf16* A = bufA + st * 64 * kFS;
+        const __bf16* Bm = bufB + st * 128 * kFS;
+        if (128 * st < din) {
+#pragma unroll
+          for (int s2 = 0; s2 < 8; ++s2) {
+            const int k = 16 * s2 + 8 * lh;
+            const tl_bf16x8 av = *reinterpret_cast<const tl_bf16x8*>(A + (rt * 32 + li) * kFS + k);
+            const tl_bf16x8 bv = *reinterpret_cast<const tl_bf16x8*>(Bm + (ct * 32 + li) * kFS + k);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (pn < h0) Pt[m * kFS + pn] = (__bf16)(acc[r] + bp);
+      }
+      __syncthreads();                                      // Pt complete; the stage buffers are free again
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps)                        // the projection tile -> x[:, 0:h0], 16 bytes per piece
+        if (xk < h0 && b0 + xrow + 32 * ps < r1)
+          *reinterpret_cast<uint4*>(f.x + (int64_t)(b0 + xrow + 32 * ps) * f.ldx + xk) =
+              *reinterpret_cast<const uint4*>(Pt + (xrow + 32 * ps) * kFS + xk);
+    }
+    // ---- block Linear: tile (rt, nh) of the 64 x 64 block, k-half kq = MFMA k-steps 4 kq .. 4 kq + 3 of each stage ----
+    {
+      const int tile = wave & 3, kq = wave >> 2, rt = tile & 1, nh = tile >> 1;
+      tl_f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      for (int s0 = 0; s0 < ns2; s0 += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int st = s0 + u;
+          __bf16* A = bufA + (st & 1) * 64 * kFS;
+          __bf16* Bm = bufB + (st & 1) * 128 * kFS;
+#pragma unroll
+          for (int ps = 0; ps < 2; ++ps)
+            *reinterpret_cast<uint4*>(A + (xrow + 32 * ps) * kFS + xk) = (128 * st + xk < kx) ? qa[u][ps] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+          for (int ps = 0; ps < 4; ++ps) front_put4(Bm + (frow + 16 * ps) * kFS + fk, qb[u][ps], 128 * st + fk < kx);
+          __syncthreads();
+          {                                                 // three stages ahead, into the registers just stored
+            const int ka = 128 * (st + 3) + xk, kb = 128 * (st + 3) + fk;
+#pragma unroll
+            for (int ps = 0; ps < 2; ++ps) qa[u][ps] = front_ld<uint4>(f.x, (ka >= h0 && ka < kx) ? ox[ps] + 256u * (uint32_t)(st + 3) : 0u);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) qb[u][ps] = front_ld<float4>(f.w, kb < kx ? ow[ps] + 512u * (uint32_t)(st + 3) : 0u);
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 4; ++s2) {
+            const int kl = 16 * (4 * kq + s2), kglob = 128 * st + kl;
+            const __bf16* asrc = kglob < h0 ? Pt + (rt * 32 + li) * kFS + kglob + 8 * lh : A + (rt * 32 + li) * kFS + kl + 8 * lh;
+            const tl_bf16x8 av = *reinterpret_cast<const tl_bf16x8*>(asrc);
+            const tl_bf16x8 bv = *reinterpret_cast<const tl_bf16x8*>(Bm + (nh * 32 + li) * kFS + kl + 8 * lh);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();                                    // last stage read: bufB becomes the partial-tile area [2][64][64]
+      const int n = nh * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[(kq * 64 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 64 + n] = acc[r];
+    }
+    __syncthreads();
+    // ---- k-halves added in order + bias -> pre; relu tile (aliases part[0]: each thread overwrites what it read) ----
+    if (c < H) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = rq + 8 * j;
+        v[j] = (part[row * 64 + c] + part[(64 + row) * 64 + c]) + bias;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int row = rq + 8 * j, r = b0 + row;
+        if (r < r1) f.pre[(int64_t)r * H + c] = v[j];
+        part[row * 64 + c] = fmaxf(v[j], 0.f);
+      }
+    }
+    __syncthreads();
+    if (t < 256 && c < H) {               // as tail_head_kernel / bn_stats_partial_kernel: rows rq, rq + 4, ... of the block
+      const int nrow = min(64, r1 - b0);
+      for (int row = rq; row < nrow; row += 4) {
+        const float xv = part[row * 64 + c];
+        if (cnt == 0.f) x0 = xv;
+        const float d = xv - x0;
+        s += d;
+        q += d * d;
+        cnt += 1.f;
+      }
+    }
+    __syncthreads();
+  }
+  if (t < 256) {
+    Wf w{0.f, 0.f, 0.f};
+    if (c < H && cnt > 0.f) {
+      w.n = cnt;
+      w.mean = x0 + s / cnt;
+      w.m2 = fmaxf(q - s * (s / cnt), 0.f);
+    }
+    sh[rq][c] = w;
+  }
+  __syncthreads();
+  if (t < 64 && c < H) {
+    Wf o = sh[0][c];
+    o = wf_combine(o, sh[1][c]);
+    o = wf_combine(o, sh[2][c]);
+    o = wf_combine(o, sh[3][c]);
+    float* p = a.partial + (int64_t)blockIdx.x * 3 * H;
+    p[c] = o.n; p[H + c] = o.mean; p[2 * H + c] = o.m2;
+  }
+}
+
 // (B) BN statistics finish (every workgroup, same order as bn_stats_finish_kernel) + BN apply + dropout + output Linear
 // (one 64 x 64 x 64 bf16 MFMA tile) + L2 normalise, for 64 rows per workgroup.  grid (cdiv(B, 64), towers)
 struct TailFwdArgs {
@@ -900,6 +1130,18 @@ inline bool tail_fusable(int n, const tt_tower_params* const* P, int train) {
     if (!tail_shape_ok(P[t]) || (P[t]->flags & TT_TOWER_UNFUSED_TAIL)) return false;
   return true;
 }
+// the one-launch front (tower_front_kernel): fused tail + ONE hidden block + bf16 tower input, projection width a multiple of
+// 32 and at most 128, 16-byte-aligned rows everywhere
+inline bool front_fusable(int n, const tt_tower_params* const* P, const tt_tower_acts* const* A) {
+  for (int t = 0; t < n; ++t) {
+    const tt_tower_params* p = P[t];
+    const int kx = p->h0 + p->kcat_e;
+    if (p->n_hidden != 1 || p->x_dtype != TT_BF16 || (p->flags & TT_TOWER_UNFUSED_FRONT)) return false;
+    if (p->h0 % 32 != 0 || p->h0 > 128 || p->din % 64 != 0 || p->din > 256 || kx % 64 != 0) return false;
+    if (!tt_aligned(A[t]->dense, 16) || !tt_aligned(A[t]->x, 16) || !tt_aligned(p->w_proj, 16) || !tt_aligned(p->w[0], 16)) return false;
+  }
+  return true;
+}
 inline size_t tail_slab_bytes(const tt_tower_params* p) {   // per-chunk output-layer gradient slabs of tail_bwd_kernel
   return sizeof(float) * (size_t)kMaxChunks * ((size_t)p->d_out * p->hidden[p->n_hidden - 1] + (size_t)p->d_out) + 256;
 }
@@ -1019,7 +1261,8 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       TT_CHECK_ARG(phase == 1 ? A[t]->bn_sync_local != nullptr : A[t]->bn_sync_all != nullptr, "tt_towers_mlp_fwd: NULL SyncBN buffer");
   }
   for (int t = 0; t < n; ++t) { nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes; }
-  if (phase != 2)
+  const bool front = fused && front_fusable(n, P, A);    // projection + block Linear + chunk statistics in one launch
+  if (phase != 2 && !front)
     if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
   NtDeferred nd[TT_MAX_SIDES];
   for (int i = 0; i < nh; ++i) {
@@ -1047,12 +1290,23 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       nt[t].bf16 = P[0]->compute_dtype == TT_BF16; nt[t].workspace = ws[t].gemm; nt[t].workspace_bytes = ws[t].gemm_bytes;
       nt[t].defer = tail ? &nd[t] : nullptr;
     }
-    if (phase != 2)
+    if (phase != 2 && !(front && tail))
       if (int rc = tt_gemm_nt_batched(st, nt, n)) return rc;
     if (tail) {
       // slabs (+ bias) -> pre with the chunk statistics in the same pass, then everything up to the unit rows in one kernel
       if (phase != 2) {
-        if (nd[0].splits > 0) {
+        if (front) {
+          static const bool lds_set = [] {
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(tower_front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kFrontLds) == hipSuccess;
+          }();
+          if (!lds_set) { tt_set_error("tt_towers_mlp_fwd: cannot reserve %d bytes of LDS for tower_front_kernel", kFrontLds); return TT_ERR_HIP; }
+          Batch<FrontArgs> fb{};
+          for (int t = 0; t < n; ++t)
+            fb.a[t] = FrontArgs{A[t]->dense, P[t]->din, P[t]->din, P[t]->w_proj, P[t]->b_proj, P[t]->h0,
+                                reinterpret_cast<uint16_t*>(A[t]->x), in_w[t], in_w[t], P[t]->w[i], P[t]->b[i], A[t]->pre[i], bs.a[t]};
+          tower_front_kernel<<<dim3((unsigned)cmax, (unsigned)n), kFrontThreads, kFrontLds, st>>>(fb);
+        } else if (nd[0].splits > 0) {
           Batch<HeadArgs> hb{};
           for (int t = 0; t < n; ++t) hb.a[t] = HeadArgs{nd[t].slabs, nd[t].slab_stride, nd[t].splits, P[t]->b[i], A[t]->pre[i], bs.a[t]};
           tail_head_kernel<<<dim3((unsigned)cmax, (unsigned)n), kTailThreads, 0, st>>>(hb);

@@ -109,24 +109,33 @@ def embed_lookup(table: Optional[torch.Tensor], sides: Sequence[LookupSide], B: 
 
 
 class LookupProfile:
-    """Ring of device-clock stamps of the lookup kernel, one slot per launch (works inside captured graphs,
-    needs no host synchronisation while measuring)."""
+    """Device-clock stamps of the lookup kernel, one block of per-workgroup pairs per launch (works inside captured graphs,
+    needs no host synchronisation and no extra launch while measuring; reduced on the host afterwards)."""
 
-    def __init__(self, device, n_slots: int = 4096):
+    MAX_WG = 4096
+
+    def __init__(self, device, n_slots: int = 256):
         self.device, self.n = torch.device(device), n_slots
-        self.ring = torch.zeros(2 + 2 * n_slots + 2 * 4096, dtype=torch.int64, device=self.device)
+        self.ring = torch.zeros(self.MAX_WG + n_slots * self.MAX_WG * 2, dtype=torch.int64, device=self.device)
         L.check(L.load().tt_embed_lookup_set_profile(L.ctx(self.device), L.ptr(self.ring), n_slots), "tt_embed_lookup_set_profile")
 
     def reset(self):
         self.ring.zero_()
 
     def durations_us(self):
-        """Kernel durations (us) of the launches since the last reset(); synchronises."""
+        """Kernel durations (us) of the (last n_slots) launches since the last reset(), oldest first; synchronises."""
         torch.cuda.synchronize(self.device)
         r = self.ring.cpu()
-        n = min(int(r[0]), self.n)
-        s, e = r[2:2 + 2 * n:2], r[3:3 + 2 * n:2]
-        return [float(x) * 0.01 for x in (e - s).tolist() if x > 0]  # 100 MHz clock
+        launches = int(r[0])
+        pairs = r[self.MAX_WG:].view(self.n, self.MAX_WG, 2)
+        same = r[:self.MAX_WG] == launches          # workgroups that took part in every launch (grids of one size)
+        out = []
+        for n in range(max(0, launches - self.n), launches):
+            blk = pairs[n % self.n]
+            live = (blk[:, 1] > 0) & same
+            if bool(live.any()):
+                out.append(float(blk[live, 1].max() - blk[live, 0].min()) * 0.01)   # 100 MHz clock
+        return out
 
     def close(self):
         L.check(L.load().tt_embed_lookup_set_profile(L.ctx(self.device), None, 0), "tt_embed_lookup_set_profile")

@@ -84,6 +84,8 @@ class BaseTower(nn.Module):
         self.dx_dtype = torch.bfloat16 if io in ("dx", "both") else torch.float32
         # TT_TOWER_UNFUSED_TAIL=1: run the BN / output-Linear / L2-normalise tail as the separate kernels (A/B runs)
         self.unfused_tail = os.environ.get("TT_TOWER_UNFUSED_TAIL", "0") == "1"
+        # TT_TOWER_UNFUSED_FRONT=1: projection GEMM, block GEMM and the slab / statistics pass as separate launches (A/B runs)
+        self.unfused_front = os.environ.get("TT_TOWER_UNFUSED_FRONT", "0") == "1"
         self.categorical_keys = list(categorical_keys)
         self.exchange = None            # set by the distributed task: sharded-table row exchange
         self.sync_comm = None           # set by the distributed task (sync_bn=True): BN statistics over all ranks' rows
@@ -139,7 +141,7 @@ class BaseTower(nn.Module):
         tensors = [self.dense_projection.weight, self.dense_projection.bias, out.weight, out.bias]
         for lin, bn in zip(lins, bns):
             tensors += [lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype, self.x_dtype, self.dx_dtype, self.unfused_tail)
+        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype, self.x_dtype, self.dx_dtype, self.unfused_tail, self.unfused_front)
         if key != self._struct_key:
             for t in tensors:
                 if t.dtype != torch.float32 or not t.is_contiguous():
@@ -154,7 +156,7 @@ class BaseTower(nn.Module):
                 compute_dtype=ops.TT_BF16 if self.mlp_dtype == "bf16" else ops.TT_F32,
                 x_dtype=ops.TT_BF16 if self.x_dtype == torch.bfloat16 else ops.TT_F32,
                 dx_dtype=ops.TT_BF16 if self.dx_dtype == torch.bfloat16 else ops.TT_F32,
-                flags=ops.L.TT_TOWER_UNFUSED_TAIL if self.unfused_tail else 0)
+                flags=(ops.L.TT_TOWER_UNFUSED_TAIL if self.unfused_tail else 0) | (ops.L.TT_TOWER_UNFUSED_FRONT if self.unfused_front else 0))
             self._struct_key = key
         return self._params_struct
 

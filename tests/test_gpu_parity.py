@@ -631,6 +631,7 @@ def test_fused_tower_tail_equals_separate_kernels(tt, manifest, schema_real, mon
     state = init_state_numpy(shapes, 91)
     b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 92, oob=False)
     outs = {}
+    monkeypatch.setenv("TT_TOWER_UNFUSED_FRONT", "1")      # the one-launch front sums K in another order: compared in its own test
     for unfused in ("1", "0"):
         monkeypatch.setenv("TT_TOWER_UNFUSED_TAIL", unfused)
         torch.manual_seed(1234)
@@ -766,6 +767,7 @@ def test_fused_tower_tail_odd_shapes(tt, manifest, monkeypatch, B, H, D, drop):
     outs = {}
     state = None
     b = synth_batch_numpy(B, cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 171, oob=True)
+    monkeypatch.setenv("TT_TOWER_UNFUSED_FRONT", "1")
     for unfused in ("1", "0"):
         monkeypatch.setenv("TT_TOWER_UNFUSED_TAIL", unfused)
         task = make_task(tt, cfg, mlp_dtype="bf16", score_dtype="bf16", dropout_rate=drop)
@@ -787,6 +789,80 @@ def test_fused_tower_tail_odd_shapes(tt, manifest, monkeypatch, B, H, D, drop):
         assert np.isfinite(gf).all(), k
         tol = 2e-5 if B >= 32 else 2e-4            # (BatchNorm over two rows: the backward terms cancel to rounding noise)
         assert np.linalg.norm(gf - g) <= tol * np.linalg.norm(g) + 1e-10, (k, np.linalg.norm(gf - g), np.linalg.norm(g))
+
+
+@pytest.mark.parametrize("E,nk_n,nk_c,h0,din_n,din_c,H,D,B,drop", [
+    (64, 5, 2, 64, 64, 128, 33, 17, 65, 0.1),        # ragged row block, widths off the 32-column grid
+    (64, 5, 2, 128, 128, 64, 64, 64, 127, 0.0),
+    (32, 3, 1, 32, 64, 64, 40, 33, 4097, 0.1),       # h0 = 32: a lane's k window is projection tile OR looked-up rows per half-wave
+    (32, 3, 1, 96, 192, 64, 64, 48, 8191, 0.2),
+    (32, 5, 2, 128, 256, 128, 64, 64, 8200, 0.1),    # keys of the synthetic schema at the reference's widths (company falls back: 192 % 64)
+])
+def test_tower_front_one_launch_vs_separate(tt, manifest, monkeypatch, E, nk_n, nk_c, h0, din_n, din_c, H, D, B, drop):
+    """tower_front_kernel (projection + block Linear + chunk BN statistics in one launch, K split over the waves of a workgroup)
+    against the same pass as projection GEMM, split-K block GEMM and tail_head_kernel.  Same operands, same rounding points
+    (bf16 x, bf16 MFMA operands, f32 accumulate) but another summation order: a projection element that sits on a bf16
+    rounding boundary may land on the other side, so the comparison is to tolerance (the parity claim of the measured mode is
+    test_bf16_step_vs_rounded_oracle, which runs the one-launch front)."""
+    cfg = dict(manifest["cases"]["wide_b40"])
+    cfg.update(E=E, hidden=[h0, H], D=D, din_n=din_n, din_c=din_c, keys_n=cfg["keys_n"][:nk_n], keys_c=cfg["keys_c"][:nk_c],
+               vocab_n=cfg["vocab_n"][:nk_n], vocab_c=cfg["vocab_c"][:nk_c])
+    b = synth_batch_numpy(B, cfg["vocab_n"], cfg["vocab_c"], din_n, din_c, 181, oob=True)
+    outs, state = {}, None
+    for unfused in ("1", "0"):
+        monkeypatch.setenv("TT_TOWER_UNFUSED_FRONT", unfused)
+        task = make_task(tt, cfg, mlp_dtype="bf16", score_dtype="bf16", dropout_rate=drop)
+        if state is None:
+            state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 182)
+        for tw in (task.two_tower_model.notice_tower, task.two_tower_model.company_tower):
+            tw._seed_override = 5
+        load_state(task, state)
+        task.train()
+        res = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+        res["loss"].backward()
+        outs[unfused] = (res["loss"].item(), {n: p.grad.cpu().numpy() for n, p in task.named_parameters() if p.grad is not None},
+                         {k: v.cpu().numpy() for k, v in task.state_dict().items() if "running" in k})
+    worst = {"loss": abs(outs["0"][0] - outs["1"][0]) / abs(outs["1"][0])}
+    for k, v in outs["1"][2].items():
+        worst["bn:" + k] = float(np.abs(outs["0"][2][k] - v).max() / (np.abs(v).max() + 1e-12))
+    for k, g in outs["1"][1].items():
+        gf = outs["0"][1][k]
+        assert np.isfinite(gf).all(), k
+        worst["grad:" + k] = float(np.linalg.norm(gf - g) / (np.linalg.norm(g) + 1e-12))
+    print("front one-launch vs separate:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert np.isfinite(outs["0"][0]) and worst["loss"] <= 2e-5, worst
+    for k, v in worst.items():
+        if k.startswith("bn:"):
+            assert v <= 1e-4, (k, v)
+        if k.startswith("grad:"):
+            tol = 3e-3 if B >= 32 else 3e-2
+            assert v <= tol, (k, v)
+
+
+def test_lookup_profile_ring(tt):
+    """ops.LookupProfile: per-launch kernel durations from in-kernel stamps -- one entry per launch, no extra launch, the ring
+    keeps the last n_slots launches, durations plausible (0.5 us .. 1 ms)."""
+    from jodalrob_twotower_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, K, E, R = 2048, 6, 32, 50000
+    table = torch.randn(R, E, device=DEV)
+    ids = torch.randint(0, R // K, (B * K,), generator=g).to(DEV)
+    off = torch.arange(K, dtype=torch.int64, device=DEV) * (R // K)
+    voc = torch.full((K,), R // K, dtype=torch.int64, device=DEV)
+    x = torch.empty(B, K * E, device=DEV)
+    prof = ops.LookupProfile(DEV, n_slots=8)
+    try:
+        for n_launch in (3, 11):
+            prof.reset()
+            for _ in range(n_launch):
+                ops.embed_lookup(table, [ops.LookupSide(ids, off, voc, x, K)], B, False)
+            d = prof.durations_us()
+            assert len(d) == min(n_launch, 8), (n_launch, d)
+            assert all(0.5 < v < 1000.0 for v in d), d
+    finally:
+        prof.close()
+    ref = table[(ids.view(B, K) + off).view(-1)].view(B, K * E)
+    assert torch.equal(x, ref)
 
 
 def test_copy_multi(tt):
