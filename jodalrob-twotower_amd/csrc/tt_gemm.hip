@@ -310,6 +310,143 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(GemmBatch batch, int
   }
 }
 
+// ---- the same tile with the loads THREE k-steps ahead ------------------------------------------------------------------
+// gemm_bf16_kernel keeps one k-step of loads in flight: a workgroup's time is (k-steps) x (one global-load round trip) --
+// 10 dependent round trips for a weight-gradient workgroup at B = 8192 (18 us for 30 MB).  This form holds three k-steps of
+// operand pieces in registers and double-buffers the LDS tiles (one barrier per step).  Every load is unconditional and in
+// a fixed order (hipcc then waits with vmcnt(N), not vmcnt(0)): it takes the shapes that need no predicates -- M, N
+// multiples of 64, every k-range a multiple of 32, 16-byte-aligned rows -- and element types as template parameters; the
+// general kernel above takes the rest.  Same k order inside a workgroup, same split-K layout: results are bit-identical.
+template <int MODE, bool BF16>
+struct FastLoader16 {
+  // raw pieces exactly as loaded (bf16: one 16-byte piece in q; f32: 8 values in r): every ALU op on them sits in store(),
+  // behind the barrier of the previous step -- an unpack in load() is scheduled early and waits for the whole pipeline
+  float r[BF16 ? 1 : KR];
+  uint4 q;
+  __device__ __forceinline__ void load(const float* __restrict__ Pf, int64_t ld, int x0, int k0, int t) {
+    if (MODE == 0) {
+      const int x = x0 + (t >> 2), k = k0 + (t & 3) * KR;
+      if (BF16) {
+        q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Pf) + (int64_t)x * ld + k);
+      } else {
+        const float4 a = *reinterpret_cast<const float4*>(Pf + (int64_t)x * ld + k);
+        const float4 b = *reinterpret_cast<const float4*>(Pf + (int64_t)x * ld + k + 4);
+        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+      }
+    } else if (BF16) {                     // 8 adjacent x at one k, transposed on the way into LDS
+      const int x = x0 + 8 * (t & 7), k = k0 + (t >> 3);
+      q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Pf) + (int64_t)k * ld + x);
+    } else {                               // one x, KR consecutive k (coalesced dword loads across x)
+      const int x = x0 + (t & 63), k = k0 + (t >> 6) * KR;
+#pragma unroll
+      for (int j = 0; j < KR; ++j) r[j] = Pf[(int64_t)(k + j) * ld + x];
+    }
+  }
+  __device__ __forceinline__ float colsum() const {       // f32 X-contiguous pieces only
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < (BF16 ? 1 : KR); ++j) s += r[j];
+    return s;
+  }
+  __device__ __forceinline__ void store(__bf16* __restrict__ S, int t) {
+    if (BF16) {
+      asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
+      if (MODE == 1) {
+        const int row = 8 * (t & 7), k = t >> 3;
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          reinterpret_cast<uint16_t*>(S)[(row + 2 * j) * LDS16 + k] = (uint16_t)(w[j] & 0xFFFFu);
+          reinterpret_cast<uint16_t*>(S)[(row + 2 * j + 1) * LDS16 + k] = (uint16_t)(w[j] >> 16);
+        }
+      } else {
+        *reinterpret_cast<uint4*>(S + (t >> 2) * LDS16 + (t & 3) * KR) = q;
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < (BF16 ? 1 : KR); ++j) asm volatile("" : "+v"(r[j]));
+    const int row = MODE == 0 ? (t >> 2) : (t & 63), kq = MODE == 0 ? (t & 3) * KR : (t >> 6) * KR;
+    bf16x8g v;
+#pragma unroll
+    for (int j = 0; j < (BF16 ? 1 : KR); ++j) v[j] = (__bf16)r[j];
+    *reinterpret_cast<bf16x8g*>(S + row * LDS16 + kq) = v;
+  }
+};
+
+template <int MODE_A, int MODE_B, bool COLSUM, bool A_BF16, bool B_BF16>
+__global__ __launch_bounds__(THREADS) void gemm_bf16_fast_kernel(GemmBatch batch, int zsplits) {
+  static_assert(!(MODE_A == 1 && A_BF16), "COLSUM reads the A pieces per column");
+  const GemmArgs& g = batch.a[blockIdx.z / zsplits];
+  const int split = blockIdx.z % zsplits;
+  const int M = g.M, N = g.N, K = g.K, kchunk = g.kchunk;
+  if ((int)blockIdx.x * BM >= M || (int)blockIdx.y * BN >= N || split >= g.splits) return;
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LDS16];
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDS16];
+  __shared__ float red[4][64];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int kbeg = split * kchunk, kend = min(K, kbeg + kchunk);
+  const int nsteps = kend > kbeg ? (kend - kbeg) / BK16 : 0;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float cs = 0.f;
+  if (nsteps > 0) {
+    FastLoader16<MODE_A, A_BF16> la[3];
+    FastLoader16<MODE_B, B_BF16> lb[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {                            // a step past the end re-reads the last one (discarded)
+      const int k = kbeg + min(u, nsteps - 1) * BK16;
+      la[u].load(g.A, g.lda, m0, k, t);
+      lb[u].load(g.B, g.ldb, n0, k, t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto step = [&](int i, FastLoader16<MODE_A, A_BF16>& a, FastLoader16<MODE_B, B_BF16>& b) {
+      __bf16* A = As[i & 1];
+      __bf16* Bm = Bs[i & 1];
+      a.store(A, t);
+      b.store(Bm, t);
+      if (COLSUM) cs += a.colsum();        // MODE_A == 1 there: this thread holds column (t & 63), 8 batch rows
+      __syncthreads();
+      const int k = kbeg + min(i + 3, nsteps - 1) * BK16;
+      a.load(g.A, g.lda, m0, k, t);
+      b.load(g.B, g.ldb, n0, k, t);
+#pragma unroll
+      for (int s2 = 0; s2 < BK16 / 16; ++s2) {
+        const bf16x8g av = *reinterpret_cast<const bf16x8g*>(A + (wr * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
+        const bf16x8g bv = *reinterpret_cast<const bf16x8g*>(Bm + (wc * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+      }
+    };
+    const int full = nsteps - nsteps % 3;
+    for (int i0 = 0; i0 < full; i0 += 3) {                  // whole groups of three: no exit inside the unrolled body
+      step(i0, la[0], lb[0]);
+      step(i0 + 1, la[1], lb[1]);
+      step(i0 + 2, la[2], lb[2]);
+    }
+    if (nsteps - full >= 1) step(full, la[0], lb[0]);
+    if (nsteps - full >= 2) step(full + 1, la[1], lb[1]);
+  }
+  if (COLSUM && g.colsum_slab && blockIdx.y == 0) {
+    red[t >> 6][t & 63] = cs;
+    __syncthreads();
+    if (t < BM) g.colsum_slab[(int64_t)split * M + m0 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+  }
+  float* Cz = g.C + (int64_t)split * g.slab_stride;
+  const int n = n0 + wc * 32 + li;
+  const float bv = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    float v = acc[r] * g.alpha + bv;
+    if (g.relu) v = fmaxf(v, 0.f);
+    if (g.c_bf16) reinterpret_cast<uint16_t*>(Cz)[(int64_t)m * g.ldc + n] = tt_f2bf(v);
+    else Cz[(int64_t)m * g.ldc + n] = v;
+  }
+}
+
 __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(SlabBatch batch) {
   const SlabArgs& a = batch.a[blockIdx.y];
   const int64_t total = (int64_t)a.M * a.N;
@@ -363,6 +500,33 @@ static int launch_gemm(hipStream_t st, const GemmBatch& b, int n, int zsplits, b
   }
   dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(n * zsplits));
   if (bf16) {
+    // shapes without edges and one element type per operand across the batch: the three-steps-ahead kernel
+    static const bool fast_off = getenv("TT_GEMM_FAST") && atoi(getenv("TT_GEMM_FAST")) == 0;
+    bool fast = vec && !fast_off;
+    for (int i = 0; i < n && fast; ++i) {
+      const GemmArgs& g = b.a[i];
+      fast = g.M % BM == 0 && g.N % BN == 0 && g.K % BK16 == 0 && g.kchunk % BK16 == 0 && g.a_bf16 == b.a[0].a_bf16 &&
+             g.b_bf16 == b.a[0].b_bf16 && !(MA == 1 && g.a_bf16) && !(MA == 0 && MB == 0 && g.b_bf16) && !(MB == 1 && MA == 0 && (g.a_bf16 || g.b_bf16));
+    }
+    if (fast) {
+      const bool ab = b.a[0].a_bf16, bb = b.a[0].b_bf16;
+      if (MA == 0 && MB == 0) {
+        if (ab) gemm_bf16_fast_kernel<0, 0, false, true, false><<<grid, THREADS, 0, st>>>(b, zsplits);
+        else gemm_bf16_fast_kernel<0, 0, false, false, false><<<grid, THREADS, 0, st>>>(b, zsplits);
+      } else if (MA == 0 && MB == 1) {
+        gemm_bf16_fast_kernel<0, 1, false, false, false><<<grid, THREADS, 0, st>>>(b, zsplits);
+      } else {
+        if (colsum) {
+          if (bb) gemm_bf16_fast_kernel<1, 1, true, false, true><<<grid, THREADS, 0, st>>>(b, zsplits);
+          else gemm_bf16_fast_kernel<1, 1, true, false, false><<<grid, THREADS, 0, st>>>(b, zsplits);
+        } else {
+          if (bb) gemm_bf16_fast_kernel<1, 1, false, false, true><<<grid, THREADS, 0, st>>>(b, zsplits);
+          else gemm_bf16_fast_kernel<1, 1, false, false, false><<<grid, THREADS, 0, st>>>(b, zsplits);
+        }
+      }
+      TT_LAUNCH_CHECK();
+      return TT_OK;
+    }
     if (colsum) gemm_bf16_kernel<MA, MB, true><<<grid, THREADS, 0, st>>>(b, zsplits, vec ? 1 : 0);
     else gemm_bf16_kernel<MA, MB, false><<<grid, THREADS, 0, st>>>(b, zsplits, vec ? 1 : 0);
     TT_LAUNCH_CHECK();

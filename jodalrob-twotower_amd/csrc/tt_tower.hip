@@ -379,8 +379,9 @@ __global__ __launch_bounds__(kTailThreads) void tail_head_kernel(Batch<HeadArgs>
 // 64-row block (the BN chunks).  Operands go through LDS in 128-wide k stages: every thread loads 16-byte pieces of whole
 // rows (coalesced: a fragment-shaped load straight from global memory -- one row per lane -- was tried first and ran at a
 // quarter of the texture-address rate, 50 us), rounds f32 to bf16 on the way in, and the loads run THREE stages ahead of
-// the MFMAs in registers -- all unconditional (pieces past the end read a dummy address and are zeroed), so the compiler
-// can count them.  The block GEMM's first stages are requested before the projection is computed.  K is split over the
+// the MFMAs in registers -- all unconditional (a piece past the end re-reads the thread's own first piece and is zeroed),
+// so the compiler can count them.  Bound: a CU draws L2-resident bytes at ~70 GB/s (MI355X_MICROARCH.md) and every
+// workgroup re-reads its tower's f32 weights -- 426 KB of the 637 KB a notice workgroup moves: ~9 us.  The block GEMM's first stages are requested before the projection is computed.  K is split over the
 // waves of the block GEMM (4 tiles x 2 k-halves; the projection's 8 tiles take a wave each), the partial tiles are added
 // through LDS in a fixed order: reproducible, but not bit-identical to the split-K GEMM path.  The projection tile goes to x AND stays in
 // LDS as the block GEMM's operand for k < h0.
@@ -442,11 +443,12 @@ __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontA
     for (int ps = 0; ps < 8; ++ps) ob[ps] = (uint32_t)(min(frow + 16 * ps, h0 - 1) * din + fk) * 4u;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      const bool live = 128 * st + fk < din;
+      // a piece past the end re-reads this thread's own first piece (discarded): never ONE address for the whole grid
+      const uint32_t ko = 128 * st + fk < din ? 512u * st : 0u;
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) pa[st][ps] = front_ld<float4>(f.dense, live ? oa[ps] + 512u * st : 0u);
+      for (int ps = 0; ps < 4; ++ps) pa[st][ps] = front_ld<float4>(f.dense, oa[ps] + ko);
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) pb[st][ps] = front_ld<float4>(f.w_proj, live ? ob[ps] + 512u * st : 0u);
+      for (int ps = 0; ps < 8; ++ps) pb[st][ps] = front_ld<float4>(f.w_proj, ob[ps] + ko);
     }
     uint4 qa[3][2];
     float4 qb[3][4];
@@ -459,9 +461,9 @@ __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontA
     for (int u = 0; u < 2; ++u) {
       const int ka = 128 * u + xk, kb = 128 * u + fk;
 #pragma unroll
-      for (int ps = 0; ps < 2; ++ps) qa[u][ps] = front_ld<uint4>(f.x, (ka >= h0 && ka < kx) ? ox[ps] + 256u * u : 0u);
+      for (int ps = 0; ps < 2; ++ps) qa[u][ps] = front_ld<uint4>(f.x, ox[ps] + (ka < kx ? 256u * u : 0u));
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) qb[u][ps] = front_ld<float4>(f.w, kb < kx ? ow[ps] + 512u * u : 0u);
+      for (int ps = 0; ps < 4; ++ps) qb[u][ps] = front_ld<float4>(f.w, ow[ps] + (kb < kx ? 512u * u : 0u));
     }
     __builtin_amdgcn_sched_barrier(0);                      // 36 loads in flight before the first one is waited for
     // ---- projection: wave = tile (rt, ct) of the 64 x h0 block, whole K ----
@@ -481,9 +483,9 @@ __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontA
       {                                                     // third block stage, into the registers the projection just freed
         const int ka = 256 + xk, kb = 256 + fk;
 #pragma unroll
-        for (int ps = 0; ps < 2; ++ps) qa[2][ps] = front_ld<uint4>(f.x, (ka >= h0 && ka < kx) ? ox[ps] + 512u : 0u);
+        for (int ps = 0; ps < 2; ++ps) qa[2][ps] = front_ld<uint4>(f.x, ox[ps] + (ka < kx ? 512u : 0u));
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) qb[2][ps] = front_ld<float4>(f.w, kb < kx ? ow[ps] + 1024u : 0u);
+        for (int ps = 0; ps < 4; ++ps) qb[2][ps] = front_ld<float4>(f.w, ow[ps] + (kb < kx ? 1024u : 0u));
       }
       __syncthreads();
 #pragma unroll
@@ -533,9 +535,9 @@ __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontA
           {                                                 // three stages ahead, into the registers just stored
             const int ka = 128 * (st + 3) + xk, kb = 128 * (st + 3) + fk;
 #pragma unroll
-            for (int ps = 0; ps < 2; ++ps) qa[u][ps] = front_ld<uint4>(f.x, (ka >= h0 && ka < kx) ? ox[ps] + 256u * (uint32_t)(st + 3) : 0u);
+            for (int ps = 0; ps < 2; ++ps) qa[u][ps] = front_ld<uint4>(f.x, ox[ps] + (ka < kx ? 256u * (uint32_t)(st + 3) : 0u));
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) qb[u][ps] = front_ld<float4>(f.w, kb < kx ? ow[ps] + 512u * (uint32_t)(st + 3) : 0u);
+            for (int ps = 0; ps < 4; ++ps) qb[u][ps] = front_ld<float4>(f.w, ow[ps] + (kb < kx ? 512u * (uint32_t)(st + 3) : 0u));
           }
 #pragma unroll
           for (int s2 = 0; s2 < 4; ++s2) {

@@ -590,6 +590,7 @@ def test_bf16_tower_input_is_bit_identical(tt, manifest, schema_real, monkeypatc
     state = init_state_numpy(shapes, 77)
     b = synth_batch_numpy(cfg["B"], vn, vc, cfg["din_n"], cfg["din_c"], 78, oob=False)
     outs = {}
+    monkeypatch.setenv("TT_TOWER_UNFUSED_FRONT", "1")      # storage type only: the one-launch front needs bf16 x and sums K in another order
     for io in ("none", "x", "both"):
         monkeypatch.setenv("TT_TOWER_IO_DTYPE", io)
         task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", mlp_dtype="bf16")
