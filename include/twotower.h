@@ -237,6 +237,7 @@ typedef struct tt_tower_params {
    the fused form applies (last hidden width and d_out <= 64, compute_dtype TT_BF16): for A/B comparison */
 #define TT_TOWER_UNFUSED_TAIL 1
 #define TT_TOWER_UNFUSED_FRONT 2 /* keep projection GEMM, block GEMM and slab/statistics pass as separate launches */
+#define TT_TOWER_UNFUSED_BACK 4  /* first-block weight / data gradients and the projection's weight gradient as separate launches */
 
 typedef struct tt_tower_acts { /* caller-allocated; kept between forward and backward */
   const float* dense;          /* [B, din] */
@@ -266,7 +267,8 @@ typedef struct tt_tower_grads { /* every buffer is overwritten, not accumulated 
   float* bn_b[TT_MAX_HIDDEN];
   float* w_out;
   float* b_out;
-  void* d_x;                     /* [B, h0 + kcat_e] of params.dx_dtype; columns [h0, ..) feed tt_embed_grad_bwd */
+  void* d_x;                     /* [B, h0 + kcat_e] of params.dx_dtype; columns [h0, ..) feed tt_embed_grad_bwd.  Columns [0, h0)
+                                    (the projection output's gradient) are scratch: the bf16 path with edge-free shapes does not write them */
   float* scratch[TT_MAX_HIDDEN]; /* [B, hidden[i]] */
   float* d_y;                    /* [B, d_out] */
   float* s_sync_local;     /* sync_phase 1 out: [2][hidden[0]] */

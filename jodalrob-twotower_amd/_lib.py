@@ -20,6 +20,7 @@ TT_MAX_SIDES, TT_MAX_HIDDEN = 4, 8
 TT_GRAD_SPARSE, TT_GRAD_DENSE_SET, TT_GRAD_DENSE_ACC = 0, 1, 2
 TT_TOWER_UNFUSED_TAIL = 1
 TT_TOWER_UNFUSED_FRONT = 2
+TT_TOWER_UNFUSED_BACK = 4
 TT_GRAD_SHORT_SEGMENTS = 0x100
 
 vp = C.c_void_p

@@ -45,3 +45,23 @@ TnPending* tt_gemm_tn_pending_create();
 void tt_gemm_tn_pending_destroy(TnPending*);
 int tt_gemm_tn_batched(hipStream_t st, const GemmTN* items, int n, TnPending* pending = nullptr);
 int tt_gemm_tn_flush(hipStream_t st, TnPending* pending);
+
+// First-block backward of up to TT_MAX_SIDES towers in ONE launch (bf16 operands, edge-free shapes): per tower
+//   dW = d_pre^T . x (+ db = column sums of d_pre),  d_x[:, h0:] = d_pre . W[:, h0:],  G = d_pre^T . dense,
+// and dW_proj = W[:, 0:h0]^T . G (each batch split's share multiplied in its own workgroup, summed by the pending
+// slab-reduction launch), db_proj = W[:, 0:h0]^T . db  (= d_proj^T . dense and the column sums of d_proj = d_pre . W[:, 0:h0],
+// without materialising d_proj: d_x[:, 0:h0] is NOT written).  H = 64 only.  tt_gemm_back_supported() says whether the shapes qualify; otherwise use the TN / NN launchers.
+struct GemmBack {
+  const float* dpre; int H;                       // [B, H] f32, ld = H
+  const void* x; int64_t ldx; int kx; bool x_bf16;
+  const float* dense; int64_t ld_dense; int din;
+  const float* w; int h0;                         // block weight [H, kx] f32, ld = kx
+  float* dx; int64_t ld_dx; bool dx_bf16;
+  float* dw; float* db; float* dwp; float* dbp;   // [H, kx], [H], [h0, din], [h0]
+  void* ws_dw; size_t ws_dw_bytes;                // >= tt_gemm_tn_workspace_bytes(H, kx, B)
+  void* ws_g; size_t ws_g_bytes;                  // >= tt_gemm_back_g_workspace_bytes(H, h0, din, B)
+  int64_t B;
+};
+bool tt_gemm_back_supported(const GemmBack* items, int n);
+size_t tt_gemm_back_g_workspace_bytes(int64_t H, int64_t h0, int64_t din, int64_t B);
+int tt_gemm_back_batched(hipStream_t st, const GemmBack* items, int n, TnPending* pending);

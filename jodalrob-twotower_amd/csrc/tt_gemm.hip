@@ -16,6 +16,8 @@ struct GemmArgs {
   int M, N, K, kchunk, splits;
   const float* bias; int relu; float alpha; float* colsum_slab;
   int a_bf16 = 0, b_bf16 = 0, c_bf16 = 0;   // bf16 kernel only: element type of A / B / C in memory
+  // gemm_back_kernel role 1 only: the tile G_z [M = H (one 64-row tile), 64 columns] leaves as proj_w[:, 0:proj_h0]^T . G_z
+  const float* proj_w = nullptr; int proj_ldw = 0, proj_h0 = 0;
 };
 struct GemmBatch { GemmArgs a[TT_MAX_SIDES]; };
 
@@ -145,6 +147,9 @@ struct SlabArgs {
   const float* colsum_slab; float* colsum_out;
   const float* bias; int relu;          // split-K forward GEMMs finish bias / ReLU here
   int c_bf16 = 0;                        // C holds bf16 elements
+  // projection bias item (gemm_back): no slabs of its own; colsum_out [proj_h0] = proj_w[:, 0:proj_h0]^T . (sum of the
+  // proj_colsum_splits slabs colsum_slab [.][M]), M = H <= 64
+  const float* proj_w = nullptr; int proj_ldw = 0, proj_h0 = 0, proj_colsum_splits = 0;
 };
 constexpr int kSlabItems = 16;
 struct SlabBatch { SlabArgs a[kSlabItems]; };
@@ -374,19 +379,26 @@ struct FastLoader16 {
   }
 };
 
-template <int MODE_A, int MODE_B, bool COLSUM, bool A_BF16, bool B_BF16>
-__global__ __launch_bounds__(THREADS) void gemm_bf16_fast_kernel(GemmBatch batch, int zsplits) {
+struct FastSmem {
+  __bf16 As[2][BM * LDS16];
+  __bf16 Bs[2][BN * LDS16];
+  float red[4][64];
+};
+struct BackSmem : FastSmem {
+  __bf16 lo[64 * 72];                      // low halves of the G_z tile (PROJ epilogue)
+};
+
+// one 64 x 64 tile (bx, by) of problem g, k-range `split`
+template <int MODE_A, int MODE_B, bool COLSUM, bool A_BF16, bool B_BF16, bool PROJ = false>
+__device__ __forceinline__ void gemm_fast_tile(const GemmArgs& g, int split, int bx, int by, FastSmem& sm) {
   static_assert(!(MODE_A == 1 && A_BF16), "COLSUM reads the A pieces per column");
-  const GemmArgs& g = batch.a[blockIdx.z / zsplits];
-  const int split = blockIdx.z % zsplits;
-  const int M = g.M, N = g.N, K = g.K, kchunk = g.kchunk;
-  if ((int)blockIdx.x * BM >= M || (int)blockIdx.y * BN >= N || split >= g.splits) return;
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][BM * LDS16];
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BN * LDS16];
-  __shared__ float red[4][64];
+  const int M = g.M, K = g.K, kchunk = g.kchunk;
+  __bf16 (&As)[2][BM * LDS16] = sm.As;
+  __bf16 (&Bs)[2][BN * LDS16] = sm.Bs;
+  float (&red)[4][64] = sm.red;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = bx * BM, n0 = by * BN;
   const int kbeg = split * kchunk, kend = min(K, kbeg + kchunk);
   const int nsteps = kend > kbeg ? (kend - kbeg) / BK16 : 0;
   f32x16 acc;
@@ -429,13 +441,60 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_fast_kernel(GemmBatch batch
     if (nsteps - full >= 1) step(full, la[0], lb[0]);
     if (nsteps - full >= 2) step(full + 1, la[1], lb[1]);
   }
-  if (COLSUM && g.colsum_slab && blockIdx.y == 0) {
+  if (COLSUM && g.colsum_slab && by == 0) {
     red[t >> 6][t & 63] = cs;
     __syncthreads();
     if (t < BM) g.colsum_slab[(int64_t)split * M + m0 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
   }
   float* Cz = g.C + (int64_t)split * g.slab_stride;
   const int n = n0 + wc * 32 + li;
+  if (PROJ) {
+    // this split's G_z tile [64 h, 64 columns] (M = H = 64: one row tile) -> slab of P_z = W[:, 0:h0]^T . G_z  [h0, 64 columns]:
+    // summed over the splits by the slab reduction that is the projection's weight gradient.  Both factors go through LDS as
+    // bf16 ([column][h] and [i][h], 72-element rows), 64 rows of i at a time
+    constexpr int LP = 72;
+    __bf16* Gt = &As[0][0];                 // 64 x 72 bf16 = 9216 B <= the two A stage buffers
+    __bf16* Gl = static_cast<BackSmem&>(sm).lo;
+    __bf16* Wt = &Bs[0][0];
+    __syncthreads();                        // every wave is done with the stage buffers
+    // G_z enters the second product as hi + lo (two bf16 terms: 16 significant bits): a split's partial sums can be much
+    // larger than the total they cancel to, and rounding them to 8 bits cost 2e-3 of the finished gradient
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int at = (wc * 32 + li) * LP + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const __bf16 hi = (__bf16)acc[r];
+      Gt[at] = hi;
+      Gl[at] = (__bf16)(acc[r] - (float)hi);
+    }
+    for (int i0 = 0; i0 < g.proj_h0; i0 += 64) {
+      {                                     // W[h][i0 .. i0 + 63] -> Wt[i][h]: thread = (h = t >> 2, 16 columns)
+        const int h = t >> 2, iq = (t & 3) * 16;
+        const float* src = g.proj_w + (int64_t)h * g.proj_ldw + i0 + iq;
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4) {
+          const float4 w = *reinterpret_cast<const float4*>(src + 4 * v4);
+          Wt[(iq + 4 * v4) * LP + h] = (__bf16)w.x; Wt[(iq + 4 * v4 + 1) * LP + h] = (__bf16)w.y;
+          Wt[(iq + 4 * v4 + 2) * LP + h] = (__bf16)w.z; Wt[(iq + 4 * v4 + 3) * LP + h] = (__bf16)w.w;
+        }
+      }
+      __syncthreads();
+      f32x16 o;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[i] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const bf16x8g av = *reinterpret_cast<const bf16x8g*>(Wt + (wr * 32 + li) * LP + 16 * s2 + 8 * lh);
+        const bf16x8g bv2 = *reinterpret_cast<const bf16x8g*>(Gt + (wc * 32 + li) * LP + 16 * s2 + 8 * lh);
+        const bf16x8g bv3 = *reinterpret_cast<const bf16x8g*>(Gl + (wc * 32 + li) * LP + 16 * s2 + 8 * lh);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv3, o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv2, o, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Cz[(int64_t)(i0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * g.ldc + n] = o[r];
+      __syncthreads();
+    }
+    return;
+  }
   const float bv = g.bias ? g.bias[n] : 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -447,8 +506,75 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_fast_kernel(GemmBatch batch
   }
 }
 
+template <int MODE_A, int MODE_B, bool COLSUM, bool A_BF16, bool B_BF16>
+__global__ __launch_bounds__(THREADS, 4) void gemm_bf16_fast_kernel(GemmBatch batch, int zsplits) {
+  const GemmArgs& g = batch.a[blockIdx.z / zsplits];
+  const int split = blockIdx.z % zsplits;
+  if ((int)blockIdx.x * BM >= g.M || (int)blockIdx.y * BN >= g.N || split >= g.splits) return;
+  __shared__ __attribute__((aligned(16))) FastSmem sm;
+  gemm_fast_tile<MODE_A, MODE_B, COLSUM, A_BF16, B_BF16>(g, split, blockIdx.x, blockIdx.y, sm);
+}
+
+// ---- first-block backward of all towers in ONE launch ---------------------------------------------------------------
+// Per tower three independent products of the block's incoming gradient d_pre [B, H]:
+//   role 0  dW  = d_pre^T . x       (+ column sums of d_pre = the bias gradient)      split over the batch, slabs
+//   role 1  G   = d_pre^T . dense                                                     split over the batch, slabs
+//   role 2  d_x[:, h0:] = d_pre . W[:, h0:]                                           (the looked-up rows' gradients)
+// The projection's weight gradient needs d_proj = d_x[:, 0:h0] as an operand when computed directly
+// (dW_proj = d_proj^T . dense) -- a dependency that costs a launch; since d_proj = d_pre . W[:, 0:h0],
+// dW_proj = W[:, 0:h0]^T . G = sum over the batch splits z of W[:, 0:h0]^T . G_z: a role-1 workgroup multiplies its own G_z
+// tile from the left before it writes the slab (one more 64-deep MFMA pass: W rounded to bf16 like every Linear operand, G_z
+// as hi + lo bf16 pairs), the ordinary slab
+// reduction finishes it; db_proj = W[:, 0:h0]^T . db is a 64 x h0 matrix-vector product in the slab-reduction launch.
+// d_x[:, 0:h0] is never materialised.  Flat grid: workgroup ->
+// (problem, split, tile) through a prefix table, long problems first.
+constexpr int kBackProbs = 3 * TT_MAX_SIDES;
+struct BackBatch {
+  GemmArgs g[kBackProbs];
+  int role[kBackProbs], tiles_m[kBackProbs], tiles[kBackProbs], wg_end[kBackProbs];
+  int n;
+};
+
+template <bool X_BF16>
+__global__ __launch_bounds__(THREADS, 4) void gemm_back_kernel(BackBatch b) {
+  int p = 0;
+  while (p + 1 < b.n && (int)blockIdx.x >= b.wg_end[p]) ++p;
+  const int local = (int)blockIdx.x - (p ? b.wg_end[p - 1] : 0);
+  const int split = local / b.tiles[p], tile = local % b.tiles[p];
+  const int bx = tile % b.tiles_m[p], by = tile / b.tiles_m[p];
+  __shared__ __attribute__((aligned(16))) BackSmem sm;
+  const GemmArgs& g = b.g[p];
+  if (b.role[p] == 0) gemm_fast_tile<1, 1, true, false, X_BF16>(g, split, bx, by, sm);
+  else if (b.role[p] == 1) gemm_fast_tile<1, 1, false, false, false, true>(g, split, bx, by, sm);
+  else gemm_fast_tile<0, 1, false, false, false>(g, split, bx, by, sm);
+}
+
+constexpr int kProjMaxH = 64;
+// colsum_out [proj_h0] = proj_w[:, 0:proj_h0]^T . (sum of the proj_colsum_splits slabs colsum_slab [.][M]): one workgroup
+__device__ __forceinline__ void proj_bias_finish(const SlabArgs& a) {
+  if (blockIdx.x != 0) return;
+  __shared__ float dbs[kProjMaxH];
+  const int H = a.M, t = threadIdx.x;
+  if (t < H) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int z = 0; z < a.proj_colsum_splits; ++z) s += a.colsum_slab[(int64_t)z * H + t];
+    dbs[t] = s;
+  }
+  __syncthreads();
+  for (int i = t; i < a.proj_h0; i += THREADS) {
+    float acc = 0.f;
+    for (int h = 0; h < H; ++h) acc = fmaf(a.proj_w[(int64_t)h * a.proj_ldw + i], dbs[h], acc);
+    a.colsum_out[i] = acc;
+  }
+}
+
 __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(SlabBatch batch) {
   const SlabArgs& a = batch.a[blockIdx.y];
+  if (a.proj_w) {
+    proj_bias_finish(a);
+    return;
+  }
   const int64_t total = (int64_t)a.M * a.N;
   const int64_t all = total + (a.colsum_out ? a.M : 0);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -705,6 +831,88 @@ int tt_gemm_tn_batched(hipStream_t st, const GemmTN* it, int n, TnPending* pendi
   if (blocks > 1024) blocks = 1024;
   slab_reduce_kernel<<<dim3((unsigned)blocks, (unsigned)m), THREADS, 0, st>>>(sb);
   TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+static int back_g_splits(int64_t H, int64_t din, int64_t B) {
+  int s = tn_splits(H, din, B);
+  return s > 32 ? 32 : s;                               // the projection finish re-reads these slabs per 16-column block
+}
+size_t tt_gemm_back_g_workspace_bytes(int64_t H, int64_t h0, int64_t din, int64_t B) {
+  return sizeof(float) * (size_t)back_g_splits(H, din, B) * (size_t)h0 * (size_t)din + 256;
+}
+
+bool tt_gemm_back_supported(const GemmBack* it, int n) {
+  static const bool off = getenv("TT_GEMM_FAST") && atoi(getenv("TT_GEMM_FAST")) == 0;
+  if (off || n < 1 || n > TT_MAX_SIDES) return false;
+  for (int i = 0; i < n; ++i) {
+    const GemmBack& g = it[i];
+    if (g.B < 64 || g.B % 64 || g.H != 64 || g.kx % 64 || g.h0 % 64 || g.h0 < 64 || g.h0 >= g.kx || g.din % 64) return false;
+    if (g.x_bf16 != it[0].x_bf16) return false;
+    if (!tt_aligned(g.dpre, 16) || !tt_aligned(g.x, 16) || g.ldx % 8 || !tt_aligned(g.dense, 16) || g.ld_dense % 4 || !tt_aligned(g.w, 16) ||
+        !tt_aligned(g.dx, 16) || g.ld_dx % 4)
+      return false;
+    if (!g.ws_dw || g.ws_dw_bytes < tt_gemm_tn_workspace_bytes(g.H, g.kx, g.B) || !g.ws_g ||
+        g.ws_g_bytes < tt_gemm_back_g_workspace_bytes(g.H, g.h0, g.din, g.B))
+      return false;
+  }
+  return true;
+}
+
+int tt_gemm_back_batched(hipStream_t st, const GemmBack* it, int n, TnPending* pending) {
+  if (!pending || !tt_gemm_back_supported(it, n)) {
+    tt_set_error("tt_gemm_back: unsupported shapes / missing pending queue");
+    return TT_ERR_INVALID_ARG;
+  }
+  BackBatch b{};
+  SlabArgs sa[3 * TT_MAX_SIDES];
+  int ns = 0, wg = 0;
+  int64_t maxtotal = 1;
+  auto kchunk_of = [](int64_t R, int splits) { return (int)(tt_cdiv(tt_cdiv(R, splits), BK16) * BK16); };
+  for (int role = 0; role < 3; ++role)                   // long problems first
+    for (int i = 0; i < n; ++i) {
+      const GemmBack& g = it[i];
+      const int s0 = tn_splits(g.H, g.kx, g.B), s1 = back_g_splits(g.H, g.din, g.B);
+      float* slabs0 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(g.ws_dw) + 255) & ~uintptr_t(255));
+      float* cslab0 = slabs0 + (size_t)s0 * (size_t)g.H * (size_t)g.kx;
+      float* slabs1 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(g.ws_g) + 255) & ~uintptr_t(255));
+      const int p = b.n++;
+      int tm, tn_;
+      if (role == 0) {
+        b.g[p] = GemmArgs{g.dpre, g.H, reinterpret_cast<const float*>(g.x), g.ldx, slabs0, g.kx, (int64_t)g.H * g.kx, g.H, g.kx, (int)g.B,
+                          kchunk_of(g.B, s0), s0, nullptr, 0, 1.f, cslab0, 0, g.x_bf16 ? 1 : 0, 0};
+        tm = g.H / BM; tn_ = g.kx / BN;
+        sa[ns++] = SlabArgs{slabs0, (int64_t)g.H * g.kx, s0, g.dw, g.kx, g.H, g.kx, cslab0, g.db, nullptr, 0};
+        maxtotal = (int64_t)g.H * g.kx + g.H > maxtotal ? (int64_t)g.H * g.kx + g.H : maxtotal;
+      } else if (role == 1) {
+        b.g[p] = GemmArgs{g.dpre, g.H, g.dense, g.ld_dense, slabs1, g.din, (int64_t)g.h0 * g.din, g.H, g.din, (int)g.B,
+                          kchunk_of(g.B, s1), s1, nullptr, 0, 1.f, nullptr, 0, 0, 0};
+        b.g[p].proj_w = g.w; b.g[p].proj_ldw = g.kx; b.g[p].proj_h0 = g.h0;
+        tm = g.H / BM; tn_ = g.din / BN;
+        sa[ns++] = SlabArgs{slabs1, (int64_t)g.h0 * g.din, s1, g.dwp, g.din, g.h0, g.din, nullptr, nullptr, nullptr, 0};
+        SlabArgs pj{nullptr, 0, 0, nullptr, 0, g.H, 0, cslab0, g.dbp, nullptr, 0};
+        pj.proj_w = g.w; pj.proj_ldw = g.kx; pj.proj_h0 = g.h0; pj.proj_colsum_splits = s0;
+        sa[ns++] = pj;
+        maxtotal = (int64_t)g.h0 * g.din > maxtotal ? (int64_t)g.h0 * g.din : maxtotal;
+      } else {
+        float* c = g.dx_bf16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(g.dx) + g.h0) : g.dx + g.h0;
+        b.g[p] = GemmArgs{g.dpre, g.H, g.w + g.h0, g.kx, c, g.ld_dx, 0, (int)g.B, g.kx - g.h0, g.H, (int)(tt_cdiv(g.H, BK16) * BK16), 1,
+                          nullptr, 0, 1.f, nullptr, 0, 0, g.dx_bf16 ? 1 : 0};
+        tm = (int)(g.B / BM); tn_ = (g.kx - g.h0) / BN;
+      }
+      b.role[p] = role;
+      b.tiles_m[p] = tm;
+      b.tiles[p] = tm * tn_;
+      wg += tm * tn_ * b.g[p].splits;
+      b.wg_end[p] = wg;
+    }
+  if (it[0].x_bf16) gemm_back_kernel<true><<<wg, THREADS, 0, st>>>(b);
+  else gemm_back_kernel<false><<<wg, THREADS, 0, st>>>(b);
+  TT_LAUNCH_CHECK();
+  if (pending->n + ns > kSlabItems)
+    if (int rc = tt_gemm_tn_flush(st, pending)) return rc;
+  for (int i = 0; i < ns; ++i) pending->sb.a[pending->n++] = sa[i];
+  pending->maxtotal = maxtotal > pending->maxtotal ? maxtotal : pending->maxtotal;
   return TT_OK;
 }
 

@@ -1175,6 +1175,10 @@ inline WsLayout ws_layout(const tt_tower_params* p, int64_t B, char* base) {
               : l == p->n_hidden + 1 ? tt_gemm_tn_workspace_bytes(p->d_out, last_width(p), B)
                                      : tt_gemm_tn_workspace_bytes(p->hidden[l - 1], in_width(p, l - 1), B);
     if (l == p->n_hidden + 1 && tail_shape_ok(p) && tail_slab_bytes(p) > nb) nb = tail_slab_bytes(p);
+    if (l == 0 && p->n_hidden >= 1) {                   // the one-launch first-block backward keeps its G slabs here
+      const size_t gb = tt_gemm_back_g_workspace_bytes(p->hidden[0], p->h0, p->din, B);
+      nb = gb > nb ? gb : nb;
+    }
     w.tn[l] = base ? base + o : nullptr;
     w.tn_bytes[l] = (nb + 255) & ~size_t(255);
     o += w.tn_bytes[l];
@@ -1549,6 +1553,24 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       dcur[t] = dnext;
     }
     for (int t = 0; t < n; ++t) tn[t].bf16 = nn[t].bf16 = P[0]->compute_dtype == TT_BF16;
+    if (i == 0 && P[0]->compute_dtype == TT_BF16) {
+      // first block + projection: three independent products of d_pre in ONE launch (tt_gemm.h: GemmBack); the projection's
+      // gradients come out of the slab-reduction launch, d_x[:, 0:h0] is not materialised
+      GemmBack gb[TT_MAX_SIDES];
+      bool ok = true;
+      for (int t = 0; t < n; ++t) {
+        const tt_tower_grads* g = G[t];
+        const int wx = P[t]->h0 + P[t]->kcat_e;
+        ok = ok && !(P[t]->flags & TT_TOWER_UNFUSED_BACK);
+        gb[t] = GemmBack{tn[t].A, P[t]->hidden[0], A[t]->x, wx, wx, P[t]->x_dtype == TT_BF16, A[t]->dense, P[t]->din, P[t]->din,
+                         P[t]->w[0], P[t]->h0, reinterpret_cast<float*>(g->d_x), wx, P[t]->dx_dtype == TT_BF16, g->w[0], g->b[0],
+                         g->w_proj, g->b_proj, ws[t].tn[1], ws[t].tn_bytes[1], ws[t].tn[0], ws[t].tn_bytes[0], B};
+      }
+      if (ok && tt_gemm_back_supported(gb, n)) {
+        if (int rc = tt_gemm_back_batched(st, gb, n, pend.p)) return rc;
+        return tt_gemm_tn_flush(st, pend.p);
+      }
+    }
     if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;
     if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
   }

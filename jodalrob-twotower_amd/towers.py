@@ -86,6 +86,8 @@ class BaseTower(nn.Module):
         self.unfused_tail = os.environ.get("TT_TOWER_UNFUSED_TAIL", "0") == "1"
         # TT_TOWER_UNFUSED_FRONT=1: projection GEMM, block GEMM and the slab / statistics pass as separate launches (A/B runs)
         self.unfused_front = os.environ.get("TT_TOWER_UNFUSED_FRONT", "0") == "1"
+        # TT_TOWER_UNFUSED_BACK=1: first-block / projection gradient GEMMs as separate launches (A/B runs)
+        self.unfused_back = os.environ.get("TT_TOWER_UNFUSED_BACK", "0") == "1"
         self.categorical_keys = list(categorical_keys)
         self.exchange = None            # set by the distributed task: sharded-table row exchange
         self.sync_comm = None           # set by the distributed task (sync_bn=True): BN statistics over all ranks' rows
@@ -141,7 +143,7 @@ class BaseTower(nn.Module):
         tensors = [self.dense_projection.weight, self.dense_projection.bias, out.weight, out.bias]
         for lin, bn in zip(lins, bns):
             tensors += [lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype, self.x_dtype, self.dx_dtype, self.unfused_tail, self.unfused_front)
+        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype, self.x_dtype, self.dx_dtype, self.unfused_tail, self.unfused_front, self.unfused_back)
         if key != self._struct_key:
             for t in tensors:
                 if t.dtype != torch.float32 or not t.is_contiguous():
@@ -156,7 +158,7 @@ class BaseTower(nn.Module):
                 compute_dtype=ops.TT_BF16 if self.mlp_dtype == "bf16" else ops.TT_F32,
                 x_dtype=ops.TT_BF16 if self.x_dtype == torch.bfloat16 else ops.TT_F32,
                 dx_dtype=ops.TT_BF16 if self.dx_dtype == torch.bfloat16 else ops.TT_F32,
-                flags=(ops.L.TT_TOWER_UNFUSED_TAIL if self.unfused_tail else 0) | (ops.L.TT_TOWER_UNFUSED_FRONT if self.unfused_front else 0))
+                flags=(ops.L.TT_TOWER_UNFUSED_TAIL if self.unfused_tail else 0) | (ops.L.TT_TOWER_UNFUSED_FRONT if self.unfused_front else 0) | (ops.L.TT_TOWER_UNFUSED_BACK if self.unfused_back else 0))
             self._struct_key = key
         return self._params_struct
 

@@ -168,10 +168,16 @@ def tower_fwd(state: dict, prefix: str, keys, vocab_sizes, dense, values, train:
     return emb, cache, bn_updates
 
 
-def tower_bwd(cache: dict, d_emb: np.ndarray, prefix: str, keys, vocab_sizes, table_grads: str = "dense"):
+def tower_bwd(cache: dict, d_emb: np.ndarray, prefix: str, keys, vocab_sizes, table_grads: str = "dense",
+              proj_grad: str = "direct"):
     """Backward of tower_fwd (train-mode BN, dropout p=0).  Returns {state_dict key: grad}.
     table_grads: "dense" = the reference's dense [V_k, E] arrays; "none" = skip them (the caller takes the
-    slot gradients `_d_concat` and forms the sparse-unique rows itself: 1 M-row tables)."""
+    slot gradients `_d_concat` and forms the sparse-unique rows itself: 1 M-row tables).
+    proj_grad: how the dense projection's gradients are formed under operand rounding (without rounding the two are the
+    same numbers): "direct" = d_proj^T . dense with d_proj = (d_pre . W)[:, :H0] rounded as a GEMM operand (autograd's
+    order); "factored" = W[:, :H0]^T . (d_pre^T . dense), the one-launch first-block backward of the HIP path (edge-free
+    shapes): d_pre, dense and W are rounded GEMM operands, the intermediate product is not (the kernel carries it as hi + lo
+    bf16 pairs); the bias gradient W[:, :H0]^T . colsum(d_pre) is formed unrounded."""
     grads = {}
     q = cache.get("q") or _ident
     emb, den, nrm = cache["emb"], cache["den"], cache["nrm"]
@@ -199,8 +205,15 @@ def tower_bwd(cache: dict, d_emb: np.ndarray, prefix: str, keys, vocab_sizes, ta
         dh = q(dpre) @ q(blk["W"])
     H0, E = cache["H0"], cache["E"]
     dproj, dcat = dh[:, :H0], dh[:, H0:]
-    grads[prefix + "dense_projection.weight"] = q(dproj).T @ q(cache["dense"])
-    grads[prefix + "dense_projection.bias"] = dproj.sum(axis=0)
+    if proj_grad == "factored" and nblk >= 1:
+        Wp = cache["blocks"][0]["W"][:, :H0]
+        grads[prefix + "dense_projection.weight"] = q(Wp).T @ (q(dpre).T @ q(cache["dense"]))
+        grads[prefix + "dense_projection.bias"] = Wp.T @ dpre.sum(axis=0)
+    elif proj_grad in ("direct", "factored"):
+        grads[prefix + "dense_projection.weight"] = q(dproj).T @ q(cache["dense"])
+        grads[prefix + "dense_projection.bias"] = dproj.sum(axis=0)
+    else:
+        raise ValueError(f"proj_grad must be 'direct' or 'factored', got {proj_grad!r}")
     if table_grads == "dense":
         for k, g in zip(keys, embed_grad_dense(dcat, cache["ids"], vocab_sizes, E)):
             grads[f"{prefix}categorical_embedder.embeddings.{k}.weight"] = g
@@ -275,7 +288,7 @@ NT, CT = "two_tower_model.notice_tower.", "two_tower_model.company_tower."
 
 
 def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, train=True, backward=True,
-              dtype=np.float32, rounding=None, table_grads="dense", keep_sim=True):
+              dtype=np.float32, rounding=None, table_grads="dense", keep_sim=True, proj_grad="direct"):
     """One forward (+backward) of the task.  batch: dict with notice_ids/company_ids [B,K] (or flat
     values) and notice_dense/company_dense.  Returns dict(loss, metrics, sim, notice_emb, company_emb,
     grads{state key: array}, bn_updates).
@@ -296,9 +309,9 @@ def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, t
     if backward:
         dN, dC = score_ce_bwd(sn, sc, S, lse, temperature, q=q)
         del S
-        g = tower_bwd(cn, dN, NT, keys_n, vocab_n, table_grads)
+        g = tower_bwd(cn, dN, NT, keys_n, vocab_n, table_grads, proj_grad)
         out["d_concat_notice"] = g.pop("_d_concat")
-        g2 = tower_bwd(cc, dC, CT, keys_c, vocab_c, table_grads)
+        g2 = tower_bwd(cc, dC, CT, keys_c, vocab_c, table_grads, proj_grad)
         out["d_concat_company"] = g2.pop("_d_concat")
         out["grads"] = {**g, **g2}
         out["ids_notice"], out["ids_company"] = cn["ids"], cc["ids"]
