@@ -554,16 +554,22 @@ def test_bf16_mlp_close_to_fp32(tt, manifest, schema_real):
     assert all(int(v) == 1 for k, v in outs["bf16"][2].items() if "num_batches" in k)       # counter bumped in-kernel
 
 
-@pytest.mark.parametrize("B,Ks,vocabs", [(8192, [32, 6], None), (1000, [5, 2], None), (1, [3], None), (4097, [4, 3, 2], None)])
+@pytest.mark.parametrize("B,Ks,vocabs", [(8192, [32, 6], None), (1000, [5, 2], None), (1, [3], None), (4097, [4, 3, 2], None),
+                                         (8192, [6, 3], "hot"), (8192, [8], "mid"), (515, [7, 2], "mid")])
 def test_dedup_plan_keyed_equals_general(tt, B, Ks, vocabs):
-    """Per-key LDS plan == the general radix-sort plan (and numpy's stable argsort), bit for bit."""
+    """Per-key LDS plan == the general radix-sort plan (and numpy's stable argsort), bit for bit.  Wide row ranges take the
+    bucket + rank path, narrow ones and keys with hot rows ("hot": Zipf-like ids, a few rows holding most slots -- a bucket
+    overflows) the stable LSD passes; "mid": vocabularies around the 9-bit switch and the per-bucket cap."""
     from jodalrob_twotower_amd import ops
     rng = np.random.default_rng(B + len(Ks))
     rows_sides, off = [], 0
     for K in Ks:
-        v = rng.choice([2, 12, 300, 70000, 1_000_000], size=K)
+        v = rng.choice({"mid": [255, 256, 257, 511, 513, 600, 1023, 1025, 5000]}.get(vocabs, [2, 12, 300, 70000, 1_000_000]), size=K)
         offs = off + np.concatenate([[0], np.cumsum(v)[:-1]])
-        ids = np.stack([rng.integers(0, vk, B) for vk in v], axis=1)
+        if vocabs == "hot":
+            ids = np.stack([np.minimum(rng.zipf(1.2, B) - 1, vk - 1) for vk in v], axis=1)
+        else:
+            ids = np.stack([rng.integers(0, vk, B) for vk in v], axis=1)
         rows_sides.append((ids + offs[None, :]).reshape(-1))
         off += int(v.sum())
     rows = np.concatenate(rows_sides).astype(np.int32)
