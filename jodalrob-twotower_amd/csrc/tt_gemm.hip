@@ -869,8 +869,10 @@ int tt_gemm_back_batched(hipStream_t st, const GemmBack* it, int n, TnPending* p
   int ns = 0, wg = 0;
   int64_t maxtotal = 1;
   auto kchunk_of = [](int64_t R, int splits) { return (int)(tt_cdiv(tt_cdiv(R, splits), BK16) * BK16); };
+  static const int role_mask = getenv("TT_BACK_ROLE_MASK") ? atoi(getenv("TT_BACK_ROLE_MASK")) : 7;   // timing experiments only
   for (int role = 0; role < 3; ++role)                   // long problems first
     for (int i = 0; i < n; ++i) {
+      if (!((role_mask >> role) & 1)) continue;
       const GemmBack& g = it[i];
       const int s0 = tn_splits(g.H, g.kx, g.B), s1 = back_g_splits(g.H, g.din, g.B);
       float* slabs0 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(g.ws_dw) + 255) & ~uintptr_t(255));
