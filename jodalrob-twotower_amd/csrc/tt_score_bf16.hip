@@ -511,6 +511,185 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
   }
 }
 
+// ---- backward, b-split form with ONE streamed image (D <= 64) ---------------------------------------------------------
+// Ablations of the kernel above (compile-time, tools/bench_score.py, B = 8192, D = 64): full 50.0 us; without the exp2 45.9;
+// without the gradient MFMAs 35.7; without ANY MFMA or exp2 32.4 -- two thirds of the time is moving the opposite side's
+// operands: each workgroup streams 2 MB (the rows image for S AND the fragment-ordered image of the same values for the
+// gradient product) at the ~65 GB/s a CU draws from L2.  Here only the rows image is streamed: a wave parks the tile's row
+// fragments (it has them in registers for the S product) in a wave-private LDS tile [32 b][64 d] and reads the gradient
+// product's operand -- 8 b-values of one column d per lane, in the accumulator's row order -- back with the transposing
+// LDS read ds_read_b64_tr_b16 (a 16-lane group reads a 4-row x 16-column block, lane i gets column i).  Half the L2
+// bytes for 8 KB of LDS traffic per tile.  Same values, same order of operations: bit-identical.
+// Result: 45.9 -> 44.4 us in the step.  The same ablations on this kernel: full 49.1; no exp2 44.9; no gradient MFMAs 30.8;
+// nothing 23.4 -- streaming is no longer the largest term; per SIMD the gradient + S MFMAs (34 GFLOP for both directions: every
+// direction recomputes S) need ~20 us of the matrix pipe, the softmax VALU work ~24 us, the loads ~20 us, and a wave runs the
+// three one after the other.
+template <int KS, bool UNIT>
+__global__ __launch_bounds__(512) void score_bwd_tr_kernel(BwdArgs args) {
+  constexpr int AT = 2, NW = 8, Dp = KS * 16, ROWS = 32 * AT, DT = KS / 2;
+  constexpr int TLD = Dp + 8;                                   // LDS row of the parked tile: 144 B at D = 64 (conflict-free b128 writes)
+  __shared__ float red[(NW / 2) * ROWS * Dp];
+  __shared__ __attribute__((aligned(16))) __bf16 park[NW][32 * TLD];
+  using s16x4 = __attribute__((ext_vector_type(4))) short;
+  using s16x8 = __attribute__((ext_vector_type(8))) short;
+  const bool d1 = blockIdx.y != 0;
+  DirBwd dr;
+  dr.a_rows = d1 ? args.d[1].a_rows : args.d[0].a_rows;
+  dr.b_rows = d1 ? args.d[1].b_rows : args.d[0].b_rows;
+  dr.sumexp_a = d1 ? args.d[1].sumexp_a : args.d[0].sumexp_a;
+  dr.sumexp_b = d1 ? args.d[1].sumexp_b : args.d[0].sumexp_b;
+  dr.dA = d1 ? args.d[1].dA : args.d[0].dA;
+  const float c1 = d1 ? args.d[1].c1 : args.d[0].c1, out_scale = d1 ? args.d[1].out_scale : args.d[0].out_scale;
+  const float* const inv_a = d1 ? args.d[1].inv_a : args.d[0].inv_a;
+  const float* const inv_b = d1 ? args.d[1].inv_b : args.d[0].inv_b;
+  const float c2 = args.c2, kx = UNIT ? args.kexp : 1.f;
+  const int Ra = (int)(d1 ? args.d[1].Ra : args.d[0].Ra), Rb = (int)(d1 ? args.d[1].Rb : args.d[0].Rb);
+  const int off = (int)(d1 ? args.d[1].off : args.d[0].off);
+  const int a0 = (int)blockIdx.x * ROWS;
+  if (a0 >= Ra) return;
+  const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nT = (Rb + 31) / 32;
+  bf16x8 ares[AT][KS];
+  float ia[AT];
+  int pos[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+    load_bfrag<KS>(dr.a_rows, a0 / 32 + i, c, h, ares[i]);
+    const int a = a0 + 32 * i + c;
+    ia[i] = a < Ra ? (inv_a ? inv_a[a] : __builtin_amdgcn_rcpf(dr.sumexp_a[a]) * kx) : 0.f;
+    pos[i] = a + off;
+  }
+  const int posmin = a0 + off, posmax = a0 + ROWS - 1 + off;
+  f32x16 dacc[AT][DT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i)
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc[i][d][r] = 0.f;
+  const bool have_inv = inv_b != nullptr;
+  const float* const ivsrc = have_inv ? inv_b : dr.sumexp_b;
+  const int tlast = nT - 1;
+  __bf16* const tile = park[wave];
+  // parked-tile addresses: write = row c, columns 16 s + 8 h; transposing read = block row q of this lane's 16-lane group,
+  // columns 4 p of the group's 16 (lane 4 q + p supplies the address, lane i of the group receives column i)
+  __bf16* const wr_at = tile + c * TLD + 8 * h;
+  const int g16 = lane & 15, cg = (lane >> 4) & 1;
+  const __bf16* const tr_at = tile + (4 * h + (g16 >> 2)) * TLD + 16 * cg + 4 * (g16 & 3);
+  struct Tile { bf16x8 b[KS]; float4 iv[4]; };
+  auto load = [&](Tile& T, int t) {
+    load_bfrag<KS>(dr.b_rows, t, c, h, T.b);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T.iv[q] = *reinterpret_cast<const float4*>(ivsrc + 32 * t + 4 * h + 8 * q);
+  };
+  auto compute = [&](const Tile& T, int t) {
+    const int b_lo = 32 * t;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) *reinterpret_cast<bf16x8*>(wr_at + 16 * s2) = T.b[s2];
+    float ib[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ib[4 * q] = T.iv[q].x; ib[4 * q + 1] = T.iv[q].y; ib[4 * q + 2] = T.iv[q].z; ib[4 * q + 3] = T.iv[q].w; }
+    if (!have_inv) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ib[r] = __builtin_amdgcn_rcpf(ib[r]) * kx;
+    }
+    if (b_lo + 31 >= Rb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ib[r] = b_lo + rowmap(r, h) < Rb ? ib[r] : 0.f;
+    }
+    const bool band = !(b_lo + 31 < posmin || b_lo > posmax);
+    // the gradient product's operand: for k-step s2 and column block d, rows {16 s2 + 4 h + 0..3, 16 s2 + 8 + 4 h + 0..3}
+    bf16x8 bm[2][DT];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(tr_at + (16 * s2) * TLD + 32 * d));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(tr_at + (16 * s2 + 8) * TLD + 32 * d));
+        const s16x8 v{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        bm[s2][d] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+    for (int i = 0; i < AT; ++i) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T.b[s2], ares[i][s2], acc, 0, 0, 0);
+      float w[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        w[r] = (UNIT ? __builtin_amdgcn_exp2f(acc[r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], c1, c2))) * (ia[i] + ib[r]);
+      if (b_lo + 31 >= Rb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) w[r] = b_lo + rowmap(r, h) < Rb ? w[r] : 0.f;
+      }
+      if (band) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (b_lo + rowmap(r, h) == pos[i]) w[r] -= 2.f;
+      }
+      bf16x8 wf[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wf[s2][j] = (__bf16)w[8 * s2 + j];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int d = 0; d < DT; ++d) dacc[i][d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s2], bm[s2][d], dacc[i][d], 0, 0, 0);
+    }
+  };
+  Tile T0, T1;
+  load(T0, min(wave, tlast));
+  __builtin_amdgcn_sched_barrier(0);
+  for (int t = wave; t < nT; t += 2 * NW) {
+    load(T1, min(t + NW, tlast));
+    compute(T0, t);
+    load(T0, min(t + 2 * NW, tlast));
+    if (t + NW < nT) compute(T1, t + NW);
+  }
+#pragma unroll
+  for (int half = NW / 2; half >= 1; half >>= 1) {
+    if (wave >= half && wave < 2 * half) {
+      float* slab = red + (wave - half) * ROWS * Dp;
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) slab[(32 * i + rowmap(r, h)) * Dp + 32 * d + c] = dacc[i][d][r];
+    }
+    __syncthreads();
+    if (wave < half) {
+      const float* slab = red + wave * ROWS * Dp;
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+#pragma unroll
+        for (int d = 0; d < DT; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dacc[i][d][r] += slab[(32 * i + rowmap(r, h)) * Dp + 32 * d + c];
+    }
+    __syncthreads();
+  }
+  if (wave == 0) {
+    const float g = args.d_loss[0] * out_scale;
+#pragma unroll
+    for (int i = 0; i < AT; ++i)
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int a = a0 + 32 * i + rowmap(r, h);
+          const int dd = 32 * d + c;
+          if (a < Ra && dd < args.D) dr.dA[(int64_t)a * args.D + dd] = dacc[i][d][r] * g;
+        }
+  }
+}
+
 // ---- backward, large-batch form ---------------------------------------------------------------------
 // When there are enough rows a for every SIMD to own its own (Ra / 64 x directions >= ~1024), nothing has to be split along b:
 // a workgroup is 4 waves, ONE per SIMD with the whole 512-register file (amdgpu_waves_per_eu(1, 1)), each wave owns two
@@ -917,7 +1096,11 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
   if (Dp == 32) TT_BWD(2, 2, 8);
   else if (Dp == 64) {
     if (bvar == 1) TT_BWD(4, 1, 8);
-    else TT_BWD(4, 2, 8);
+    else if (bvar != 2) {                                 // one streamed image, transposing LDS reads (TT_SCORE_BWD_VARIANT=2: two images)
+      const dim3 grid((unsigned)tt_cdiv(maxRa, 64), (unsigned)n_dirs);
+      if (unit) score_bwd_tr_kernel<4, true><<<grid, 512, 0, st>>>(a);
+      else score_bwd_tr_kernel<4, false><<<grid, 512, 0, st>>>(a);
+    } else TT_BWD(4, 2, 8);
   } else if (Dp == 128) TT_BWD(8, 1, 8);
   else TT_BWD(16, 1, 4);
 #undef TT_BWD
