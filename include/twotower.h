@@ -414,6 +414,20 @@ int tt_score_fwd_sym_fp8(tt_ctx* ctx, const void* N_packed, const void* C_packed
                          size_t workspace_bytes, tt_stream stream);
 int tt_score_bwd_fp8(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, int32_t D, float inv_t,
                      float shift, const float* d_loss, float scale, tt_stream stream);
+/* Dense loss path: the loss variants the fused kernels do not cover, on the MATERIALISED score matrix --
+ * label-smoothed cross-entropy (loss_type 0; two_tower_train_task.py:114-133, F.cross_entropy(label_smoothing=e) in both
+ * directions) and cosine-embedding loss (loss_type 1; :135-158: F.cosine_embedding_loss of [s] against [1], positives on the
+ * diagonal, negatives off it, mean over all B^2 entries).  f32 throughout, exact-f32 GEMMs, O(B^2) memory: S [B, B] (holds
+ * d loss / d (N C^T) after the backward call), stats [6 B] floats and hit [2 B] int32 are caller memory kept between the calls.
+ * out8 = {loss, row top-1 accuracy, positive mean, negative mean, gap, column top-1 accuracy, sum of S, 0} as
+ * tt_score_loss_finish. */
+size_t tt_score_dense_workspace_bytes(int64_t B, int32_t D);
+int tt_score_dense_fwd(tt_ctx* ctx, const float* N, const float* Cm, int64_t B, int32_t D, float inv_t, int32_t loss_type,
+                       float label_smoothing, float* S, float* stats, int32_t* hit, float* out8, float* loss_out,
+                       tt_stream stream);
+int tt_score_dense_bwd(tt_ctx* ctx, const float* N, const float* Cm, int64_t B, int32_t D, float inv_t, int32_t loss_type,
+                       float label_smoothing, float* S, const float* stats, const float* d_loss, float* dN, float* dC,
+                       void* workspace, size_t workspace_bytes, tt_stream stream);
 /* dense score matrix S[Ra, Rb] = A Bm^T * inv_t (result["similarity_matrix"], predict_batch
  * "all_similarities": two_tower_train_task.py:94, :206) */
 int tt_score_matrix(tt_ctx* ctx, const float* A, const float* Bm, int64_t Ra, int64_t Rb, int32_t D,

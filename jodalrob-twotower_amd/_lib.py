@@ -117,6 +117,9 @@ SIGNATURES = {
     "tt_score_fwd_sym_workspace_bytes": (sz, [i64, i32]),
     "tt_score_fwd_sym_bf16": (C.c_int, [vp, vp, vp, i64, i32, f32, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "tt_score_matrix": (C.c_int, [vp, vp, vp, i64, i64, i32, f32, vp, i64, vp]),
+    "tt_score_dense_workspace_bytes": (sz, [i64, i32]),
+    "tt_score_dense_fwd": (C.c_int, [vp, vp, vp, i64, i32, f32, i32, f32, vp, vp, vp, vp, vp, vp]),
+    "tt_score_dense_bwd": (C.c_int, [vp, vp, vp, i64, i32, f32, i32, f32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "tt_diag_rank_rows": (C.c_int, [vp, vp, i64, i64, i64, i64, vp, vp]),
     "tt_topk_rows": (C.c_int, [vp, vp, i64, i64, i64, i32, vp, vp, vp]),
     "tt_linear_fwd": (C.c_int, [vp, vp, i64, vp, vp, vp, i64, i64, i32, i32, i32, vp]),

@@ -280,6 +280,142 @@ __global__ __launch_bounds__(1024) void loss_finish_kernel(int64_t B, float shif
   }
 }
 
+// ---- dense loss path: label-smoothed cross-entropy and cosine-embedding loss on the MATERIALISED score matrix --------
+// (two_tower_train_task.py:114-160; neither is used by scripts/train.py -- the fused kernels cover the default loss only).
+// S [B, B] = N C^T / T in memory; everything f32, fixed summation orders.
+//   CE with smoothing e:  row term  lse_r[a] - (1 - e) s_aa - (e / B) sum_b s_ab   (F.cross_entropy(label_smoothing=e)),
+//                         the same over columns; loss = (mean row term + mean column term) / 2
+//   cosine embedding:     F.cosine_embedding_loss on the 1-vectors [s] vs [1]: cos = s / sqrt((s^2 + 1e-12)(1 + 1e-12));
+//                         positives (diagonal) 1 - cos, negatives max(0, cos); mean over all B^2 entries
+constexpr float kCosEps = 1e-12f;
+__device__ __forceinline__ float cos1(float s) { return s / sqrtf((s * s + kCosEps) * (1.f + kCosEps)); }
+__device__ __forceinline__ float dcos1(float s) {                 // d cos / d s = eps (s^2 + eps)^(-3/2) / sqrt(1 + eps)
+  const float q = s * s + kCosEps;
+  return kCosEps / (q * sqrtf(q) * sqrtf(1.f + kCosEps));
+}
+
+// one wave per row: max / first argmax, logsumexp, plain sum, cosine loss sum of the row
+__global__ __launch_bounds__(kThreads) void dense_row_stats_kernel(const float* __restrict__ S, int64_t B, float* __restrict__ lse,
+                                                                  float* __restrict__ sum, float* __restrict__ cosl,
+                                                                  float* __restrict__ diag, int32_t* __restrict__ hit) {
+  const int lane = threadIdx.x & 63;
+  const int64_t a = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+  if (a >= B) return;
+  const float* row = S + a * B;
+  float m = -INFINITY;
+  int64_t mi = B;
+  for (int64_t b = lane; b < B; b += 64) {
+    const float v = row[b];
+    if (v > m) { m = v; mi = b; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float m2 = __shfl_xor(m, o);
+    const int64_t i2 = (int64_t)__shfl_xor((int)mi, o);
+    if (m2 > m || (m2 == m && i2 < mi)) { m = m2; mi = i2; }
+  }
+  float e = 0.f, t = 0.f, cl = 0.f;
+  for (int64_t b = lane; b < B; b += 64) {
+    const float v = row[b];
+    e += expf(v - m);
+    t += v;
+    const float c = cos1(v);
+    cl += b == a ? 1.f - c : fmaxf(c, 0.f);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { e += __shfl_xor(e, o); t += __shfl_xor(t, o); cl += __shfl_xor(cl, o); }
+  if (lane == 0) {
+    lse[a] = m + logf(e);
+    sum[a] = t;
+    cosl[a] = cl;
+    diag[a] = row[a];
+    hit[a] = mi == a ? 1 : 0;
+  }
+}
+
+// one thread per column: online logsumexp and plain sum down the column (coalesced across the threads of a wave)
+__global__ __launch_bounds__(kThreads) void dense_col_stats_kernel(const float* __restrict__ S, int64_t B, float* __restrict__ lse,
+                                                                  float* __restrict__ sum, int32_t* __restrict__ hit) {
+  const int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (b >= B) return;
+  float m = -INFINITY, e = 0.f, t = 0.f;
+  int64_t mi = B;
+  for (int64_t a = 0; a < B; ++a) {
+    const float v = S[a * B + b];
+    if (v > m) { e = e * expf(m - v) + 1.f; m = v; mi = a; }      // strict >: the first maximal row, as torch.argmax
+    else e += expf(v - m);
+    t += v;
+  }
+  lse[b] = m + logf(e);
+  sum[b] = t;
+  hit[b] = mi == b ? 1 : 0;
+}
+
+// loss + metrics (one workgroup, fixed order).  stats = [lse_r | sum_r | lse_c | sum_c | cos_r | diag] (B each)
+__global__ __launch_bounds__(1024) void dense_finish_kernel(int64_t B, int loss_type, float smooth, const float* __restrict__ stats,
+                                                            const int32_t* __restrict__ hit, float* __restrict__ out,
+                                                            float* __restrict__ loss_out) {
+  __shared__ float sh4[5][16];
+  const float* lse_r = stats; const float* sum_r = stats + B; const float* lse_c = stats + 2 * B; const float* sum_c = stats + 3 * B;
+  const float* cos_r = stats + 4 * B; const float* diag = stats + 5 * B;
+  const float fb = (float)B;
+  float l = 0.f, h = 0.f, ds = 0.f, tot = 0.f, hc = 0.f;
+  for (int64_t i = threadIdx.x; i < B; i += blockDim.x) {
+    const float d = diag[i];
+    if (loss_type == 0) l += (lse_r[i] - (1.f - smooth) * d - smooth / fb * sum_r[i]) + (lse_c[i] - (1.f - smooth) * d - smooth / fb * sum_c[i]);
+    else l += cos_r[i];
+    h += hit[i] ? 1.f : 0.f;
+    hc += hit[B + i] ? 1.f : 0.f;
+    ds += d;
+    tot += sum_r[i];
+  }
+  float v[5] = {l, h, ds, tot, hc};
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) v[j] += __shfl_xor(v[j], o);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) sh4[j][threadIdx.x >> 6] = v[j];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      float t = 0.f;
+      for (int w = 0; w < nw; ++w) t += sh4[j][w];
+      v[j] = t;
+    }
+    const float pos = v[2] / fb, neg = (v[3] - v[2]) / (fb * fb - fb);
+    out[0] = loss_type == 0 ? 0.5f * v[0] / fb : v[0] / (fb * fb);
+    out[1] = v[1] / fb;
+    out[2] = pos; out[3] = neg; out[4] = pos - neg;
+    out[5] = v[4] / fb; out[6] = v[3]; out[7] = 0.f;
+    if (loss_out) loss_out[0] = out[0];
+  }
+}
+
+// S -> d loss / d (N C^T) in place (the 1 / T of S = N C^T / T included), times the incoming gradient
+__global__ __launch_bounds__(kThreads) void dense_grad_kernel(float* __restrict__ S, int64_t B, int loss_type, float smooth, float inv_t,
+                                                             const float* __restrict__ stats, const float* __restrict__ d_loss) {
+  const float* lse_r = stats; const float* lse_c = stats + 2 * B;
+  const float fb = (float)B, g = d_loss[0] * inv_t;
+  const int64_t total = B * B;
+  for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+    const int64_t a = i / B, b = i - a * B;
+    const float v = S[i];
+    float d;
+    if (loss_type == 0) {
+      const float onehot = a == b ? 1.f - smooth : 0.f;
+      d = 0.5f / fb * ((expf(v - lse_r[a]) - onehot - smooth / fb) + (expf(v - lse_c[b]) - onehot - smooth / fb));
+    } else {
+      const float dc = dcos1(v);
+      d = (a == b ? -dc : (cos1(v) > 0.f ? dc : 0.f)) / (fb * fb);
+    }
+    S[i] = d * g;
+  }
+}
+
 // top-k per row: one wave per row, k selection passes over the row in the total order
 // (value descending, column ascending) -- no marking, no scratch
 __global__ __launch_bounds__(kThreads) void topk_rows_kernel(const float* __restrict__ S, int64_t R, int64_t C, int64_t lds, int k,
@@ -421,6 +557,48 @@ int tt_topk_rows(tt_ctx* ctx, const float* S, int64_t R, int64_t Ccols, int64_t 
   topk_rows_kernel<<<(unsigned)tt_cdiv(R, 4), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(S, R, Ccols, lds, k, vals, idx);
   TT_LAUNCH_CHECK();
   return TT_OK;
+}
+
+size_t tt_score_dense_workspace_bytes(int64_t B, int32_t D) {
+  if (B < 1 || D < 1) return 0;
+  return tt_gemm_tn_workspace_bytes(B, D, B) + 256;
+}
+
+int tt_score_dense_fwd(tt_ctx* ctx, const float* N, const float* Cm, int64_t B, int32_t D, float inv_t, int32_t loss_type,
+                       float label_smoothing, float* S, float* stats, int32_t* hit, float* out8, float* loss_out, tt_stream stream) {
+  TT_CHECK_ARG(ctx && N && Cm && S && stats && hit && out8, "tt_score_dense_fwd: NULL argument");
+  TT_CHECK_ARG(B >= 1 && B < ((int64_t)1 << 24) && D >= 1, "tt_score_dense_fwd: bad shape");
+  TT_CHECK_ARG(loss_type == 0 || loss_type == 1, "tt_score_dense_fwd: loss_type %d (0 = cross entropy, 1 = cosine embedding)", loss_type);
+  TT_CHECK_ARG(label_smoothing >= 0.f && label_smoothing <= 1.f, "tt_score_dense_fwd: label_smoothing not in [0, 1]");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (int rc = tt_gemm_nt(st, N, D, Cm, D, nullptr, S, B, B, B, D, false, inv_t)) return rc;
+  dense_row_stats_kernel<<<(unsigned)tt_cdiv(B, kThreads / 64), kThreads, 0, st>>>(S, B, stats, stats + B, stats + 4 * B, stats + 5 * B, hit);
+  TT_LAUNCH_CHECK();
+  dense_col_stats_kernel<<<(unsigned)tt_cdiv(B, kThreads), kThreads, 0, st>>>(S, B, stats + 2 * B, stats + 3 * B, hit + B);
+  TT_LAUNCH_CHECK();
+  dense_finish_kernel<<<1, 1024, 0, st>>>(B, loss_type, label_smoothing, stats, hit, out8, loss_out);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_score_dense_bwd(tt_ctx* ctx, const float* N, const float* Cm, int64_t B, int32_t D, float inv_t, int32_t loss_type,
+                       float label_smoothing, float* S, const float* stats, const float* d_loss, float* dN, float* dC,
+                       void* workspace, size_t workspace_bytes, tt_stream stream) {
+  TT_CHECK_ARG(ctx && N && Cm && S && stats && d_loss && dN && dC && workspace, "tt_score_dense_bwd: NULL argument");
+  TT_CHECK_ARG(B >= 1 && D >= 1 && (loss_type == 0 || loss_type == 1), "tt_score_dense_bwd: bad arguments");
+  if (workspace_bytes < tt_score_dense_workspace_bytes(B, D)) {
+    tt_set_error("tt_score_dense_bwd: workspace %zu < required %zu", workspace_bytes, tt_score_dense_workspace_bytes(B, D));
+    return TT_ERR_WORKSPACE;
+  }
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  int64_t blocks = tt_cdiv(B * B, kThreads);
+  if (blocks > 8192) blocks = 8192;
+  dense_grad_kernel<<<(unsigned)blocks, kThreads, 0, st>>>(S, B, loss_type, label_smoothing, inv_t, stats, d_loss);
+  TT_LAUNCH_CHECK();
+  GemmNN nn{S, B, Cm, D, dN, D, B, D, B};                                 // dN = dS . C
+  if (int rc = tt_gemm_nn_batched(st, &nn, 1)) return rc;
+  GemmTN tn{S, B, N, D, dC, D, B, D, B, workspace, workspace_bytes, nullptr};       // dC = dS^T . N
+  return tt_gemm_tn_batched(st, &tn, 1);
 }
 
 }  // extern "C"

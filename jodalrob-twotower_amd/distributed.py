@@ -506,6 +506,8 @@ class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
 
     def _score_ce(self, n, c, inv_t, first_call):
         if self.negatives == "global" and self.exchange.world > 1:
+            if self._dense_loss:
+                raise NotImplementedError("global in-batch negatives support the default cross-entropy loss only")
             if self.score_dtype != "bf16":
                 raise NotImplementedError("global in-batch negatives run on the bf16 score kernels (score_dtype='bf16')")
             return _GlobalScoreCEFn.apply(n, c, inv_t, self.exchange.comm)

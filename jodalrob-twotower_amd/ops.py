@@ -527,6 +527,31 @@ def score_matrix(A, Bm, inv_t):
     return S
 
 
+def score_dense_fwd(n, c, inv_t: float, loss_type: int, label_smoothing: float):
+    """Dense loss path (tt_score_dense_fwd): returns (S [B, B], stats, out8, loss[1]) -- S and stats feed score_dense_bwd."""
+    dev, B, D = n.device, n.shape[0], n.shape[1]
+    S = torch.empty((B, B), dtype=torch.float32, device=dev)
+    stats = torch.empty(6 * B, dtype=torch.float32, device=dev)
+    hit = torch.empty(2 * B, dtype=torch.int32, device=dev)
+    out8 = torch.empty(8, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    with _timed("tt_score_dense_fwd"):
+        L.check(L.load().tt_score_dense_fwd(L.ctx(dev), L.ptr(n), L.ptr(c), B, D, inv_t, loss_type, label_smoothing, L.ptr(S), L.ptr(stats),
+                                            L.ptr(hit), L.ptr(out8), L.ptr(loss), L.stream(dev)), "tt_score_dense_fwd")
+    return S, stats, out8, loss
+
+
+def score_dense_bwd(n, c, inv_t: float, loss_type: int, label_smoothing: float, S, stats, d_loss):
+    """(dN, dC) of the dense loss path; S is overwritten by d loss / d (N C^T)."""
+    dev, B, D = n.device, n.shape[0], n.shape[1]
+    dN, dC = torch.empty_like(n), torch.empty_like(c)
+    ws = torch.empty(L.load().tt_score_dense_workspace_bytes(B, D), dtype=torch.uint8, device=dev)
+    with _timed("tt_score_dense_bwd"):
+        L.check(L.load().tt_score_dense_bwd(L.ctx(dev), L.ptr(n), L.ptr(c), B, D, inv_t, loss_type, label_smoothing, L.ptr(S), L.ptr(stats),
+                                            L.ptr(d_loss), L.ptr(dN), L.ptr(dC), L.ptr(ws), ws.numel(), L.stream(dev)), "tt_score_dense_bwd")
+    return dN, dC
+
+
 def diag_rank_rows(S, diag_offset=0):
     dev, R, Cc = S.device, S.shape[0], S.shape[1]
     assert S.stride(1) == 1 and S.dtype == torch.float32

@@ -25,6 +25,27 @@ _PRESCALE = __import__("os").environ.get("TT_SCORE_PRESCALE", "1") != "0"      #
 _SYM_FWD = __import__("os").environ.get("TT_SCORE_SYM_FWD", "1") != "0"        # TT_SCORE_SYM_FWD=0: the two-direction forward kernel (A/B)
 
 
+class _DenseLossFn(torch.autograd.Function):
+    """The loss variants the fused kernels do not cover, on the materialised score matrix (tt_score_dense_fwd / _bwd):
+    loss_type 0 = cross-entropy with label smoothing (:114-133), 1 = cosine-embedding loss (:135-158).  O(B^2) memory."""
+
+    @staticmethod
+    def forward(ctx, n, c, inv_t, loss_type, label_smoothing):
+        n, c = n.contiguous().float(), c.contiguous().float()
+        S, stats, out8, loss = ops.score_dense_fwd(n, c, inv_t, loss_type, label_smoothing)
+        ctx.save_for_backward(n, c, S, stats)
+        ctx.cfg = (inv_t, loss_type, label_smoothing)
+        ctx.mark_non_differentiable(out8)
+        return loss.reshape(()), out8
+
+    @staticmethod
+    def backward(ctx, d_loss, _d_out8):
+        n, c, S, stats = ctx.saved_tensors
+        inv_t, loss_type, label_smoothing = ctx.cfg
+        dN, dC = ops.score_dense_bwd(n, c, inv_t, loss_type, label_smoothing, S, stats, d_loss.reshape(1).contiguous().float())
+        return dN, dC, None, None, None
+
+
 class _ScoreCEFn(torch.autograd.Function):
     """loss = 0.5 * [CE(S, diag) + CE(S^T, diag)],  S = N C^T / T   (:99-134); out8 carries the metrics.
     score_dtype 'fp32': exact-f32 MFMA path (parity); 'bf16': bf16-operand MFMA fast path."""
@@ -159,11 +180,11 @@ class TwoTowerTrainTask(nn.Module):
         self.label_smoothing = label_smoothing
         if loss_type not in ["cross_entropy", "cosine_embedding"]:
             raise ValueError(f"Unsupported loss_type: {loss_type}")                         # :37-38
-        if loss_type != "cross_entropy":
-            raise NotImplementedError("loss_type='cosine_embedding' (reference :136-158, unused by scripts/train.py) "
-                                      "has no HIP kernel; use 'cross_entropy'")
-        if label_smoothing != 0.0:
-            raise NotImplementedError("label_smoothing != 0 is not supported (the reference factory never sets it: :243-247)")
+        if not 0.0 <= float(label_smoothing) <= 1.0:
+            raise ValueError(f"label_smoothing must be in [0, 1], got {label_smoothing}")
+        # cosine-embedding loss (:135-158) and label smoothing (never set by the reference's factory or driver) run on the
+        # dense path: the score matrix is materialised (O(B^2) memory), f32 throughout -- see _DenseLossFn
+        self._dense_loss = loss_type != "cross_entropy" or float(label_smoothing) != 0.0
 
     # ---- forward: :40-97 ----------------------------------------------------------------------------
     def forward(self, batch, return_metrics: bool = False):
@@ -206,6 +227,11 @@ class TwoTowerTrainTask(nn.Module):
 
     def _score_ce(self, n, c, inv_t, first_call):
         """(loss, out8, row_rank) of the symmetric in-batch-negative softmax-CE (:99-134); the sharded task overrides it."""
+        if self._dense_loss:
+            if n.shape != c.shape:
+                raise ValueError("the dense loss path needs as many notice rows as company rows")
+            loss, out8 = _DenseLossFn.apply(n, c, inv_t, 0 if self.loss_type == "cross_entropy" else 1, float(self.label_smoothing))
+            return loss, out8, None
         pn, pc = getattr(n, "_tt_packed", None), getattr(c, "_tt_packed", None)     # (buffer, scale) emitted by the towers
         if self.score_dtype != "bf16" or n.shape != c.shape or pn is None or pc is None or pc[1] != 1.0:
             return _ScoreCEFn.apply(n, c, inv_t, self.score_dtype, first_call, False)

@@ -283,12 +283,46 @@ def score_operands_bf16(N, C, temperature=1.0):
 
 # ------------------------------------------------------------------------------------------------
 # a9/a10  TwoTowerModel.forward + TwoTowerTrainTask.forward (+ a16 backward)
+COS_EPS = 1e-12      # EPSILON of ATen's cosine_embedding_loss
+
+
+def score_variant_fwd_bwd(N, C, temperature=1.0, loss_type="cross_entropy", label_smoothing=0.0, dloss=1.0):
+    """The loss variants of two_tower_train_task.py:114-160 on the materialised S = N C^T / T, with their gradients:
+      cross_entropy + label_smoothing e (:118-133, F.cross_entropy(label_smoothing=e) on S and S^T):
+          row term = lse_a - (1 - e) s_aa - (e / B) sum_b s_ab ; loss = (mean rows + mean columns) / 2
+      cosine_embedding (:135-158): F.cosine_embedding_loss([s], [1], +-1) = 1 - cos on the diagonal, max(0, cos) off it,
+          cos = s / sqrt((s^2 + 1e-12)(1 + 1e-12)), mean over all B^2 entries.
+    Returns (loss, metrics, S, dN, dC)."""
+    _, metrics, S, lse = score_ce_fwd(N, C, temperature)
+    B = S.shape[0]
+    eye = np.eye(B, dtype=bool)
+    if loss_type == "cross_entropy":
+        e = S.dtype.type(label_smoothing)
+        d = np.diagonal(S)
+        rows = lse[0] - (1 - e) * d - e / B * S.sum(axis=1)
+        cols = lse[1] - (1 - e) * d - e / B * S.sum(axis=0)
+        loss = 0.5 * (rows.mean() + cols.mean())
+        onehot = np.where(eye, 1 - e, 0).astype(S.dtype)
+        dS = 0.5 / B * ((np.exp(S - lse[0][:, None]) - onehot - e / B) + (np.exp(S - lse[1][None, :]) - onehot - e / B))
+    elif loss_type == "cosine_embedding":
+        q = S * S + COS_EPS
+        cos = S / np.sqrt(q * (1 + COS_EPS))
+        loss = np.where(eye, 1 - cos, np.maximum(cos, 0)).mean()
+        dcos = COS_EPS / (q * np.sqrt(q) * np.sqrt(1 + COS_EPS))
+        dS = np.where(eye, -dcos, np.where(cos > 0, dcos, 0)) / (B * B)
+    else:
+        raise ValueError(f"Unsupported loss_type: {loss_type}")
+    dS = dS * S.dtype.type(dloss) / S.dtype.type(temperature)
+    return loss, metrics, S, dS @ C, dS.T @ N
+
+
 # ------------------------------------------------------------------------------------------------
 NT, CT = "two_tower_model.notice_tower.", "two_tower_model.company_tower."
 
 
 def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, train=True, backward=True,
-              dtype=np.float32, rounding=None, table_grads="dense", keep_sim=True, proj_grad="direct"):
+              dtype=np.float32, rounding=None, table_grads="dense", keep_sim=True, proj_grad="direct",
+              loss_type="cross_entropy", label_smoothing=0.0):
     """One forward (+backward) of the task.  batch: dict with notice_ids/company_ids [B,K] (or flat
     values) and notice_dense/company_dense.  Returns dict(loss, metrics, sim, notice_emb, company_emb,
     grads{state key: array}, bn_updates).
@@ -303,11 +337,18 @@ def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, t
     ne, cn, bn_n = tower_fwd(state, NT, keys_n, vocab_n, batch["notice_dense"], vals_n, train, dtype, q)
     ce, cc, bn_c = tower_fwd(state, CT, keys_c, vocab_c, batch["company_dense"], vals_c, train, dtype, q)
     sn, sc = score_operands_bf16(ne, ce, temperature) if q is not None else (ne, ce)
-    loss, metrics, S, lse = score_ce_fwd(sn, sc, temperature)
+    variant = loss_type != "cross_entropy" or label_smoothing != 0.0          # the dense loss path (f32 only)
+    if variant:
+        if q is not None:
+            raise ValueError("the loss variants run in f32 (no operand rounding)")
+        loss, metrics, S, dN, dC = score_variant_fwd_bwd(sn, sc, temperature, loss_type, label_smoothing)
+    else:
+        loss, metrics, S, lse = score_ce_fwd(sn, sc, temperature)
     out = {"loss": loss, **metrics, "sim": S if keep_sim else None, "notice_emb": ne, "company_emb": ce,
            "bn_updates": {**bn_n, **bn_c}}
     if backward:
-        dN, dC = score_ce_bwd(sn, sc, S, lse, temperature, q=q)
+        if not variant:
+            dN, dC = score_ce_bwd(sn, sc, S, lse, temperature, q=q)
         del S
         g = tower_bwd(cn, dN, NT, keys_n, vocab_n, table_grads, proj_grad)
         out["d_concat_notice"] = g.pop("_d_concat")

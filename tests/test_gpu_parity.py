@@ -83,6 +83,38 @@ def test_task_matches_reference_golden(tt, manifest, case):
     np.testing.assert_allclose(ne.norm(dim=1).cpu().numpy(), 1.0, atol=1e-5)
 
 
+@pytest.mark.parametrize("case", ["loss_smooth_0p1", "loss_smooth_0p3_temp", "loss_cosine", "loss_cosine_temp"])
+def test_loss_variants_match_reference_golden(tt, case):
+    """loss_type="cosine_embedding" and label_smoothing != 0 (two_tower_train_task.py:114-160) run on the dense loss path
+    (tt_score_dense_fwd / _bwd: materialised score matrix, f32): loss, metrics and every gradient against the reference's
+    own vectors.  (Cosine gradients: see tests/test_oracle_golden.py::test_loss_variants_match_reference.)"""
+    import json
+    cfg = json.loads((GOLD / "loss_variants.json").read_text())["cases"][case]
+    g = load_case(case)
+    from jodalrob_twotower_amd import two_tower_train_task as T3
+    model_task = make_task(tt, cfg, loss_type=cfg["loss_type"])
+    task = T3.TwoTowerTrainTask(model_task.two_tower_model, temperature=cfg["T"], loss_type=cfg["loss_type"],
+                                label_smoothing=cfg["label_smoothing"])
+    load_state(task, split_prefix(g, "state."))
+    task.train()
+    res = task(to_batch(tt, split_prefix(g, "in."), cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
+    np.testing.assert_allclose(res["loss"].item(), g["out.loss"], rtol=2e-5)
+    np.testing.assert_allclose(res["similarity_matrix"].cpu().numpy(), g["sim"], rtol=2e-5, atol=5e-6)
+    assert res["accuracy"].item() == pytest.approx(float(g["out.accuracy"]), abs=1e-7)
+    for k in ("positive_similarity_mean", "negative_similarity_mean", "similarity_gap"):
+        np.testing.assert_allclose(res[k].item(), g["out." + k], rtol=1e-4, atol=2e-6)
+    res["loss"].backward()
+    ref = split_prefix(g, "grad.")
+    got = {n: p.grad.cpu().numpy() for n, p in task.named_parameters()}
+    assert set(ref) == set(got)
+    gmax = max(float(np.abs(v).max()) for v in ref.values())
+    for k, v in ref.items():
+        if cfg["loss_type"] == "cosine_embedding":
+            assert np.abs(got[k] - v).max() <= 5e-2 * gmax + 1e-6, (k, np.abs(got[k] - v).max(), gmax)
+        else:
+            np.testing.assert_allclose(got[k], v, rtol=3e-4, atol=3e-7, err_msg=k)
+
+
 def test_real_schema_golden(tt, manifest, schema_real):
     cfg = dict(manifest["cases"]["real_schema"])
     cfg.update(keys_n=schema_real["notice"]["categorical"], keys_c=schema_real["company"]["categorical"])
