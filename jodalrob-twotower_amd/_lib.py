@@ -196,3 +196,14 @@ def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 
 def num_cus(device: torch.device) -> int:
     return int(load().tt_ctx_num_cus(ctx(device)))
+
+
+def no_dynamo(fn):
+    """Keep torch.compile's tracer out of `fn`: the arithmetic behind it is ctypes calls into the HIP library, which the
+    tracer cannot see through (it hands our stream / pointer plumbing proxy objects).  torch.compile(task) -- the reference
+    driver's optional mode, scripts/train.py:223-225 -- then runs the step as it is; GraphedTrainStep is the counterpart."""
+    try:
+        import torch._dynamo as _d
+        return _d.disable(fn)
+    except Exception:                                      # pragma: no cover - torch builds without dynamo
+        return fn

@@ -16,6 +16,7 @@ from pathlib import Path
 from typing import Dict, List, Optional, Union
 
 import torch
+from ._lib import no_dynamo as _no_dynamo
 import torch.nn as nn
 
 from . import ops
@@ -261,6 +262,7 @@ class CategoricalEmbedder(nn.Module):
     def lookup_side(self, values: torch.Tensor, out_view: torch.Tensor) -> ops.LookupSide:
         return ops.LookupSide(values, self._key_row_offset, self._key_vocab, out_view, len(self.keys))
 
+    @_no_dynamo
     def forward(self, kjt, return_dict: bool = True):
         K, E = len(self.keys), self.embedding_dim
         if kjt is None:                                                    # :143-150

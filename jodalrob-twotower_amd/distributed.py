@@ -30,6 +30,7 @@ import math
 from typing import List, Optional, Sequence
 
 import torch
+from ._lib import no_dynamo as _no_dynamo
 import torch.distributed as dist
 import torch.nn as nn
 
@@ -499,6 +500,7 @@ class DistributedTwoTowerTrainTask(TwoTowerTrainTask):
             if b.is_floating_point():
                 dist.broadcast(b, src=0, group=group)
 
+    @_no_dynamo
     def forward(self, batch, return_metrics: bool = False):
         if hasattr(self.exchange, "poll_overflow"):
             self.exchange.poll_overflow()          # rejects a step whose rows did not fit the buckets (non-blocking, <= poll_lag steps late)

@@ -20,6 +20,7 @@ import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
+from ._lib import no_dynamo as _no_dynamo
 import torch.nn as nn
 
 from . import _lib as L
@@ -167,6 +168,7 @@ class BaseTower(nn.Module):
         return self.tower_hidden_dims[0] + len(self.categorical_keys) * self.categorical_embedder.embedding_dim
 
     # ---- forward: src/towers/tower/base_tower.py:101-147 ------------------------------------------
+    @_no_dynamo
     def forward(self, tower_input: Dict[str, torch.Tensor]) -> torch.Tensor:
         return run_towers([self], [tower_input])[0]
 

@@ -8,6 +8,7 @@ from __future__ import annotations
 from typing import Dict, List, Optional
 
 import torch
+from ._lib import no_dynamo as _no_dynamo
 import torch.nn as nn
 
 from . import ops
@@ -37,6 +38,7 @@ class TwoTowerModel(nn.Module):
     def embedding_store(self) -> EmbeddingStore:
         return self.notice_tower.categorical_embedder.store
 
+    @_no_dynamo
     def forward(self, notice_input, company_input, return_similarity: bool = False, temperature: float = 1.0):
         notice_embeddings, company_embeddings = run_towers([self.notice_tower, self.company_tower],
                                                            [notice_input, company_input])

@@ -13,6 +13,7 @@ from __future__ import annotations
 from typing import Dict, Union
 
 import torch
+from ._lib import no_dynamo as _no_dynamo
 import torch.nn as nn
 
 from . import ops
@@ -187,6 +188,7 @@ class TwoTowerTrainTask(nn.Module):
         self._dense_loss = loss_type != "cross_entropy" or float(label_smoothing) != 0.0
 
     # ---- forward: :40-97 ----------------------------------------------------------------------------
+    @_no_dynamo
     def forward(self, batch, return_metrics: bool = False):
         notice_input, company_input = batch["notice"], batch["company"]
         nb, cb = notice_input["dense"].size(0), company_input["dense"].size(0)
@@ -258,6 +260,7 @@ class TwoTowerTrainTask(nn.Module):
         print()
 
     # ---- predict_batch: :181-207 ----------------------------------------------------------------------
+    @_no_dynamo
     def predict_batch(self, batch, top_k: int = 10) -> Dict[str, torch.Tensor]:
         self.eval()
         with torch.no_grad():

@@ -115,6 +115,27 @@ def test_loss_variants_match_reference_golden(tt, case):
             np.testing.assert_allclose(got[k], v, rtol=3e-4, atol=3e-7, err_msg=k)
 
 
+def test_torch_compile_wrapper_survives(tt, manifest):
+    """scripts/train.py:223-225 optionally wraps the task in torch.compile(mode="reduce-overhead").  The tracer cannot see
+    through ctypes calls, so the modules keep it out (_lib.no_dynamo): the compiled wrapper runs the same HIP step --
+    loss equal to the golden value, gradients present."""
+    cfg = manifest["cases"]["tiny_train"]
+    g = load_case("tiny_train")
+    task = make_task(tt, cfg)
+    load_state(task, split_prefix(g, "state."))
+    task.train()
+    batch = to_batch(tt, split_prefix(g, "in."), cfg["keys_n"], cfg["keys_c"])
+    compiled = torch.compile(task, mode="reduce-overhead", fullgraph=False)
+    for _ in range(2):
+        task.zero_grad()
+        res = compiled(batch, return_metrics=True)
+        res["loss"].backward()
+    np.testing.assert_allclose(res["loss"].item(), g["out.loss"], rtol=2e-5)
+    ref = split_prefix(g, "grad.")
+    for n_, p in task.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref[n_], rtol=3e-4, atol=3e-7, err_msg=n_)
+
+
 def test_real_schema_golden(tt, manifest, schema_real):
     cfg = dict(manifest["cases"]["real_schema"])
     cfg.update(keys_n=schema_real["notice"]["categorical"], keys_c=schema_real["company"]["categorical"])
