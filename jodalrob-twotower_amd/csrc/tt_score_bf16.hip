@@ -524,9 +524,9 @@ __global__ __launch_bounds__(NW * 64) void score_bwd_bf16_kernel(BwdArgs args) {
 // nothing 23.4 -- streaming is no longer the largest term; per SIMD the gradient + S MFMAs (34 GFLOP for both directions: every
 // direction recomputes S) need ~20 us of the matrix pipe, the softmax VALU work ~24 us, the loads ~20 us, and a wave runs the
 // three one after the other.
-template <int KS, bool UNIT>
+template <int KS, int AT, bool UNIT>
 __global__ __launch_bounds__(512) void score_bwd_tr_kernel(BwdArgs args) {
-  constexpr int AT = 2, NW = 8, Dp = KS * 16, ROWS = 32 * AT, DT = KS / 2;
+  constexpr int NW = 8, Dp = KS * 16, ROWS = 32 * AT, DT = KS / 2;
   constexpr int TLD = Dp + 8;                                   // LDS row of the parked tile: 144 B at D = 64 (conflict-free b128 writes)
   __shared__ float red[(NW / 2) * ROWS * Dp];
   __shared__ __attribute__((aligned(16))) __bf16 park[NW][32 * TLD];
@@ -1098,10 +1098,16 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
     if (bvar == 1) TT_BWD(4, 1, 8);
     else if (bvar != 2) {                                 // one streamed image, transposing LDS reads (TT_SCORE_BWD_VARIANT=2: two images)
       const dim3 grid((unsigned)tt_cdiv(maxRa, 64), (unsigned)n_dirs);
-      if (unit) score_bwd_tr_kernel<4, true><<<grid, 512, 0, st>>>(a);
-      else score_bwd_tr_kernel<4, false><<<grid, 512, 0, st>>>(a);
+      if (unit) score_bwd_tr_kernel<4, 2, true><<<grid, 512, 0, st>>>(a);
+      else score_bwd_tr_kernel<4, 2, false><<<grid, 512, 0, st>>>(a);
     } else TT_BWD(4, 2, 8);
-  } else if (Dp == 128) TT_BWD(8, 1, 8);
+  } else if (Dp == 128) {
+    if (bvar != 2) {                                      // D <= 128: the one-image form, one a tile per workgroup
+      const dim3 grid((unsigned)tt_cdiv(maxRa, 32), (unsigned)n_dirs);
+      if (unit) score_bwd_tr_kernel<8, 1, true><<<grid, 512, 0, st>>>(a);
+      else score_bwd_tr_kernel<8, 1, false><<<grid, 512, 0, st>>>(a);
+    } else TT_BWD(8, 1, 8);
+  }
   else TT_BWD(16, 1, 4);
 #undef TT_BWD
   TT_LAUNCH_CHECK();
