@@ -50,7 +50,7 @@ int tt_gemm_tn_flush(hipStream_t st, TnPending* pending);
 //   dW = d_pre^T . x (+ db = column sums of d_pre),  d_x[:, h0:] = d_pre . W[:, h0:],  G = d_pre^T . dense,
 // and dW_proj = W[:, 0:h0]^T . G (each batch split's share multiplied in its own workgroup, summed by the pending
 // slab-reduction launch), db_proj = W[:, 0:h0]^T . db  (= d_proj^T . dense and the column sums of d_proj = d_pre . W[:, 0:h0],
-// without materialising d_proj: d_x[:, 0:h0] is NOT written).  H = 64 only.  tt_gemm_back_supported() says whether the shapes qualify; otherwise use the TN / NN launchers.
+// without materialising d_proj: d_x[:, 0:h0] is NOT written).  H a multiple of 64, at most 256.  tt_gemm_back_supported() says whether the shapes qualify; otherwise use the TN / NN launchers.
 struct GemmBack {
   const float* dpre; int H;                       // [B, H] f32, ld = H
   const void* x; int64_t ldx; int kx; bool x_bf16;

@@ -16,7 +16,7 @@ struct GemmArgs {
   int M, N, K, kchunk, splits;
   const float* bias; int relu; float alpha; float* colsum_slab;
   int a_bf16 = 0, b_bf16 = 0, c_bf16 = 0;   // bf16 kernel only: element type of A / B / C in memory
-  // gemm_back_kernel role 1 only: the tile G_z [M = H (one 64-row tile), 64 columns] leaves as proj_w[:, 0:proj_h0]^T . G_z
+  // gemm_back_kernel role 1 only: the tile G_z [64 rows of H, 64 columns] leaves as proj_w[those rows, 0:proj_h0]^T . G_z
   const float* proj_w = nullptr; int proj_ldw = 0, proj_h0 = 0;
 };
 struct GemmBatch { GemmArgs a[TT_MAX_SIDES]; };
@@ -148,7 +148,7 @@ struct SlabArgs {
   const float* bias; int relu;          // split-K forward GEMMs finish bias / ReLU here
   int c_bf16 = 0;                        // C holds bf16 elements
   // projection bias item (gemm_back): no slabs of its own; colsum_out [proj_h0] = proj_w[:, 0:proj_h0]^T . (sum of the
-  // proj_colsum_splits slabs colsum_slab [.][M]), M = H <= 64
+  // proj_colsum_splits slabs colsum_slab [.][M]), M = H <= 256
   const float* proj_w = nullptr; int proj_ldw = 0, proj_h0 = 0, proj_colsum_splits = 0;
 };
 constexpr int kSlabItems = 16;
@@ -449,8 +449,9 @@ __device__ __forceinline__ void gemm_fast_tile(const GemmArgs& g, int split, int
   float* Cz = g.C + (int64_t)split * g.slab_stride;
   const int n = n0 + wc * 32 + li;
   if (PROJ) {
-    // this split's G_z tile [64 h, 64 columns] (M = H = 64: one row tile) -> slab of P_z = W[:, 0:h0]^T . G_z  [h0, 64 columns]:
-    // summed over the splits by the slab reduction that is the projection's weight gradient.  Both factors go through LDS as
+    Cz = g.C + ((int64_t)split * (M / BM) + bx) * g.slab_stride;      // one slab per (split, 64-row block of h)
+    // this split's G_z tile [64 h of block bx, 64 columns] -> slab of P = W[block bx, 0:h0]^T . G_z  [h0, 64 columns]: summed over
+    // the splits AND the H / 64 row blocks by the slab reduction, that is the projection's weight gradient.  Both factors go through LDS as
     // bf16 ([column][h] and [i][h], 72-element rows), 64 rows of i at a time
     constexpr int LP = 72;
     __bf16* Gt = &As[0][0];                 // 64 x 72 bf16 = 9216 B <= the two A stage buffers
@@ -469,7 +470,7 @@ __device__ __forceinline__ void gemm_fast_tile(const GemmArgs& g, int split, int
     for (int i0 = 0; i0 < g.proj_h0; i0 += 64) {
       {                                     // W[h][i0 .. i0 + 63] -> Wt[i][h]: thread = (h = t >> 2, 16 columns)
         const int h = t >> 2, iq = (t & 3) * 16;
-        const float* src = g.proj_w + (int64_t)h * g.proj_ldw + i0 + iq;
+        const float* src = g.proj_w + (int64_t)(m0 + h) * g.proj_ldw + i0 + iq;
 #pragma unroll
         for (int v4 = 0; v4 < 4; ++v4) {
           const float4 w = *reinterpret_cast<const float4*>(src + 4 * v4);
@@ -598,17 +599,17 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_back_kernel(BackBatch b) {
   } else gemm_fast_tile<0, 1, false, false, false>(g, split, bx, by, sm);
 }
 
-constexpr int kProjMaxH = 64;
+constexpr int kProjMaxH = 256;
 // colsum_out [proj_h0] = proj_w[:, 0:proj_h0]^T . (sum of the proj_colsum_splits slabs colsum_slab [.][M]): one workgroup
 __device__ __forceinline__ void proj_bias_finish(const SlabArgs& a) {
   if (blockIdx.x != 0) return;
   __shared__ float dbs[kProjMaxH];
   const int H = a.M, t = threadIdx.x;
-  if (t < H) {
+  for (int h = t; h < H; h += THREADS) {
     float s = 0.f;
 #pragma unroll 8
-    for (int z = 0; z < a.proj_colsum_splits; ++z) s += a.colsum_slab[(int64_t)z * H + t];
-    dbs[t] = s;
+    for (int z = 0; z < a.proj_colsum_splits; ++z) s += a.colsum_slab[(int64_t)z * H + h];
+    dbs[h] = s;
   }
   __syncthreads();
   for (int i = t; i < a.proj_h0; i += THREADS) {
@@ -888,7 +889,7 @@ static int back_g_splits(int64_t H, int64_t din, int64_t B) {
   return s > 32 ? 32 : s;                               // the projection finish re-reads these slabs per 16-column block
 }
 size_t tt_gemm_back_g_workspace_bytes(int64_t H, int64_t h0, int64_t din, int64_t B) {
-  return sizeof(float) * (size_t)back_g_splits(H, din, B) * (size_t)h0 * (size_t)din + 256;
+  return sizeof(float) * (size_t)back_g_splits(H, din, B) * (size_t)(H / BM) * (size_t)h0 * (size_t)din + 256;
 }
 
 bool tt_gemm_back_supported(const GemmBack* it, int n) {
@@ -896,7 +897,10 @@ bool tt_gemm_back_supported(const GemmBack* it, int n) {
   if (off || n < 1 || n > TT_MAX_SIDES) return false;
   for (int i = 0; i < n; ++i) {
     const GemmBack& g = it[i];
-    if (g.B < 64 || g.B % 64 || g.H != 64 || g.kx % 64 || g.h0 % 64 || g.h0 < 64 || g.h0 >= g.kx || g.din % 64) return false;
+    if (g.B < 64 || g.B % 64 || g.H < 64 || g.H % 64 || g.H > kProjMaxH || g.kx % 64 || g.h0 % 64 || g.h0 < 64 || g.h0 >= g.kx || g.din % 64) return false;
+    // every (split, 64-row block of h) writes an [h0, din] slab: beyond (H / 64) x h0 = 256 the slabs outweigh what the one launch
+    // saves (H = 256, h0 = 512: 67 MB of slabs, 61 us to add them up) -- the separate launches take those shapes
+    if ((g.H / BM) * g.h0 > 256) return false;
     if (g.x_bf16 != it[0].x_bf16) return false;
     if (!tt_aligned(g.dpre, 16) || !tt_aligned(g.x, 16) || g.ldx % 8 || !tt_aligned(g.dense, 16) || g.ld_dense % 4 || !tt_aligned(g.w, 16) ||
         !tt_aligned(g.dx, 16) || g.ld_dx % 4)
@@ -940,7 +944,7 @@ int tt_gemm_back_batched(hipStream_t st, const GemmBack* it, int n, TnPending* p
                           kchunk_of(g.B, s1), s1, nullptr, 0, 1.f, nullptr, 0, 0, 0};
         b.g[p].proj_w = g.w; b.g[p].proj_ldw = g.kx; b.g[p].proj_h0 = g.h0;
         tm = g.H / BM; tn_ = g.din / BN;
-        sa[ns++] = SlabArgs{slabs1, (int64_t)g.h0 * g.din, s1, g.dwp, g.din, g.h0, g.din, nullptr, nullptr, nullptr, 0};
+        sa[ns++] = SlabArgs{slabs1, (int64_t)g.h0 * g.din, s1 * (g.H / BM), g.dwp, g.din, g.h0, g.din, nullptr, nullptr, nullptr, 0};
         SlabArgs pj{nullptr, 0, 0, nullptr, 0, g.H, 0, cslab0, g.dbp, nullptr, 0};
         pj.proj_w = g.w; pj.proj_ldw = g.kx; pj.proj_h0 = g.h0; pj.proj_colsum_splits = s0;
         sa[ns++] = pj;

@@ -899,8 +899,9 @@ def test_tower_front_one_launch_vs_separate(tt, manifest, monkeypatch, E, nk_n, 
             assert v <= tol, (k, v)
 
 
-@pytest.mark.parametrize("B,drop", [(8192, 0.1), (640, 0.0), (64, 0.0)])
-def test_tower_first_block_backward_one_launch_vs_separate(tt, manifest, schema_real, monkeypatch, B, drop):
+@pytest.mark.parametrize("B,drop,hidden,D", [(8192, 0.1, None, None), (640, 0.0, None, None), (64, 0.0, None, None),
+                                             (1024, 0.1, [128, 128], 128), (512, 0.0, [64, 256], 64), (512, 0.0, [512, 128], 64)])
+def test_tower_first_block_backward_one_launch_vs_separate(tt, manifest, schema_real, monkeypatch, B, drop, hidden, D):
     """gemm_back_kernel (block weight gradient, looked-up rows' gradient and G = d_pre^T . dense in one launch; projection
     gradients = W[:, :h0]^T . G in the slab-reduction launch) against the separate TN / NN / TN launches on the reference's
     tower shapes.  The block's weight / bias gradients and the row gradients keep their k order: bit-identical; the projection's
@@ -909,9 +910,11 @@ def test_tower_first_block_backward_one_launch_vs_separate(tt, manifest, schema_
     (1.6e-3 norm-wise at B = 8192); each is pinned against the oracle with ITS rounding in test_bf16_step_vs_rounded_oracle."""
     cfg = dict(manifest["cases"]["real_schema"])
     cfg.update(keys_n=schema_real["notice"]["categorical"], keys_c=schema_real["company"]["categorical"])
+    if hidden is not None:                      # wider first blocks (H = 128, 256: several 64-row blocks of h per G tile; the last case falls back)
+        cfg.update(hidden=hidden, D=D)
     vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
     shapes = {k: tuple(v) for k, v in manifest["state_dict_keys_real"].items()}
-    state = init_state_numpy(shapes, 191)
+    state = init_state_numpy(shapes, 191) if hidden is None else None
     b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 192, oob=False)
     outs = {}
     for unfused in ("1", "0"):
@@ -919,6 +922,8 @@ def test_tower_first_block_backward_one_launch_vs_separate(tt, manifest, schema_
         task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", mlp_dtype="bf16", score_dtype="bf16", dropout_rate=drop)
         for tw in (task.two_tower_model.notice_tower, task.two_tower_model.company_tower):
             tw._seed_override = 7
+        if state is None:
+            state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 191)
         load_state(task, state)
         task.train()
         res = task(to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]), return_metrics=True)
