@@ -760,6 +760,185 @@ __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArg
   }
 }
 
+// (B') the same kernel for wider towers: last hidden width H <= 256, output D <= 128 (scripts/train.py's own [512, 256] -> 128).
+// 64 rows per workgroup as above; the column-wise parts run over H / 64 column blocks, the output Linear is a [64 x H] . [H x D]
+// product on 8 waves (one 32 x 32 tile each, the whole K in one MFMA chain: the order of gemm_bf16_kernel without split-K),
+// a lane of the L2-normalise owns D / 64 columns.  Statistics finish, BN apply and the normalise keep the separate kernels'
+// arithmetic and order.  Dynamic LDS: A tile [64][H + 8] bf16 | W_out [D][H + 8] bf16 | Y [64][D + 1] f32 | statistics.
+constexpr int kWideH = 256, kWideD = 128;
+constexpr int kWideLds = 64 * (kWideH + 8) * 2 + kWideD * (kWideH + 8) * 2 + 64 * (kWideD + 1) * 4 + 4 * 4 * 64 * 12 + 2 * kWideH * 4;
+
+__global__ __launch_bounds__(kTailThreads) void tail_fwd_wide_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed0,
+                                                                    const uint64_t* __restrict__ seed_dev) {
+  const TailFwdArgs& f = batch.a[blockIdx.y];
+  const BnStatArgs& a = f.s;
+  const int H = a.H, D = f.D, B = a.B;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= B) return;
+  const int Hp = (H + 15) & ~15;                             // K of the output product: H padded to the MFMA's 16 (pad columns are zeros)
+  const int ldA = Hp + 8;                                    // bf16 elements per LDS row of the A tile and of W_out
+  extern __shared__ __attribute__((aligned(16))) char wide_smem[];
+  __bf16* As = reinterpret_cast<__bf16*>(wide_smem);                                   // [64][ldA]
+  __bf16* Bs = As + 64 * (kWideH + 8);                                                  // [D][ldA]
+  float* Y = reinterpret_cast<float*>(Bs + kWideD * (kWideH + 8));                      // [64][D + 1]
+  Wf (*sh)[4][64] = reinterpret_cast<Wf (*)[4][64]>(Y + 64 * (kWideD + 1));             // [4 column blocks][4 chunk lanes][64]
+  float* s_mean = reinterpret_cast<float*>(sh + 4);
+  float* s_rstd = s_mean + kWideH;
+  const int t = threadIdx.x, c = t & 63, rq = t >> 6;
+  const int HB = (H + 63) / 64;
+  // statistics: thread = (column block t >> 8, chunk lane (t >> 6) & 3, column): the order of bn_stats_finish_kernel
+  {
+    const int cb = t >> 8, jl = (t >> 6) & 3, col = cb * 64 + c;
+    Wf o{0.f, 0.f, 0.f};
+    if (cb < HB && col < H) {
+      Wf v[kMaxChunks / 4];
+      const int64_t ps = a.pstride ? a.pstride : 3 * H;
+#pragma unroll
+      for (int i = 0; i < kMaxChunks / 4; ++i) {
+        const int k = jl + 4 * i;
+        const float* q = a.partial + (int64_t)k * ps;
+        v[i] = k < a.nchunks ? Wf{q[col], q[H + col], q[2 * H + col]} : Wf{0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxChunks / 4; ++i) o = wf_combine(o, v[i]);
+    }
+    sh[cb][jl][c] = o;
+  }
+  // W_out [D, H] -> Bs[n][k] (coalesced along k); columns H .. Hp - 1 of both operand tiles are zeros
+  for (int e = t; e < D * H; e += kTailThreads) {
+    const int n = e / H, k = e - n * H;
+    Bs[n * ldA + k] = (__bf16)f.w_out[e];
+  }
+  for (int e = t; e < (D + 64) * (Hp - H); e += kTailThreads) {
+    const int r = e / (Hp - H), k = H + e % (Hp - H);
+    if (r < D) Bs[r * ldA + k] = (__bf16)0.f;
+    else As[(r - D) * ldA + k] = (__bf16)0.f;
+  }
+  __syncthreads();
+  if (t < 256) {
+    const int col = t;                                        // one thread per column finishes its four chunk lanes
+    if (col < H) {
+      const int cb = col >> 6, cc = col & 63;
+      const Wf o = wf_combine(wf_combine(sh[cb][0][cc], sh[cb][1][cc]), wf_combine(sh[cb][2][cc], sh[cb][3][cc]));
+      const float var = o.n > 0.f ? o.m2 / o.n : 0.f;
+      const float rstd = 1.f / sqrtf(var + kBnEps);
+      s_mean[col] = o.mean;
+      s_rstd[col] = rstd;
+      if (blockIdx.x == 0) {
+        a.mean[col] = o.mean;
+        a.rstd[col] = rstd;
+        if (a.rm) {
+          a.rm[col] = (1.f - kBnMomentum) * a.rm[col] + kBnMomentum * o.mean;
+          a.rv[col] = (1.f - kBnMomentum) * a.rv[col] + kBnMomentum * (o.n > 1.f ? o.m2 / (o.n - 1.f) : var);
+        }
+        if (a.nbt && col == 0) a.nbt[0] += 1;
+      }
+    }
+  }
+  __syncthreads();
+  {
+    const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
+    for (int cb = 0; cb < HB; ++cb) {
+      const int col = cb * 64 + c;
+      const bool on = col < H;
+      const float mean = on ? s_mean[col] : 0.f, rstd = on ? s_rstd[col] : 0.f;
+      const float g = on ? f.g[col] : 0.f, bb = on ? f.b[col] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = rq + 16 * j, r = m0 + row;
+        float v = 0.f;
+        if (on && r < B) {
+          const int64_t i = (int64_t)r * H + col;
+          const float x = fmaxf(a.pre[i], 0.f);
+          const float yv = (x - mean) * rstd * g + bb;
+          v = yv * dropout_scale(drop, p, seed, f.salt + (uint64_t)i);
+          f.act[i] = v;
+        }
+        if (on) As[row * ldA + col] = (__bf16)v;
+      }
+    }
+  }
+  __syncthreads();
+  const int lane = t & 63, wave = t >> 6;
+  const int DT = (D + 31) / 32;                               // 32-column tiles of the output (<= 4)
+  if (wave < 2 * DT) {
+    const int wr = wave & 1, wc = wave >> 1, li = lane & 31, lh = lane >> 5;
+    tl_f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    const int nrow = min(wc * 32 + li, D - 1);                // (columns past D: a valid row of W_out, result discarded)
+    for (int k0 = 0; k0 < Hp; k0 += 16) {
+      const tl_bf16x8 av = *reinterpret_cast<const tl_bf16x8*>(As + (wr * 32 + li) * ldA + k0 + 8 * lh);
+      const tl_bf16x8 bv = *reinterpret_cast<const tl_bf16x8*>(Bs + nrow * ldA + k0 + 8 * lh);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
+    }
+    const int n = wc * 32 + li;
+    const float bo = n < D ? f.b_out[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (n < D) Y[m * (kWideD + 1) + n] = acc[r] + bo;
+    }
+  }
+  __syncthreads();
+  // one wave per row as l2norm_fwd_kernel, four rows per wave in flight; a lane owns columns lane and lane + 64
+  float v[4][2], den[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float ssq = 0.f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = lane + 64 * u;
+      v[j][u] = col < D ? Y[(wave * 4 + j) * (kWideD + 1) + col] : 0.f;
+    }
+    // per-lane partial in column order (lane, lane + 64), then the butterfly: l2norm_fwd_kernel's order
+    ssq = __builtin_fmaf(v[j][1], v[j][1], mul_rn(v[j][0], v[j][0]));    // l2norm_fwd_kernel's contracted `ss += v * v` over lane, lane + 64
+    den[j] = ssq;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) den[j] += __shfl_xor(den[j], o);
+  }
+  float e[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = m0 + wave * 4 + j;
+    const float d = fmaxf(sqrtf(den[j]), kNormEps);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int col = lane + 64 * u;
+      e[j][u] = 0.f;
+      if (r < B && col < D) {
+        e[j][u] = v[j][u] / d;
+        f.y[(int64_t)r * D + col] = v[j][u];
+        f.emb[(int64_t)r * D + col] = e[j][u];
+      }
+    }
+  }
+  if (f.pk_rows) {
+    const int Dp = f.Dp;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int d = lane + 64 * u;
+      if (d >= Dp) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = m0 + wave * 4 + j;
+        const int64_t cidx = (((int64_t)(row >> 5) * (Dp >> 4) + (d >> 4)) * 2 + ((d >> 3) & 1)) * 32 + (row & 31);
+        f.pk_rows[cidx * 8 + (d & 7)] = (__bf16)(e[j][u] * f.pk_scale);
+      }
+      const int row0 = m0 + wave * 4, rr = row0 & 31, q = rr & 15;
+      const int64_t fi = (((int64_t)(row0 >> 5) * 2 + (rr >> 4)) * 2 + ((q & 7) >> 2)) * Dp + d;
+      using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+      bf16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (__bf16)(e[j][u] * f.pk_scale);
+      *reinterpret_cast<bf16x4*>(f.pk_frag + fi * 8 + (q >> 3) * 4) = o;
+    }
+  }
+}
+
 // (C) backward head: L2-normalise backward -> d_y; d_act = d_y . W_out; the chunk's share of the output-layer weight /
 // bias gradients (d_y^T . act, column sums of d_y) into slabs; per-chunk BN column sums S1 / S2.  One workgroup per
 // row chunk (the chunks of colsum_partial_kernel), 64 rows at a time.  d_act leaves this kernel already multiplied by
@@ -1144,6 +1323,16 @@ inline bool front_fusable(int n, const tt_tower_params* const* P, const tt_tower
   }
   return true;
 }
+// the wide forward tail (tail_fwd_wide_kernel): training, bf16 operands, last hidden width <= 256, output <= 128 -- shapes the
+// narrow fused tail does not take
+inline bool wide_tail_ok(int n, const tt_tower_params* const* P, int train) {
+  if (!train || P[0]->compute_dtype != TT_BF16) return false;
+  for (int t = 0; t < n; ++t) {
+    const tt_tower_params* p = P[t];
+    if (p->n_hidden < 1 || p->hidden[p->n_hidden - 1] > kWideH || p->d_out > kWideD || (p->flags & TT_TOWER_UNFUSED_TAIL)) return false;
+  }
+  return true;
+}
 inline size_t tail_slab_bytes(const tt_tower_params* p) {   // per-chunk output-layer gradient slabs of tail_bwd_kernel
   return sizeof(float) * (size_t)kMaxChunks * ((size_t)p->d_out * p->hidden[p->n_hidden - 1] + (size_t)p->d_out) + 256;
 }
@@ -1365,6 +1554,30 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
         for (int t = 0; t < n; ++t) {
           bs.a[t].partial = const_cast<float*>(A[t]->bn_sync_all); bs.a[t].nchunks = P[t]->sync_ranks; bs.a[t].pstride = A[t]->bn_sync_stride;
         }
+      if (i == nh - 1 && !fused && wide_tail_ok(n, P, train)) {
+        // statistics finish + BN apply + dropout + output Linear + L2 normalise + the score kernels' operand images in one launch
+        static const bool lds_set = [] {
+          return hipFuncSetAttribute(reinterpret_cast<const void*>(tail_fwd_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kWideLds) == hipSuccess;
+        }();
+        if (!lds_set) { tt_set_error("tt_towers_mlp_fwd: cannot reserve %d bytes of LDS for tail_fwd_wide_kernel", kWideLds); return TT_ERR_HIP; }
+        Batch<TailFwdArgs> tf{};
+        for (int t = 0; t < n; ++t) {
+          tf.a[t] = TailFwdArgs{bs.a[t], P[t]->bn_w[i], P[t]->bn_b[i], ba.a[t].salt, A[t]->act[i], P[t]->w_out, P[t]->b_out, P[t]->d_out,
+                                A[t]->y, A[t]->emb, nullptr, nullptr, 0, 1.f};
+          if (A[t]->emb_packed) {
+            const int Dp = P[t]->d_out <= 32 ? 32 : (P[t]->d_out <= 64 ? 64 : 128);
+            __bf16* base = reinterpret_cast<__bf16*>(A[t]->emb_packed);
+            tf.a[t].pk_rows = base;
+            tf.a[t].pk_frag = base + tt_cdiv(B, 64) * 64 * Dp;
+            tf.a[t].Dp = Dp;
+            tf.a[t].pk_scale = A[t]->emb_pack_scale == 0.f ? 1.f : A[t]->emb_pack_scale;
+          }
+        }
+        tail_fwd_wide_kernel<<<dim3((unsigned)tt_cdiv(B, 64), (unsigned)n), kTailThreads, kWideLds, st>>>(tf, drop, dropout_p, seed, seed_dev);
+        TT_LAUNCH_CHECK();
+        return TT_OK;
+      }
       bn_stats_finish_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)n), kThreads, 0, st>>>(bs);
       TT_LAUNCH_CHECK();
     } else {

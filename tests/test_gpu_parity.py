@@ -818,10 +818,12 @@ def test_score_prescaled_operands(tt, B, D, inv_t):
 
 
 @pytest.mark.parametrize("B,H,D,drop", [(65, 33, 17, 0.1), (127, 64, 64, 0.0), (4097, 40, 33, 0.1), (64, 63, 1, 0.0), (2, 8, 8, 0.0),
-                                        (8191, 24, 48, 0.2)])
+                                        (8191, 24, 48, 0.2), (300, 256, 128, 0.1), (129, 200, 100, 0.0), (64, 65, 70, 0.2),
+                                        (8192, 256, 128, 0.1), (1000, 96, 128, 0.0)])
 def test_fused_tower_tail_odd_shapes(tt, manifest, monkeypatch, B, H, D, drop):
     """Fused tail against the separate kernels on shapes off the tile grid: widths that are not multiples of 8 or 32, ragged
-    last row blocks and chunks, a single output column, two rows -- loss bit-identical, gradients to rounding."""
+    last row blocks and chunks, a single output column, two rows -- loss bit-identical, gradients to rounding.  Last hidden
+    widths up to 256 and outputs up to 128 (scripts/train.py's own [512, 256] -> 128 among them) take the wide forward kernel."""
     cfg = dict(manifest["cases"]["wide_b40"])
     cfg.update(hidden=[32, H], D=D)
     outs = {}
@@ -841,13 +843,20 @@ def test_fused_tower_tail_odd_shapes(tt, manifest, monkeypatch, B, H, D, drop):
         res["loss"].backward()
         outs[unfused] = (res["loss"].item(), {n: p.grad.cpu().numpy() for n, p in task.named_parameters()},
                          {k: v.cpu().numpy() for k, v in task.state_dict().items() if "running" in k})
-    assert outs["0"][0] == outs["1"][0] and np.isfinite(outs["0"][0])
+    wide = H > 64 or D > 64      # tail_fwd_wide_kernel (forward only): its output Linear is ONE MFMA chain over H, the separate GEMM
+    #                              splits K when the batch is small -- same operands, another association: loss to rounding
+    assert np.isfinite(outs["0"][0])
+    if wide:
+        np.testing.assert_allclose(outs["0"][0], outs["1"][0], rtol=2e-6)
+    else:
+        assert outs["0"][0] == outs["1"][0]
     for k, v in outs["1"][2].items():
-        assert np.array_equal(outs["0"][2][k], v), k
+        assert np.array_equal(outs["0"][2][k], v), k          # BN running statistics: the same ordered combine on every path
     for k, g in outs["1"][1].items():
         gf = outs["0"][1][k]
         assert np.isfinite(gf).all(), k
-        tol = 2e-5 if B >= 32 else 2e-4            # (BatchNorm over two rows: the backward terms cancel to rounding noise)
+        tol = (1e-3 if wide else 2e-5) if B >= 32 else 2e-4            # (BatchNorm over two rows: the backward terms cancel to rounding noise;
+        #                                                                   wide: a y that differs in the last bit moves bf16 operand roundings downstream)
         assert np.linalg.norm(gf - g) <= tol * np.linalg.norm(g) + 1e-10, (k, np.linalg.norm(gf - g), np.linalg.norm(g))
 
 
