@@ -1214,6 +1214,199 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<Tail
   }
 }
 
+// (C') wide backward tail (last hidden width <= kWideH, output <= kWideD): L2-normalise backward, the data gradient
+// d_act = d_y . W_out on MFMA (dropout scale applied) and the per-chunk BN column sums S1 / S2 taken from the accumulators, in
+// one launch -- l2norm_bwd_kernel + the data-gradient GEMM + colsum_partial_kernel.  The weight gradient d_y^T . act stays the
+// split-K GEMM (per-chunk slabs of [D x H] would be 17 MB per tower here).  At most 128 chunks per tower exist, so a workgroup
+// has its CU to itself: 8 waves with up to 256 registers each.  Wave w owns columns 32 w .. 32 w + 31 of every 64-row block
+// (two 32 x 32 accumulator tiles); its W_out operand fragments are loaded straight from global memory -- a lane's 8 k-values are
+// 8 rows of the row-major [D, H] matrix, each load coalesced over the 32 columns -- converted once and kept in registers for
+// the whole chunk, so W_out is read once per workgroup and never staged.  Only d_y goes through LDS.  grid (nchunks, towers)
+constexpr int kWbLd = kWideD + 8;                                      // bf16 per LDS row of the d_y tile (K = D)
+constexpr int kWideBwdThreads = 512;
+static_assert(kWideH == 32 * (kWideBwdThreads / 64), "one 32-column strip per wave");
+
+__global__ __launch_bounds__(kWideBwdThreads) void tail_bwd_wide_kernel(Batch<TailBwdArgs> batch, bool drop, float p, uint64_t seed0,
+                                                                       const uint64_t* __restrict__ seed_dev) {
+  const TailBwdArgs& f = batch.a[blockIdx.y];
+  const ColArgs& a = f.col;
+  const int H = a.H, D = f.D;
+  if ((int)blockIdx.x >= a.nchunks) return;
+  __shared__ __attribute__((aligned(16))) __bf16 dyA[64 * kWbLd];      // d_y rows of the current block (k = d)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int Dp = (D + 15) & ~15;                                        // K zero-padded to whole MFMA steps
+  const int r0 = blockIdx.x * a.rows_per_chunk, r1 = min(a.B, r0 + a.rows_per_chunk);
+  const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
+  const int li = lane & 31, lh = lane >> 5;
+  const int n = wave * 32 + li;
+  const bool col_ok = n < H, wave_on = wave * 32 < H;
+  const int ncl = min(n, H - 1);
+  tl_bf16x8 bw[kWideD / 16];                                            // B operand: element (k = d, n = h) = W_out[d][h]
+  if (wave_on) {
+    float wq[kWideD / 16][8];
+#pragma unroll
+    for (int ks = 0; ks < kWideD / 16; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int d = 16 * ks + 8 * lh + e;
+        wq[ks][e] = f.w_out[(int64_t)min(d, D - 1) * H + ncl];          // (clamped address, masked below: no branch around a load)
+      }
+#pragma unroll
+    for (int ks = 0; ks < kWideD / 16; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int d = 16 * ks + 8 * lh + e;
+        bw[ks][e] = (__bf16)((d < D && col_ok) ? wq[ks][e] : 0.f);
+      }
+  }
+  const float mean = a.mean[ncl], rstd = a.rstd[ncl];
+  float s0 = 0.f, s1 = 0.f;
+  for (int b0 = r0; b0 < r1; b0 += 64) {
+    // 1. d_y of rows b0 .. b0 + 63 (l2norm_bwd_kernel's arithmetic): wave w rows 8 w + j, lane columns lane, lane + 64
+    float yv[8][2], e[8][2], de[8][2], pr[2][16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = b0 + wave * 8 + j, col = lane + 64 * u;
+        const bool ok = r < r1 && col < D;
+        const int64_t i = (int64_t)min(r, r1 - 1) * D + min(col, D - 1);
+        const float v0 = f.y[i], v1 = f.emb[i], v2 = f.d_emb[i];
+        yv[j][u] = ok ? v0 : 0.f;
+        e[j][u] = ok ? v1 : 0.f;
+        de[j][u] = ok ? v2 : 0.f;
+      }
+    if (wave_on) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                  // pre at this lane's accumulator positions
+          const int row = b0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          pr[rt][r] = a.pre[(int64_t)min(row, r1 - 1) * H + ncl];       // (rows / columns past the end never reach a sum: da = 0)
+        }
+    }
+    float ss[8], dot[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      ss[j] = fmaf(yv[j][1], yv[j][1], mul_rn(yv[j][0], yv[j][0]));
+      dot[j] = fmaf(e[j][1], de[j][1], mul_rn(e[j][0], de[j][0]));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ss[j] += __shfl_xor(ss[j], o);
+        dot[j] += __shfl_xor(dot[j], o);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = wave * 8 + j, r = b0 + row;
+      const float nrm = sqrtf(ss[j]);
+      const float den = fmaxf(nrm, kNormEps);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int col = lane + 64 * u;
+        float out = nrm > kNormEps ? (de[j][u] - e[j][u] * dot[j]) / den : de[j][u] / den;
+        if (r < r1 && col < D) f.d_y[(int64_t)r * D + col] = out;
+        else out = 0.f;
+        if (col < Dp) dyA[row * kWbLd + col] = (__bf16)out;
+      }
+    }
+    __syncthreads();
+    // 2. d_act tiles on MFMA; dropout scale, store, column sums straight from the accumulators (rows in accumulator order)
+    if (wave_on) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        tl_f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < kWideD / 16; ++ks)
+          if (16 * ks < Dp) {
+            const tl_bf16x8 a1 = *reinterpret_cast<const tl_bf16x8*>(dyA + (rt * 32 + li) * kWbLd + 16 * ks + 8 * lh);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bw[ks], acc, 0, 0, 0);
+          }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = b0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const bool ok = col_ok && row < r1;
+          const int64_t i = (int64_t)row * H + n;
+          const float da = ok ? acc[r] * dropout_scale(drop, p, seed, a.salt + (uint64_t)i) : 0.f;
+          if (ok) f.d_act[i] = da;
+          s0 += da;
+          s1 += da * ((fmaxf(pr[rt][r], 0.f) - mean) * rstd);
+        }
+      }
+    }
+    __syncthreads();                                     // dyA is rewritten by the next block
+  }
+  s0 += __shfl_xor(s0, 32);
+  s1 += __shfl_xor(s1, 32);
+  if (lh == 0 && col_ok) {
+    float* q = a.partial + (int64_t)blockIdx.x * 2 * H;
+    q[n] = s0;
+    q[H + n] = s1;
+  }
+}
+
+// (D') wide backward apply: S1 / S2 finish (every workgroup, colsum_finish_kernel's order) + BN backward apply in place on the
+// already dropout-scaled d_act, 64 rows per workgroup: thread (c, rq) = column c < 256, rows rq + 4 j.  grid (cdiv(B, 64), towers)
+__global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_wide_kernel(Batch<TailApplyArgs> batch) {
+  const TailApplyArgs& ta = batch.a[blockIdx.y];
+  const ColArgs& a = ta.col;
+  const BnBwdArgs& b = ta.bn;
+  const int H = a.H, B = a.B;
+  const int t = threadIdx.x, c = t & 255, rq = t >> 8;
+  const int m0 = blockIdx.x * 64;
+  if (m0 >= B) return;
+  __shared__ float sh[2][4][kWideH];
+  float pr[16], da[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int64_t i = (int64_t)min(m0 + rq + 4 * j, B - 1) * H + min(c, H - 1);      // (clamped: stores are guarded below)
+    pr[j] = b.pre[i];
+    da[j] = b.d[i];
+  }
+  float s0 = 0.f, s1 = 0.f;
+  {
+    const int64_t ps = a.pstride ? a.pstride : 2 * H;
+    const int cc = min(c, H - 1);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {              // chunks rq, rq + 4, ... in order, 32 loads in flight at a time
+      float v0[kMaxChunks / 8], v1[kMaxChunks / 8];
+#pragma unroll
+      for (int i = 0; i < kMaxChunks / 8; ++i) {
+        const int k = rq + 4 * (i + half * (kMaxChunks / 8));
+        const float* q = a.partial + (int64_t)min(k, a.nchunks - 1) * ps;
+        const float x0 = q[cc], x1 = q[H + cc];
+        v0[i] = k < a.nchunks ? x0 : 0.f;
+        v1[i] = k < a.nchunks ? x1 : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < kMaxChunks / 8; ++i) { s0 += v0[i]; s1 += v1[i]; }
+    }
+  }
+  sh[0][rq][c] = s0;
+  sh[1][rq][c] = s1;
+  __syncthreads();
+  if (c < H) {
+    const float S1 = (sh[0][0][c] + sh[0][1][c]) + (sh[0][2][c] + sh[0][3][c]);
+    const float S2 = (sh[1][0][c] + sh[1][1][c]) + (sh[1][2][c] + sh[1][3][c]);
+    if (blockIdx.x == 0 && rq == 0) { a.out0[c] = S1 * ta.out_scale; a.out1[c] = S2 * ta.out_scale; }
+    const float mean = b.mean[c], rstd = b.rstd[c], g = b.g[c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int r = m0 + rq + 4 * j;
+      if (r < B) {
+        const float xh = (fmaxf(pr[j], 0.f) - mean) * rstd;
+        const float dv = g * rstd * (da[j] - S1 * b.invB - xh * (S2 * b.invB));
+        b.d[(int64_t)r * H + c] = pr[j] > 0.f ? dv : 0.f;
+      }
+    }
+  }
+}
+
 // SyncBN phase 1: this rank's chunk statistics merged (bn_stats_finish_kernel's order) into ONE (n, mean, M2) triple per
 // column, and its column sums S1 / S2 into one pair -- what the caller exchanges between the ranks.  grid (1, towers)
 struct LocalArgs { const float* partial; int nchunks, H; float* out; };
@@ -1633,6 +1826,7 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     na.a[t] = NormArgs{A[t]->y, A[t]->emb, d_emb[t], (int)B, P[t]->d_out, g->d_y};
   }
   const bool fused = tail_fusable(n, P, train);
+  const bool wide = !fused && wide_tail_ok(n, P, train);  // tail_bwd_wide_kernel + tail_bwd_apply_wide_kernel
   const int phase = P[0]->sync_phase;
   if (phase != 0) {
     if (nh != 1 || !train) {
@@ -1642,7 +1836,7 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     for (int t = 0; t < n; ++t)
       TT_CHECK_ARG(G[t] && (phase == 1 ? G[t]->s_sync_local != nullptr : G[t]->s_sync_all != nullptr), "tt_towers_mlp_bwd: NULL SyncBN buffer");
   }
-  if (!fused && phase != 2) {
+  if (!fused && !wide && phase != 2) {
     l2norm_bwd_kernel<<<dim3((unsigned)tt_cdiv(B, 4), (unsigned)n), kThreads, 0, st>>>(na);
     TT_LAUNCH_CHECK();
   }
@@ -1702,6 +1896,26 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
     }
     tail_bwd_apply_kernel<<<dim3((unsigned)tt_cdiv(B, 64), (unsigned)n), kTailThreads, 0, st>>>(tp);
     TT_LAUNCH_CHECK();
+  } else if (wide) {
+    // L2-normalise backward, the output layer's data-gradient GEMM and the BN column sums of the last block in one kernel (the
+    // weight-gradient GEMM stays the split-K one); column-sum finish + BN backward apply in a second, below
+    const int i = nh - 1;
+    if (phase != 2) {
+      Batch<TailBwdArgs> tb{};
+      int cmax = 1;
+      for (int t = 0; t < n; ++t) {
+        const int H = P[t]->hidden[i];
+        const int nchunks = chunks_for(B, H);
+        const uint64_t salt = (((uint64_t)(i + 1) << 40) ^ ((uint64_t)t << 52)) + (uint64_t)P[t]->rng_row_offset * (uint64_t)H;
+        const ColArgs col{nullptr, 0, A[t]->pre[i], A[t]->mean[i], A[t]->rstd[i], salt, (int)B, H, (int)tt_cdiv(B, nchunks), nchunks,
+                          ws[t].col, G[t]->bn_b[i], G[t]->bn_w[i]};
+        tb.a[t] = TailBwdArgs{A[t]->y, A[t]->emb, d_emb[t], G[t]->d_y, P[t]->d_out, P[t]->w_out, nullptr, dcur[t], col, nullptr, nullptr};
+        cmax = nchunks > cmax ? nchunks : cmax;
+      }
+      tail_bwd_wide_kernel<<<dim3((unsigned)cmax, (unsigned)n), kWideBwdThreads, 0, st>>>(tb, drop, dropout_p, seed, seed_dev);
+      TT_LAUNCH_CHECK();
+      if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;
+    }
   } else if (phase != 2) {
     if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;
     if (int rc = tt_gemm_nn_batched(st, nn, n)) return rc;
@@ -1726,8 +1940,21 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       cmax = nchunks > cmax ? nchunks : cmax;
       tmax = B * H > tmax ? B * H : tmax;
     }
-    if (!(fused && i == nh - 1)) {
-      if (phase != 2) {
+    if (wide && i == nh - 1 && phase != 1) {
+      // the column sums of tail_bwd_wide_kernel (phase 2: of every rank, one "chunk" each) finished and applied in one launch
+      Batch<TailApplyArgs> tp{};
+      for (int t = 0; t < n; ++t) {
+        ColArgs colD = cb.a[t];
+        const int ranks = phase == 2 ? P[t]->sync_ranks : 1;
+        if (phase == 2) { colD.partial = const_cast<float*>(G[t]->s_sync_all); colD.nchunks = ranks; colD.pstride = G[t]->s_sync_stride; }
+        BnBwdArgs bn = bb.a[t];
+        bn.invB = 1.f / ((float)B * (float)ranks);
+        tp.a[t] = TailApplyArgs{colD, bn, nullptr, nullptr, P[t]->d_out, nullptr, nullptr, 0, 1.f / (float)ranks};
+      }
+      tail_bwd_apply_wide_kernel<<<dim3((unsigned)tt_cdiv(B, 64), (unsigned)n), kTailThreads, 0, st>>>(tp);
+      TT_LAUNCH_CHECK();
+    } else if (!(fused && i == nh - 1)) {
+      if (phase != 2 && !(wide && i == nh - 1)) {
         colsum_partial_kernel<<<dim3((unsigned)tt_cdiv(hmax, 64), (unsigned)cmax, (unsigned)n), kThreads, 0, st>>>(cb, drop, dropout_p, seed, seed_dev);
         TT_LAUNCH_CHECK();
       }

@@ -819,11 +819,13 @@ def test_score_prescaled_operands(tt, B, D, inv_t):
 
 @pytest.mark.parametrize("B,H,D,drop", [(65, 33, 17, 0.1), (127, 64, 64, 0.0), (4097, 40, 33, 0.1), (64, 63, 1, 0.0), (2, 8, 8, 0.0),
                                         (8191, 24, 48, 0.2), (300, 256, 128, 0.1), (129, 200, 100, 0.0), (64, 65, 70, 0.2),
-                                        (8192, 256, 128, 0.1), (1000, 96, 128, 0.0)])
+                                        (8192, 256, 128, 0.1), (1000, 96, 128, 0.0), (8300, 250, 120, 0.1)])
 def test_fused_tower_tail_odd_shapes(tt, manifest, monkeypatch, B, H, D, drop):
     """Fused tail against the separate kernels on shapes off the tile grid: widths that are not multiples of 8 or 32, ragged
     last row blocks and chunks, a single output column, two rows -- loss bit-identical, gradients to rounding.  Last hidden
-    widths up to 256 and outputs up to 128 (scripts/train.py's own [512, 256] -> 128 among them) take the wide forward kernel."""
+    widths up to 256 and outputs up to 128 (scripts/train.py's own [512, 256] -> 128 among them) take the wide kernels (forward:
+    tail_fwd_wide_kernel; backward: tail_bwd_wide_kernel + tail_bwd_apply_wide_kernel -- B = 8300 gives chunks of 65 rows: a
+    second, one-row block per workgroup)."""
     cfg = dict(manifest["cases"]["wide_b40"])
     cfg.update(hidden=[32, H], D=D)
     outs = {}
@@ -843,7 +845,7 @@ def test_fused_tower_tail_odd_shapes(tt, manifest, monkeypatch, B, H, D, drop):
         res["loss"].backward()
         outs[unfused] = (res["loss"].item(), {n: p.grad.cpu().numpy() for n, p in task.named_parameters()},
                          {k: v.cpu().numpy() for k, v in task.state_dict().items() if "running" in k})
-    wide = H > 64 or D > 64      # tail_fwd_wide_kernel (forward only): its output Linear is ONE MFMA chain over H, the separate GEMM
+    wide = H > 64 or D > 64      # the wide kernels: the output Linear is ONE MFMA chain over H, the separate GEMM
     #                              splits K when the batch is small -- same operands, another association: loss to rounding
     assert np.isfinite(outs["0"][0])
     if wide:
