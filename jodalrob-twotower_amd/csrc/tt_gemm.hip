@@ -322,6 +322,16 @@ __global__ __launch_bounds__(THREADS) void gemm_bf16_kernel(GemmBatch batch, int
 // a fixed order (hipcc then waits with vmcnt(N), not vmcnt(0)): it takes the shapes that need no predicates -- M, N
 // multiples of 64, every k-range a multiple of 32, 16-byte-aligned rows -- and element types as template parameters; the
 // general kernel above takes the rest.  Same k order inside a workgroup, same split-K layout: results are bit-identical.
+// LDS tiles: a K-contiguous operand (MODE 0) is staged [x][k] (LDS16-element rows), read as one 16-byte fragment per lane.  An
+// X-contiguous operand (MODE 1: the batch-major matrices of the weight-gradient products, W in the data-gradient product) is
+// staged AS LOADED, [k][x] with LDT1-element rows -- one 16-byte store per thread -- and the MFMA fragments come out of
+// ds_read_b64_tr_b16 (a 16-lane group reads a 4 k x 16 x block, lane i receives column i): the first version transposed on the
+// way in with eight 2-byte stores per thread, 8- to 16-way bank conflicts each, and loaded f32 operands one dword at a time.
+constexpr int LDT1 = 72;
+static_assert(BK16 * LDT1 <= BM * LDS16, "a [k][x] tile fits the stage buffer of an [x][k] one");
+using s16x4g = __attribute__((ext_vector_type(4))) short;
+using s16x8g = __attribute__((ext_vector_type(8))) short;
+
 template <int MODE, bool BF16>
 struct FastLoader16 {
   // raw pieces exactly as loaded (bf16: one 16-byte piece in q; f32: 8 values in r): every ALU op on them sits in store(),
@@ -329,55 +339,50 @@ struct FastLoader16 {
   float r[BF16 ? 1 : KR];
   uint4 q;
   __device__ __forceinline__ void load(const float* __restrict__ Pf, int64_t ld, int x0, int k0, int t) {
-    if (MODE == 0) {
-      const int x = x0 + (t >> 2), k = k0 + (t & 3) * KR;
-      if (BF16) {
-        q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Pf) + (int64_t)x * ld + k);
-      } else {
-        const float4 a = *reinterpret_cast<const float4*>(Pf + (int64_t)x * ld + k);
-        const float4 b = *reinterpret_cast<const float4*>(Pf + (int64_t)x * ld + k + 4);
-        r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
-      }
-    } else if (BF16) {                     // 8 adjacent x at one k, transposed on the way into LDS
-      const int x = x0 + 8 * (t & 7), k = k0 + (t >> 3);
-      q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Pf) + (int64_t)k * ld + x);
-    } else {                               // one x, KR consecutive k (coalesced dword loads across x)
-      const int x = x0 + (t & 63), k = k0 + (t >> 6) * KR;
-#pragma unroll
-      for (int j = 0; j < KR; ++j) r[j] = Pf[(int64_t)(k + j) * ld + x];
+    // MODE 0: row x0 + t / 4, 8 consecutive k ; MODE 1: row k0 + t / 8, 8 consecutive x -- 16 (bf16) or 32 (f32) contiguous bytes
+    const int64_t at = MODE == 0 ? (int64_t)(x0 + (t >> 2)) * ld + k0 + (t & 3) * KR : (int64_t)(k0 + (t >> 3)) * ld + x0 + 8 * (t & 7);
+    if (BF16) {
+      q = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(Pf) + at);
+    } else {
+      const float4 a = *reinterpret_cast<const float4*>(Pf + at);
+      const float4 b = *reinterpret_cast<const float4*>(Pf + at + 4);
+      r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
     }
   }
-  __device__ __forceinline__ float colsum() const {       // f32 X-contiguous pieces only
-    float s = 0.f;
+  // MODE 1, f32: this thread's 8 values are columns x0 + 8 (t & 7) + j of batch row k0 + t / 8
+  __device__ __forceinline__ void colsum(float (&cs)[KR]) const {
 #pragma unroll
-    for (int j = 0; j < (BF16 ? 1 : KR); ++j) s += r[j];
-    return s;
+    for (int j = 0; j < (BF16 ? 1 : KR); ++j) cs[j] += r[j];
   }
   __device__ __forceinline__ void store(__bf16* __restrict__ S, int t) {
+    __bf16* at = MODE == 0 ? S + (t >> 2) * LDS16 + (t & 3) * KR : S + (t >> 3) * LDT1 + 8 * (t & 7);
     if (BF16) {
       asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w));
-      if (MODE == 1) {
-        const int row = 8 * (t & 7), k = t >> 3;
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          reinterpret_cast<uint16_t*>(S)[(row + 2 * j) * LDS16 + k] = (uint16_t)(w[j] & 0xFFFFu);
-          reinterpret_cast<uint16_t*>(S)[(row + 2 * j + 1) * LDS16 + k] = (uint16_t)(w[j] >> 16);
-        }
-      } else {
-        *reinterpret_cast<uint4*>(S + (t >> 2) * LDS16 + (t & 3) * KR) = q;
-      }
+      *reinterpret_cast<uint4*>(at) = q;
       return;
     }
 #pragma unroll
     for (int j = 0; j < (BF16 ? 1 : KR); ++j) asm volatile("" : "+v"(r[j]));
-    const int row = MODE == 0 ? (t >> 2) : (t & 63), kq = MODE == 0 ? (t & 3) * KR : (t >> 6) * KR;
     bf16x8g v;
 #pragma unroll
     for (int j = 0; j < (BF16 ? 1 : KR); ++j) v[j] = (__bf16)r[j];
-    *reinterpret_cast<bf16x8g*>(S + row * LDS16 + kq) = v;
+    *reinterpret_cast<bf16x8g*>(at) = v;
   }
 };
+
+// one MFMA operand fragment of k-step s2 (k = 16 s2 + 8 lh + 0..7) for the 32 rows / columns w32 of a staged tile
+template <int MODE>
+__device__ __forceinline__ bf16x8g fast_frag(const __bf16* __restrict__ S, int w32, int s2, int lane) {
+  const int li = lane & 31, lh = lane >> 5;
+  if (MODE == 0) return *reinterpret_cast<const bf16x8g*>(S + (w32 * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
+  // lane 4 q + p of a 16-lane group supplies the address of block row q, columns 4 p .. 4 p + 3; lane i receives column i
+  const int g16 = lane & 15, cg = (lane >> 4) & 1;
+  const __bf16* at = S + (16 * s2 + 8 * lh + (g16 >> 2)) * LDT1 + w32 * 32 + 16 * cg + 4 * (g16 & 3);
+  const s16x4g lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4g*)(at));
+  const s16x4g hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4g*)(at + 4 * LDT1));
+  const s16x8g v{lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  return __builtin_bit_cast(bf16x8g, v);
+}
 
 struct FastSmem {
   __bf16 As[2][BM * LDS16];
@@ -404,7 +409,9 @@ __device__ __forceinline__ void gemm_fast_tile(const GemmArgs& g, int split, int
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  float cs = 0.f;
+  float cs[KR];
+#pragma unroll
+  for (int j = 0; j < KR; ++j) cs[j] = 0.f;
   if (nsteps > 0) {
     FastLoader16<MODE_A, A_BF16> la[3];
     FastLoader16<MODE_B, B_BF16> lb[3];
@@ -420,15 +427,15 @@ __device__ __forceinline__ void gemm_fast_tile(const GemmArgs& g, int split, int
       __bf16* Bm = Bs[i & 1];
       a.store(A, t);
       b.store(Bm, t);
-      if (COLSUM) cs += a.colsum();        // MODE_A == 1 there: this thread holds column (t & 63), 8 batch rows
+      if (COLSUM) a.colsum(cs);            // MODE_A == 1 there: columns 8 (t & 7) + j of one batch row per step
       __syncthreads();
       const int k = kbeg + min(i + 3, nsteps - 1) * BK16;
       a.load(g.A, g.lda, m0, k, t);
       b.load(g.B, g.ldb, n0, k, t);
 #pragma unroll
       for (int s2 = 0; s2 < BK16 / 16; ++s2) {
-        const bf16x8g av = *reinterpret_cast<const bf16x8g*>(A + (wr * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
-        const bf16x8g bv = *reinterpret_cast<const bf16x8g*>(Bm + (wc * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
+        const bf16x8g av = fast_frag<MODE_A>(A, wr, s2, lane);
+        const bf16x8g bv = fast_frag<MODE_B>(Bm, wc, s2, lane);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
       }
     };
@@ -442,10 +449,21 @@ __device__ __forceinline__ void gemm_fast_tile(const GemmArgs& g, int split, int
     if (nsteps - full >= 2) step(full + 1, la[1], lb[1]);
   }
   if (COLSUM && g.colsum_slab && by == 0) {
-    red[t >> 6][t & 63] = cs;
+    // thread (k lane t / 8, column group t & 7) holds 8 column sums over its batch rows: the 32 k lanes are added in order
+    float* red32 = reinterpret_cast<float*>(&As[0][0]);    // [32][64] f32 = 8 KB over the two A stage buffers
+    static_assert(sizeof(float) * 32 * 64 <= sizeof(__bf16) * 2 * BM * LDS16, "column-sum staging fits the A stage buffers");
+    __syncthreads();                        // every wave is done with the stage buffers
+#pragma unroll
+    for (int j = 0; j < KR; ++j) red32[(t >> 3) * 64 + 8 * (t & 7) + j] = cs[j];
     __syncthreads();
-    if (t < BM) g.colsum_slab[(int64_t)split * M + m0 + t] = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    if (t < BM) {
+      float sum = 0.f;
+#pragma unroll 8
+      for (int kl = 0; kl < 32; ++kl) sum += red32[kl * 64 + t];
+      g.colsum_slab[(int64_t)split * M + m0 + t] = sum;
+    }
   }
+  (void)red;
   float* Cz = g.C + (int64_t)split * g.slab_stride;
   const int n = n0 + wc * 32 + li;
   if (PROJ) {
@@ -560,8 +578,8 @@ __device__ __forceinline__ void gemm_nn_k64_tiles(const GemmArgs& g, int bx, int
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int s2 = 0; s2 < BK16 / 16; ++s2) {
-        const bf16x8g av = *reinterpret_cast<const bf16x8g*>(sm.As[st] + (wr * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
-        const bf16x8g bv = *reinterpret_cast<const bf16x8g*>(sm.Bs[st] + (wc * 32 + li) * LDS16 + 16 * s2 + 8 * lh);
+        const bf16x8g av = fast_frag<0>(sm.As[st], wr, s2, lane);
+        const bf16x8g bv = fast_frag<1>(sm.Bs[st], wc, s2, lane);
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc, 0, 0, 0);
       }
     const int n = n0 + wc * 32 + li;
