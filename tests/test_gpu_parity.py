@@ -1433,7 +1433,7 @@ BF16_STEP_BOUNDS = {
 
 
 @pytest.mark.parametrize("rows_per_tower,B,T,hidden,D", [(1_000_000, 8192, 1.0, [128, 64], 64), (None, 1000, 0.5, [128, 64], 64),
-                                                         (None, 2240, 1.0, [512, 256], 128)])
+                                                         (None, 2240, 1.0, [512, 256], 128), (None, 4096, 0.7, [256, 128], 96)])
 def test_bf16_step_vs_rounded_oracle(tt, schema_real, tmp_path, rows_per_tower, B, T, hidden, D):
     """ONE step of exactly bench.py's task (real 32 + 6 key schema, vocabularies scaled to 1 M + 1 M rows, B = 8192, E = 32,
     towers [128, 64] -> 64, mlp_dtype = score_dtype = "bf16", embedding_grad = "sparse"; dropout 0 so that the oracle needs
