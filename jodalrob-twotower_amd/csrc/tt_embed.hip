@@ -464,18 +464,25 @@ struct KeyedArgs {
   int32_t K[TT_MAX_SIDES];
   int32_t n_sides;
   int32_t B;
+  int32_t parts;                         // workgroups per key (range partition of the key's rows)
 };
+constexpr int kKeyedMaxParts = 8;
 
 __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, const int32_t* __restrict__ rows,
                                                                   int32_t* __restrict__ sorted_src, int32_t* __restrict__ uniq_stage,
-                                                                  int32_t* __restrict__ seg_stage, int32_t* __restrict__ ucount) {
+                                                                  int32_t* __restrict__ seg_stage, int32_t* __restrict__ ucount,
+                                                                  int32_t* __restrict__ ubase) {
   __shared__ uint32_t keys[2][kKeyedB];
   __shared__ uint16_t vals[2][kKeyedB];
   __shared__ uint32_t whist[16][256];
   __shared__ unsigned long long peers_mask[16][256];   // lane sets per (wave, digit); all zero between batches
   __shared__ uint32_t red[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ki = blockIdx.x, B = a.B;
+  // `parts` workgroups per key: every one loads the key's B rows and builds the same bucket histogram, then scatters, ranks and
+  // writes only the buckets of ITS share of the key's row range (whole rows: a row never straddles two shares) -- the sorted
+  // positions follow from the common prefix, so there is nothing to merge.  Every workgroup of a key reaches the same decision
+  // about the LSD fallback (same histogram); share 0 then sorts the whole key alone.
+  const int P = a.parts, ki = (int)blockIdx.x / P, part = (int)blockIdx.x % P, B = a.B;
   for (int d = tid; d < 16 * 256; d += kKeyedThreads) (&peers_mask[0][0])[d] = 0ull;
   int side = 0;
 #pragma unroll
@@ -544,6 +551,7 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
   // produce the same unique order.
   bool sorted_by_buckets = false;
   const uint32_t range = hi - lo + 1u;
+  int e_lo = 0, e_hi = B;                              // this workgroup's share of the sorted positions
   if (B > 64) {
     constexpr uint32_t kBucketCap = 32;
     // bucket = leading part of the pair (row - lo, slot), <= 4096 buckets, monotone in (row, slot):
@@ -598,13 +606,27 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
 #pragma unroll
       for (int q = 0; q < 4; ++q) { start[tid * 4 + q] = run; run += c4[q]; }
       __syncthreads();
+      // this share's buckets: rows [r_lo, r_hi) of the key's range (fine: a row owns 2^sub_log buckets; wider: a row owns one)
+      uint32_t bk_lo, bk_hi;
+      if (fine) {
+        const uint32_t per = (range + (uint32_t)P - 1u) / (uint32_t)P;
+        const uint32_t r_lo = min((uint32_t)part * per, range), r_hi = min(r_lo + per, range);
+        bk_lo = r_lo << sub_log; bk_hi = r_hi << sub_log;
+      } else {
+        bk_lo = (uint32_t)part * 4096u / (uint32_t)P; bk_hi = (uint32_t)(part + 1) * 4096u / (uint32_t)P;
+      }
+      e_lo = bk_lo < (uint32_t)nbk ? (int)start[bk_lo] : B;
+      e_hi = bk_hi < (uint32_t)nbk ? (int)start[bk_hi] : B;
 #pragma unroll
       for (int j = 0; j < PERL; ++j) {
         const int b = tid + j * kKeyedThreads;
         if (b < B) {
-          const uint32_t pos = start[bucket_of(kk[j], (uint32_t)b)] + pp[j];
-          w1[pos] = one_word ? (kk[j] << 13) | (uint32_t)b : kk[j];
-          if (!one_word) s1[pos] = (uint16_t)b;
+          const uint32_t bk = bucket_of(kk[j], (uint32_t)b);
+          if (bk >= bk_lo && bk < bk_hi) {
+            const uint32_t pos = start[bk] + pp[j];
+            w1[pos] = one_word ? (kk[j] << 13) | (uint32_t)b : kk[j];
+            if (!one_word) s1[pos] = (uint16_t)b;
+          }
         }
       }
       __syncthreads();
@@ -613,8 +635,8 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
       uint32_t ek[PERL], ev[PERL], es[PERL], el[PERL], rk[PERL], maxlen = 0;
 #pragma unroll
       for (int j = 0; j < PERL; ++j) {
-        const int q = tid + j * kKeyedThreads;
-        const bool on = q < B;
+        const int q = e_lo + tid + j * kKeyedThreads;
+        const bool on = q < e_hi;
         const uint32_t w = on ? w1[q] : 0u;
         ek[j] = one_word ? w >> 13 : w;                 // row - lo
         ev[j] = one_word ? (w & 8191u) : (on ? (uint32_t)s1[q] : 0u);
@@ -642,7 +664,7 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
       }
 #pragma unroll
       for (int j = 0; j < PERL; ++j)
-        if (tid + j * kKeyedThreads < B) {
+        if (e_lo + tid + j * kKeyedThreads < e_hi) {
           keys[0][es[j] + rk[j]] = ek[j] + lo;
           vals[0][es[j] + rk[j]] = (uint16_t)ev[j];
         }
@@ -651,6 +673,14 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
     __syncthreads();
     for (int d = tid; d < 16 * 256; d += kKeyedThreads) (&peers_mask[0][0])[d] = 0ull;     // `start` lived there
     __syncthreads();
+  }
+  if (!sorted_by_buckets) {                            // LSD passes: share 0 sorts the whole key, the others have nothing
+    e_lo = 0;
+    e_hi = part == 0 ? B : 0;
+    if (part != 0) {
+      if (tid == 0) { ucount[blockIdx.x] = 0; ubase[blockIdx.x] = ki * B; }
+      return;
+    }
   }
   for (int p = 0; p < (sorted_by_buckets ? 0 : passes); ++p) {
     const int shift = dbits * p;
@@ -736,14 +766,14 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
   // outputs: sorted slots, then the heads of this key (staged; compacted across keys by the second kernel)
   const int64_t gbase = (int64_t)ki * B;
   constexpr int PER = kKeyedB / kKeyedThreads;        // 8 contiguous elements per thread
-  const int i_lo = tid * PER;
+  const int i_lo = e_lo + tid * PER;
   uint32_t flags = 0, c = 0;
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int i = i_lo + j;
-    if (i < B) {
+    if (i < e_hi) {
       sorted_src[gbase + i] = sbase + (int)vals[cur][i] * K + k;
-      if (i == 0 || keys[cur][i] != keys[cur][i - 1]) { flags |= 1u << j; ++c; }
+      if (i == e_lo || keys[cur][i] != keys[cur][i - 1]) { flags |= 1u << j; ++c; }   // (a share starts at a row boundary)
     }
   }
   uint32_t x = c;
@@ -759,28 +789,41 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
   for (int w = 0; w < wave; ++w) u += red[w];
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
-    if (flags & (1u << j)) {
-      uniq_stage[gbase + u] = (int32_t)keys[cur][i_lo + j];
-      seg_stage[gbase + u] = (int32_t)(gbase + i_lo + j);
+    if (flags & (1u << j)) {                            // staged at the share's own positions: it has at most e_hi - e_lo heads
+      uniq_stage[gbase + e_lo + u] = (int32_t)keys[cur][i_lo + j];
+      seg_stage[gbase + e_lo + u] = (int32_t)(gbase + i_lo + j);
       ++u;
     }
   }
-  if (tid == kKeyedThreads - 1) ucount[ki] = (int32_t)u;
+  if (tid == kKeyedThreads - 1) { ucount[blockIdx.x] = (int32_t)u; ubase[blockIdx.x] = (int32_t)(gbase + e_lo); }
 }
 
 __global__ __launch_bounds__(kKeyedThreads) void keyed_compact_kernel(const int32_t* __restrict__ uniq_stage, const int32_t* __restrict__ seg_stage,
-                                                                const int32_t* __restrict__ ucount, int n_keys, int B, int64_t M,
+                                                                const int32_t* __restrict__ ucount, const int32_t* __restrict__ ubase,
+                                                                int n_keys, int64_t M,
                                                                 int32_t* __restrict__ unique_rows, int32_t* __restrict__ seg_offsets,
                                                                 int32_t* __restrict__ n_unique) {
-  const int ki = blockIdx.x;
+  const int ki = blockIdx.x;                           // (key, share) in ascending row order
+  // head counts of all (key, share) pairs -- a few dozen to a few hundred -- added up in parallel (integer sums: any order)
+  __shared__ int sred[2][kKeyedThreads / 64];
   int before = 0, all = 0;
-  for (int q = 0; q < n_keys; ++q) {                   // n_keys is a few dozen
+  for (int q = threadIdx.x; q < n_keys; q += kKeyedThreads) {
     const int v = ucount[q];
     all += v;
     if (q < ki) before += v;
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    before += __shfl_xor(before, o);
+    all += __shfl_xor(all, o);
+  }
+  if ((threadIdx.x & 63) == 0) { sred[0][threadIdx.x >> 6] = before; sred[1][threadIdx.x >> 6] = all; }
+  __syncthreads();
+  before = 0; all = 0;
+#pragma unroll
+  for (int w = 0; w < kKeyedThreads / 64; ++w) { before += sred[0][w]; all += sred[1][w]; }
   const int U = ucount[ki];
-  const int64_t gbase = (int64_t)ki * B;
+  const int64_t gbase = ubase[ki];
   for (int u = threadIdx.x; u < U; u += kKeyedThreads) {
     unique_rows[before + u] = uniq_stage[gbase + u];
     seg_offsets[before + u] = seg_stage[gbase + u];
@@ -1670,7 +1713,8 @@ int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, i
 }
 
 size_t tt_dedup_keyed_workspace_bytes(int64_t M, int32_t n_keys) {
-  return align256(sizeof(int32_t) * (size_t)(M > 0 ? M : 1)) * 2 + align256(sizeof(int32_t) * (size_t)(n_keys > 0 ? n_keys : 1));
+  return align256(sizeof(int32_t) * (size_t)(M > 0 ? M : 1)) * 2 +
+         2 * align256(sizeof(int32_t) * (size_t)(n_keys > 0 ? n_keys : 1) * kKeyedMaxParts);      // + head counts and stage bases per (key, share)
 }
 
 int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K, int32_t n_sides, int64_t B, int32_t* sorted_src,
@@ -1712,9 +1756,18 @@ int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K,
   int32_t* uniq_stage = reinterpret_cast<int32_t*>(w);
   int32_t* seg_stage = reinterpret_cast<int32_t*>(w + align256(sizeof(int32_t) * (size_t)slots));
   int32_t* ucount = reinterpret_cast<int32_t*>(w + 2 * align256(sizeof(int32_t) * (size_t)slots));
-  keyed_sort_kernel<<<n_keys, kKeyedThreads, 0, st>>>(a, rows, sorted_src, uniq_stage, seg_stage, ucount);
+  int32_t* ubase = reinterpret_cast<int32_t*>(w + 2 * align256(sizeof(int32_t) * (size_t)slots) +
+                                              align256(sizeof(int32_t) * (size_t)n_keys * kKeyedMaxParts));
+  // workgroups per key (TT_KEYED_PARTS: A/B runs): the sort's scatter, ranking and output phases split P ways, the load and
+  // histogram phases are repeated by every share; small batches are launch-bound anyway
+  const int parts_env = getenv("TT_KEYED_PARTS") ? atoi(getenv("TT_KEYED_PARTS")) : 0;      // (read per call: tests vary it)
+  int parts = parts_env > 0 ? parts_env : (B >= 2048 ? 4 : 1);
+  if (parts > kKeyedMaxParts) parts = kKeyedMaxParts;
+  while (parts > 1 && (int64_t)n_keys * parts > (int64_t)ctx->num_cus) parts /= 2;     // a workgroup needs a CU of its own (144 KB of LDS)
+  a.parts = parts;
+  keyed_sort_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(a, rows, sorted_src, uniq_stage, seg_stage, ucount, ubase);
   TT_LAUNCH_CHECK();
-  keyed_compact_kernel<<<n_keys, kKeyedThreads, 0, st>>>(uniq_stage, seg_stage, ucount, n_keys, (int)B, slots, unique_rows, seg_offsets, n_unique);
+  keyed_compact_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(uniq_stage, seg_stage, ucount, ubase, n_keys * parts, slots, unique_rows, seg_offsets, n_unique);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

@@ -607,13 +607,21 @@ def test_bf16_mlp_close_to_fp32(tt, manifest, schema_real):
     assert all(int(v) == 1 for k, v in outs["bf16"][2].items() if "num_batches" in k)       # counter bumped in-kernel
 
 
-@pytest.mark.parametrize("B,Ks,vocabs", [(8192, [32, 6], None), (1000, [5, 2], None), (1, [3], None), (4097, [4, 3, 2], None),
-                                         (8192, [6, 3], "hot"), (8192, [8], "mid"), (515, [7, 2], "mid")])
-def test_dedup_plan_keyed_equals_general(tt, B, Ks, vocabs):
+@pytest.mark.parametrize("B,Ks,vocabs,parts", [(8192, [32, 6], None, 0), (1000, [5, 2], None, 0), (1, [3], None, 0), (4097, [4, 3, 2], None, 0),
+                                               (8192, [6, 3], "hot", 0), (8192, [8], "mid", 0), (515, [7, 2], "mid", 0),
+                                               (8192, [32, 6], None, 1), (8192, [32, 6], None, 2), (1000, [5, 2], None, 8), (515, [7, 2], "mid", 3),
+                                               (8192, [6, 3], "hot", 8), (8192, [8], "mid", 5), (70, [4], None, 4), (33, [2, 2], "mid", 2)])
+def test_dedup_plan_keyed_equals_general(tt, monkeypatch, B, Ks, vocabs, parts):
     """Per-key LDS plan == the general radix-sort plan (and numpy's stable argsort), bit for bit.  Wide row ranges take the
     bucket + rank path, narrow ones and keys with hot rows ("hot": Zipf-like ids, a few rows holding most slots -- a bucket
-    overflows) the stable LSD passes; "mid": vocabularies around the 9-bit switch and the per-bucket cap."""
+    overflows) the stable LSD passes; "mid": vocabularies around the 9-bit switch and the per-bucket cap.  parts: workgroups
+    per key (0 = the library's choice: 4 from B = 2048 up) -- shares of the key's row range, also odd counts, more shares than
+    rows (a two-row key), the LSD fallback (share 0 sorts alone) and batches below the bucket path."""
     from jodalrob_twotower_amd import ops
+    if parts:
+        monkeypatch.setenv("TT_KEYED_PARTS", str(parts))
+    else:
+        monkeypatch.delenv("TT_KEYED_PARTS", raising=False)
     rng = np.random.default_rng(B + len(Ks))
     rows_sides, off = [], 0
     for K in Ks:
