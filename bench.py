@@ -394,7 +394,9 @@ def config_of(args, leg, world, ctx, B_global, workload):
     cfg = {"workload": workload, "batch_per_gpu": leg.B, "global_batch": B_global, "rows_notice": sum(leg.vocab_n),
            "rows_company": sum(leg.vocab_c), "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})",
            "optimizer": args.optimizer, "score_dtype": args.score_dtype, "mlp_dtype": args.mlp_dtype,
-           "launch": "hip graph replay" if leg.gstep is not None else "eager"}
+           "launch": "hip graph replay" if leg.gstep is not None else "eager",
+           "batch_handover": ("one launch: copies + key-major rows for the dedup plan (tt_batch_ingest)"
+                              if getattr(leg.gstep, "_ingest", None) is not None else "one launch: copies (tt_copy_multi)") if leg.gstep is not None else "none"}
     if leg.sharded and ex is not None and hasattr(ex, "C"):
         cfg.update({"exchange_capacity_rows_per_peer": ex.C,
                     "exchange_bytes_per_rank_fwd": world * ex.C * leg.E * (2 if (x_bf16 and ex.wire_bf16) else 4),

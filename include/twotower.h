@@ -111,6 +111,13 @@ int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K 
                         int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
                         tt_stream stream);
 
+/* The same plan from rows in KEY-MAJOR order, rows_km[side_base + k*B + b] (written by tt_batch_ingest): a key's B rows are
+ * one contiguous run instead of one word per K*4 bytes -- the sort's own strided load is 6.5 of a workgroup's 18 us. */
+int tt_dedup_plan_keyed_km(tt_ctx* ctx, const int32_t* rows_km, const int32_t* side_K /* host [n_sides] */,
+                           int32_t n_sides, int64_t B, int32_t* sorted_src, int32_t* unique_rows,
+                           int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
+                           tt_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Embedding gradient -- replaces autograd's nn.Embedding backward (dense index_add; reference
  * builds its tables with sparse=False, src/towers/cat_embed.py:42-45; scripts/train.py:326).
@@ -501,6 +508,14 @@ int tt_gather_rows(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t 
 #define TT_MAX_COPIES 8
 int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                   tt_stream stream);
+
+/* Batch hand-over of a graph-replayed step in ONE launch: the n copy segments of tt_copy_multi (the batch's dense features and
+ * ids into the graph's static buffers, the step scalars) and, for every side, the fused rows of the batch's ids in key-major
+ * order for tt_dedup_plan_keyed_km:  rows_km[side_base + k*B + b] = key_row_offset[k] + clamp(ids[b*K + k], 0, key_vocab[k] - 1)
+ * (the lookup's own id -> row rule, src/towers/cat_embed.py:114-117; side_base = sum of B*K of the earlier sides).
+ * sides[i].ids is the SOURCE of the hand-over (the incoming batch); out / ld_out / out_dtype are ignored.  1 <= K <= 64 per side. */
+int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
+                    const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_km, tt_stream stream);
 
 #ifdef __cplusplus
 }

@@ -85,6 +85,7 @@ SIGNATURES = {
     "tt_dedup_plan": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_dedup_keyed_workspace_bytes": (sz, [i64, i32]),
     "tt_dedup_plan_keyed": (C.c_int, [vp, vp, C.POINTER(i32), i32, i64, vp, vp, vp, vp, vp, sz, vp]),
+    "tt_dedup_plan_keyed_km": (C.c_int, [vp, vp, C.POINTER(i32), i32, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_embed_grad_workspace_bytes": (sz, [i64, i32]),
     "tt_embed_grad_bwd": (C.c_int, [vp, C.POINTER(GradSrc), i32, i64, i32, vp, vp, vp, vp, i64, i32, vp, vp, vp, sz, vp]),
     "tt_adam_hparams": (None, [i64, f32, f32, f32, f32, f32, C.POINTER(f32 * 6)]),
@@ -129,6 +130,7 @@ SIGNATURES = {
     "tt_dedup_plan_runs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_gather_rows": (C.c_int, [vp, vp, i64, i32, vp, i64, vp, i32, vp]),
     "tt_copy_multi": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]),
+    "tt_batch_ingest": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp, vp]),
     "tt_batch_gather": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]),
 }
 

@@ -38,6 +38,20 @@ class EmbeddingStore:
         self.members: List["CategoricalEmbedder"] = []
         self.version = 0
         self._grad_counters = None                      # 4 int32 words the gradient reduction keeps zero between calls
+        # set by GraphedTrainStep: (static id tensors per side, their _version at the last hand-over, rows_km) -- the fused rows of
+        # exactly those id tensors in key-major order, written by ops.batch_ingest.  A pass over other tensors, or over these
+        # after anybody else wrote to them, does not see it (rows_km_for).
+        self.ingest = None
+
+    def rows_km_for(self, id_tensors) -> Optional[torch.Tensor]:
+        """The key-major rows of ops.batch_ingest if they describe exactly `id_tensors` as they are now, else None."""
+        reg = self.ingest
+        if reg is None or len(reg[0]) != len(id_tensors):
+            return None
+        for t, r, v in zip(id_tensors, reg[0], reg[1]):
+            if t.data_ptr() != r.data_ptr() or t.numel() != r.numel() or r._version != v:
+                return None
+        return reg[2]
 
     def grad_counters(self) -> Optional[torch.Tensor]:
         """Allocated on first use OUTSIDE a graph capture (a zero-fill inside one would become a memset node: DESIGN.md section 6);

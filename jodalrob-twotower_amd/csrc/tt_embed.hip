@@ -471,7 +471,7 @@ constexpr int kKeyedMaxParts = 8;
 __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, const int32_t* __restrict__ rows,
                                                                   int32_t* __restrict__ sorted_src, int32_t* __restrict__ uniq_stage,
                                                                   int32_t* __restrict__ seg_stage, int32_t* __restrict__ ucount,
-                                                                  int32_t* __restrict__ ubase) {
+                                                                  int32_t* __restrict__ ubase, bool key_major) {
   __shared__ uint32_t keys[2][kKeyedB];
   __shared__ uint16_t vals[2][kKeyedB];
   __shared__ uint32_t whist[16][256];
@@ -497,12 +497,13 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
     // samples so that they do not all ask for the same line at the same moment: 10.5 -> 7.9 us for the 32 notice keys)
     constexpr int PERL = kKeyedB / kKeyedThreads;
     uint32_t r[PERL];
-    const int rot = (int)(((unsigned)k * 264u) % (unsigned)B);
+    // key_major: the rows arrive as [key][sample] (tt_batch_ingest) -- this key's B rows are one contiguous run: 6.5 -> 2 us
+    const int rot = key_major ? 0 : (int)(((unsigned)k * 264u) % (unsigned)B);
 #pragma unroll
     for (int j = 0; j < PERL; ++j) {
       int b = tid + j * kKeyedThreads + rot;
       b = b >= B ? b - B : b;
-      r[j] = tid + j * kKeyedThreads < B ? (uint32_t)rows[sbase + b * K + k] : 0u;
+      r[j] = tid + j * kKeyedThreads < B ? (uint32_t)rows[key_major ? sbase + k * B + b : sbase + b * K + k] : 0u;
     }
 #pragma unroll
     for (int j = 0; j < PERL; ++j) {
@@ -1344,6 +1345,75 @@ __global__ __launch_bounds__(kThreads) void copy_multi_kernel(CopyArgs a) {
     for (int64_t i = tail0 + threadIdx.x; i < a.bytes[seg]; i += blockDim.x) a.dst[seg][i] = a.src[seg][i];
 }
 
+// Batch hand-over of a graph-replayed step: the copy segments of copy_multi_kernel plus, per side, the fused row of every id
+// in KEY-MAJOR order (rows_km[side_base + k * B + b] = key_row_offset[k] + clamp(ids[b * K + k])) -- the input
+// tt_dedup_plan_keyed_km sorts.  A key's rows sit one per K * 4 bytes in the lookup's sample-major array: gathered by the sort
+// itself that is a 128-byte line per lane (6.5 of a share's 18 us); here a workgroup reads 64 samples' ids as one run, turns the
+// tile in LDS and writes 256-byte runs per key.  blockIdx.y < n_sides: side (dispatched first: the handful of transposing
+// workgroups must not queue behind the thousands of copy workgroups); else copy segment blockIdx.y - n_sides.
+constexpr int kIngestMaxK = 64;
+struct IngestArgs {
+  CopyArgs c;
+  int32_t n_copy, n_sides, B;
+  const int64_t* ids[TT_MAX_SIDES];
+  const int64_t* off[TT_MAX_SIDES];
+  const int64_t* vocab[TT_MAX_SIDES];
+  int32_t K[TT_MAX_SIDES];
+  int32_t side_base[TT_MAX_SIDES];
+  int32_t* rows_km;
+};
+
+__global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
+  if ((int)blockIdx.y >= a.n_sides) {
+    const int seg = blockIdx.y - a.n_sides;
+    const int64_t n16 = a.c.bytes[seg] / 16, tail0 = n16 * 16;
+    const float4* __restrict__ s = reinterpret_cast<const float4*>(a.c.src[seg]);
+    float4* __restrict__ d = reinterpret_cast<float4*>(a.c.dst[seg]);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) d[i] = s[i];
+    if (blockIdx.x == 0)
+      for (int64_t i = tail0 + threadIdx.x; i < a.c.bytes[seg]; i += blockDim.x) a.c.dst[seg][i] = a.c.src[seg][i];
+    return;
+  }
+  const int si = blockIdx.y;
+  const int K = a.K[si], B = a.B;
+  if ((int)blockIdx.x * 64 >= B) return;
+  __shared__ int32_t tile[kIngestMaxK][65];
+  __shared__ int64_t s_off[kIngestMaxK], s_hi[kIngestMaxK];
+  const int64_t* __restrict__ ids = a.ids[si];
+  if ((int)threadIdx.x < K) {
+    s_off[threadIdx.x] = a.off[si][threadIdx.x];
+    s_hi[threadIdx.x] = a.vocab[si][threadIdx.x] - 1;
+  }
+  __syncthreads();
+  constexpr int PER = kIngestMaxK * 64 / kThreads;            // ids per thread and tile: all loads issued before the first use
+  for (int b0 = blockIdx.x * 64; b0 < B; b0 += gridDim.x * 64) {
+    const int nb = min(64, B - b0), n = nb * K;
+    int64_t idv[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {                           // the tile's ids are one contiguous run
+      const int e = threadIdx.x + u * kThreads;
+      idv[u] = ids[(int64_t)b0 * K + (e < n ? e : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = threadIdx.x + u * kThreads;
+      if (e < n) {
+        const int bl = e / K, k = e - bl * K;
+        int64_t id = idv[u];
+        id = id < 0 ? 0 : (id > s_hi[k] ? s_hi[k] : id);      // clamp: cat_embed.py:117 (as the lookup)
+        tile[k][bl] = (int32_t)(s_off[k] + id);
+      }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < K * 64; e += kThreads) {
+      const int k = e >> 6, bl = e & 63;
+      if (bl < nb) a.rows_km[a.side_base[si] + (int64_t)k * B + b0 + bl] = tile[k][bl];
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // multi-GPU routing: distinct rows -> fixed-capacity owner buckets (stable, no host sync)
 //   a workgroup of 4 waves covers 2048 consecutive plan rows, a wave 512 of them in 8 batches of 64
@@ -1717,9 +1787,9 @@ size_t tt_dedup_keyed_workspace_bytes(int64_t M, int32_t n_keys) {
          2 * align256(sizeof(int32_t) * (size_t)(n_keys > 0 ? n_keys : 1) * kKeyedMaxParts);      // + head counts and stage bases per (key, share)
 }
 
-int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K, int32_t n_sides, int64_t B, int32_t* sorted_src,
-                        int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
-                        tt_stream stream) {
+static int dedup_plan_keyed_impl(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K, int32_t n_sides, int64_t B, int32_t* sorted_src,
+                                 int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
+                                 tt_stream stream, bool key_major) {
   TT_CHECK_ARG(ctx && rows && side_K && sorted_src && unique_rows && seg_offsets && n_unique && workspace, "tt_dedup_plan_keyed: NULL argument");
   TT_CHECK_ARG(n_sides >= 1 && n_sides <= TT_MAX_SIDES, "tt_dedup_plan_keyed: n_sides=%d", n_sides);
   if (B < 1 || B > kKeyedB) {
@@ -1765,11 +1835,25 @@ int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K,
   if (parts > kKeyedMaxParts) parts = kKeyedMaxParts;
   while (parts > 1 && (int64_t)n_keys * parts > (int64_t)ctx->num_cus) parts /= 2;     // a workgroup needs a CU of its own (144 KB of LDS)
   a.parts = parts;
-  keyed_sort_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(a, rows, sorted_src, uniq_stage, seg_stage, ucount, ubase);
+  keyed_sort_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(a, rows, sorted_src, uniq_stage, seg_stage, ucount, ubase, key_major);
   TT_LAUNCH_CHECK();
   keyed_compact_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(uniq_stage, seg_stage, ucount, ubase, n_keys * parts, slots, unique_rows, seg_offsets, n_unique);
   TT_LAUNCH_CHECK();
   return TT_OK;
+}
+
+int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K, int32_t n_sides, int64_t B, int32_t* sorted_src,
+                        int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
+                        tt_stream stream) {
+  return dedup_plan_keyed_impl(ctx, rows, side_K, n_sides, B, sorted_src, unique_rows, seg_offsets, n_unique, workspace, workspace_bytes,
+                               stream, false);
+}
+
+int tt_dedup_plan_keyed_km(tt_ctx* ctx, const int32_t* rows_km, const int32_t* side_K, int32_t n_sides, int64_t B, int32_t* sorted_src,
+                           int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
+                           tt_stream stream) {
+  return dedup_plan_keyed_impl(ctx, rows_km, side_K, n_sides, B, sorted_src, unique_rows, seg_offsets, n_unique, workspace, workspace_bytes,
+                               stream, true);
 }
 
 size_t tt_embed_grad_workspace_bytes(int64_t M, int32_t E) { return grad_layout(nullptr, M > 0 ? M : 1, E > 0 ? E : 1).bytes; }
@@ -2027,6 +2111,46 @@ int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* s
   const int64_t cap = (int64_t)ctx->num_cus * 4;
   if (gx > cap) gx = cap;
   copy_multi_kernel<<<dim3((unsigned)gx, (unsigned)n), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
+                    int32_t n_sides, int64_t B, int32_t* rows_km, tt_stream stream) {
+  TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest: bad copy arguments");
+  TT_CHECK_ARG(sides && rows_km && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest: bad side arguments");
+  IngestArgs a{};
+  int64_t mx = 0, slots = 0;
+  for (int i = 0; i < n; ++i) {
+    TT_CHECK_ARG(bytes[i] >= 0 && (bytes[i] == 0 || (dst[i] && src[i])), "tt_batch_ingest: segment %d NULL", i);
+    TT_CHECK_ARG(tt_aligned(dst[i], 16) && tt_aligned(src[i], 16), "tt_batch_ingest: segment %d not 16-byte aligned", i);
+    a.c.dst[i] = reinterpret_cast<char*>(dst[i]);
+    a.c.src[i] = reinterpret_cast<const char*>(src[i]);
+    a.c.bytes[i] = bytes[i];
+    mx = bytes[i] > mx ? bytes[i] : mx;
+  }
+  a.n_copy = n;
+  a.n_sides = n_sides;
+  a.B = (int32_t)B;
+  a.rows_km = rows_km;
+  for (int i = 0; i < n_sides; ++i) {
+    const tt_embed_side& s = sides[i];
+    TT_CHECK_ARG(s.K >= 1 && s.ids && s.key_row_offset && s.key_vocab, "tt_batch_ingest: side %d NULL / no keys", i);
+    if (s.K > kIngestMaxK) {
+      tt_set_error("tt_batch_ingest: side %d has %d keys (max %d)", i, s.K, kIngestMaxK);
+      return TT_ERR_UNSUPPORTED;
+    }
+    a.ids[i] = s.ids; a.off[i] = s.key_row_offset; a.vocab[i] = s.key_vocab; a.K[i] = s.K;
+    a.side_base[i] = (int32_t)slots;
+    slots += B * s.K;
+  }
+  TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_batch_ingest: too many slots");
+  int64_t gx = tt_cdiv(mx / 16 + 1, kThreads);
+  const int64_t tiles = tt_cdiv(B, 64);
+  if (tiles > gx) gx = tiles;
+  const int64_t cap = (int64_t)ctx->num_cus * 4;
+  if (gx > cap) gx = cap;
+  batch_ingest_kernel<<<dim3((unsigned)gx, (unsigned)(n + n_sides)), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

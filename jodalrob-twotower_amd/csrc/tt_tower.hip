@@ -429,6 +429,11 @@ __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontA
   const float bias = (f.bias && c < H) ? f.bias[c] : 0.f;
   // piece of an f32 stage: row (t >> 5) + 16 pass, k = 4 (t & 31); piece of a bf16 stage: row (t >> 4) + 32 pass, k = 8 (t & 15)
   const int frow = t >> 5, fk = 4 * (t & 31), xrow = t >> 4, xk = 8 * (t & 15);
+  // ADDRESS columns of a thread's first piece: a 64-wide operand (din = 64, kx = 64) fills only half of the 128-wide first stage,
+  // and the lanes of the other half must re-read columns that exist -- unclamped, their piece of the LAST row lay up to 256 bytes
+  // behind the end of the buffer (harmless for the result: those columns are zeroed on the way into LDS; a fault when the
+  // buffer ends a mapping)
+  const int fkp = din >= 128 ? fk : (fk & 63), fkb = kx >= 128 ? fk : (fk & 63), xkb = kx >= 128 ? xk : (xk & 63);
   const int ns2 = 3 * ((kx + 383) / 384);                       // block stages, padded to the unroll of 3 (pad stages are zeros)
   const int pn = (wave >> 1) * 32 + li;                         // this lane's projection column
   const float bp = pn < h0 ? f.b_proj[pn] : 0.f;
@@ -438,9 +443,9 @@ __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontA
     float4 pa[2][4], pb[2][8];
     uint32_t oa[4], ob[8];                                  // byte offsets of this thread's rows (k = fk)
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) oa[ps] = (uint32_t)(min(b0 + frow + 16 * ps, B - 1) * (int)f.ld_dense + fk) * 4u;
+    for (int ps = 0; ps < 4; ++ps) oa[ps] = (uint32_t)(min(b0 + frow + 16 * ps, B - 1) * (int)f.ld_dense + fkp) * 4u;
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) ob[ps] = (uint32_t)(min(frow + 16 * ps, h0 - 1) * din + fk) * 4u;
+    for (int ps = 0; ps < 8; ++ps) ob[ps] = (uint32_t)(min(frow + 16 * ps, h0 - 1) * din + fkp) * 4u;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       // a piece past the end re-reads this thread's own first piece (discarded): never ONE address for the whole grid
@@ -454,9 +459,9 @@ __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontA
     float4 qb[3][4];
     uint32_t ox[2], ow[4];
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) ox[ps] = (uint32_t)(min(b0 + xrow + 32 * ps, B - 1) * (int)f.ldx + xk) * 2u;
+    for (int ps = 0; ps < 2; ++ps) ox[ps] = (uint32_t)(min(b0 + xrow + 32 * ps, B - 1) * (int)f.ldx + xkb) * 2u;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) ow[ps] = (uint32_t)(min(frow + 16 * ps, H - 1) * kx + fk) * 4u;
+    for (int ps = 0; ps < 4; ++ps) ow[ps] = (uint32_t)(min(frow + 16 * ps, H - 1) * kx + fkb) * 4u;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int ka = 128 * u + xk, kb = 128 * u + fk;

@@ -6,7 +6,9 @@ Why: at batch 8192 the step is ~75 short kernels (0.9 ms of GPU time); launched 
 host needs ~1.5 ms, so the GPU idles 40 % of the time.  A replay costs one launch.
 
 What makes the capture replayable with NEW data every step:
-  * the batch is copied into static input buffers before the replay (4 small device copies);
+  * the batch is copied into static input buffers before the replay -- one launch (`ops.batch_ingest`) that also leaves the
+    fused table rows of the batch's ids in key-major order for the duplicate-row plan (the plan's own strided load of one
+    key's rows is 6.5 of a sort workgroup's 18 us);
   * Adam's per-step scalars (lr from the scheduler, the bias corrections) and the dropout seed live in
     device memory (`hparams_dev` / `seed_dev` arguments of the C ABI) and are refreshed by one small
     pinned-memory copy before each replay;
@@ -48,6 +50,9 @@ class GraphedTrainStep:
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
         self._towers = [m for m in task.modules() if hasattr(m, "_seed_dev") and hasattr(m, "dense_parameters")]
         self._steps_done = 0
+        self._ingest = self._setup_ingest()
+        if self._ingest is not None:
+            self._run_ingest([], None)                           # rows_km of the example batch: warm-up and capture see it
         # eager warm-up on a side stream (allocator + first-call paths), then capture
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -80,6 +85,37 @@ class GraphedTrainStep:
                 t._seed_dev = None
         # the capture itself ran the host-side bookkeeping of one optimiser step without executing it
         optimizer.advance_steps(-1)
+
+    def _setup_ingest(self):
+        """Key-major row hand-over (ops.batch_ingest) when the step looks the static ids up in ONE local fused table with the
+        per-key plan: returns (store, embedders, rows_km, static id tensors, B) or None (then the batch is handed over by plain
+        copies and the plan gathers its rows out of the lookup's slot-major array)."""
+        import os
+        if os.environ.get("TT_GRAPH_INGEST", "1") == "0" or getattr(self.task, "exchange", None) is not None:
+            return None
+        model = getattr(self.task, "two_tower_model", None)
+        towers = [getattr(model, n, None) for n in ("notice_tower", "company_tower")]
+        if model is None or any(t is None or getattr(t, "exchange", None) is not None for t in towers):
+            return None
+        embs = [t.categorical_embedder for t in towers]
+        store = embs[0].store
+        ids = [self.static[side]["kjt"].values() for side in ("notice", "company")]
+        B = self.static["notice"]["dense"].shape[0]
+        if any(e.store is not store for e in embs) or store.weight is None or not (0 < B <= ops.KEYED_MAX_B):
+            return None
+        if any(len(e.keys) == 0 or len(e.keys) > 64 or v.dtype != torch.int64 or not v.is_contiguous() or v.numel() != B * len(e.keys)
+               for e, v in zip(embs, ids)):
+            return None
+        rows_km = torch.empty(sum(v.numel() for v in ids), dtype=torch.int32, device=ids[0].device)
+        return store, embs, rows_km, ids, B
+
+    def _run_ingest(self, pairs, src_ids):
+        """One launch: the copy segments + the key-major rows of `src_ids` (default: the static id buffers themselves)."""
+        store, embs, rows_km, ids, B = self._ingest
+        src = ids if src_ids is None else src_ids
+        sides = [ops.LookupSide(v, e._key_row_offset, e._key_vocab, None, len(e.keys)) for e, v in zip(embs, src)]
+        ops.batch_ingest(pairs, sides, B, rows_km)
+        store.ingest = (ids, [v._version for v in ids], rows_km)
 
     def _body(self):
         self.opt.zero_grad(set_to_none=True)
@@ -122,6 +158,7 @@ class GraphedTrainStep:
 
     def step(self, batch: Optional[Dict] = None):
         """Train on `batch` (or on whatever the static buffers hold); returns the static result."""
+        src_ids = []                                            # per side: where this step's ids are read from
         if batch is not None:
             pairs = []
             for side in ("notice", "company"):
@@ -129,14 +166,21 @@ class GraphedTrainStep:
                 sd, sv = self.static[side]["dense"], self.static[side]["kjt"].values()
                 if d.device == sd.device and d.dtype == sd.dtype and v.dtype == sv.dtype and d.is_contiguous() and v.is_contiguous():
                     pairs += [(sd, d), (sv, v)]
+                    src_ids.append(v)
                 else:                                           # host batch / other dtype: ordinary copies
                     sd.copy_(d, non_blocking=True)
                     sv.copy_(v, non_blocking=True)
+                    src_ids.append(sv)
         else:
             pairs = []
         if __import__("os").environ.get("TT_GRAPH_SKIP_PUSH"):       # fault hunting
             if pairs:
                 ops.copy_multi(pairs)
+        elif self._ingest is not None and (batch is not None or self._ingest[0].rows_km_for(self._ingest[3]) is None):
+            # ONE launch: the four batch buffers + the scalars + the key-major rows of this batch's ids (also when nobody handed a
+            # batch over but the static ids were written to since the last hand-over)
+            self._run_ingest(pairs + [self._fill_slot()], src_ids if batch is not None else None)
+            self._mark_slot()
         else:
             ops.copy_multi(pairs + [self._fill_slot()])         # ONE launch: the four batch buffers + the scalars
             self._mark_slot()
@@ -164,6 +208,9 @@ class GraphedTrainStep:
                 ex.check_overflow()
         finally:
             self.result = None
+            if self._ingest is not None:
+                self._ingest[0].ingest = None                   # the key-major rows belonged to this object's static buffers
+                self._ingest = None
             if self.graph is not None:
                 self.graph.reset()
                 self.graph = None

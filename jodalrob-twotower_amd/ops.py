@@ -188,8 +188,9 @@ def dedup_plan_runs(rows: torch.Tensor, G: int, C: int, row_limit: int = 0) -> D
 KEYED_MAX_B = 8192
 
 
-def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int) -> DedupPlan:
-    """Plan for slot rows straight from embed_lookup (slot = side_base + b*K + k): per-key LDS sorts, 2 launches."""
+def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int, key_major: bool = False) -> DedupPlan:
+    """Plan for slot rows straight from embed_lookup (slot = side_base + b*K + k): per-key LDS sorts, 2 launches.
+    key_major: `rows` is batch_ingest's [key][sample] array instead (rows[side_base + k*B + b]); same plan."""
     dev, M = rows.device, rows.numel()
     assert M == B * sum(side_K)
     buf = torch.empty(3 * M + 2, dtype=torch.int32, device=dev)
@@ -198,9 +199,10 @@ def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int) -> Dedup
     nk = sum(side_K)
     ws = L.workspace(dev, lib.tt_dedup_keyed_workspace_bytes(M, nk))
     ks = (L.i32 * len(side_K))(*side_K)
+    fn = lib.tt_dedup_plan_keyed_km if key_major else lib.tt_dedup_plan_keyed
     with _timed("tt_dedup_plan_keyed"):
-        L.check(lib.tt_dedup_plan_keyed(L.ctx(dev), L.ptr(rows), ks, len(side_K), B, L.ptr(plan.sorted_src), L.ptr(plan.unique_rows),
-                                        L.ptr(plan.seg_offsets), L.ptr(plan.n_unique), L.ptr(ws), ws.numel(), L.stream(dev)),
+        L.check(fn(L.ctx(dev), L.ptr(rows), ks, len(side_K), B, L.ptr(plan.sorted_src), L.ptr(plan.unique_rows),
+                   L.ptr(plan.seg_offsets), L.ptr(plan.n_unique), L.ptr(ws), ws.numel(), L.stream(dev)),
                 "tt_dedup_plan_keyed")
     return plan
 
@@ -595,6 +597,29 @@ def copy_multi(pairs):
             raise ValueError("copy_multi: segments must be contiguous and equally sized")
     with _timed("tt_copy_multi"):
         L.check(L.load().tt_copy_multi(L.ctx(dev), n, dst, src, nb, L.stream(dev)), "tt_copy_multi")
+
+
+def batch_ingest(pairs, sides: Sequence[LookupSide], B: int, rows_km: torch.Tensor):
+    """copy_multi's segments plus, per side, the fused rows of the side's ids in key-major order (tt_batch_ingest): the batch
+    hand-over of a graph-replayed step in one launch.  sides[i].ids is the id source (the incoming batch or the static buffer)."""
+    dev, n = rows_km.device, len(pairs)
+    dst = (L.vp * max(n, 1))(*[d.data_ptr() for d, _ in pairs])
+    src = (L.vp * max(n, 1))(*[s.data_ptr() for _, s in pairs])
+    nb = (L.i64 * max(n, 1))(*[d.numel() * d.element_size() for d, _ in pairs])
+    for d, s_ in pairs:
+        if d.numel() * d.element_size() != s_.numel() * s_.element_size() or not d.is_contiguous() or not s_.is_contiguous():
+            raise ValueError("batch_ingest: segments must be contiguous and equally sized")
+    arr = (L.EmbedSide * len(sides))()
+    M = 0
+    for i, s in enumerate(sides):
+        if s.ids.dtype != torch.int64 or not s.ids.is_contiguous() or s.ids.device != dev or s.ids.numel() != B * s.K:
+            raise ValueError(f"batch_ingest: side {i} needs {B}*{s.K} contiguous int64 ids on {dev}")
+        arr[i] = L.EmbedSide(L.ptr(s.ids), L.ptr(s.key_row_offset), L.ptr(s.key_vocab), None, 0, s.K, TT_F32)
+        M += B * s.K
+    if rows_km.dtype != torch.int32 or rows_km.numel() != M or not rows_km.is_contiguous():
+        raise ValueError("batch_ingest: rows_km must be a contiguous int32 tensor of sum(B*K) elements")
+    with _timed("tt_batch_ingest"):
+        L.check(L.load().tt_batch_ingest(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), L.stream(dev)), "tt_batch_ingest")
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU routing

@@ -299,12 +299,15 @@ class _TowersFn(torch.autograd.Function):
                     rows = ops.embed_lookup(store.weight, [g[1]], g[0].B, want_rows=grad_on)
                     plans.append([store, [g[0]], ops.dedup_plan(rows, store.rows) if grad_on else None])
                 continue
-            rows = ops.embed_lookup(store.weight, [g[1] for g in group], B, want_rows=grad_on)
+            # a graph-replayed step hands the batch over with ops.batch_ingest, which leaves the fused rows of exactly these id
+            # tensors in key-major order: the plan sorts those, the lookup need not write its slot-major copy
+            km = store.rows_km_for([g[1].ids for g in group]) if (grad_on and 0 < B <= ops.KEYED_MAX_B) else None
+            rows = ops.embed_lookup(store.weight, [g[1] for g in group], B, want_rows=grad_on and km is None)
             ev = None
             if grad_on:
                 ev = torch.cuda.Event()
                 ev.record()                                        # rows are ready here
-            plans.append([store, [g[0] for g in group], None, rows, ev])
+            plans.append([store, [g[0] for g in group], None, rows if km is None else km, ev, km is not None])
         live = [s for s in sides if s.B]
         fused = len(live) > 1 and len({s.B for s in live}) == 1 and len({s.tower.n_hidden for s in live}) == 1 and \
             len({(s.train, s.p_drop) for s in live}) == 1
@@ -350,8 +353,8 @@ class _TowersFn(torch.autograd.Function):
         # captured graph with two streams is replayed node by node with cross-queue signals: 4-6 us gaps in front of
         # eight kernels and 0.20 ms instead of 0.05 ms of host time per replay -- as much as the overlap saves.
         for pl in plans:
-            if len(pl) == 5:
-                store, psides, _, rows, ev = pl
+            if len(pl) == 6:
+                store, psides, _, rows, ev, key_major = pl
                 plan = None
                 if ev is not None:
                     inline = os.environ.get("TT_DEDUP_STREAM", "inline") != "side"
@@ -361,7 +364,7 @@ class _TowersFn(torch.autograd.Function):
                     with torch.cuda.stream(ds):
                         Bs = psides[0].B
                         if 0 < Bs <= ops.KEYED_MAX_B:       # per-key LDS sorts (2 launches)
-                            plan = ops.dedup_plan_keyed(rows, [len(q.tower.categorical_embedder.keys) for q in psides], Bs)
+                            plan = ops.dedup_plan_keyed(rows, [len(q.tower.categorical_embedder.keys) for q in psides], Bs, key_major)
                         else:
                             plan = ops.dedup_plan(rows, store.rows)
                     plan.keep, plan.stream = rows, (None if inline else ds)   # keep the sort input alive until it has run

@@ -575,6 +575,50 @@ def test_graphed_step_equals_eager(tt, manifest, mlp_dtype):
         assert np.array_equal(v, finals["graph"][1][k]), k
 
 
+def test_graph_ingest_key_major_plan(tt, manifest, monkeypatch):
+    """GraphedTrainStep hands a batch over with ops.batch_ingest (copies + the fused rows of the batch's ids in key-major order,
+    which the duplicate-row plan then sorts instead of gathering every key's rows out of the sample-major array) == the same
+    replayed steps with plain copies and the strided gather (TT_GRAPH_INGEST=0), bit for bit: ragged last 64-sample tile,
+    out-of-range ids (the ingest clamps like the lookup), a batch that arrives in host memory, and static id buffers that
+    somebody overwrote with a torch op between replays (the stale key-major rows must not be used)."""
+    from jodalrob_twotower_amd.graph import GraphedTrainStep
+    from jodalrob_twotower_amd.optim import FusedAdam
+    from jodalrob_twotower_amd import ops as _ops
+    cfg = dict(manifest["cases"]["wide_b40"])
+    cfg["B"] = 300
+    batches = [synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 930 + i, oob=True) for i in range(5)]
+    finals = {}
+    for ingest in ("0", "1"):
+        monkeypatch.setenv("TT_GRAPH_INGEST", ingest)
+        task = make_task(tt, cfg, embedding_grad="sparse", score_dtype="bf16", mlp_dtype="bf16", dropout_rate=0.0)
+        load_state(task, init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 56))
+        task.train()
+        opt = FusedAdam.for_task(task, lr=1e-2)
+        tb = [to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]) for b in batches]
+        seen, plain = [], _ops.dedup_plan_keyed
+        monkeypatch.setattr(_ops, "dedup_plan_keyed", lambda rows, ks, B_, key_major=False: (seen.append(key_major), plain(rows, ks, B_, key_major))[1])
+        gs = GraphedTrainStep(task, opt, tb[0], warmup=2)
+        monkeypatch.setattr(_ops, "dedup_plan_keyed", plain)
+        store = task.two_tower_model.embedding_store
+        store = store() if callable(store) else store
+        assert (gs._ingest is not None) == (ingest == "1") and (store.ingest is not None) == (ingest == "1")
+        assert len(seen) == 3 and all(k == (ingest == "1") for k in seen)      # warm-up and capture sort the key-major rows
+        losses = [gs.step(b)["loss"].item() for b in tb[:3]]
+        host = {s: {"dense": tb[3][s]["dense"].cpu(), "kjt": type(tb[3][s]["kjt"])(tb[3][s]["kjt"].keys(), tb[3][s]["kjt"].values().cpu())}
+                for s in ("notice", "company")}
+        losses.append(gs.step(host)["loss"].item())                       # host batch: ordinary copies into the static buffers
+        for s in ("notice", "company"):                                   # somebody writes the static buffers directly ...
+            gs.static[s]["dense"].copy_(tb[4][s]["dense"])
+            gs.static[s]["kjt"].values().copy_(tb[4][s]["kjt"].values())
+        losses.append(gs.step(None)["loss"].item())                       # ... and replays on "whatever the static buffers hold"
+        losses.append(gs.step(None)["loss"].item())                       # unchanged buffers: no new hand-over needed
+        finals[ingest] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in task.state_dict().items()})
+        gs.close()
+    assert finals["0"][0] == finals["1"][0] and len(set(finals["0"][0])) > 1
+    for k, v in finals["0"][1].items():
+        assert np.array_equal(v, finals["1"][1][k]), k
+
+
 def test_bf16_mlp_close_to_fp32(tt, manifest, schema_real):
     """mlp_dtype='bf16' (GEMM operands rounded to bf16, f32 accumulate, f32 tensors in memory) against the exact-f32
     MFMA path on the real 32+6-key schema: loss within 5e-3, gradients within 6e-2 norm-wise.  This is a SANITY bound on
