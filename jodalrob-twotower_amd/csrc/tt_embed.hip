@@ -1349,8 +1349,8 @@ __global__ __launch_bounds__(kThreads) void copy_multi_kernel(CopyArgs a) {
 // in KEY-MAJOR order (rows_km[side_base + k * B + b] = key_row_offset[k] + clamp(ids[b * K + k])) -- the input
 // tt_dedup_plan_keyed_km sorts.  A key's rows sit one per K * 4 bytes in the lookup's sample-major array: gathered by the sort
 // itself that is a 128-byte line per lane (6.5 of a share's 18 us); here a workgroup reads 64 samples' ids as one run, turns the
-// tile in LDS and writes 256-byte runs per key.  blockIdx.y < n_sides: side (dispatched first: the handful of transposing
-// workgroups must not queue behind the thousands of copy workgroups); else copy segment blockIdx.y - n_sides.
+// tile in LDS and writes 256-byte runs per key.  Grid row 0: every side's 64-sample tiles, side by side (dispatched first: the
+// few transposing workgroups must not queue behind the thousands of copy workgroups); row y >= 1: copy segment y - 1.
 constexpr int kIngestMaxK = 64;
 struct IngestArgs {
   CopyArgs c;
@@ -1364,8 +1364,8 @@ struct IngestArgs {
 };
 
 __global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
-  if ((int)blockIdx.y >= a.n_sides) {
-    const int seg = blockIdx.y - a.n_sides;
+  if (blockIdx.y >= 1) {
+    const int seg = blockIdx.y - 1;
     const int64_t n16 = a.c.bytes[seg] / 16, tail0 = n16 * 16;
     const float4* __restrict__ s = reinterpret_cast<const float4*>(a.c.src[seg]);
     float4* __restrict__ d = reinterpret_cast<float4*>(a.c.dst[seg]);
@@ -1375,10 +1375,12 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
       for (int64_t i = tail0 + threadIdx.x; i < a.c.bytes[seg]; i += blockDim.x) a.c.dst[seg][i] = a.c.src[seg][i];
     return;
   }
-  const int si = blockIdx.y;
-  const int K = a.K[si], B = a.B;
-  if ((int)blockIdx.x * 64 >= B) return;
-  __shared__ int32_t tile[kIngestMaxK][65];
+  // row 0 of the grid: every side's 64-sample tiles side by side (an own grid row per side meant a thousand empty workgroups each)
+  const int B = a.B, tiles = (B + 63) / 64;
+  const int si = (int)blockIdx.x / tiles, tile = (int)blockIdx.x % tiles;
+  if (si >= a.n_sides) return;
+  const int K = a.K[si];
+  __shared__ int32_t tl[kIngestMaxK][65];
   __shared__ int64_t s_off[kIngestMaxK], s_hi[kIngestMaxK];
   const int64_t* __restrict__ ids = a.ids[si];
   if ((int)threadIdx.x < K) {
@@ -1387,7 +1389,8 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
   }
   __syncthreads();
   constexpr int PER = kIngestMaxK * 64 / kThreads;            // ids per thread and tile: all loads issued before the first use
-  for (int b0 = blockIdx.x * 64; b0 < B; b0 += gridDim.x * 64) {
+  {
+    const int b0 = tile * 64;
     const int nb = min(64, B - b0), n = nb * K;
     int64_t idv[PER];
 #pragma unroll
@@ -1402,15 +1405,14 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
         const int bl = e / K, k = e - bl * K;
         int64_t id = idv[u];
         id = id < 0 ? 0 : (id > s_hi[k] ? s_hi[k] : id);      // clamp: cat_embed.py:117 (as the lookup)
-        tile[k][bl] = (int32_t)(s_off[k] + id);
+        tl[k][bl] = (int32_t)(s_off[k] + id);
       }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < K * 64; e += kThreads) {
       const int k = e >> 6, bl = e & 63;
-      if (bl < nb) a.rows_km[a.side_base[si] + (int64_t)k * B + b0 + bl] = tile[k][bl];
+      if (bl < nb) a.rows_km[a.side_base[si] + (int64_t)k * B + b0 + bl] = tl[k][bl];
     }
-    __syncthreads();
   }
 }
 
@@ -2146,11 +2148,11 @@ int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const*
   }
   TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_batch_ingest: too many slots");
   int64_t gx = tt_cdiv(mx / 16 + 1, kThreads);
-  const int64_t tiles = tt_cdiv(B, 64);
-  if (tiles > gx) gx = tiles;
   const int64_t cap = (int64_t)ctx->num_cus * 4;
   if (gx > cap) gx = cap;
-  batch_ingest_kernel<<<dim3((unsigned)gx, (unsigned)(n + n_sides)), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+  const int64_t tiles = tt_cdiv(B, 64) * n_sides;        // row 0 holds every tile (the copy rows stride over their segments)
+  if (tiles > gx) gx = tiles;
+  batch_ingest_kernel<<<dim3((unsigned)gx, (unsigned)(n + 1)), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }
