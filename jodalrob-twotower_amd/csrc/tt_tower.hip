@@ -636,7 +636,8 @@ __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArg
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = m0 + rq + 16 * j;
-    pre[j] = (c < H && r < B) ? a.pre[(int64_t)r * H + c] : 0.f;
+    const float v = a.pre[(int64_t)min(r, B - 1) * H + min(c, H - 1)];     // (clamped address, no branch around the load)
+    pre[j] = (c < H && r < B) ? v : 0.f;
   }
   if (t < 256) {
     Wf o{0.f, 0.f, 0.f};
@@ -657,7 +658,8 @@ __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArg
 #pragma unroll
   for (int j = 0; j < 4; ++j) {                          // W_out [D, H] -> Bs[n][k]
     const int n = rq + 16 * j;
-    Bs[n * kTailLd + c] = (__bf16)((n < D && c < H) ? f.w_out[(int64_t)n * H + c] : 0.f);
+    const float w = f.w_out[(int64_t)min(n, D - 1) * H + min(c, H - 1)];
+    Bs[n * kTailLd + c] = (__bf16)((n < D && c < H) ? w : 0.f);
   }
   __syncthreads();
   if (t < 64 && c < H) {
@@ -978,7 +980,8 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_kernel(Batch<TailBwdArg
 #pragma unroll
   for (int j = 0; j < 4; ++j) {                         // W_out [D, H]: element (k = d, n = h) -> Wn[h][d]
     const int d = rq + 16 * j;
-    Wn[c * kTailLd + d] = (__bf16)((d < D && c < H) ? f.w_out[(int64_t)d * H + c] : 0.f);
+    const float w = f.w_out[(int64_t)min(d, D - 1) * H + min(c, H - 1)];
+    Wn[c * kTailLd + d] = (__bf16)((d < D && c < H) ? w : 0.f);
   }
   const float mean = c < H ? a.mean[c] : 0.f, rstd = c < H ? a.rstd[c] : 0.f;
   tl_f32x16 accw;
@@ -991,19 +994,22 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_kernel(Batch<TailBwdArg
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int r = b0 + wave * 4 + j;
-      const bool ok = r < r1 && lane < D;
-      const int64_t i = (int64_t)r * D + lane;
-      yv[j] = ok ? f.y[i] : 0.f;
-      e[j] = ok ? f.emb[i] : 0.f;
-      de[j] = ok ? f.d_emb[i] : 0.f;
+      const bool ok = r < r1 && lane < D;                 // (unconditional loads at clamped addresses: a load under a per-lane
+      const int64_t i = (int64_t)min(r, r1 - 1) * D + min(lane, D - 1);   //  condition is waited for before the next is issued)
+      const float v0 = f.y[i], v1 = f.emb[i], v2 = f.d_emb[i];
+      yv[j] = ok ? v0 : 0.f;
+      e[j] = ok ? v1 : 0.f;
+      de[j] = ok ? v2 : 0.f;
     }
     float av[4], pr[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {                       // thread (c, rq): rows rq + 16 j of act / pre
       const int r = b0 + rq + 16 * j;
       const bool ok = c < H && r < r1;
-      av[j] = ok ? f.act[(int64_t)r * H + c] : 0.f;
-      pr[j] = ok ? a.pre[(int64_t)r * H + c] : 0.f;
+      const int64_t i = (int64_t)min(r, r1 - 1) * H + min(c, H - 1);
+      const float v0 = f.act[i], v1 = a.pre[i];
+      av[j] = ok ? v0 : 0.f;
+      pr[j] = ok ? v1 : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -1164,8 +1170,10 @@ __global__ __launch_bounds__(kTailThreads) void tail_bwd_apply_kernel(Batch<Tail
   for (int j = 0; j < 4; ++j) {
     const int r = m0 + rq + 16 * j;
     const bool ok = c < H && r < B;
-    pr[j] = ok ? b.pre[(int64_t)r * H + c] : 0.f;
-    da[j] = ok ? b.d[(int64_t)r * H + c] : 0.f;
+    const int64_t i = (int64_t)min(r, B - 1) * H + min(c, H - 1);          // (clamped address, no branch around the loads)
+    const float v0 = b.pre[i], v1 = b.d[i];
+    pr[j] = ok ? v0 : 0.f;
+    da[j] = ok ? v1 : 0.f;
   }
   if (t < 256) {
     float s0 = 0.f, s1 = 0.f;
