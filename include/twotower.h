@@ -118,6 +118,16 @@ int tt_dedup_plan_keyed_km(tt_ctx* ctx, const int32_t* rows_km, const int32_t* s
                            int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
                            tt_stream stream);
 
+/* The per-key plan that ALSO prepares the gradient reduction: rows with more than 64 slots (the two-row keys: thousands each)
+ * are summed chunk by chunk, and the list of those rows / chunks depends on the plan only.  Built here -- into the workspace
+ * tt_embed_grad_bwd will be called with (size tt_embed_grad_workspace_bytes(M, E), flag TT_GRAD_PLANNED; nobody else may touch
+ * it in between) -- the reduction's row pass and chunk pass run as ONE launch instead of one after the other.
+ * rows_key_major: 0 = the lookup's slot-major rows, 1 = tt_batch_ingest's [key][sample] rows. */
+int tt_dedup_plan_keyed_long(tt_ctx* ctx, const int32_t* rows, int32_t rows_key_major, const int32_t* side_K /* host [n_sides] */,
+                             int32_t n_sides, int64_t B, int32_t E, int32_t* sorted_src, int32_t* unique_rows,
+                             int32_t* seg_offsets, int32_t* n_unique, void* grad_workspace, size_t grad_workspace_bytes,
+                             void* workspace, size_t workspace_bytes, tt_stream stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Embedding gradient -- replaces autograd's nn.Embedding backward (dense index_add; reference
  * builds its tables with sparse=False, src/towers/cat_embed.py:42-45; scripts/train.py:326).
@@ -135,6 +145,7 @@ int tt_dedup_plan_keyed_km(tt_ctx* ctx, const int32_t* rows_km, const int32_t* s
 #define TT_GRAD_DENSE_SET 1
 #define TT_GRAD_DENSE_ACC 2
 #define TT_GRAD_SHORT_SEGMENTS 0x100
+#define TT_GRAD_PLANNED 0x200 /* the workspace was handed to tt_dedup_plan_keyed_long, which left the long-row list in it */
 
 typedef struct tt_grad_src {
   const void* d_out; /* gradient w.r.t. the lookup output of this side */

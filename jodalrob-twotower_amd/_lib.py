@@ -22,6 +22,7 @@ TT_TOWER_UNFUSED_TAIL = 1
 TT_TOWER_UNFUSED_FRONT = 2
 TT_TOWER_UNFUSED_BACK = 4
 TT_GRAD_SHORT_SEGMENTS = 0x100
+TT_GRAD_PLANNED = 0x200
 
 vp = C.c_void_p
 i32, i64, f32, u64, sz = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -86,6 +87,7 @@ SIGNATURES = {
     "tt_dedup_keyed_workspace_bytes": (sz, [i64, i32]),
     "tt_dedup_plan_keyed": (C.c_int, [vp, vp, C.POINTER(i32), i32, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_dedup_plan_keyed_km": (C.c_int, [vp, vp, C.POINTER(i32), i32, i64, vp, vp, vp, vp, vp, sz, vp]),
+    "tt_dedup_plan_keyed_long": (C.c_int, [vp, vp, i32, C.POINTER(i32), i32, i64, i32, vp, vp, vp, vp, vp, sz, vp, sz, vp]),
     "tt_embed_grad_workspace_bytes": (sz, [i64, i32]),
     "tt_embed_grad_bwd": (C.c_int, [vp, C.POINTER(GradSrc), i32, i64, i32, vp, vp, vp, vp, i64, i32, vp, vp, vp, sz, vp]),
     "tt_adam_hparams": (None, [i64, f32, f32, f32, f32, f32, C.POINTER(f32 * 6)]),

@@ -467,11 +467,19 @@ struct KeyedArgs {
   int32_t parts;                         // workgroups per key (range partition of the key's rows)
 };
 constexpr int kKeyedMaxParts = 8;
+// the long-row list of the segmented gradient reduction (rows with more than kPlanLongSeg slots are summed chunk by chunk), built
+// by the plan's compaction instead of by the reduction itself: the reduction's row and chunk passes then run as ONE launch
+constexpr int kPlanLongSeg = 64;
+struct PlanLong {
+  int32_t* counters;     // [0] chunks, [1] long rows (zeroed by keyed_sort_kernel, filled by keyed_compact_kernel)
+  int32_t* long_row; int32_t* long_base; int32_t* chunk_lo; int32_t* chunk_hi;
+};
 
 __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, const int32_t* __restrict__ rows,
                                                                   int32_t* __restrict__ sorted_src, int32_t* __restrict__ uniq_stage,
                                                                   int32_t* __restrict__ seg_stage, int32_t* __restrict__ ucount,
-                                                                  int32_t* __restrict__ ubase, bool key_major) {
+                                                                  int32_t* __restrict__ ubase, int32_t* __restrict__ uend, bool key_major,
+                                                                  int32_t* __restrict__ long_counters) {
   __shared__ uint32_t keys[2][kKeyedB];
   __shared__ uint16_t vals[2][kKeyedB];
   __shared__ uint32_t whist[16][256];
@@ -483,6 +491,7 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
   // positions follow from the common prefix, so there is nothing to merge.  Every workgroup of a key reaches the same decision
   // about the LSD fallback (same histogram); share 0 then sorts the whole key alone.
   const int P = a.parts, ki = (int)blockIdx.x / P, part = (int)blockIdx.x % P, B = a.B;
+  if (long_counters && blockIdx.x == 0 && tid < 2) long_counters[tid] = 0;      // the compaction (next launch) counts from zero
   for (int d = tid; d < 16 * 256; d += kKeyedThreads) (&peers_mask[0][0])[d] = 0ull;
   int side = 0;
 #pragma unroll
@@ -679,7 +688,7 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
     e_lo = 0;
     e_hi = part == 0 ? B : 0;
     if (part != 0) {
-      if (tid == 0) { ucount[blockIdx.x] = 0; ubase[blockIdx.x] = ki * B; }
+      if (tid == 0) { ucount[blockIdx.x] = 0; ubase[blockIdx.x] = ki * B; uend[blockIdx.x] = ki * B; }
       return;
     }
   }
@@ -796,11 +805,16 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
       ++u;
     }
   }
-  if (tid == kKeyedThreads - 1) { ucount[blockIdx.x] = (int32_t)u; ubase[blockIdx.x] = (int32_t)(gbase + e_lo); }
+  if (tid == kKeyedThreads - 1) {
+    ucount[blockIdx.x] = (int32_t)u;
+    ubase[blockIdx.x] = (int32_t)(gbase + e_lo);
+    uend[blockIdx.x] = (int32_t)(gbase + e_hi);           // where the share's last segment ends
+  }
 }
 
 __global__ __launch_bounds__(kKeyedThreads) void keyed_compact_kernel(const int32_t* __restrict__ uniq_stage, const int32_t* __restrict__ seg_stage,
                                                                 const int32_t* __restrict__ ucount, const int32_t* __restrict__ ubase,
+                                                                const int32_t* __restrict__ uend, PlanLong pl,
                                                                 int n_keys, int64_t M,
                                                                 int32_t* __restrict__ unique_rows, int32_t* __restrict__ seg_offsets,
                                                                 int32_t* __restrict__ n_unique) {
@@ -827,7 +841,22 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_compact_kernel(const int3
   const int64_t gbase = ubase[ki];
   for (int u = threadIdx.x; u < U; u += kKeyedThreads) {
     unique_rows[before + u] = uniq_stage[gbase + u];
-    seg_offsets[before + u] = seg_stage[gbase + u];
+    const int32_t s0 = seg_stage[gbase + u];
+    seg_offsets[before + u] = s0;
+    if (pl.counters) {                                   // long rows -> chunk list (what seg_reduce_kernel registers otherwise)
+      const int32_t s1 = u + 1 < U ? seg_stage[gbase + u + 1] : uend[ki];
+      if (s1 - s0 > kPlanLongSeg) {
+        const int32_t nch = (s1 - s0 + kPlanLongSeg - 1) / kPlanLongSeg;
+        const int32_t cb = atomicAdd(&pl.counters[0], nch);
+        const int32_t li = atomicAdd(&pl.counters[1], 1);
+        pl.long_row[li] = before + u;
+        pl.long_base[li] = cb;
+        for (int32_t c = 0; c < nch; ++c) {
+          pl.chunk_lo[cb + c] = s0 + c * kPlanLongSeg;
+          pl.chunk_hi[cb + c] = min(s1, s0 + (c + 1) * kPlanLongSeg);
+        }
+      }
+    }
   }
   if (ki == 0 && threadIdx.x == 0) {
     n_unique[0] = all;
@@ -1046,17 +1075,20 @@ __device__ __forceinline__ void write_row(float* __restrict__ out, int64_t row, 
   }
 }
 
+// planned: the long rows are already in the workspace's lists (built by the plan's compaction): nothing to register here
 template <int VEC, int DT, int LGT>
-__global__ __launch_bounds__(kThreads) void seg_reduce_kernel(SideSet a, const int32_t* __restrict__ sorted_src,
-                                                             const int32_t* __restrict__ seg, const int32_t* __restrict__ unique_rows,
-                                                             const int32_t* __restrict__ n_unique, int32_t mode,
-                                                             float* __restrict__ out, GradWs ws, uint32_t LG, bool all_short) {
+__device__ __forceinline__ void seg_reduce_body(const SideSet& a, const int32_t* __restrict__ sorted_src,
+                                                const int32_t* __restrict__ seg, const int32_t* __restrict__ unique_rows,
+                                                const int32_t* __restrict__ n_unique, int32_t mode,
+                                                float* __restrict__ out, const GradWs& ws, uint32_t LG, bool all_short, bool planned,
+                                                uint32_t bid, uint32_t nblocks) {
   const uint32_t U = (uint32_t)*n_unique;
-  const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t gthread = bid * blockDim.x + threadIdx.x;
   const uint32_t lig = gthread % LG;
-  const uint32_t ngroups = gridDim.x * blockDim.x / LG;
+  const uint32_t ngroups = nblocks * blockDim.x / LG;
   for (uint32_t u = gthread / LG; u < U; u += ngroups) {
     const int32_t s0 = seg[u], s1 = seg[u + 1];
+    if (planned && s1 - s0 > kLongSeg) continue;
     if (!all_short && s1 - s0 > kLongSeg) {
       const int32_t nch = (s1 - s0 + kLongSeg - 1) / kLongSeg;
       int32_t base = 0;
@@ -1084,12 +1116,21 @@ __global__ __launch_bounds__(kThreads) void seg_reduce_kernel(SideSet a, const i
 }
 
 template <int VEC, int DT, int LGT>
-__global__ __launch_bounds__(kThreads) void seg_chunk_kernel(SideSet a, const int32_t* __restrict__ sorted_src, GradWs ws, uint32_t LG) {
+__global__ __launch_bounds__(kThreads) void seg_reduce_kernel(SideSet a, const int32_t* __restrict__ sorted_src,
+                                                             const int32_t* __restrict__ seg, const int32_t* __restrict__ unique_rows,
+                                                             const int32_t* __restrict__ n_unique, int32_t mode,
+                                                             float* __restrict__ out, GradWs ws, uint32_t LG, bool all_short) {
+  seg_reduce_body<VEC, DT, LGT>(a, sorted_src, seg, unique_rows, n_unique, mode, out, ws, LG, all_short, false, blockIdx.x, gridDim.x);
+}
+
+template <int VEC, int DT, int LGT>
+__device__ __forceinline__ void seg_chunk_body(const SideSet& a, const int32_t* __restrict__ sorted_src, const GradWs& ws, uint32_t LG,
+                                               uint32_t bid, uint32_t nblocks) {
   const uint32_t nchunks = (uint32_t)ws.counters[0];
-  if (blockIdx.x == 0 && threadIdx.x == 0) ws.counters[2] = ws.counters[1];      // snapshot for seg_long_finish_kernel
-  const uint32_t gthread = blockIdx.x * blockDim.x + threadIdx.x;
+  if (bid == 0 && threadIdx.x == 0) ws.counters[2] = ws.counters[1];      // snapshot for seg_long_finish_kernel
+  const uint32_t gthread = bid * blockDim.x + threadIdx.x;
   const uint32_t lig = gthread % LG;
-  const uint32_t ngroups = gridDim.x * blockDim.x / LG;
+  const uint32_t ngroups = nblocks * blockDim.x / LG;
   for (uint32_t c = gthread / LG; c < nchunks; c += ngroups) {
     for (uint32_t chunk = lig; chunk < a.C; chunk += LG) {
       Acc<VEC> acc;
@@ -1098,6 +1139,22 @@ __global__ __launch_bounds__(kThreads) void seg_chunk_kernel(SideSet a, const in
       write_row<VEC>(ws.chunk_partial, (int64_t)c, a.E, chunk, acc, false);
     }
   }
+}
+
+template <int VEC, int DT, int LGT>
+__global__ __launch_bounds__(kThreads) void seg_chunk_kernel(SideSet a, const int32_t* __restrict__ sorted_src, GradWs ws, uint32_t LG) {
+  seg_chunk_body<VEC, DT, LGT>(a, sorted_src, ws, LG, blockIdx.x, gridDim.x);
+}
+
+// rows and chunks in ONE launch when the plan's compaction has already built the long-row list: workgroups [0, g1) take the
+// rows (long ones skipped), workgroups [g1, g1 + g2) the chunks -- the chunk pass no longer waits for the row pass to register them
+template <int VEC, int DT, int LGT>
+__global__ __launch_bounds__(kThreads) void seg_reduce_chunk_kernel(SideSet a, const int32_t* __restrict__ sorted_src,
+                                                                   const int32_t* __restrict__ seg, const int32_t* __restrict__ unique_rows,
+                                                                   const int32_t* __restrict__ n_unique, int32_t mode,
+                                                                   float* __restrict__ out, GradWs ws, uint32_t LG, uint32_t g1) {
+  if (blockIdx.x < g1) seg_reduce_body<VEC, DT, LGT>(a, sorted_src, seg, unique_rows, n_unique, mode, out, ws, LG, false, true, blockIdx.x, g1);
+  else seg_chunk_body<VEC, DT, LGT>(a, sorted_src, ws, LG, blockIdx.x - g1, gridDim.x - g1);
 }
 
 // one WORKGROUP per long row: its lane groups sum contiguous ranges of the row's chunk partials (8 loads in flight,
@@ -1786,12 +1843,12 @@ int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, i
 
 size_t tt_dedup_keyed_workspace_bytes(int64_t M, int32_t n_keys) {
   return align256(sizeof(int32_t) * (size_t)(M > 0 ? M : 1)) * 2 +
-         2 * align256(sizeof(int32_t) * (size_t)(n_keys > 0 ? n_keys : 1) * kKeyedMaxParts);      // + head counts and stage bases per (key, share)
+         3 * align256(sizeof(int32_t) * (size_t)(n_keys > 0 ? n_keys : 1) * kKeyedMaxParts);      // + head counts, stage bases and ends per (key, share)
 }
 
 static int dedup_plan_keyed_impl(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K, int32_t n_sides, int64_t B, int32_t* sorted_src,
                                  int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique, void* workspace, size_t workspace_bytes,
-                                 tt_stream stream, bool key_major) {
+                                 tt_stream stream, bool key_major, int32_t E = 0, void* grad_ws = nullptr, size_t grad_ws_bytes = 0) {
   TT_CHECK_ARG(ctx && rows && side_K && sorted_src && unique_rows && seg_offsets && n_unique && workspace, "tt_dedup_plan_keyed: NULL argument");
   TT_CHECK_ARG(n_sides >= 1 && n_sides <= TT_MAX_SIDES, "tt_dedup_plan_keyed: n_sides=%d", n_sides);
   if (B < 1 || B > kKeyedB) {
@@ -1830,6 +1887,17 @@ static int dedup_plan_keyed_impl(tt_ctx* ctx, const int32_t* rows, const int32_t
   int32_t* ucount = reinterpret_cast<int32_t*>(w + 2 * align256(sizeof(int32_t) * (size_t)slots));
   int32_t* ubase = reinterpret_cast<int32_t*>(w + 2 * align256(sizeof(int32_t) * (size_t)slots) +
                                               align256(sizeof(int32_t) * (size_t)n_keys * kKeyedMaxParts));
+  int32_t* uend = reinterpret_cast<int32_t*>(w + 2 * align256(sizeof(int32_t) * (size_t)slots) +
+                                             2 * align256(sizeof(int32_t) * (size_t)n_keys * kKeyedMaxParts));
+  PlanLong pl{};
+  if (grad_ws) {                                         // the gradient reduction's own workspace layout: its lists are filled here
+    if (E < 1 || grad_ws_bytes < tt_embed_grad_workspace_bytes(slots, E)) {
+      tt_set_error("tt_dedup_plan_keyed_long: gradient workspace %zu < required %zu", grad_ws_bytes, tt_embed_grad_workspace_bytes(slots, E));
+      return TT_ERR_WORKSPACE;
+    }
+    const GradLayout gl = grad_layout(reinterpret_cast<char*>(grad_ws), slots, E);
+    pl = PlanLong{gl.ws.counters, gl.ws.long_row, gl.ws.long_base, gl.ws.chunk_lo, gl.ws.chunk_hi};
+  }
   // workgroups per key (TT_KEYED_PARTS: A/B runs): the sort's scatter, ranking and output phases split P ways, the load and
   // histogram phases are repeated by every share; small batches are launch-bound anyway
   const int parts_env = getenv("TT_KEYED_PARTS") ? atoi(getenv("TT_KEYED_PARTS")) : 0;      // (read per call: tests vary it)
@@ -1837,9 +1905,11 @@ static int dedup_plan_keyed_impl(tt_ctx* ctx, const int32_t* rows, const int32_t
   if (parts > kKeyedMaxParts) parts = kKeyedMaxParts;
   while (parts > 1 && (int64_t)n_keys * parts > (int64_t)ctx->num_cus) parts /= 2;     // a workgroup needs a CU of its own (144 KB of LDS)
   a.parts = parts;
-  keyed_sort_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(a, rows, sorted_src, uniq_stage, seg_stage, ucount, ubase, key_major);
+  keyed_sort_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(a, rows, sorted_src, uniq_stage, seg_stage, ucount, ubase, uend, key_major,
+                                                              pl.counters);
   TT_LAUNCH_CHECK();
-  keyed_compact_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(uniq_stage, seg_stage, ucount, ubase, n_keys * parts, slots, unique_rows, seg_offsets, n_unique);
+  keyed_compact_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(uniq_stage, seg_stage, ucount, ubase, uend, pl, n_keys * parts, slots,
+                                                                 unique_rows, seg_offsets, n_unique);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }
@@ -1849,6 +1919,14 @@ int tt_dedup_plan_keyed(tt_ctx* ctx, const int32_t* rows, const int32_t* side_K,
                         tt_stream stream) {
   return dedup_plan_keyed_impl(ctx, rows, side_K, n_sides, B, sorted_src, unique_rows, seg_offsets, n_unique, workspace, workspace_bytes,
                                stream, false);
+}
+
+int tt_dedup_plan_keyed_long(tt_ctx* ctx, const int32_t* rows, int32_t rows_key_major, const int32_t* side_K, int32_t n_sides, int64_t B,
+                             int32_t E, int32_t* sorted_src, int32_t* unique_rows, int32_t* seg_offsets, int32_t* n_unique,
+                             void* grad_workspace, size_t grad_workspace_bytes, void* workspace, size_t workspace_bytes, tt_stream stream) {
+  TT_CHECK_ARG(grad_workspace, "tt_dedup_plan_keyed_long: NULL gradient workspace");
+  return dedup_plan_keyed_impl(ctx, rows, side_K, n_sides, B, sorted_src, unique_rows, seg_offsets, n_unique, workspace, workspace_bytes,
+                               stream, rows_key_major != 0, E, grad_workspace, grad_workspace_bytes);
 }
 
 int tt_dedup_plan_keyed_km(tt_ctx* ctx, const int32_t* rows_km, const int32_t* side_K, int32_t n_sides, int64_t B, int32_t* sorted_src,
@@ -1869,7 +1947,8 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   // three launches fewer) when the caller knows no segment is long, e.g. the owner side of the row exchange, where a
   // row arrives at most once per rank.  Results do not depend on the flag.
   const bool all_short = (mode & TT_GRAD_SHORT_SEGMENTS) != 0;
-  mode &= ~TT_GRAD_SHORT_SEGMENTS;
+  const bool planned = (mode & TT_GRAD_PLANNED) != 0 && !all_short;      // the workspace holds the plan's long-row list and counters
+  mode &= ~(TT_GRAD_SHORT_SEGMENTS | TT_GRAD_PLANNED);
   TT_CHECK_ARG(mode >= TT_GRAD_SPARSE && mode <= TT_GRAD_DENSE_ACC, "tt_embed_grad_bwd: bad mode %d", mode);
   TT_CHECK_ARG(E >= 1 && B >= 0, "tt_embed_grad_bwd: bad E/B");
   if (M == 0) return TT_OK;
@@ -1900,7 +1979,9 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   const int dt = srcs[0].dtype;
   GradLayout gl = grad_layout(reinterpret_cast<char*>(workspace), M, E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (counters) {
+  if (planned) {
+    // counters and lists were written into THIS workspace by tt_dedup_plan_keyed_long: nothing to zero, nothing to register
+  } else if (counters) {
     gl.ws.counters = counters;      // caller-kept, zero on entry: the finish kernel re-zeroes them (one launch fewer per step)
   } else if (!all_short) {
     zero_words_kernel<<<1, 64, 0, st>>>(gl.ws.counters, 2);    // (a kernel, not a memset node: see graph notes in DESIGN.md)
@@ -1917,6 +1998,13 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   // the lane-group width when every lane of a group owns exactly one chunk (shared decode, see sum_range)
 #define TT_SEG_LAUNCH(V, D, G)                                                                                                  \
   do {                                                                                                                          \
+    if (planned) {                                                                                                              \
+      seg_reduce_chunk_kernel<V, D, G><<<g1 + g2, kThreads, 0, st>>>(a, sorted_src, seg_offsets, unique_rows, n_unique, mode,   \
+                                                                     out, gl.ws, LG, (uint32_t)g1);                             \
+      TT_LAUNCH_CHECK();                                                                                                        \
+      seg_long_finish_kernel<V><<<g3, kThreads, 0, st>>>(E, a.C, seg_offsets, unique_rows, mode, out, gl.ws, LG);               \
+      break;                                                                                                                    \
+    }                                                                                                                           \
     seg_reduce_kernel<V, D, G><<<g1, kThreads, 0, st>>>(a, sorted_src, seg_offsets, unique_rows, n_unique, mode, out, gl.ws, LG, \
                                                         all_short);                                                             \
     TT_LAUNCH_CHECK();                                                                                                          \

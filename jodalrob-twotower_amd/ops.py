@@ -153,6 +153,7 @@ class DedupPlan:
     M: int
     keep: object = None           # tensors that must outlive the plan's kernels
     stream: object = None         # stream the plan was built on (joined before first use)
+    grad_ws: object = None        # (uint8 workspace, E): the gradient reduction's workspace with the long-row list already in it
 
 
 def dedup_plan(rows: torch.Tensor, table_rows: int) -> DedupPlan:
@@ -188,9 +189,11 @@ def dedup_plan_runs(rows: torch.Tensor, G: int, C: int, row_limit: int = 0) -> D
 KEYED_MAX_B = 8192
 
 
-def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int, key_major: bool = False) -> DedupPlan:
+def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int, key_major: bool = False, E: int = 0) -> DedupPlan:
     """Plan for slot rows straight from embed_lookup (slot = side_base + b*K + k): per-key LDS sorts, 2 launches.
-    key_major: `rows` is batch_ingest's [key][sample] array instead (rows[side_base + k*B + b]); same plan."""
+    key_major: `rows` is batch_ingest's [key][sample] array instead (rows[side_base + k*B + b]); same plan.
+    E > 0: the plan also prepares embed_grad's long-row list for rows of E floats (tt_dedup_plan_keyed_long): its own gradient
+    workspace travels with the plan, and embed_grad then runs its row and chunk passes as one launch."""
     dev, M = rows.device, rows.numel()
     assert M == B * sum(side_K)
     buf = torch.empty(3 * M + 2, dtype=torch.int32, device=dev)
@@ -199,6 +202,14 @@ def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int, key_majo
     nk = sum(side_K)
     ws = L.workspace(dev, lib.tt_dedup_keyed_workspace_bytes(M, nk))
     ks = (L.i32 * len(side_K))(*side_K)
+    if E > 0 and __import__("os").environ.get("TT_GRAD_PLANNED", "1") != "0":
+        gws = torch.empty(lib.tt_embed_grad_workspace_bytes(M, E), dtype=torch.uint8, device=dev)
+        with _timed("tt_dedup_plan_keyed"):
+            L.check(lib.tt_dedup_plan_keyed_long(L.ctx(dev), L.ptr(rows), int(key_major), ks, len(side_K), B, E, L.ptr(plan.sorted_src),
+                                                 L.ptr(plan.unique_rows), L.ptr(plan.seg_offsets), L.ptr(plan.n_unique), L.ptr(gws),
+                                                 gws.numel(), L.ptr(ws), ws.numel(), L.stream(dev)), "tt_dedup_plan_keyed_long")
+        plan.grad_ws = (gws, E)
+        return plan
     fn = lib.tt_dedup_plan_keyed_km if key_major else lib.tt_dedup_plan_keyed
     with _timed("tt_dedup_plan_keyed"):
         L.check(fn(L.ctx(dev), L.ptr(rows), ks, len(side_K), B, L.ptr(plan.sorted_src), L.ptr(plan.unique_rows),
@@ -221,7 +232,11 @@ def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int
         arr[i] = L.GradSrc(L.ptr(d), d.stride(0), K, _dt(d))
     lib = L.load()
     nb = lib.tt_embed_grad_workspace_bytes(plan.M, E)
-    ws = L.workspace(dev, nb)
+    if plan.grad_ws is not None and plan.grad_ws[1] == E and not short_segments:
+        ws = plan.grad_ws[0]                                # the plan left the long-row list in its own workspace
+        mode |= L.TT_GRAD_PLANNED
+    else:
+        ws = L.workspace(dev, nb)
     with _timed("tt_embed_grad_bwd"):
         L.check(lib.tt_embed_grad_bwd(L.ctx(dev), arr, len(srcs), B, E, L.ptr(plan.sorted_src), L.ptr(plan.seg_offsets),
                                       L.ptr(plan.unique_rows), L.ptr(plan.n_unique), plan.M, mode, L.ptr(out),

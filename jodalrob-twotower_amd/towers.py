@@ -364,7 +364,8 @@ class _TowersFn(torch.autograd.Function):
                     with torch.cuda.stream(ds):
                         Bs = psides[0].B
                         if 0 < Bs <= ops.KEYED_MAX_B:       # per-key LDS sorts (2 launches)
-                            plan = ops.dedup_plan_keyed(rows, [len(q.tower.categorical_embedder.keys) for q in psides], Bs, key_major)
+                            plan = ops.dedup_plan_keyed(rows, [len(q.tower.categorical_embedder.keys) for q in psides], Bs, key_major,
+                                                        E=int(store.E))
                         else:
                             plan = ops.dedup_plan(rows, store.rows)
                     plan.keep, plan.stream = rows, (None if inline else ds)   # keep the sort input alive until it has run

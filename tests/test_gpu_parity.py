@@ -596,7 +596,7 @@ def test_graph_ingest_key_major_plan(tt, manifest, monkeypatch):
         opt = FusedAdam.for_task(task, lr=1e-2)
         tb = [to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]) for b in batches]
         seen, plain = [], _ops.dedup_plan_keyed
-        monkeypatch.setattr(_ops, "dedup_plan_keyed", lambda rows, ks, B_, key_major=False: (seen.append(key_major), plain(rows, ks, B_, key_major))[1])
+        monkeypatch.setattr(_ops, "dedup_plan_keyed", lambda rows, ks, B_, key_major=False, E=0: (seen.append(key_major), plain(rows, ks, B_, key_major, E))[1])
         gs = GraphedTrainStep(task, opt, tb[0], warmup=2)
         monkeypatch.setattr(_ops, "dedup_plan_keyed", plain)
         store = task.two_tower_model.embedding_store
@@ -617,6 +617,39 @@ def test_graph_ingest_key_major_plan(tt, manifest, monkeypatch):
     assert finals["0"][0] == finals["1"][0] and len(set(finals["0"][0])) > 1
     for k, v in finals["0"][1].items():
         assert np.array_equal(v, finals["1"][1][k]), k
+
+
+@pytest.mark.parametrize("B,grad", [(2048, "sparse"), (777, "sparse"), (8192, "dense")])
+def test_planned_long_rows_equal_unplanned(tt, manifest, schema_real, monkeypatch, B, grad):
+    """The long-row list of the gradient reduction built by the plan's compaction (tt_dedup_plan_keyed_long: row and chunk passes in
+    ONE launch) == the list the reduction registers itself (TT_GRAD_PLANNED=0), bit for bit: same chunks, same order.  Real 32 + 6
+    key schema (17 two-row keys: rows of thousands of slots) with out-of-range ids (clamping piles slots onto the border rows)."""
+    cfg = dict(manifest["cases"]["real_schema"])
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    cfg.update(keys_n=kn, keys_c=kc)
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 610, oob=True)
+    outs, state = {}, None
+    for planned in ("0", "1"):
+        monkeypatch.setenv("TT_GRAD_PLANNED", planned)
+        task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", embedding_grad=grad, mlp_dtype="bf16", score_dtype="bf16")
+        if state is None:
+            state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 611)
+        load_state(task, state)
+        task.train()
+        res = task(to_batch(tt, b, kn, kc), return_metrics=True)
+        res["loss"].backward()
+        store = task.two_tower_model.embedding_store
+        store = store() if callable(store) else store
+        if grad == "sparse":
+            plan, rows = store.sparse_grad
+            U = int(plan.n_unique.item())
+            assert (plan.grad_ws is not None) == (planned == "1")
+            outs[planned] = (plan.unique_rows[:U].cpu().numpy(), rows[:U].cpu().numpy())
+        else:
+            outs[planned] = (np.zeros(1), store.grad.cpu().numpy())
+    assert np.array_equal(outs["0"][0], outs["1"][0]) and np.array_equal(outs["0"][1], outs["1"][1])
+    assert np.abs(outs["1"][1]).sum() > 0
 
 
 def test_bf16_mlp_close_to_fp32(tt, manifest, schema_real):
