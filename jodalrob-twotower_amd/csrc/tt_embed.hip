@@ -872,6 +872,7 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_compact_kernel(const int3
 // (16 = one trip per chunk was tried: at the bench's 6,200 rows of 17-64 slots the two same-address atomics per long
 //  row and a workgroup-per-row finish cost more than the serial trips save: 25 + 8 + 11 us against 14 + 9 + 5.)
 constexpr int kLongSeg = 64;
+static_assert(kPlanLongSeg == kLongSeg, "the plan's compaction and the reduction must cut long rows into the same chunks");
 
 struct GradWs {
   int32_t* counters;     // [0] chunks allocated, [1] long rows
