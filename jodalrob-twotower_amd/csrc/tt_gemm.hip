@@ -471,29 +471,36 @@ __device__ __forceinline__ void gemm_fast_tile(const GemmArgs& g, int split, int
     // this split's G_z tile [64 h of block bx, 64 columns] -> slab of P = W[block bx, 0:h0]^T . G_z  [h0, 64 columns]: summed over
     // the splits AND the H / 64 row blocks by the slab reduction, that is the projection's weight gradient.  Both factors go through LDS as
     // bf16 ([column][h] and [i][h], 72-element rows), 64 rows of i at a time
-    constexpr int LP = 72;
-    __bf16* Gt = &As[0][0];                 // 64 x 72 bf16 = 9216 B <= the two A stage buffers
+    static_assert(LDT1 == 72 && 64 * LDT1 <= 2 * BM * LDS16, "a 64-deep [k][x] tile fits the two stage buffers of an operand");
+    __bf16* Gt = &As[0][0];                 // [h][column]: 64 x 72 bf16 = 9216 B <= the two A stage buffers
     __bf16* Gl = static_cast<BackSmem&>(sm).lo;
-    __bf16* Wt = &Bs[0][0];
+    __bf16* Wt = &Bs[0][0];                 // [h][i]
     __syncthreads();                        // every wave is done with the stage buffers
     // G_z enters the second product as hi + lo (two bf16 terms: 16 significant bits): a split's partial sums can be much
-    // larger than the total they cancel to, and rounding them to 8 bits cost 2e-3 of the finished gradient
+    // larger than the total they cancel to, and rounding them to 8 bits cost 2e-3 of the finished gradient.  Both factors of
+    // that product have the contraction index h as their ROW index in memory (W[h][i], G_z[h][column]): they are staged as
+    // they lie -- k-major, contiguous stores -- and the fragments come out of transposing LDS reads (fast_frag<1>); the first
+    // version transposed both on the way in with 2-byte stores (W: 16 per thread and 64-column block, 4-way conflicts and worse)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int at = (wc * 32 + li) * LP + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int at = (wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDT1 + wc * 32 + li;
       const __bf16 hi = (__bf16)acc[r];
       Gt[at] = hi;
       Gl[at] = (__bf16)(acc[r] - (float)hi);
     }
     for (int i0 = 0; i0 < g.proj_h0; i0 += 64) {
-      {                                     // W[h][i0 .. i0 + 63] -> Wt[i][h]: thread = (h = t >> 2, 16 columns)
+      {                                     // W[h][i0 .. i0 + 63] -> Wt[h][i]: thread = (h = t >> 2, 16 columns), two 16-byte stores
         const int h = t >> 2, iq = (t & 3) * 16;
         const float* src = g.proj_w + (int64_t)(m0 + h) * g.proj_ldw + i0 + iq;
+        float4 w[4];
 #pragma unroll
-        for (int v4 = 0; v4 < 4; ++v4) {
-          const float4 w = *reinterpret_cast<const float4*>(src + 4 * v4);
-          Wt[(iq + 4 * v4) * LP + h] = (__bf16)w.x; Wt[(iq + 4 * v4 + 1) * LP + h] = (__bf16)w.y;
-          Wt[(iq + 4 * v4 + 2) * LP + h] = (__bf16)w.z; Wt[(iq + 4 * v4 + 3) * LP + h] = (__bf16)w.w;
+        for (int v4 = 0; v4 < 4; ++v4) w[v4] = *reinterpret_cast<const float4*>(src + 4 * v4);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          bf16x8g v;
+          v[0] = (__bf16)w[2 * hf].x; v[1] = (__bf16)w[2 * hf].y; v[2] = (__bf16)w[2 * hf].z; v[3] = (__bf16)w[2 * hf].w;
+          v[4] = (__bf16)w[2 * hf + 1].x; v[5] = (__bf16)w[2 * hf + 1].y; v[6] = (__bf16)w[2 * hf + 1].z; v[7] = (__bf16)w[2 * hf + 1].w;
+          *reinterpret_cast<bf16x8g*>(Wt + h * LDT1 + iq + 8 * hf) = v;
         }
       }
       __syncthreads();
@@ -502,9 +509,9 @@ __device__ __forceinline__ void gemm_fast_tile(const GemmArgs& g, int split, int
       for (int i = 0; i < 16; ++i) o[i] = 0.f;
 #pragma unroll
       for (int s2 = 0; s2 < 4; ++s2) {
-        const bf16x8g av = *reinterpret_cast<const bf16x8g*>(Wt + (wr * 32 + li) * LP + 16 * s2 + 8 * lh);
-        const bf16x8g bv2 = *reinterpret_cast<const bf16x8g*>(Gt + (wc * 32 + li) * LP + 16 * s2 + 8 * lh);
-        const bf16x8g bv3 = *reinterpret_cast<const bf16x8g*>(Gl + (wc * 32 + li) * LP + 16 * s2 + 8 * lh);
+        const bf16x8g av = fast_frag<1>(Wt, wr, s2, lane);
+        const bf16x8g bv2 = fast_frag<1>(Gt, wc, s2, lane);
+        const bf16x8g bv3 = fast_frag<1>(Gl, wc, s2, lane);
         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv3, o, 0, 0, 0);
         o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv2, o, 0, 0, 0);
       }
