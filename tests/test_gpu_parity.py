@@ -722,6 +722,71 @@ def test_dedup_plan_keyed_equals_general(tt, monkeypatch, B, Ks, vocabs, parts):
     assert torch.equal(pk.unique_rows[:U], pg.unique_rows[:U]) and torch.equal(pk.seg_offsets[:U + 1], pg.seg_offsets[:U + 1])
 
 
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_dedup_plan_keyed_random_shapes(tt, monkeypatch, seed):
+    """Randomised shapes for the per-key plan: batch, key counts, vocabularies (two-row keys to millions of rows), id
+    distributions (uniform, Zipf-like, constant), share counts, key-major or slot-major rows, with or without the gradient
+    reduction's long-row list -- always the order numpy's stable argsort gives, and a chunk list that tiles every long row."""
+    from jodalrob_twotower_amd import ops
+    rng = np.random.default_rng(1000 + seed)
+    B = int(rng.choice([1, 63, 64, 65, 700, 2047, 2048, 3000, 8191, 8192]))
+    Ks = [int(k) for k in rng.integers(1, 9, size=int(rng.integers(1, 4)))]
+    parts = int(rng.choice([0, 1, 2, 3, 4, 6, 8]))
+    key_major = bool(rng.integers(0, 2))
+    E = int(rng.choice([0, 16, 32]))
+    if parts:
+        monkeypatch.setenv("TT_KEYED_PARTS", str(parts))
+    else:
+        monkeypatch.delenv("TT_KEYED_PARTS", raising=False)
+    sides_sm, sides_km, off = [], [], 0
+    for K in Ks:
+        v = rng.choice([2, 3, 17, 300, 4096, 4097, 70000, 1_000_000], size=K)
+        offs = off + np.concatenate([[0], np.cumsum(v)[:-1]])
+        cols = []
+        for vk in v:
+            mode = rng.integers(0, 3)
+            cols.append(rng.integers(0, vk, B) if mode == 0 else np.minimum(rng.zipf(1.3, B) - 1, vk - 1) if mode == 1
+                        else np.full(B, int(rng.integers(0, vk))))
+        ids = np.stack(cols, axis=1) + offs[None, :]
+        sides_sm.append(ids.reshape(-1))
+        sides_km.append(ids.T.reshape(-1))
+        off += int(v.sum())
+    rows = np.concatenate(sides_sm).astype(np.int32)
+    t_in = torch.from_numpy(np.concatenate(sides_km).astype(np.int32) if key_major else rows).to(DEV)
+    pk = ops.dedup_plan_keyed(t_in, Ks, B, key_major, E=E)
+    order = np.argsort(rows, kind="stable")
+    assert np.array_equal(pk.sorted_src.cpu().numpy(), order.astype(np.int32)), (B, Ks, parts, key_major, E)
+    srt = rows[order]
+    heads = np.flatnonzero(np.concatenate([[True], srt[1:] != srt[:-1]]))
+    U = int(pk.n_unique.item())
+    assert U == len(heads)
+    assert np.array_equal(pk.unique_rows[:U].cpu().numpy(), srt[heads])
+    seg = pk.seg_offsets[:U + 1].cpu().numpy()
+    assert np.array_equal(seg, np.concatenate([heads, [len(rows)]]))
+    if E and pk.grad_ws is not None:                      # the long-row list: every row longer than 64 slots, tiled by 64-slot chunks
+        ws = pk.grad_ws[0].cpu().numpy()                  # layout: grad_layout() in csrc/tt_embed.hip (256-byte aligned regions)
+        M = len(rows)
+        al = lambda n: (n + 255) // 256 * 256
+        max_long = M // 64 + 1
+        max_chunks = M // 64 + max_long + 1
+        o = 0
+        counters = ws[o:o + 12].view(np.int32); o += al(12)
+        long_row = ws[o:o + 4 * max_long].view(np.int32); o += al(4 * max_long)
+        long_base = ws[o:o + 4 * max_long].view(np.int32); o += al(4 * max_long)
+        chunk_lo = ws[o:o + 4 * max_chunks].view(np.int32); o += al(4 * max_chunks)
+        chunk_hi = ws[o:o + 4 * max_chunks].view(np.int32)
+        lens = np.diff(seg)
+        want_long = set(np.flatnonzero(lens > 64).tolist())
+        n_long, n_ch = int(counters[1]), int(counters[0])
+        assert set(long_row[:n_long].tolist()) == want_long and n_long == len(want_long)
+        assert n_ch == int(sum((lens[u] + 63) // 64 for u in want_long))
+        for li in range(n_long):
+            u, cb = int(long_row[li]), int(long_base[li])
+            nch = (lens[u] + 63) // 64
+            assert np.array_equal(chunk_lo[cb:cb + nch], seg[u] + 64 * np.arange(nch))
+            assert np.array_equal(chunk_hi[cb:cb + nch], np.minimum(seg[u + 1], seg[u] + 64 * (np.arange(nch) + 1)))
+
+
 def test_bf16_tower_input_is_bit_identical(tt, manifest, schema_real, monkeypatch):
     """mlp_dtype='bf16' with the tower input x stored in bf16 (default) == the same mode with x in f32: the GEMMs round x
     to bf16 on the way into LDS either way, so loss and every gradient agree to the last bit; a bf16 d_x (opt-in) only
