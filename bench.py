@@ -229,6 +229,9 @@ class Leg:
         dt = time.perf_counter() - t0
         ops.set_timer(None)
         self.lookup_us = self.profile.durations_us() if self.profile is not None else []
+        if self.profile is not None and os.environ.get("TT_LOOKUP_WG_DUMP"):     # per-workgroup stamps of the last launches (analysis)
+            import numpy as _np
+            _np.save(os.environ["TT_LOOKUP_WG_DUMP"], self.profile.ring.cpu().numpy())
         self.dispatch_us = lookup_dispatch_overhead_us(self.task, self.pool, ctx["dev"], self.profile) if self.profile is not None else None
         if self.profile is not None:
             self.profile.close()
