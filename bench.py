@@ -432,6 +432,9 @@ def bench_single(args, ctx, sharded):
     if not args.no_h2d and not sharded:
         try:
             out.update(h2d_leg(args, leg, ctx))
+            if args.mlp_dtype == "bf16":                      # the same leg with bf16 dense features on the host side (never `value`)
+                import torch as _torch
+                out.update(h2d_leg(args, leg, ctx, dense_dtype=_torch.bfloat16, key="value_with_h2d_bf16_dense"))
         except Exception as e:
             out["value_with_h2d"] = None
             out["h2d_error"] = f"{type(e).__name__}: {e}"
@@ -619,16 +622,19 @@ def score_mfma_leg(args, dev, B, D, reps: int = 8):
             "algorithmic_flops_per_iteration": flops, "flop_count": "2 B^2 D forward + 4 B^2 D backward (SURVEY 8d); recomputation not credited"}
 
 
-def h2d_leg(args, leg, ctx):
+def h2d_leg(args, leg, ctx, dense_dtype=None, key="value_with_h2d"):
     """The same step fed from PINNED HOST batches (what the reference pays every step: scripts/train.py:261-273, 315-316):
     ids + dense features cross PCIe into one of two device staging sets on a side stream while the previous step computes;
     the step waits for its batch's copy event.  Returns value_with_h2d = pairs/s of K such steps."""
     import torch
     dev, B = ctx["dev"], leg.B
-    host = [{s: {"dense": b[s]["dense"].cpu().pin_memory(), "ids": b[s]["kjt"].values().cpu().pin_memory()} for s in ("notice", "company")}
+    # dense_dtype=torch.bfloat16: the loader keeps the dense features in bf16 (what the projection GEMM of the bf16 MLP rounds them
+    # to anyway: identical results) -- half of the 12.6 MB of dense features per step on the PCIe link
+    cast = (lambda t: t.to(dense_dtype)) if dense_dtype is not None else (lambda t: t)
+    host = [{s: {"dense": cast(b[s]["dense"].cpu()).pin_memory(), "ids": b[s]["kjt"].values().cpu().pin_memory()} for s in ("notice", "company")}
             for b in leg.pool]
     from jodalrob_twotower_amd.kjt import KeyedJaggedTensor
-    stage = [{s: {"dense": torch.empty_like(leg.pool[0][s]["dense"]),
+    stage = [{s: {"dense": torch.empty_like(cast(leg.pool[0][s]["dense"])),
                   "kjt": KeyedJaggedTensor(leg.pool[0][s]["kjt"].keys(), torch.empty_like(leg.pool[0][s]["kjt"].values()))}
               for s in ("notice", "company")} for _ in range(2)]
     copy_stream = torch.cuda.Stream(device=dev)
@@ -666,9 +672,9 @@ def h2d_leg(args, leg, ctx):
         freed[i % 2].record(main)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    nbytes = sum(h[s]["dense"].numel() * 4 + h[s]["ids"].numel() * 8 for h in host[:1] for s in ("notice", "company"))
-    return {"value_with_h2d": B * K / dt, "ms_per_step_with_h2d": dt / K * 1e3,
-            "h2d": {"bytes_per_step": nbytes, "how": "pinned host batches -> two device staging sets on a copy stream, the step waits for its batch's copy event "
+    nbytes = sum(h[s]["dense"].numel() * h[s]["dense"].element_size() + h[s]["ids"].numel() * 8 for h in host[:1] for s in ("notice", "company"))
+    return {key: B * K / dt, "ms_per_step" + key[5:]: dt / K * 1e3,
+            key[11:]: {"bytes_per_step": nbytes, "how": "pinned host batches -> two device staging sets on a copy stream, the step waits for its batch's copy event "
                                                      "(the copy of step i+1 overlaps the compute of step i)"}}
 
 

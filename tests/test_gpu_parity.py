@@ -787,6 +787,34 @@ def test_dedup_plan_keyed_random_shapes(tt, monkeypatch, seed):
             assert np.array_equal(chunk_hi[cb:cb + nch], np.minimum(seg[u + 1], seg[u] + 64 * (np.arange(nch) + 1)))
 
 
+def test_bf16_dense_features_from_the_loader_are_bit_identical(tt, manifest, schema_real):
+    """mlp_dtype='bf16': a loader that keeps the dense features in bf16 (half the PCIe bytes of a host-fed step: bench.py's
+    value_with_h2d_bf16_dense) changes nothing -- the projection GEMM rounds them to bf16 on the way into LDS anyway: loss and
+    every gradient equal to the last bit."""
+    cfg = dict(manifest["cases"]["real_schema"])
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    cfg.update(keys_n=kn, keys_c=kc)
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    b = synth_batch_numpy(320, vn, vc, cfg["din_n"], cfg["din_c"], 620, oob=False)
+    outs, state = [], None
+    for as_bf16 in (False, True):
+        task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", mlp_dtype="bf16", score_dtype="bf16", dropout_rate=0.0)
+        if state is None:
+            state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 621)
+        load_state(task, state)
+        task.train()
+        batch = to_batch(tt, b, kn, kc)
+        if as_bf16:
+            for s_ in ("notice", "company"):
+                batch[s_]["dense"] = batch[s_]["dense"].to(torch.bfloat16)
+        res = task(batch, return_metrics=True)
+        res["loss"].backward()
+        outs.append((res["loss"].item(), {n: p.grad.cpu().numpy() for n, p in task.named_parameters()}))
+    assert outs[0][0] == outs[1][0]
+    for k, g in outs[0][1].items():
+        assert np.array_equal(outs[1][1][k], g), k
+
+
 def test_bf16_tower_input_is_bit_identical(tt, manifest, schema_real, monkeypatch):
     """mlp_dtype='bf16' with the tower input x stored in bf16 (default) == the same mode with x in f32: the GEMMs round x
     to bf16 on the way into LDS either way, so loss and every gradient agree to the last bit; a bf16 d_x (opt-in) only
