@@ -176,9 +176,10 @@ class GraphedTrainStep:
         if __import__("os").environ.get("TT_GRAPH_SKIP_PUSH"):       # fault hunting
             if pairs:
                 ops.copy_multi(pairs)
-        elif self._ingest is not None and (batch is not None or self._ingest[0].rows_km_for(self._ingest[3]) is None):
-            # ONE launch: the four batch buffers + the scalars + the key-major rows of this batch's ids (also when nobody handed a
-            # batch over but the static ids were written to since the last hand-over)
+        elif self._ingest is not None:
+            # ONE launch: the four batch buffers + the scalars + the key-major rows of this step's ids -- also when nobody handed a
+            # batch over: the static id buffers may have been written to by means no version counter sees (`.data`), and the
+            # replayed plan sorts whatever rows_km holds
             self._run_ingest(pairs + [self._fill_slot()], src_ids if batch is not None else None)
             self._mark_slot()
         else:

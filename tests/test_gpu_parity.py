@@ -611,7 +611,9 @@ def test_graph_ingest_key_major_plan(tt, manifest, monkeypatch):
             gs.static[s]["dense"].copy_(tb[4][s]["dense"])
             gs.static[s]["kjt"].values().copy_(tb[4][s]["kjt"].values())
         losses.append(gs.step(None)["loss"].item())                       # ... and replays on "whatever the static buffers hold"
-        losses.append(gs.step(None)["loss"].item())                       # unchanged buffers: no new hand-over needed
+        with torch.no_grad():                                             # a write no version counter sees
+            gs.static["notice"]["kjt"].values().data.copy_(tb[2]["notice"]["kjt"].values())
+        losses.append(gs.step(None)["loss"].item())
         finals[ingest] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in task.state_dict().items()})
         gs.close()
     assert finals["0"][0] == finals["1"][0] and len(set(finals["0"][0])) > 1
