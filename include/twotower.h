@@ -146,6 +146,10 @@ int tt_dedup_plan_keyed_long(tt_ctx* ctx, const int32_t* rows, int32_t rows_key_
 #define TT_GRAD_DENSE_ACC 2
 #define TT_GRAD_SHORT_SEGMENTS 0x100
 #define TT_GRAD_PLANNED 0x200 /* the workspace was handed to tt_dedup_plan_keyed_long, which left the long-row list in it */
+/* with TT_GRAD_PLANNED | TT_GRAD_SPARSE: leave the long rows' chunk sums unadded (their rows of `out` are not written) -- the
+ * caller completes `out` on the same workspace with tt_adam_fused_step_finish (inside the optimiser's launch: one launch
+ * fewer in the step's dependent chain) or tt_embed_grad_finish, before anything else reads those rows */
+#define TT_GRAD_DEFER_FINISH 0x400
 
 typedef struct tt_grad_src {
   const void* d_out; /* gradient w.r.t. the lookup output of this side */
@@ -203,6 +207,18 @@ int tt_adam_fused_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_ten
                        int64_t table_rows, int32_t E, const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique, int64_t M,
                        int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
                        const float* hparams_dev, tt_stream stream);
+
+/* tt_adam_fused_step for a gradient whose long-row finish was deferred (TT_GRAD_DEFER_FINISH): extra workgroups add each long
+ * row's chunk partials (same order as the reduction's own finish: bit-identical), store the sum into grad_rows and update that
+ * table row; grad_rows is complete when the launch has run. */
+int tt_adam_fused_step_finish(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, float* table, float* m, float* v,
+                              int64_t table_rows, int32_t E, const int32_t* unique_rows, float* grad_rows, const int32_t* n_unique,
+                              int64_t M, const int32_t* seg_offsets, void* grad_workspace, size_t grad_workspace_bytes,
+                              int64_t step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              const float* hparams_dev, tt_stream stream);
+/* The deferred finish on its own (sparse mode: out = grad_rows [M, E]) -- for a consumer other than the fused optimiser. */
+int tt_embed_grad_finish(tt_ctx* ctx, int32_t E, const int32_t* seg_offsets, int64_t M, float* out, void* workspace,
+                         size_t workspace_bytes, tt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tower MLP -- replaces BaseTower.forward after the lookup (src/towers/tower/base_tower.py:133-145)

@@ -23,6 +23,7 @@ TT_TOWER_UNFUSED_FRONT = 2
 TT_TOWER_UNFUSED_BACK = 4
 TT_GRAD_SHORT_SEGMENTS = 0x100
 TT_GRAD_PLANNED = 0x200
+TT_GRAD_DEFER_FINISH = 0x400
 
 vp = C.c_void_p
 i32, i64, f32, u64, sz = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -96,6 +97,9 @@ SIGNATURES = {
     "tt_sparse_adam_step": (C.c_int, [vp, vp, vp, vp, i64, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32, f32, vp, vp]),
     "tt_adam_fused_step": (C.c_int, [vp, C.POINTER(AdamTensor), i32, vp, vp, vp, i64, i32, vp, vp, vp, i64, i64, f32, f32, f32, f32,
                                      f32, vp, vp]),
+    "tt_adam_fused_step_finish": (C.c_int, [vp, C.POINTER(AdamTensor), i32, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp, sz, i64, f32,
+                                            f32, f32, f32, f32, vp, vp]),
+    "tt_embed_grad_finish": (C.c_int, [vp, i32, vp, i64, vp, vp, sz, vp]),
     "tt_tower_workspace_bytes": (sz, [C.POINTER(TowerParams), i64]),
     "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, vp, sz, vp]),
     "tt_tower_mlp_bwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), vp, C.POINTER(TowerGrads), i64, i32,

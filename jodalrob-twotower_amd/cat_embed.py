@@ -35,6 +35,7 @@ class EmbeddingStore:
         self.weight: Optional[torch.Tensor] = None      # [R, E] f32
         self.grad: Optional[torch.Tensor] = None        # dense mode: [R, E]
         self.sparse_grad = None                         # sparse mode: (DedupPlan, grad_rows [M, E])
+        self.defer_long_finish = False                  # GraphedTrainStep: the optimiser's launch finishes the long rows
         self.members: List["CategoricalEmbedder"] = []
         self.version = 0
         self._grad_counters = None                      # 4 int32 words the gradient reduction keeps zero between calls
@@ -120,7 +121,8 @@ class EmbeddingStore:
         """srcs: [(d_out view [B, K*E], K)] in slot order of `plan`."""
         if self.grad_mode == "sparse":
             grad_rows = torch.empty((max(plan.M, 1), self.E), dtype=torch.float32, device=self.device)
-            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_SPARSE, grad_rows, short_segments, self.grad_counters())
+            ops.embed_grad(plan, srcs, B, self.E, ops.TT_GRAD_SPARSE, grad_rows, short_segments, self.grad_counters(),
+                           defer_finish=self.defer_long_finish)
             self.sparse_grad = (plan, grad_rows)
             return
         params = self.optim_parameters()

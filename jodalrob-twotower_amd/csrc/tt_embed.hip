@@ -1162,18 +1162,13 @@ __global__ __launch_bounds__(kThreads) void seg_reduce_chunk_kernel(SideSet a, c
 // chunk order), the group sums are added in group order through LDS -- one or two trips however long the row is
 // (a binary key at B = 8192 has ~4096-slot rows = 256 partials)
 constexpr int kFinishMaxFloats = 4096;     // (kThreads / LG) * E floats of LDS
-template <int VEC>
-__global__ __launch_bounds__(kThreads) void seg_long_finish_kernel(int32_t E, uint32_t C, const int32_t* __restrict__ seg,
-                                                                  const int32_t* __restrict__ unique_rows, int32_t mode,
-                                                                  float* __restrict__ out, GradWs ws, uint32_t LG) {
-  __shared__ float part[kFinishMaxFloats];
-  // counters[2] = the long-row count as seg_chunk_kernel saw it: nobody reads the live words [0] / [1] any more, so one
-  // thread zeroes them here for the next call -- a caller that keeps the words between calls needs no zeroing launch
-  // (a "last workgroup done" atomic instead cost 35 us: 2048 same-address atomics with return serialise at ~17 ns each)
-  const uint32_t nlong = (uint32_t)ws.counters[2];
-  if (blockIdx.x == 0 && threadIdx.x == 0) { ws.counters[0] = 0; ws.counters[1] = 0; }
+// emit(u, col, total): called once per (long row, column) by the thread that added the group sums
+template <int VEC, typename EMIT>
+__device__ __forceinline__ void long_rows_finish(int32_t E, uint32_t C, const int32_t* __restrict__ seg, const GradWs& ws, uint32_t LG,
+                                                 uint32_t bid, uint32_t nblocks, float* __restrict__ part, EMIT&& emit) {
+  const uint32_t nlong = (uint32_t)ws.counters[2];        // the long-row count as seg_chunk_body saw it
   const uint32_t grp = threadIdx.x / LG, lig = threadIdx.x % LG, ngrp = blockDim.x / LG;
-  for (uint32_t li = blockIdx.x; li < nlong; li += gridDim.x) {
+  for (uint32_t li = bid; li < nlong; li += nblocks) {
     const int32_t u = ws.long_row[li], base = ws.long_base[li];
     const int32_t nch = (seg[u + 1] - seg[u] + kLongSeg - 1) / kLongSeg;
     const int32_t per = (nch + (int32_t)ngrp - 1) / (int32_t)ngrp;
@@ -1202,15 +1197,29 @@ __global__ __launch_bounds__(kThreads) void seg_long_finish_kernel(int32_t E, ui
       for (int e = 0; e < VEC; ++e) part[grp * E + chunk * VEC + e] = acc.v[e];
     }
     __syncthreads();
-    const int64_t orow = mode == TT_GRAD_SPARSE ? (int64_t)u : (int64_t)unique_rows[u];
     for (int32_t col = threadIdx.x; col < E; col += blockDim.x) {
       float tot = 0.f;
       for (uint32_t g = 0; g < ngrp; ++g) tot += part[g * E + col];
-      float* o = out + orow * E + col;
-      *o = mode == TT_GRAD_DENSE_ACC ? *o + tot : tot;
+      emit(u, col, tot);
     }
     __syncthreads();
   }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(kThreads) void seg_long_finish_kernel(int32_t E, uint32_t C, const int32_t* __restrict__ seg,
+                                                                  const int32_t* __restrict__ unique_rows, int32_t mode,
+                                                                  float* __restrict__ out, GradWs ws, uint32_t LG) {
+  __shared__ float part[kFinishMaxFloats];
+  // nobody reads the live words [0] / [1] any more (counters[2] holds the snapshot), so one thread zeroes them here for the
+  // next call -- a caller that keeps the words between calls needs no zeroing launch
+  // (a "last workgroup done" atomic instead cost 35 us: 2048 same-address atomics with return serialise at ~17 ns each)
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ws.counters[0] = 0; ws.counters[1] = 0; }
+  long_rows_finish<VEC>(E, C, seg, ws, LG, blockIdx.x, gridDim.x, part, [&](int32_t u, int32_t col, float tot) {
+    const int64_t orow = mode == TT_GRAD_SPARSE ? (int64_t)u : (int64_t)unique_rows[u];
+    float* o = out + orow * E + col;
+    *o = mode == TT_GRAD_DENSE_ACC ? *o + tot : tot;
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1230,11 +1239,13 @@ __device__ __forceinline__ AdamK adam_resolve(const AdamK& k) {
 }
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamK& k) {
-  g = k.wd != 0.f ? g + k.wd * p : g;
-  m = k.b1 * m + (1.f - k.b1) * g;
-  v = k.b2 * v + (1.f - k.b2) * g * g;
-  const float denom = sqrtf(v) * k.inv_sqrt_bc2 + k.eps;
-  p -= k.lr_over_bc1 * (m / denom);
+  // explicit fused multiply-adds: left to the compiler, the contraction of a * b + c * d differs from one inlining context
+  // to the next (the float4 row path and the scalar long-row path of adam_fused_kernel disagreed in the last bit)
+  g = k.wd != 0.f ? __builtin_fmaf(k.wd, p, g) : g;
+  m = __builtin_fmaf(k.b1, m, (1.f - k.b1) * g);
+  v = __builtin_fmaf(k.b2, v, (1.f - k.b2) * g * g);
+  const float denom = __builtin_fmaf(sqrtf(v), k.inv_sqrt_bc2, k.eps);
+  p = __builtin_fmaf(-k.lr_over_bc1, m / denom, p);
 }
 
 __global__ __launch_bounds__(kThreads) void adam_dense_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -1319,11 +1330,15 @@ struct AdamFusedArgs {
   int32_t n;
 };
 
-template <int VEC>
+// LONG: the gradient reduction left its long rows unfinished (TT_GRAD_DEFER_FINISH): blocks [nd, nd + nlb) add a long row's
+// chunk partials exactly as seg_long_finish_kernel does, store the sum into grad_rows and update that table row; the row
+// blocks skip those rows.  One launch fewer in the step's dependent chain, the same values.
+template <int VEC, bool LONG>
 __global__ __launch_bounds__(kThreads) void adam_fused_kernel(AdamFusedArgs a, float* __restrict__ table, float* __restrict__ m,
                                                              float* __restrict__ v, int32_t E, uint32_t C,
-                                                             const int32_t* __restrict__ unique_rows, const float* __restrict__ grad_rows,
-                                                             const int32_t* __restrict__ n_unique, AdamK k0, uint32_t LG, int64_t table_rows) {
+                                                             const int32_t* __restrict__ unique_rows, float* __restrict__ grad_rows,
+                                                             const int32_t* __restrict__ n_unique, AdamK k0, uint32_t LG, int64_t table_rows,
+                                                             const int32_t* __restrict__ seg, GradWs ws, int nlb) {
   const AdamK k = adam_resolve(k0);
   const int nd = a.blk0[a.n];
   if ((int)blockIdx.x < nd) {
@@ -1340,13 +1355,28 @@ __global__ __launch_bounds__(kThreads) void adam_fused_kernel(AdamFusedArgs a, f
     }
     return;
   }
+  const int first = nd + (LONG ? nlb : 0);
+  if (LONG && (int)blockIdx.x < first) {
+    __shared__ float part[kFinishMaxFloats];
+    long_rows_finish<VEC>(E, C, seg, ws, LG, blockIdx.x - nd, (uint32_t)nlb, part, [&](int32_t u, int32_t col, float tot) {
+      grad_rows[(int64_t)u * E + col] = tot;
+      const int64_t row = unique_rows[u];
+      if (row >= table_rows) return;
+      const int64_t o = row * E + col;
+      float pp = table[o], mm = m[o], vv = v[o];
+      adam1(pp, tot, mm, vv, k);
+      table[o] = pp; m[o] = mm; v[o] = vv;
+    });
+    return;
+  }
   const uint32_t U = (uint32_t)*n_unique;
-  const uint32_t gthread = (blockIdx.x - nd) * blockDim.x + threadIdx.x;
+  const uint32_t gthread = (blockIdx.x - first) * blockDim.x + threadIdx.x;
   const uint32_t lig = gthread % LG;
-  const uint32_t ngroups = (gridDim.x - nd) * blockDim.x / LG;
+  const uint32_t ngroups = (gridDim.x - first) * blockDim.x / LG;
   for (uint32_t u = gthread / LG; u < U; u += ngroups) {
     const int64_t row = unique_rows[u];
     if (row >= table_rows) continue;                   // routing pad (multi-GPU fixed-capacity buckets)
+    if (LONG && seg[u + 1] - seg[u] > kLongSeg) continue;   // finished and applied by the long-row blocks
     for (uint32_t chunk = lig; chunk < C; chunk += LG) {
       const int64_t o = row * E + chunk * VEC;
       const float* gp = grad_rows + (int64_t)u * E + chunk * VEC;
@@ -1949,7 +1979,11 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   // row arrives at most once per rank.  Results do not depend on the flag.
   const bool all_short = (mode & TT_GRAD_SHORT_SEGMENTS) != 0;
   const bool planned = (mode & TT_GRAD_PLANNED) != 0 && !all_short;      // the workspace holds the plan's long-row list and counters
-  mode &= ~(TT_GRAD_SHORT_SEGMENTS | TT_GRAD_PLANNED);
+  // TT_GRAD_DEFER_FINISH: the long rows' chunk partials are left unadded -- tt_adam_fused_step_finish (or tt_embed_grad_finish)
+  // on the same workspace completes `out`; sparse mode on a planned workspace only
+  const bool defer = (mode & TT_GRAD_DEFER_FINISH) != 0;
+  mode &= ~(TT_GRAD_SHORT_SEGMENTS | TT_GRAD_PLANNED | TT_GRAD_DEFER_FINISH);
+  TT_CHECK_ARG(!defer || (planned && mode == TT_GRAD_SPARSE), "tt_embed_grad_bwd: TT_GRAD_DEFER_FINISH needs TT_GRAD_PLANNED | TT_GRAD_SPARSE");
   TT_CHECK_ARG(mode >= TT_GRAD_SPARSE && mode <= TT_GRAD_DENSE_ACC, "tt_embed_grad_bwd: bad mode %d", mode);
   TT_CHECK_ARG(E >= 1 && B >= 0, "tt_embed_grad_bwd: bad E/B");
   if (M == 0) return TT_OK;
@@ -2003,7 +2037,7 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
       seg_reduce_chunk_kernel<V, D, G><<<g1 + g2, kThreads, 0, st>>>(a, sorted_src, seg_offsets, unique_rows, n_unique, mode,   \
                                                                      out, gl.ws, LG, (uint32_t)g1);                             \
       TT_LAUNCH_CHECK();                                                                                                        \
-      seg_long_finish_kernel<V><<<g3, kThreads, 0, st>>>(E, a.C, seg_offsets, unique_rows, mode, out, gl.ws, LG);               \
+      if (!defer) seg_long_finish_kernel<V><<<g3, kThreads, 0, st>>>(E, a.C, seg_offsets, unique_rows, mode, out, gl.ws, LG);   \
       break;                                                                                                                    \
     }                                                                                                                           \
     seg_reduce_kernel<V, D, G><<<g1, kThreads, 0, st>>>(a, sorted_src, seg_offsets, unique_rows, n_unique, mode, out, gl.ws, LG, \
@@ -2097,19 +2131,20 @@ int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int64_t t
   return TT_OK;
 }
 
-int tt_adam_fused_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, float* table, float* m, float* v, int64_t table_rows,
-                       int32_t E,
-                       const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique, int64_t M, int64_t step, float lr,
-                       float beta1, float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream) {
-  TT_CHECK_ARG(ctx && tensors && table && m && v && unique_rows && grad_rows && n_unique, "tt_adam_fused_step: NULL argument");
-  TT_CHECK_ARG(n_tensors >= 1 && n_tensors <= kAdamMulti, "tt_adam_fused_step: n_tensors=%d not in [1,%d]", n_tensors, kAdamMulti);
-  TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 1 && table_rows >= 1, "tt_adam_fused_step: bad step/E/M/table_rows");
+static int adam_fused_impl(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, float* table, float* m, float* v,
+                           int64_t table_rows, int32_t E, const int32_t* unique_rows, float* grad_rows, const int32_t* n_unique, int64_t M,
+                           const int32_t* seg_offsets, void* grad_workspace, size_t grad_workspace_bytes, int64_t step, float lr,
+                           float beta1, float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream,
+                           const char* who) {
+  TT_CHECK_ARG(ctx && tensors && table && m && v && unique_rows && grad_rows && n_unique, "%s: NULL argument", who);
+  TT_CHECK_ARG(n_tensors >= 1 && n_tensors <= kAdamMulti, "%s: n_tensors=%d not in [1,%d]", who, n_tensors, kAdamMulti);
+  TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 1 && table_rows >= 1, "%s: bad step/E/M/table_rows", who);
   AdamFusedArgs a{};
   a.n = n_tensors;
   int nd = 0;
   for (int i = 0; i < n_tensors; ++i) {
     const tt_adam_tensor& t = tensors[i];
-    TT_CHECK_ARG(t.n >= 0 && (t.n == 0 || (t.p && t.g && t.m && t.v)), "tt_adam_fused_step: tensor %d has NULL pointers", i);
+    TT_CHECK_ARG(t.n >= 0 && (t.n == 0 || (t.p && t.g && t.m && t.v)), "%s: tensor %d has NULL pointers", who, i);
     a.t[i] = t;
     a.blk0[i] = nd;
     int64_t nb = tt_cdiv(t.n > 0 ? t.n : 1, kThreads);
@@ -2120,10 +2155,68 @@ int tt_adam_fused_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_ten
   const bool vec4 = (E % 4 == 0) && tt_aligned(table, 16) && tt_aligned(m, 16) && tt_aligned(v, 16) && tt_aligned(grad_rows, 16);
   const uint32_t C = vec4 ? E / 4 : E;
   const uint32_t LG = pow2_at_least(C) > 64 ? 64 : pow2_at_least(C);
-  const int grid = nd + grid_for(ctx, M * LG);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (vec4) adam_fused_kernel<4><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG, table_rows);
-  else adam_fused_kernel<1><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG, table_rows);
+  if (grad_workspace) {
+    // the reduction's deferred finish (tt_embed_grad_bwd with TT_GRAD_DEFER_FINISH) rides in this launch
+    TT_CHECK_ARG(seg_offsets, "%s: NULL seg_offsets", who);
+    if (grad_workspace_bytes < tt_embed_grad_workspace_bytes(M, E)) {
+      tt_set_error("%s: gradient workspace %zu < required %zu", who, grad_workspace_bytes, tt_embed_grad_workspace_bytes(M, E));
+      return TT_ERR_WORKSPACE;
+    }
+    if ((int64_t)(kThreads / LG) * E > kFinishMaxFloats) {
+      tt_set_error("%s: E=%d too wide for the long-row finish (max %d)", who, E, kFinishMaxFloats * (int)LG / kThreads);
+      return TT_ERR_UNSUPPORTED;
+    }
+    const GradLayout gl = grad_layout(reinterpret_cast<char*>(grad_workspace), M, E);
+    const int nlb = (int)(gl.max_long < (int64_t)ctx->num_cus * 8 ? gl.max_long : (int64_t)ctx->num_cus * 8);
+    const int grid = nd + nlb + grid_for(ctx, M * LG);
+    if (vec4) adam_fused_kernel<4, true><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG, table_rows, seg_offsets, gl.ws, nlb);
+    else adam_fused_kernel<1, true><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG, table_rows, seg_offsets, gl.ws, nlb);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+  }
+  const int grid = nd + grid_for(ctx, M * LG);
+  if (vec4) adam_fused_kernel<4, false><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG, table_rows, nullptr, GradWs{}, 0);
+  else adam_fused_kernel<1, false><<<grid, kThreads, 0, st>>>(a, table, m, v, E, C, unique_rows, grad_rows, n_unique, k, LG, table_rows, nullptr, GradWs{}, 0);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_adam_fused_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, float* table, float* m, float* v, int64_t table_rows,
+                       int32_t E,
+                       const int32_t* unique_rows, const float* grad_rows, const int32_t* n_unique, int64_t M, int64_t step, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream) {
+  return adam_fused_impl(ctx, tensors, n_tensors, table, m, v, table_rows, E, unique_rows, const_cast<float*>(grad_rows), n_unique, M,
+                         nullptr, nullptr, 0, step, lr, beta1, beta2, eps, weight_decay, hparams_dev, stream, "tt_adam_fused_step");
+}
+
+int tt_adam_fused_step_finish(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, float* table, float* m, float* v,
+                              int64_t table_rows, int32_t E, const int32_t* unique_rows, float* grad_rows, const int32_t* n_unique,
+                              int64_t M, const int32_t* seg_offsets, void* grad_workspace, size_t grad_workspace_bytes, int64_t step,
+                              float lr, float beta1, float beta2, float eps, float weight_decay, const float* hparams_dev,
+                              tt_stream stream) {
+  TT_CHECK_ARG(grad_workspace, "tt_adam_fused_step_finish: NULL gradient workspace");
+  return adam_fused_impl(ctx, tensors, n_tensors, table, m, v, table_rows, E, unique_rows, grad_rows, n_unique, M, seg_offsets,
+                         grad_workspace, grad_workspace_bytes, step, lr, beta1, beta2, eps, weight_decay, hparams_dev, stream,
+                         "tt_adam_fused_step_finish");
+}
+
+int tt_embed_grad_finish(tt_ctx* ctx, int32_t E, const int32_t* seg_offsets, int64_t M, float* out, void* workspace,
+                         size_t workspace_bytes, tt_stream stream) {
+  TT_CHECK_ARG(ctx && seg_offsets && out && workspace, "tt_embed_grad_finish: NULL argument");
+  TT_CHECK_ARG(E >= 1 && M >= 1, "tt_embed_grad_finish: bad E/M");
+  if (workspace_bytes < tt_embed_grad_workspace_bytes(M, E)) {
+    tt_set_error("tt_embed_grad_finish: workspace %zu < required %zu", workspace_bytes, tt_embed_grad_workspace_bytes(M, E));
+    return TT_ERR_WORKSPACE;
+  }
+  const bool vec4 = (E % 4 == 0) && tt_aligned(out, 16);
+  const uint32_t C = vec4 ? E / 4 : E;
+  const uint32_t LG = pow2_at_least(C) > 64 ? 64 : pow2_at_least(C);
+  const GradLayout gl = grad_layout(reinterpret_cast<char*>(workspace), M, E);
+  const int g3 = (int)(gl.max_long < (int64_t)ctx->num_cus * 8 ? gl.max_long : (int64_t)ctx->num_cus * 8);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (vec4) seg_long_finish_kernel<4><<<g3, kThreads, 0, st>>>(E, C, seg_offsets, nullptr, TT_GRAD_SPARSE, out, gl.ws, LG);
+  else seg_long_finish_kernel<1><<<g3, kThreads, 0, st>>>(E, C, seg_offsets, nullptr, TT_GRAD_SPARSE, out, gl.ws, LG);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

@@ -119,10 +119,20 @@ class GraphedTrainStep:
 
     def _body(self):
         self.opt.zero_grad(set_to_none=True)
-        res = self.task(self.static, return_metrics=self.return_metrics)
-        loss = res["loss"] if isinstance(res, dict) else res
-        loss.backward(self._ones)                      # preallocated seed gradient: no fill kernel per step
-        self.opt.step()
+        # backward and optimiser step are one unit here: the gradient reduction leaves its long rows to the optimiser's launch
+        # (FusedAdam finishes them whichever of its paths it takes) -- one launch fewer in the dependent chain
+        defer = __import__("os").environ.get("TT_DEFER_LONG", "1") != "0"
+        stores = list(getattr(self.opt, "_stores", ()))
+        for st in stores:
+            st.defer_long_finish = defer
+        try:
+            res = self.task(self.static, return_metrics=self.return_metrics)
+            loss = res["loss"] if isinstance(res, dict) else res
+            loss.backward(self._ones)                  # preallocated seed gradient: no fill kernel per step
+            self.opt.step()
+        finally:
+            for st in stores:
+                st.defer_long_finish = False
         return res
 
     def _eager_once(self):

@@ -154,6 +154,7 @@ class DedupPlan:
     keep: object = None           # tensors that must outlive the plan's kernels
     stream: object = None         # stream the plan was built on (joined before first use)
     grad_ws: object = None        # (uint8 workspace, E): the gradient reduction's workspace with the long-row list already in it
+    finish_deferred: object = None  # grad_rows whose long rows embed_grad left unfinished (adam_fused / embed_grad_finish complete them)
 
 
 def dedup_plan(rows: torch.Tensor, table_rows: int) -> DedupPlan:
@@ -219,10 +220,12 @@ def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int, key_majo
 
 
 def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int, out: torch.Tensor, short_segments: bool = False,
-               counters: Optional[torch.Tensor] = None):
+               counters: Optional[torch.Tensor] = None, defer_finish: bool = False):
     """srcs: [(d_out 2-D view [B, K*E], K)].  short_segments: the caller knows no row has many contributions (skips the
     chunk passes; results do not depend on it).  counters: >= 3 int32 words the caller keeps ZERO between calls (allocated
-    once, outside any graph capture): the reduction re-zeroes them itself and needs no zeroing launch in front."""
+    once, outside any graph capture): the reduction re-zeroes them itself and needs no zeroing launch in front.
+    defer_finish (sparse mode, planned workspace; ignored otherwise): the long rows of `out` are left for adam_fused /
+    embed_grad_finish -- plan.finish_deferred then holds `out` until one of them has run."""
     if short_segments:
         mode |= L.TT_GRAD_SHORT_SEGMENTS
     dev = out.device
@@ -234,13 +237,29 @@ def embed_grad(plan: DedupPlan, srcs: Sequence[tuple], B: int, E: int, mode: int
     nb = lib.tt_embed_grad_workspace_bytes(plan.M, E)
     if plan.grad_ws is not None and plan.grad_ws[1] == E and not short_segments:
         ws = plan.grad_ws[0]                                # the plan left the long-row list in its own workspace
-        mode |= L.TT_GRAD_PLANNED
+        deferred = defer_finish and mode == L.TT_GRAD_SPARSE and plan.M >= 1
+        mode |= L.TT_GRAD_PLANNED | (L.TT_GRAD_DEFER_FINISH if deferred else 0)
     else:
         ws = L.workspace(dev, nb)
+        deferred = False
     with _timed("tt_embed_grad_bwd"):
         L.check(lib.tt_embed_grad_bwd(L.ctx(dev), arr, len(srcs), B, E, L.ptr(plan.sorted_src), L.ptr(plan.seg_offsets),
                                       L.ptr(plan.unique_rows), L.ptr(plan.n_unique), plan.M, mode, L.ptr(out),
                                       L.ptr(counters), L.ptr(ws), ws.numel(), L.stream(dev)), "tt_embed_grad_bwd")
+    plan.finish_deferred = out if deferred else None
+
+
+def embed_grad_finish(plan: DedupPlan):
+    """Complete a gradient whose long-row finish was deferred (no-op otherwise)."""
+    out = plan.finish_deferred
+    if out is None:
+        return
+    ws, E = plan.grad_ws
+    dev = out.device
+    with _timed("tt_embed_grad_finish"):
+        L.check(L.load().tt_embed_grad_finish(L.ctx(dev), E, L.ptr(plan.seg_offsets), plan.M, L.ptr(out), L.ptr(ws), ws.numel(),
+                                              L.stream(dev)), "tt_embed_grad_finish")
+    plan.finish_deferred = None
 
 
 # ---------------------------------------------------------------------------------------------- Adam
@@ -266,6 +285,7 @@ def adam_multi(items, step, lr, b1, b2, eps, wd, hp_dev=None):
 
 def adam_sparse(table, m, v, plan: DedupPlan, grad_rows, step, lr, b1, b2, eps, wd, hp_dev=None):
     dev = table.device
+    embed_grad_finish(plan)
     with _timed("tt_sparse_adam_step"):
         L.check(L.load().tt_sparse_adam_step(L.ctx(dev), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[0], table.shape[1],
                                              L.ptr(plan.unique_rows), L.ptr(grad_rows), L.ptr(plan.n_unique), plan.M, step,
@@ -278,6 +298,17 @@ def adam_fused(items, table, m, v, plan: DedupPlan, grad_rows, step, lr, b1, b2,
     arr = (L.AdamTensor * len(items))()
     for i, (p, g, mm, vv) in enumerate(items):
         arr[i] = L.AdamTensor(p.data_ptr(), g.data_ptr(), mm.data_ptr(), vv.data_ptr(), p.numel())
+    if plan.finish_deferred is not None:
+        if plan.finish_deferred.data_ptr() != grad_rows.data_ptr():
+            raise RuntimeError("adam_fused: the plan's deferred gradient is not the one handed to the optimiser")
+        ws, E = plan.grad_ws
+        with _timed("tt_adam_fused_step"):
+            L.check(L.load().tt_adam_fused_step_finish(L.ctx(dev), arr, len(items), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[0],
+                                                       table.shape[1], L.ptr(plan.unique_rows), L.ptr(grad_rows), L.ptr(plan.n_unique),
+                                                       plan.M, L.ptr(plan.seg_offsets), L.ptr(ws), ws.numel(), step, lr, b1, b2, eps, wd,
+                                                       L.ptr(hp_dev), L.stream(dev)), "tt_adam_fused_step_finish")
+        plan.finish_deferred = None
+        return
     with _timed("tt_adam_fused_step"):
         L.check(L.load().tt_adam_fused_step(L.ctx(dev), arr, len(items), L.ptr(table), L.ptr(m), L.ptr(v), table.shape[0], table.shape[1],
                                             L.ptr(plan.unique_rows), L.ptr(grad_rows), L.ptr(plan.n_unique), plan.M, step,

@@ -654,6 +654,61 @@ def test_planned_long_rows_equal_unplanned(tt, manifest, schema_real, monkeypatc
     assert np.abs(outs["1"][1]).sum() > 0
 
 
+@pytest.mark.parametrize("B,consumer", [(2048, "fused"), (777, "fused"), (2048, "finish"), (2048, "sparse_adam")])
+def test_deferred_long_finish_equals_immediate(tt, manifest, schema_real, B, consumer):
+    """The long rows of the sparse gradient finished inside the optimiser's launch (TT_GRAD_DEFER_FINISH +
+    tt_adam_fused_step_finish: what GraphedTrainStep replays), by tt_embed_grad_finish, or ahead of the row-sparse Adam ==
+    the reduction's own finish launch, bit for bit: gradient rows, table, both Adam moments and every dense weight after two
+    steps.  Real 32 + 6 key schema (17 two-row keys: rows of thousands of slots), out-of-range ids."""
+    from jodalrob_twotower_amd.optim import FusedAdam
+    from jodalrob_twotower_amd import ops
+    cfg = dict(manifest["cases"]["real_schema"])
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    cfg.update(keys_n=kn, keys_c=kc)
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    batches = [synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 640 + i, oob=True) for i in range(2)]
+    outs, state = {}, None
+    for defer in (False, True):
+        task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", embedding_grad="sparse", mlp_dtype="bf16", score_dtype="bf16")
+        if state is None:
+            state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 641)
+        load_state(task, state)
+        task.train()
+        opt = FusedAdam.for_task(task, lr=1e-2, weight_decay=1e-5)
+        store = task.two_tower_model.embedding_store
+        store = store() if callable(store) else store
+        grads = []
+        for b in batches:
+            opt.zero_grad()
+            store.defer_long_finish = defer
+            task(to_batch(tt, b, kn, kc), return_metrics=True)["loss"].backward()
+            store.defer_long_finish = False
+            plan, rows = store.sparse_grad
+            assert (plan.finish_deferred is not None) == defer and plan.grad_ws is not None
+            if consumer == "finish":
+                ops.embed_grad_finish(plan)
+                assert plan.finish_deferred is None
+                opt.step()
+            elif consumer == "sparse_adam":                # the optimiser's unfused path: tower weights first, then the rows
+                opt._fusable_store = lambda *a, **k: None
+                opt.step()
+            else:
+                opt.step()
+            assert plan.finish_deferred is None
+            U = int(plan.n_unique.item())
+            grads.append((plan.unique_rows[:U].cpu().numpy(), rows[:U].cpu().numpy()))
+        st = opt._state_of(store)
+        outs[defer] = (grads, store.weight.cpu().numpy(), st["m"].cpu().numpy(), st["v"].cpu().numpy(),
+                       {k: v.detach().cpu().numpy() for k, v in task.state_dict().items()})
+    for (u0, g0), (u1, g1) in zip(outs[False][0], outs[True][0]):
+        assert np.array_equal(u0, u1) and np.array_equal(g0, g1)
+        assert np.abs(g1).sum() > 0
+    for i in (1, 2, 3):
+        assert np.array_equal(outs[False][i], outs[True][i]), i
+    for k, v in outs[False][4].items():
+        assert np.array_equal(v, outs[True][4][k]), k
+
+
 def test_bf16_mlp_close_to_fp32(tt, manifest, schema_real):
     """mlp_dtype='bf16' (GEMM operands rounded to bf16, f32 accumulate, f32 tensors in memory) against the exact-f32
     MFMA path on the real 32+6-key schema: loss within 5e-3, gradients within 6e-2 norm-wise.  This is a SANITY bound on
