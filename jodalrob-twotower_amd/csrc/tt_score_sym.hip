@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) e[r] = ex(acc[r]);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) colacc[r] += e[r];
+          for (int r = 0; r < 16; ++r) colacc[r] = add_asm(colacc[r], e[r]);
           float t0 = (e[0] + e[1]) + (e[2] + e[3]), t1 = (e[4] + e[5]) + (e[6] + e[7]);
           float t2 = (e[8] + e[9]) + (e[10] + e[11]), t3 = (e[12] + e[13]) + (e[14] + e[15]);
           const float rsum = half_sum((t0 + t1) + (t2 + t3));
