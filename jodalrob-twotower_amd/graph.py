@@ -130,6 +130,9 @@ class GraphedTrainStep:
             loss = res["loss"] if isinstance(res, dict) else res
             loss.backward(self._ones)                  # preallocated seed gradient: no fill kernel per step
             self.opt.step()
+            for st in stores:                          # a store this optimiser did not step: nobody else will finish its gradient
+                if st.sparse_grad is not None:
+                    ops.embed_grad_finish(st.sparse_grad[0])
         finally:
             for st in stores:
                 st.defer_long_finish = False
