@@ -50,6 +50,16 @@ const char* tt_last_error_string(void);
 /* number of compute units of the context's device (used by callers to size synthetic work) */
 int tt_ctx_num_cus(const tt_ctx* ctx);
 
+/* Options of a context.  TT_OPT_DEFER_SLAB_REDUCE (default 0): tt_towers_mlp_bwd's one-launch first-block backward leaves the
+ * split-K slab reduction of its weight gradients queued in the context instead of launching it; the next tt_embed_grad_bwd
+ * with TT_GRAD_PLANNED runs it in the first workgroups of its own launch (the two are independent: one launch fewer in the
+ * step's dependent chain); tt_flush_deferred launches it on its own, and the tt_adam_* entries do that themselves before
+ * they read a gradient.  Nothing else may write the towers' workspace while tt_deferred_pending() is 1. */
+#define TT_OPT_DEFER_SLAB_REDUCE 1
+int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value);
+int tt_flush_deferred(tt_ctx* ctx, tt_stream stream);
+int tt_deferred_pending(const tt_ctx* ctx);
+
 /* ------------------------------------------------------------------------------------------------
  * Categorical embedding lookup  -- replaces CategoricalEmbedder._kjt_to_dict + .forward
  * (src/towers/cat_embed.py:88-123 id unpack + clamp, :157-178 per-key nn.Embedding gather + cat)

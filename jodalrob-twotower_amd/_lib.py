@@ -100,6 +100,9 @@ SIGNATURES = {
     "tt_adam_fused_step_finish": (C.c_int, [vp, C.POINTER(AdamTensor), i32, vp, vp, vp, i64, i32, vp, vp, vp, i64, vp, vp, sz, i64, f32,
                                             f32, f32, f32, f32, vp, vp]),
     "tt_embed_grad_finish": (C.c_int, [vp, i32, vp, i64, vp, vp, sz, vp]),
+    "tt_ctx_set_option": (C.c_int, [vp, i32, i32]),
+    "tt_flush_deferred": (C.c_int, [vp, vp]),
+    "tt_deferred_pending": (C.c_int, [vp]),
     "tt_tower_workspace_bytes": (sz, [C.POINTER(TowerParams), i64]),
     "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, vp, sz, vp]),
     "tt_tower_mlp_bwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), vp, C.POINTER(TowerGrads), i64, i32,
@@ -142,6 +145,7 @@ SIGNATURES = {
 
 _lib: Optional[C.CDLL] = None
 _ctxs: dict = {}
+_defer_on: set = set()       # devices whose context queues the towers' slab reduction (set_defer_slab_reduce)
 _workspaces: dict = {}
 
 
@@ -192,8 +196,31 @@ def ptr(t: Optional[torch.Tensor]) -> vp:
     return vp(0 if t is None else t.data_ptr())
 
 
+TT_OPT_DEFER_SLAB_REDUCE = 1
+
+
+def set_defer_slab_reduce(device: torch.device, on: bool):
+    """tt_towers_mlp_bwd leaves its slab reduction queued in the context (include/twotower.h: TT_OPT_DEFER_SLAB_REDUCE)."""
+    check(load().tt_ctx_set_option(ctx(device), TT_OPT_DEFER_SLAB_REDUCE, 1 if on else 0), "tt_ctx_set_option")
+    idx = torch.device(device).index
+    (_defer_on.add if on else _defer_on.discard)(idx if idx is not None else torch.cuda.current_device())
+    if not on:
+        flush_deferred(device)
+
+
+def flush_deferred(device: torch.device):
+    """Launch a queued slab reduction now (no-op when nothing is queued)."""
+    lib = load()
+    c = ctx(device)
+    if lib.tt_deferred_pending(c):
+        check(lib.tt_flush_deferred(c, stream(device)), "tt_flush_deferred")
+
+
 def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Stream-ordered scratch: one growable buffer per (device, stream)."""
+    """Stream-ordered scratch: one growable buffer per (device, stream).  The slabs of a queued (deferred) reduction live in
+    it: they are reduced before the buffer is handed to anybody else."""
+    if _defer_on:
+        flush_deferred(device)
     key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:

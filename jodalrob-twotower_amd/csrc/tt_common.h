@@ -13,6 +13,10 @@ struct tt_ctx {
   size_t lds_per_block;
   unsigned long long* lookup_stamps;   // optional device ring (tt_embed_lookup_set_profile)
   int lookup_stamp_slots;
+  // TT_OPT_DEFER_SLAB_REDUCE: tt_towers_mlp_bwd leaves the split-K slab reduction of its weight gradients queued here; the
+  // next tt_embed_grad_bwd on a planned workspace runs it inside its own launch, tt_flush_deferred / the Adam entries otherwise
+  int defer_slab_reduce;
+  struct TnPending* deferred;
 };
 
 void tt_set_error(const char* fmt, ...);

@@ -1,5 +1,6 @@
 // Context, error string, ABI version.
 #include "tt_common.h"
+#include "tt_gemm.h"
 
 #include <string.h>
 
@@ -36,14 +37,31 @@ int tt_ctx_create(int device, tt_ctx** out) {
   c->lds_per_block = prop.sharedMemPerBlock;
   c->lookup_stamps = nullptr;
   c->lookup_stamp_slots = 0;
+  c->defer_slab_reduce = 0;
+  c->deferred = nullptr;
   *out = c;
   return TT_OK;
 }
 
 int tt_ctx_destroy(tt_ctx* ctx) {
+  if (ctx && ctx->deferred) tt_gemm_tn_pending_destroy(ctx->deferred);
   delete ctx;
   return TT_OK;
 }
+
+int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value) {
+  TT_CHECK_ARG(ctx != nullptr, "tt_ctx_set_option: NULL context");
+  TT_CHECK_ARG(option == TT_OPT_DEFER_SLAB_REDUCE, "tt_ctx_set_option: unknown option %d", option);
+  ctx->defer_slab_reduce = value != 0;
+  return TT_OK;
+}
+
+int tt_flush_deferred(tt_ctx* ctx, tt_stream stream) {
+  TT_CHECK_ARG(ctx != nullptr, "tt_flush_deferred: NULL context");
+  return tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream));
+}
+
+int tt_deferred_pending(const tt_ctx* ctx) { return ctx && ctx->deferred && ctx->deferred->n > 0 ? 1 : 0; }
 
 int tt_ctx_num_cus(const tt_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
 

@@ -3,6 +3,7 @@
 // device-side batch gather.  All kernels are HBM-bound byte movers: 64-wide waves, 16-byte lanes,
 // grids capped at 8 workgroups per CU with grid-stride loops.
 #include "tt_common.h"
+#include "tt_gemm.h"
 
 #include <stdlib.h>
 
@@ -1158,6 +1159,24 @@ __global__ __launch_bounds__(kThreads) void seg_reduce_chunk_kernel(SideSet a, c
   else seg_chunk_body<VEC, DT, LGT>(a, sorted_src, ws, LG, blockIdx.x - g1, gridDim.x - g1);
 }
 
+// ... and, in front of both, the workgroups of a slab reduction tt_towers_mlp_bwd left queued in the context
+// (TT_OPT_DEFER_SLAB_REDUCE): the weight gradients' split-K slabs and this reduction do not depend on each other
+template <int VEC, int DT, int LGT>
+__global__ __launch_bounds__(kThreads) void seg_reduce_chunk_slab_kernel(SideSet a, const int32_t* __restrict__ sorted_src,
+                                                                        const int32_t* __restrict__ seg, const int32_t* __restrict__ unique_rows,
+                                                                        const int32_t* __restrict__ n_unique, int32_t mode,
+                                                                        float* __restrict__ out, GradWs ws, uint32_t LG, uint32_t g1,
+                                                                        SlabBatch sb, uint32_t nsx, uint32_t nsy) {
+  const uint32_t ns = nsx * nsy;
+  if (blockIdx.x < ns) {
+    slab_reduce_block(sb, (int)(blockIdx.x % nsx), (int)nsx, (int)(blockIdx.x / nsx));
+    return;
+  }
+  const uint32_t bid = blockIdx.x - ns, nb = gridDim.x - ns;
+  if (bid < g1) seg_reduce_body<VEC, DT, LGT>(a, sorted_src, seg, unique_rows, n_unique, mode, out, ws, LG, false, true, bid, g1);
+  else seg_chunk_body<VEC, DT, LGT>(a, sorted_src, ws, LG, bid - g1, nb - g1);
+}
+
 // one WORKGROUP per long row: its lane groups sum contiguous ranges of the row's chunk partials (8 loads in flight,
 // chunk order), the group sums are added in group order through LDS -- one or two trips however long the row is
 // (a binary key at B = 8192 has ~4096-slot rows = 256 partials)
@@ -2022,6 +2041,14 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
     zero_words_kernel<<<1, 64, 0, st>>>(gl.ws.counters, 2);    // (a kernel, not a memset node: see graph notes in DESIGN.md)
     TT_LAUNCH_CHECK();
   }
+  // a slab reduction the tower backward left in the context: inside this launch when the workspace is the plan's own (nothing
+  // here then writes the shared scratch the slabs live in), launched on its own first otherwise
+  TnPending* slabs = (ctx->deferred && ctx->deferred->n > 0) ? ctx->deferred : nullptr;
+  if (slabs && !planned) {
+    if (int rc = tt_gemm_deferred_flush(ctx, st)) return rc;
+    slabs = nullptr;
+  }
+  const int nsx = slabs ? tt_slab_blocks_x(slabs) : 0;
   const int g1 = grid_for(ctx, M * LG);
   const int g2 = grid_for(ctx, gl.max_chunks * LG);
   const int g3 = (int)(gl.max_long < (int64_t)ctx->num_cus * 8 ? gl.max_long : (int64_t)ctx->num_cus * 8);   // a workgroup per long row
@@ -2033,6 +2060,16 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   // the lane-group width when every lane of a group owns exactly one chunk (shared decode, see sum_range)
 #define TT_SEG_LAUNCH(V, D, G)                                                                                                  \
   do {                                                                                                                          \
+    if (planned && slabs) {                                                                                                     \
+      seg_reduce_chunk_slab_kernel<V, D, G><<<nsx * slabs->n + g1 + g2, kThreads, 0, st>>>(                                     \
+          a, sorted_src, seg_offsets, unique_rows, n_unique, mode, out, gl.ws, LG, (uint32_t)g1, slabs->sb, (uint32_t)nsx,      \
+          (uint32_t)slabs->n);                                                                                                  \
+      TT_LAUNCH_CHECK();                                                                                                        \
+      slabs->n = 0;                                                                                                             \
+      slabs->maxtotal = 1;                                                                                                      \
+      if (!defer) seg_long_finish_kernel<V><<<g3, kThreads, 0, st>>>(E, a.C, seg_offsets, unique_rows, mode, out, gl.ws, LG);   \
+      break;                                                                                                                    \
+    }                                                                                                                           \
     if (planned) {                                                                                                              \
       seg_reduce_chunk_kernel<V, D, G><<<g1 + g2, kThreads, 0, st>>>(a, sorted_src, seg_offsets, unique_rows, n_unique, mode,   \
                                                                      out, gl.ws, LG, (uint32_t)g1);                             \
@@ -2073,6 +2110,8 @@ void tt_adam_hparams(int64_t step, float lr, float beta1, float beta2, float eps
 
 int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1,
                        float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream) {
+  if (ctx && ctx->deferred && ctx->deferred->n > 0)      // a queued slab reduction: the gradients are not complete before it
+    if (int rc = tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;
   TT_CHECK_ARG(ctx && (n == 0 || (p && g && m && v)), "tt_adam_dense_step: NULL argument");
   TT_CHECK_ARG(step >= 1 && n >= 0, "tt_adam_dense_step: step must be >= 1");
   if (n == 0) return TT_OK;
@@ -2090,6 +2129,8 @@ int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v
 
 int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, int64_t step, float lr, float beta1,
                        float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream) {
+  if (ctx && ctx->deferred && ctx->deferred->n > 0)      // a queued slab reduction: the gradients are not complete before it
+    if (int rc = tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;
   TT_CHECK_ARG(ctx && (n_tensors == 0 || tensors), "tt_adam_multi_step: NULL argument");
   TT_CHECK_ARG(step >= 1 && n_tensors >= 0, "tt_adam_multi_step: step must be >= 1");
   const AdamK k = make_adam(step, lr, beta1, beta2, eps, weight_decay, hparams_dev);
@@ -2115,6 +2156,8 @@ int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_ten
 int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int64_t table_rows, int32_t E, const int32_t* unique_rows,
                         const float* grad_rows, const int32_t* n_unique, int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,
                         float weight_decay, const float* hparams_dev, tt_stream stream) {
+  if (ctx && ctx->deferred && ctx->deferred->n > 0)      // a queued slab reduction: the gradients are not complete before it
+    if (int rc = tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;
   TT_CHECK_ARG(ctx && table && m && v, "tt_sparse_adam_step: NULL state");
   TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 0 && table_rows >= 1, "tt_sparse_adam_step: bad step/E/M/table_rows");
   if (M == 0) return TT_OK;
@@ -2136,6 +2179,8 @@ static int adam_fused_impl(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n
                            const int32_t* seg_offsets, void* grad_workspace, size_t grad_workspace_bytes, int64_t step, float lr,
                            float beta1, float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream,
                            const char* who) {
+  if (ctx && ctx->deferred && ctx->deferred->n > 0)      // a queued slab reduction: the gradients are not complete before it
+    if (int rc = tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;
   TT_CHECK_ARG(ctx && tensors && table && m && v && unique_rows && grad_rows && n_unique, "%s: NULL argument", who);
   TT_CHECK_ARG(n_tensors >= 1 && n_tensors <= kAdamMulti, "%s: n_tensors=%d not in [1,%d]", who, n_tensors, kAdamMulti);
   TT_CHECK_ARG(step >= 1 && E >= 1 && M >= 1 && table_rows >= 1, "%s: bad step/E/M/table_rows", who);

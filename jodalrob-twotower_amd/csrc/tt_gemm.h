@@ -40,11 +40,86 @@ struct GemmTN {
 // `pending` (optional): the split-K slab reductions are queued there instead of being launched, and
 // tt_gemm_tn_flush() covers everything queued with ONE launch (each small launch in a dependent chain costs ~5 us
 // on this part).  Every queued problem needs its own workspace until the flush.
-struct TnPending;
+struct SlabArgs {
+  const float* slabs; int64_t slab_stride; int splits; float* C; int64_t ldc; int M, N;
+  const float* colsum_slab; float* colsum_out;
+  const float* bias; int relu;          // split-K forward GEMMs finish bias / ReLU here
+  int c_bf16 = 0;                        // C holds bf16 elements
+  // projection bias item (gemm_back): no slabs of its own; colsum_out [proj_h0] = proj_w[:, 0:proj_h0]^T . (sum of the
+  // proj_colsum_splits slabs colsum_slab [.][M]), M = H <= 256
+  const float* proj_w = nullptr; int proj_ldw = 0, proj_h0 = 0, proj_colsum_splits = 0;
+};
+constexpr int kSlabItems = 16;
+struct SlabBatch { SlabArgs a[kSlabItems]; };
+struct TnPending {
+  SlabBatch sb;
+  int n = 0;
+  int64_t maxtotal = 1;
+};
+inline int tt_slab_blocks_x(const TnPending* p) {
+  int64_t b = (p->maxtotal + 255) / 256;
+  return (int)(b > 1024 ? 1024 : b);
+}
+
+constexpr int kProjMaxH = 256;
+#ifdef __HIPCC__
+// colsum_out [proj_h0] = proj_w[:, 0:proj_h0]^T . (sum of the proj_colsum_splits slabs colsum_slab [.][M]): one workgroup
+__device__ __forceinline__ void proj_bias_finish(const SlabArgs& a, int bx) {
+  if (bx != 0) return;
+  __shared__ float dbs[kProjMaxH];
+  const int H = a.M, t = threadIdx.x, nt = blockDim.x;
+  for (int h = t; h < H; h += nt) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int z = 0; z < a.proj_colsum_splits; ++z) s += a.colsum_slab[(int64_t)z * H + h];
+    dbs[h] = s;
+  }
+  __syncthreads();
+  for (int i = t; i < a.proj_h0; i += nt) {
+    float acc = 0.f;
+    for (int h = 0; h < H; ++h) acc = fmaf(a.proj_w[(int64_t)h * a.proj_ldw + i], dbs[h], acc);
+    a.colsum_out[i] = acc;
+  }
+}
+
+// workgroup (bx of nbx, item by) of the slab reduction: the body of slab_reduce_kernel, also run by the first workgroups of
+// tt_embed_grad_bwd's launch when the reduction was deferred (TT_OPT_DEFER_SLAB_REDUCE)
+__device__ __forceinline__ void slab_reduce_block(const SlabBatch& batch, int bx, int nbx, int by) {
+  const SlabArgs& a = batch.a[by];
+  if (a.proj_w) {
+    proj_bias_finish(a, bx);
+    return;
+  }
+  const int64_t total = (int64_t)a.M * a.N;
+  const int64_t all = total + (a.colsum_out ? a.M : 0);
+  const int64_t stride = (int64_t)nbx * blockDim.x;
+  for (int64_t i = (int64_t)bx * blockDim.x + threadIdx.x; i < all; i += stride) {
+    float s = 0.f;
+    if (i < total) {
+#pragma unroll 8
+      for (int z = 0; z < a.splits; ++z) s += a.slabs[(int64_t)z * a.slab_stride + i];
+      const int64_t m = i / a.N, n = i - m * a.N;
+      if (a.bias) s += a.bias[n];
+      if (a.relu) s = fmaxf(s, 0.f);
+      if (a.c_bf16) reinterpret_cast<uint16_t*>(a.C)[m * a.ldc + n] = tt_f2bf(s);
+      else a.C[m * a.ldc + n] = s;
+    } else {
+      const int64_t m = i - total;
+#pragma unroll 8
+      for (int z = 0; z < a.splits; ++z) s += a.colsum_slab[(int64_t)z * a.M + m];
+      a.colsum_out[m] = s;
+    }
+  }
+}
+#endif
+
 TnPending* tt_gemm_tn_pending_create();
 void tt_gemm_tn_pending_destroy(TnPending*);
 int tt_gemm_tn_batched(hipStream_t st, const GemmTN* items, int n, TnPending* pending = nullptr);
 int tt_gemm_tn_flush(hipStream_t st, TnPending* pending);
+// move the queue into the context instead of flushing it (tt_ctx.defer_slab_reduce); launch whatever the context holds
+int tt_gemm_tn_defer(tt_ctx* ctx, TnPending* pending);
+int tt_gemm_deferred_flush(tt_ctx* ctx, hipStream_t st);
 
 // First-block backward of up to TT_MAX_SIDES towers in ONE launch (bf16 operands, edge-free shapes): per tower
 //   dW = d_pre^T . x (+ db = column sums of d_pre),  d_x[:, h0:] = d_pre . W[:, h0:],  G = d_pre^T . dense,

@@ -142,17 +142,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch, int zspl
   }
 }
 
-struct SlabArgs {
-  const float* slabs; int64_t slab_stride; int splits; float* C; int64_t ldc; int M, N;
-  const float* colsum_slab; float* colsum_out;
-  const float* bias; int relu;          // split-K forward GEMMs finish bias / ReLU here
-  int c_bf16 = 0;                        // C holds bf16 elements
-  // projection bias item (gemm_back): no slabs of its own; colsum_out [proj_h0] = proj_w[:, 0:proj_h0]^T . (sum of the
-  // proj_colsum_splits slabs colsum_slab [.][M]), M = H <= 256
-  const float* proj_w = nullptr; int proj_ldw = 0, proj_h0 = 0, proj_colsum_splits = 0;
-};
-constexpr int kSlabItems = 16;
-struct SlabBatch { SlabArgs a[kSlabItems]; };
+// (SlabArgs / SlabBatch: tt_gemm.h)
 
 // ---- bf16-operand variant: f32 tensors in memory, rounded to bf16 (RNE) on the way into LDS, f32 accumulate on
 // v_mfma_f32_32x32x16_bf16 (16x fewer matrix cycles than the exact-f32 form).  LDS tiles are [x][k] with k
@@ -624,52 +614,8 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_back_kernel(BackBatch b) {
   } else gemm_fast_tile<0, 1, false, false, false>(g, split, bx, by, sm);
 }
 
-constexpr int kProjMaxH = 256;
-// colsum_out [proj_h0] = proj_w[:, 0:proj_h0]^T . (sum of the proj_colsum_splits slabs colsum_slab [.][M]): one workgroup
-__device__ __forceinline__ void proj_bias_finish(const SlabArgs& a) {
-  if (blockIdx.x != 0) return;
-  __shared__ float dbs[kProjMaxH];
-  const int H = a.M, t = threadIdx.x;
-  for (int h = t; h < H; h += THREADS) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int z = 0; z < a.proj_colsum_splits; ++z) s += a.colsum_slab[(int64_t)z * H + h];
-    dbs[h] = s;
-  }
-  __syncthreads();
-  for (int i = t; i < a.proj_h0; i += THREADS) {
-    float acc = 0.f;
-    for (int h = 0; h < H; ++h) acc = fmaf(a.proj_w[(int64_t)h * a.proj_ldw + i], dbs[h], acc);
-    a.colsum_out[i] = acc;
-  }
-}
-
 __global__ __launch_bounds__(THREADS) void slab_reduce_kernel(SlabBatch batch) {
-  const SlabArgs& a = batch.a[blockIdx.y];
-  if (a.proj_w) {
-    proj_bias_finish(a);
-    return;
-  }
-  const int64_t total = (int64_t)a.M * a.N;
-  const int64_t all = total + (a.colsum_out ? a.M : 0);
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < all; i += stride) {
-    float s = 0.f;
-    if (i < total) {
-#pragma unroll 8
-      for (int z = 0; z < a.splits; ++z) s += a.slabs[(int64_t)z * a.slab_stride + i];
-      const int64_t m = i / a.N, n = i - m * a.N;
-      if (a.bias) s += a.bias[n];
-      if (a.relu) s = fmaxf(s, 0.f);
-      if (a.c_bf16) reinterpret_cast<uint16_t*>(a.C)[m * a.ldc + n] = tt_f2bf(s);
-      else a.C[m * a.ldc + n] = s;
-    } else {
-      const int64_t m = i - total;
-#pragma unroll 8
-      for (int z = 0; z < a.splits; ++z) s += a.colsum_slab[(int64_t)z * a.M + m];
-      a.colsum_out[m] = s;
-    }
-  }
+  slab_reduce_block(batch, (int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y);
 }
 
 inline bool vec_ok(const float* p, int64_t ld, bool bf16_elems = false) {
@@ -843,13 +789,21 @@ size_t tt_gemm_tn_workspace_bytes(int64_t M, int64_t N, int64_t R) {
   return sizeof(float) * (size_t)tn_splits(M, N, R) * ((size_t)M * (size_t)N + (size_t)M) + 256;
 }
 
-struct TnPending {
-  SlabBatch sb;
-  int n = 0;
-  int64_t maxtotal = 1;
-};
+// (TnPending: tt_gemm.h)
 TnPending* tt_gemm_tn_pending_create() { return new TnPending(); }
 void tt_gemm_tn_pending_destroy(TnPending* p) { delete p; }
+
+int tt_gemm_tn_defer(tt_ctx* ctx, TnPending* p) {
+  if (!p || p->n == 0) return TT_OK;
+  if (!ctx->deferred) ctx->deferred = tt_gemm_tn_pending_create();
+  TT_CHECK_ARG(ctx->deferred->n == 0, "deferred slab reduction: the previous one was never flushed");
+  *ctx->deferred = *p;
+  p->n = 0;
+  p->maxtotal = 1;
+  return TT_OK;
+}
+
+int tt_gemm_deferred_flush(tt_ctx* ctx, hipStream_t st) { return ctx && ctx->deferred ? tt_gemm_tn_flush(st, ctx->deferred) : TT_OK; }
 
 int tt_gemm_tn_flush(hipStream_t st, TnPending* p) {
   if (!p || p->n == 0) return TT_OK;

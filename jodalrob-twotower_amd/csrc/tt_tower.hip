@@ -2021,6 +2021,7 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       }
       if (ok && tt_gemm_back_supported(gb, n)) {
         if (int rc = tt_gemm_back_batched(st, gb, n, pend.p)) return rc;
+        if (ctx->defer_slab_reduce) return tt_gemm_tn_defer(ctx, pend.p);     // rides in tt_embed_grad_bwd's launch
         return tt_gemm_tn_flush(st, pend.p);
       }
     }

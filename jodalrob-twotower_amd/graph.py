@@ -20,6 +20,7 @@ from typing import Dict, Optional
 
 import torch
 
+from . import _lib as L
 from . import ops
 from .kjt import KeyedJaggedTensor
 from .optim import FusedAdam
@@ -125,10 +126,20 @@ class GraphedTrainStep:
         stores = list(getattr(self.opt, "_stores", ()))
         for st in stores:
             st.defer_long_finish = defer
+        # likewise the slab reduction of the towers' weight gradients rides in the embedding gradient's launch (the two do not
+        # depend on each other); whatever is still queued after the backward is launched on its own
+        dev = self._dev.device
+        slabs = __import__("os").environ.get("TT_DEFER_SLABS", "1") != "0"
         try:
             res = self.task(self.static, return_metrics=self.return_metrics)
             loss = res["loss"] if isinstance(res, dict) else res
-            loss.backward(self._ones)                  # preallocated seed gradient: no fill kernel per step
+            if slabs:
+                L.set_defer_slab_reduce(dev, True)
+            try:
+                loss.backward(self._ones)              # preallocated seed gradient: no fill kernel per step
+            finally:
+                if slabs:
+                    L.set_defer_slab_reduce(dev, False)      # (flushes)
             self.opt.step()
             for st in stores:                          # a store this optimiser did not step: nobody else will finish its gradient
                 if st.sparse_grad is not None:

@@ -709,6 +709,48 @@ def test_deferred_long_finish_equals_immediate(tt, manifest, schema_real, B, con
         assert np.array_equal(v, outs[True][4][k]), k
 
 
+@pytest.mark.parametrize("B,planned", [(2048, "1"), (8192, "1"), (2048, "0")])
+def test_deferred_slab_reduce_equals_immediate(tt, manifest, schema_real, monkeypatch, B, planned):
+    """The slab reduction of the towers' weight gradients run by the first workgroups of the embedding gradient's launch
+    (TT_OPT_DEFER_SLAB_REDUCE: what GraphedTrainStep replays; planned workspace), or flushed ahead of it (unplanned: the
+    reduction's scratch is the buffer the slabs live in) == its own launch at the end of tt_towers_mlp_bwd, bit for bit: every
+    dense gradient and the sparse gradient rows.  Real 32 + 6 key schema, bf16 towers (the one-launch first-block backward)."""
+    from jodalrob_twotower_amd import _lib as L
+    monkeypatch.setenv("TT_GRAD_PLANNED", planned)
+    cfg = dict(manifest["cases"]["real_schema"])
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    cfg.update(keys_n=kn, keys_c=kc)
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 650, oob=True)
+    outs, state = {}, None
+    dev = tt.device("cuda:0") if hasattr(tt, "device") else "cuda:0"
+    for defer in (False, True):
+        task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", embedding_grad="sparse", mlp_dtype="bf16", score_dtype="bf16")
+        if state is None:
+            state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 651)
+        load_state(task, state)
+        task.train()
+        loss = task(to_batch(tt, b, kn, kc), return_metrics=True)["loss"]
+        L.set_defer_slab_reduce(loss.device, defer)
+        try:
+            loss.backward()
+            pending = bool(L.load().tt_deferred_pending(L.ctx(loss.device)))
+        finally:
+            L.set_defer_slab_reduce(loss.device, False)
+        assert not pending                                   # consumed by the gradient launch (planned) or flushed ahead of it
+        store = task.two_tower_model.embedding_store
+        store = store() if callable(store) else store
+        plan, rows = store.sparse_grad
+        U = int(plan.n_unique.item())
+        outs[defer] = ({n: p.grad.cpu().numpy() for n, p in task.named_parameters() if p.grad is not None},
+                       plan.unique_rows[:U].cpu().numpy(), rows[:U].cpu().numpy())
+    assert len(outs[True][0]) >= 10
+    for k, g in outs[False][0].items():
+        assert np.array_equal(g, outs[True][0][k]), k
+        assert np.isfinite(g).all()
+    assert np.array_equal(outs[False][1], outs[True][1]) and np.array_equal(outs[False][2], outs[True][2])
+
+
 def test_bf16_mlp_close_to_fp32(tt, manifest, schema_real):
     """mlp_dtype='bf16' (GEMM operands rounded to bf16, f32 accumulate, f32 tensors in memory) against the exact-f32
     MFMA path on the real 32+6-key schema: loss within 5e-3, gradients within 6e-2 norm-wise.  This is a SANITY bound on
