@@ -2038,6 +2038,8 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
   }
   for (int t = 0; t < n; ++t) tn[t].bf16 = P[0]->compute_dtype == TT_BF16;
   if (int rc = tt_gemm_tn_batched(st, tn, n, pend.p)) return rc;
+  // (not deferred like the one-launch first-block backward above: at these widths the slabs are HBM traffic, not launch
+  //  latency -- measured 0.508 ms per step either way at scripts/train.py's [512, 256] -> 128)
   return tt_gemm_tn_flush(st, pend.p);
 }
 

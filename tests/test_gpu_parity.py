@@ -709,8 +709,8 @@ def test_deferred_long_finish_equals_immediate(tt, manifest, schema_real, B, con
         assert np.array_equal(v, outs[True][4][k]), k
 
 
-@pytest.mark.parametrize("B,planned", [(2048, "1"), (8192, "1"), (2048, "0")])
-def test_deferred_slab_reduce_equals_immediate(tt, manifest, schema_real, monkeypatch, B, planned):
+@pytest.mark.parametrize("B,planned,hidden", [(2048, "1", None), (8192, "1", None), (2048, "0", None), (2048, "1", [512, 256]), (1000, "1", None)])
+def test_deferred_slab_reduce_equals_immediate(tt, manifest, schema_real, monkeypatch, B, planned, hidden):
     """The slab reduction of the towers' weight gradients run by the first workgroups of the embedding gradient's launch
     (TT_OPT_DEFER_SLAB_REDUCE: what GraphedTrainStep replays; planned workspace), or flushed ahead of it (unplanned: the
     reduction's scratch is the buffer the slabs live in) == its own launch at the end of tt_towers_mlp_bwd, bit for bit: every
@@ -721,9 +721,10 @@ def test_deferred_slab_reduce_equals_immediate(tt, manifest, schema_real, monkey
     kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
     cfg.update(keys_n=kn, keys_c=kc)
     vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    if hidden is not None:                                   # scripts/train.py's widths: the general backward (separate GEMMs)
+        cfg.update(hidden=hidden, D=128)
     b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 650, oob=True)
     outs, state = {}, None
-    dev = tt.device("cuda:0") if hasattr(tt, "device") else "cuda:0"
     for defer in (False, True):
         task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", embedding_grad="sparse", mlp_dtype="bf16", score_dtype="bf16")
         if state is None:
