@@ -70,6 +70,9 @@ def parse(argv=None):
     ap.add_argument("--sync-bn", action="store_true", help="multi-GPU: BatchNorm statistics over all ranks' rows also in the weak leg")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-to-device-inclusive leg")
     ap.add_argument("--breakdown", action="store_true", help="extra instrumented pass: per-kernel HIP-event times")
+    ap.add_argument("--dist-eager", action="store_true", help="sharded path launched from Python instead of replayed (analysis)")
+    ap.add_argument("--no-lookup-profile", action="store_true", help="do not stamp the lookup launches (no `roofline` object then)")
+    ap.add_argument("--lookup-wg-dump", default=None, help="write the lookup's per-workgroup stamps to this .npy (tools/lookup_wg.py)")
     return ap.parse_args(argv)
 
 
@@ -162,11 +165,11 @@ class Leg:
         # global-batch legs: rank r holds rows [r*B_local, (r+1)*B_local) of the global batch -- its own seeded slice
         self.pool = [synthetic.make_batch(B, self.vocab_n, self.vocab_c, self.keys_n, self.keys_c, self.din_n, self.din_c, dev,
                                           seed=1234 + 7919 * (rank * args.pool + i), zipf_alpha=args.zipf) for i in range(args.pool)]
-        eager_only = ctx["staged"] or os.environ.get("TT_DIST_EAGER")
+        eager_only = ctx["staged"] or args.dist_eager
         self.use_graph = (args.mode == "graph" and args.optimizer == "fused_sparse" and not eager_only) if sharded else \
             (args.mode == "graph" and args.optimizer != "torch_adam")
         self.gstep = None
-        self.profile = ops.LookupProfile(dev) if (self.use_graph and not os.environ.get("TT_BENCH_NO_PROFILE")) else None
+        self.profile = ops.LookupProfile(dev) if (self.use_graph and not args.no_lookup_profile) else None
         ex = getattr(task, "exchange", None)
         if sharded and ex is not None and hasattr(ex, "reset_capacity"):
             # fixed-capacity exchange: size the buckets for the largest need over the whole batch pool (one forward per
@@ -229,9 +232,9 @@ class Leg:
         dt = time.perf_counter() - t0
         ops.set_timer(None)
         self.lookup_us = self.profile.durations_us() if self.profile is not None else []
-        if self.profile is not None and os.environ.get("TT_LOOKUP_WG_DUMP"):     # per-workgroup stamps of the last launches (analysis)
+        if self.profile is not None and self.args.lookup_wg_dump:     # per-workgroup stamps of the last launches (analysis)
             import numpy as _np
-            _np.save(os.environ["TT_LOOKUP_WG_DUMP"], self.profile.ring.cpu().numpy())
+            _np.save(self.args.lookup_wg_dump, self.profile.ring.cpu().numpy())
         self.dispatch_us = lookup_dispatch_overhead_us(self.task, self.pool, ctx["dev"], self.profile) if self.profile is not None else None
         if self.profile is not None:
             self.profile.close()
@@ -336,10 +339,15 @@ def run(args):
             print(json.dumps(out), flush=True)
 
 
+def _tower_io_dtype() -> str:
+    from jodalrob_twotower_amd.config import settings
+    return settings.tower_io_dtype
+
+
 def base_line(args, leg, world, scaling, B_global):
     dt = leg.dt
     bf = args.score_dtype == "bf16" and args.mlp_dtype == "bf16"
-    x_bf16 = args.mlp_dtype == "bf16" and os.environ.get("TT_TOWER_IO_DTYPE", "x") in ("x", "both")
+    x_bf16 = args.mlp_dtype == "bf16" and _tower_io_dtype() in ("x", "both")
     return {
         "metric": "training pairs/sec at batch 8192 (embedding-lookup HBM GB/s in roofline)",
         "value": B_global * args.steps / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -355,7 +363,7 @@ def base_line(args, leg, world, scaling, B_global):
 
 def roofline_of(args, leg, world):
     """the lookup kernel: algorithmic bytes per launch / mean launch duration, measured live in the timed region"""
-    x_bf16 = args.mlp_dtype == "bf16" and os.environ.get("TT_TOWER_IO_DTYPE", "x") in ("x", "both")
+    x_bf16 = args.mlp_dtype == "bf16" and _tower_io_dtype() in ("x", "both")
     K_tot, E, B = len(leg.keys_n) + len(leg.keys_c), leg.E, leg.B
     s_out = 2 if x_bf16 else 4                                # the lookup writes straight into the tower input x
     bytes_per_pair = K_tot * (E * 4 + 8 + E * s_out)         # table row + i64 id + output row (SURVEY 8d: 10,032 / 7,600 B)
@@ -393,7 +401,7 @@ def roofline_of(args, leg, world):
 
 def config_of(args, leg, world, ctx, B_global, workload):
     ex = getattr(leg.task, "exchange", None)
-    x_bf16 = args.mlp_dtype == "bf16" and os.environ.get("TT_TOWER_IO_DTYPE", "x") in ("x", "both")
+    x_bf16 = args.mlp_dtype == "bf16" and _tower_io_dtype() in ("x", "both")
     cfg = {"workload": workload, "batch_per_gpu": leg.B, "global_batch": B_global, "rows_notice": sum(leg.vocab_n),
            "rows_company": sum(leg.vocab_c), "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})",
            "optimizer": args.optimizer, "score_dtype": args.score_dtype, "mlp_dtype": args.mlp_dtype,
@@ -438,6 +446,12 @@ def bench_single(args, ctx, sharded):
         except Exception as e:
             out["value_with_h2d"] = None
             out["h2d_error"] = f"{type(e).__name__}: {e}"
+    if not args.no_h2d and not sharded:
+        try:
+            out.update(device_store_leg(args, leg, ctx))
+        except Exception as e:
+            out["value_with_device_store"] = None
+            out["device_store_error"] = f"{type(e).__name__}: {e}"
     if args.breakdown:
         from jodalrob_twotower_amd import ops
         t2 = ops.KernelTimer()
@@ -676,6 +690,49 @@ def h2d_leg(args, leg, ctx, dense_dtype=None, key="value_with_h2d"):
     return {key: B * K / dt, "ms_per_step" + key[5:]: dt / K * 1e3,
             key[11:]: {"bytes_per_step": nbytes, "how": "pinned host batches -> two device staging sets on a copy stream, the step waits for its batch's copy event "
                                                      "(the copy of step i+1 overlaps the compute of step i)"}}
+
+
+def device_store_leg(args, leg, ctx, entities: int = 262_144, key: str = "value_with_device_store"):
+    """The captured step fed from DEVICE-RESIDENT feature stores (never `value`): per step ONE hand-over launch gathers the batch's
+    pairs -> entity rows -> dense features + ids + key-major fused rows into the graph's static buffers
+    (GraphedTrainStep.step_from_store / tt_batch_ingest_store), then the replay -- the loop scripts/train.py --fast runs.  Nothing
+    per step crosses PCIe.  Stores: `entities` notice and company rows (dense f32 [N, 256] / [N, 128], ids int64 [N, 32] / [N, 6],
+    uniform over the leg's vocabularies), 64 batches of shuffled pairs."""
+    import torch
+    from jodalrob_twotower_amd.data_loader import DeviceFeatureStore
+    dev, B = ctx["dev"], leg.B
+    if leg.gstep is None or not hasattr(leg.gstep, "step_from_store"):
+        return {key: None}
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+
+    def make(n, din, vocab, keys):
+        cat = torch.stack([torch.randint(0, v, (n,), generator=g, device=dev, dtype=torch.int64) for v in vocab], dim=1)
+        return DeviceFeatureStore({"dense_projected": torch.randn((n, din), generator=g, device=dev), "categorical": cat}, keys, dev)
+    ns, cs = make(entities, leg.din_n, leg.vocab_n, leg.keys_n), make(entities, leg.din_c, leg.vocab_c, leg.keys_c)
+    P = 64 * B
+    pairs = torch.randint(0, entities, (P, 2), generator=g, device=dev, dtype=torch.int64)
+    order = torch.randperm(P, generator=g, device=dev)
+    K = args.steps
+
+    def one(j):
+        res = leg.gstep.step_from_store(ns, cs, pairs, order, (j % 64) * B)
+        leg.sched.step()
+        return res
+    for j in range(min(10, K)):
+        one(j)
+    ctx["fence"]()
+    t0 = time.perf_counter()
+    for j in range(K):
+        res = one(10 + j)
+    ctx["fence"]()
+    dt = ctx["max_over_ranks"](time.perf_counter() - t0)
+    loss = float(res["loss"].detach())
+    del ns, cs, pairs, order
+    return {key: B * K / dt, "ms_per_step" + key[5:]: dt / K * 1e3,
+            key[11:]: {"entities_per_store": entities, "pairs": P, "final_loss": loss,
+                       "how": "GraphedTrainStep.step_from_store: tt_batch_ingest_store (pair -> entity row -> dense features, ids, key-major "
+                              "fused rows, step scalars; one launch) + graph replay; stores and pair list resident in HBM"}}
 
 
 def _physical_cores() -> int:

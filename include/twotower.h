@@ -56,6 +56,12 @@ int tt_ctx_num_cus(const tt_ctx* ctx);
  * step's dependent chain); tt_flush_deferred launches it on its own, and the tt_adam_* entries do that themselves before
  * they read a gradient.  Nothing else may write the towers' workspace while tt_deferred_pending() is 1. */
 #define TT_OPT_DEFER_SLAB_REDUCE 1
+/* TT_OPT_KEYED_PARTS (default 0 = chosen from the batch size): workgroups per key of tt_dedup_plan_keyed* -- every value gives
+ * the same plan bit for bit (tests vary it).  TT_OPT_SCORE_BWD_ROWS_MIN (default 32768): number of rows from which
+ * tt_score_bwd_bf16 takes the workgroup-staged form instead of the b-split form (same results up to summation order; tests
+ * force either form). */
+#define TT_OPT_KEYED_PARTS 2
+#define TT_OPT_SCORE_BWD_ROWS_MIN 3
 int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value);
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream);
 int tt_deferred_pending(const tt_ctx* ctx);
@@ -553,6 +559,32 @@ int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* s
  * sides[i].ids is the SOURCE of the hand-over (the incoming batch); out / ld_out / out_dtype are ignored.  1 <= K <= 64 per side. */
 int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                     const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_km, tt_stream stream);
+
+/* The same hand-over STRAIGHT FROM THE DEVICE-RESIDENT FEATURE STORES (two-level gather: pair -> entity row -> dense features
+ * and ids -> fused table rows) -- replaces UnifiedBidDataset.__getitem__ + collate_fn_gpu_optimized + _build_batch_kjt
+ * (src/towers/pairs/unified_bid_data_loader.py:461-504, :630-684, :827-841) and the host-to-device copy of the batch
+ * (scripts/train.py:261-273) with ONE launch and no intermediate batch tensors.  For side i, sample b:
+ *   o = order ? order[b] : b ;  e = stores[i].entity[o * stores[i].entity_stride]      (entity row of the pair's side)
+ *   dense_out[b, :]   = dense_store[e, :]                                              (f32 copy)
+ *   ids_out[b*K + k]  = cat_store[e*K + k]                                             (sample-major: the KJT values())
+ *   rows_km[side_base + k*B + b] = key_row_offset[k] + clamp(ids_out[b*K + k], 0, key_vocab[k] - 1)   (as tt_batch_ingest)
+ * plus the n copy segments (the step scalars).  sides[i] gives K / key_row_offset / key_vocab (ids, out, ld_out, out_dtype
+ * ignored); rows_km may be NULL (no key-major rows wanted).  Entity indices are trusted to lie inside the stores (the
+ * loader validates the pair list once: KeyError as unified_bid_data_loader.py:495-498).  Bit-identical to tt_batch_gather per
+ * side followed by tt_batch_ingest (test). */
+typedef struct tt_store_side {
+  const int64_t* entity;     /* entity index per pair, read at [o * entity_stride] (an interleaved [P, 2] pair list: stride 2) */
+  int64_t entity_stride;
+  const float* dense_store;  /* [N, dense_dim] */
+  const int64_t* cat_store;  /* [N, K] */
+  float* dense_out;          /* [B, dense_dim] */
+  int64_t* ids_out;          /* [B * K] */
+  int32_t dense_dim;
+  int32_t reserved;
+} tt_store_side;
+int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
+                          const tt_embed_side* sides, const tt_store_side* stores, int32_t n_sides, int64_t B,
+                          const int64_t* order /* [B] or NULL */, int32_t* rows_km /* or NULL */, tt_stream stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,11 @@ class EmbedSide(C.Structure):
                 ("K", i32), ("out_dtype", i32)]
 
 
+class StoreSide(C.Structure):
+    _fields_ = [("entity", vp), ("entity_stride", i64), ("dense_store", vp), ("cat_store", vp), ("dense_out", vp), ("ids_out", vp),
+                ("dense_dim", i32), ("reserved", i32)]
+
+
 class GradSrc(C.Structure):
     _fields_ = [("d_out", vp), ("ld", i64), ("K", i32), ("dtype", i32)]
 
@@ -141,6 +146,8 @@ SIGNATURES = {
     "tt_copy_multi": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]),
     "tt_batch_ingest": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp, vp]),
     "tt_batch_gather": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]),
+    "tt_batch_ingest_store": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), C.POINTER(StoreSide), i32,
+                                        i64, vp, vp, vp]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -197,6 +204,13 @@ def ptr(t: Optional[torch.Tensor]) -> vp:
 
 
 TT_OPT_DEFER_SLAB_REDUCE = 1
+TT_OPT_KEYED_PARTS = 2
+TT_OPT_SCORE_BWD_ROWS_MIN = 3
+
+
+def set_option(device: torch.device, option: int, value: int):
+    """tt_ctx_set_option on the device's context (include/twotower.h: TT_OPT_*)."""
+    check(load().tt_ctx_set_option(ctx(device), int(option), int(value)), "tt_ctx_set_option")
 
 
 def set_defer_slab_reduce(device: torch.device, on: bool):

@@ -11,7 +11,6 @@ checkpoints see the reference's tensors while the lookup / gradient kernels see 
 """
 from __future__ import annotations
 
-import os
 from pathlib import Path
 from typing import Dict, List, Optional, Union
 
@@ -20,6 +19,7 @@ from ._lib import no_dynamo as _no_dynamo
 import torch.nn as nn
 
 from . import ops
+from .config import settings
 from .schema import category_counts
 
 
@@ -165,7 +165,7 @@ class CategoricalEmbedder(nn.Module):
         self.safety_margin = safety_margin
         self.vocab_sizes = self._extract_vocab_sizes(metadata_path, table_name, self.keys)
         print(f"[CategoricalEmbedder] Initializing with {len(self.keys)} features")
-        mode = embedding_grad or os.environ.get("TT_EMBEDDING_GRAD", "dense")
+        mode = embedding_grad or settings.embedding_grad
         self.store = EmbeddingStore(embedding_dim, torch.device(self.device_str), mode)
         self.embeddings = nn.ModuleDict()
         offs = []

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "twotower.h"
 
@@ -17,6 +18,8 @@ struct tt_ctx {
   // next tt_embed_grad_bwd on a planned workspace runs it inside its own launch, tt_flush_deferred / the Adam entries otherwise
   int defer_slab_reduce;
   struct TnPending* deferred;
+  int keyed_parts;          // TT_OPT_KEYED_PARTS: workgroups per key of the keyed dedup plan (0 = chosen from the batch)
+  int score_bwd_rows_min;   // TT_OPT_SCORE_BWD_ROWS_MIN: rows from which tt_score_bwd_bf16 takes the workgroup-staged form
 };
 
 void tt_set_error(const char* fmt, ...);
@@ -39,6 +42,18 @@ void tt_set_error(const char* fmt, ...);
   } while (0)
 
 #define TT_LAUNCH_CHECK() TT_HIP(hipGetLastError())
+
+// hipFuncAttributeMaxDynamicSharedMemorySize of one kernel instantiation, set once per device (a static per expansion site; the
+// kernel goes last because its template arguments carry commas).  Needs `ctx` in scope.
+#define TT_LDS_ONCE(bytes, ...)                                                                                     \
+  do {                                                                                                              \
+    static std::atomic<uint64_t> tt_lds_done{0};                                                                    \
+    const uint64_t tt_bit = 1ull << (ctx->device & 63);                                                             \
+    if (!(tt_lds_done.load(std::memory_order_acquire) & tt_bit)) {                                                  \
+      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      tt_lds_done.fetch_or(tt_bit, std::memory_order_release);                                                      \
+    }                                                                                                               \
+  } while (0)
 
 static inline int64_t tt_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline bool tt_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }

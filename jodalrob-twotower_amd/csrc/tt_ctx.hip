@@ -39,6 +39,8 @@ int tt_ctx_create(int device, tt_ctx** out) {
   c->lookup_stamp_slots = 0;
   c->defer_slab_reduce = 0;
   c->deferred = nullptr;
+  c->keyed_parts = 0;
+  c->score_bwd_rows_min = 32768;
   *out = c;
   return TT_OK;
 }
@@ -51,8 +53,18 @@ int tt_ctx_destroy(tt_ctx* ctx) {
 
 int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value) {
   TT_CHECK_ARG(ctx != nullptr, "tt_ctx_set_option: NULL context");
-  TT_CHECK_ARG(option == TT_OPT_DEFER_SLAB_REDUCE, "tt_ctx_set_option: unknown option %d", option);
-  ctx->defer_slab_reduce = value != 0;
+  switch (option) {
+    case TT_OPT_DEFER_SLAB_REDUCE: ctx->defer_slab_reduce = value != 0; break;
+    case TT_OPT_KEYED_PARTS:
+      TT_CHECK_ARG(value >= 0, "tt_ctx_set_option: TT_OPT_KEYED_PARTS needs a value >= 0");
+      ctx->keyed_parts = value;
+      break;
+    case TT_OPT_SCORE_BWD_ROWS_MIN:
+      TT_CHECK_ARG(value >= 1, "tt_ctx_set_option: TT_OPT_SCORE_BWD_ROWS_MIN needs a value >= 1");
+      ctx->score_bwd_rows_min = value;
+      break;
+    default: tt_set_error("tt_ctx_set_option: unknown option %d", option); return TT_ERR_INVALID_ARG;
+  }
   return TT_OK;
 }
 

@@ -123,8 +123,7 @@ struct SlotRec {
 };
 using f32x4n = __attribute__((ext_vector_type(4))) float;
 
-template <int C, int SPW, int MODE>   // SPW slots per wave pass; MODE 0: nt stores (default); 1: loads only;
-                                      // 2: stores only (ablations); 4: plain stores; 5: nt loads + nt stores
+template <int C, int SPW>   // C 16-byte chunks per row, SPW slots per wave pass
 __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const float* __restrict__ table,
                                                               int32_t* __restrict__ rows_out,
                                                               unsigned long long* __restrict__ ring, int ring_slots) {
@@ -174,38 +173,20 @@ __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const 
     for (int j = 0; j < NIT; ++j) {
       const SlotRec r = recs[wave][j * RPI + sub];
       v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r.src != nullptr && MODE != 2) {
-        if (MODE == 5) {
-          const f32x4n t = __builtin_nontemporal_load(reinterpret_cast<const f32x4n*>(r.src + part * 4));
-          v[j] = make_float4(t[0], t[1], t[2], t[3]);
-        } else {
-          v[j] = *reinterpret_cast<const float4*>(r.src + part * 4);
-        }
-      }
+      if (r.src != nullptr) v[j] = *reinterpret_cast<const float4*>(r.src + part * 4);
     }
-    if (MODE == 1) {                                      // keep the loads alive, write one word per lane
-      float acc = 0.f;
 #pragma unroll
-      for (int j = 0; j < NIT; ++j) acc += v[j].x + v[j].y + v[j].z + v[j].w;
-      if (acc == 12345.678f && rows_out) rows_out[0] = 1;
-    } else {
-#pragma unroll
-      for (int j = 0; j < NIT; ++j) {
-        const SlotRec r = recs[wave][j * RPI + sub];
-        if (r.dst == nullptr) continue;
-        if (dts[wave][j * RPI + sub] == TT_F32) {
-          if (MODE == 0 || MODE == 5) {
-            f32x4n t;
-            t[0] = v[j].x; t[1] = v[j].y; t[2] = v[j].z; t[3] = v[j].w;
-            __builtin_nontemporal_store(t, reinterpret_cast<f32x4n*>(r.dst + part * 16));
-          } else {
-            *reinterpret_cast<float4*>(r.dst + part * 16) = v[j];
-          }
-        } else {
-          ushort4 o;
-          o.x = tt_f2bf(v[j].x); o.y = tt_f2bf(v[j].y); o.z = tt_f2bf(v[j].z); o.w = tt_f2bf(v[j].w);
-          *reinterpret_cast<ushort4*>(r.dst + part * 8) = o;
-        }
+    for (int j = 0; j < NIT; ++j) {
+      const SlotRec r = recs[wave][j * RPI + sub];
+      if (r.dst == nullptr) continue;
+      if (dts[wave][j * RPI + sub] == TT_F32) {            // non-temporal: the rows are read next by another kernel, not this one
+        f32x4n t;
+        t[0] = v[j].x; t[1] = v[j].y; t[2] = v[j].z; t[3] = v[j].w;
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4n*>(r.dst + part * 16));
+      } else {
+        ushort4 o;
+        o.x = tt_f2bf(v[j].x); o.y = tt_f2bf(v[j].y); o.z = tt_f2bf(v[j].z); o.w = tt_f2bf(v[j].w);
+        *reinterpret_cast<ushort4*>(r.dst + part * 8) = o;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -1523,6 +1504,100 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
   }
 }
 
+// The hand-over straight from the device-resident feature stores (tt_batch_ingest_store): grid row 0 = every side's 64-sample
+// tiles (entity rows of the tile's pairs -> the tile's ids as one sample-major run + the key-major fused rows, turned in LDS as
+// above); rows 1 .. n_sides = the dense feature rows of side y - 1 (16-byte pieces, a row's pieces on consecutive lanes);
+// the rows after that = the copy segments.
+struct StoreIngestArgs {
+  IngestArgs g;                                  // ids[] unused
+  const int64_t* order;
+  const int64_t* entity[TT_MAX_SIDES];
+  int64_t entity_stride[TT_MAX_SIDES];
+  const float* dense_store[TT_MAX_SIDES];
+  const int64_t* cat_store[TT_MAX_SIDES];
+  float* dense_out[TT_MAX_SIDES];
+  int64_t* ids_out[TT_MAX_SIDES];
+  int32_t dense_dim[TT_MAX_SIDES];
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(kThreads) void batch_ingest_store_kernel(StoreIngestArgs a) {
+  const int B = a.g.B;
+  if ((int)blockIdx.y > a.g.n_sides) {
+    const int seg = blockIdx.y - 1 - a.g.n_sides;
+    const int64_t n16 = a.g.c.bytes[seg] / 16, tail0 = n16 * 16;
+    const float4* __restrict__ s = reinterpret_cast<const float4*>(a.g.c.src[seg]);
+    float4* __restrict__ d = reinterpret_cast<float4*>(a.g.c.dst[seg]);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) d[i] = s[i];
+    if (blockIdx.x == 0)
+      for (int64_t i = tail0 + threadIdx.x; i < a.g.c.bytes[seg]; i += blockDim.x) a.g.c.dst[seg][i] = a.g.c.src[seg][i];
+    return;
+  }
+  if (blockIdx.y >= 1) {                                       // dense feature rows of one side
+    const int si = blockIdx.y - 1;
+    const int dd = a.dense_dim[si];
+    if (dd == 0) return;
+    const int64_t* __restrict__ ent = a.entity[si];
+    const int64_t es = a.entity_stride[si];
+    const int per = VEC ? dd / 4 : dd;                         // pieces per row
+    const int64_t total = (int64_t)B * per, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+      const int b = (int)(t / per), j = (int)(t - (int64_t)b * per);
+      const int64_t o = a.order ? a.order[b] : b;
+      const int64_t e = ent[o * es];
+      if (VEC) reinterpret_cast<float4*>(a.dense_out[si] + (int64_t)b * dd)[j] = reinterpret_cast<const float4*>(a.dense_store[si] + e * dd)[j];
+      else a.dense_out[si][(int64_t)b * dd + j] = a.dense_store[si][e * dd + j];
+    }
+    return;
+  }
+  const int tiles = (B + 63) / 64;
+  const int si = (int)blockIdx.x / tiles, tile = (int)blockIdx.x % tiles;
+  if (si >= a.g.n_sides) return;
+  const int K = a.g.K[si];
+  __shared__ int32_t tl[kIngestMaxK][65];
+  __shared__ int64_t s_off[kIngestMaxK], s_hi[kIngestMaxK], s_ent[64];
+  const int b0 = tile * 64;
+  const int nb = min(64, B - b0), n = nb * K;
+  if ((int)threadIdx.x < K) {
+    s_off[threadIdx.x] = a.g.off[si][threadIdx.x];
+    s_hi[threadIdx.x] = a.g.vocab[si][threadIdx.x] - 1;
+  }
+  if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + nb) {
+    const int bl = threadIdx.x - 64;
+    const int64_t o = a.order ? a.order[b0 + bl] : b0 + bl;
+    s_ent[bl] = a.entity[si][o * a.entity_stride[si]];
+  }
+  __syncthreads();
+  constexpr int PER = kIngestMaxK * 64 / kThreads;
+  const int64_t* __restrict__ cat = a.cat_store[si];
+  int64_t idv[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {                              // a sample's K ids are one contiguous run of its entity row
+    const int e = threadIdx.x + u * kThreads;
+    const int ec = e < n ? e : 0;
+    const int bl = ec / K, k = ec - bl * K;
+    idv[u] = cat[s_ent[bl] * K + k];
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + u * kThreads;
+    if (e < n) {
+      const int bl = e / K, k = e - bl * K;
+      int64_t id = idv[u];
+      a.ids_out[si][(int64_t)b0 * K + e] = id;                 // sample-major: the KJT values() of the batch
+      id = id < 0 ? 0 : (id > s_hi[k] ? s_hi[k] : id);         // clamp: cat_embed.py:117 (as the lookup)
+      tl[k][bl] = (int32_t)(s_off[k] + id);
+    }
+  }
+  if (a.g.rows_km == nullptr) return;
+  __syncthreads();
+  for (int e = threadIdx.x; e < K * 64; e += kThreads) {
+    const int k = e >> 6, bl = e & 63;
+    if (bl < nb) a.g.rows_km[a.g.side_base[si] + (int64_t)k * B + b0 + bl] = tl[k][bl];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // multi-GPU routing: distinct rows -> fixed-capacity owner buckets (stable, no host sync)
 //   a workgroup of 4 waves covers 2048 consecutive plan rows, a wave 512 of them in 8 batches of 64
@@ -1782,37 +1857,23 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
   a.total_slots = (uint32_t)slots;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   constexpr int U = 4;
-  static const int variant = getenv("TT_LOOKUP_VARIANT") ? atoi(getenv("TT_LOOKUP_VARIANT")) : 0;
   const bool pow2c = vec4 && table && C <= 64 && (C & (C - 1)) == 0;
-  if (pow2c && variant != 1) {
-    static const int spw_env = getenv("TT_LOOKUP_SPW") ? atoi(getenv("TT_LOOKUP_SPW")) : 0;
-    const int rpi = 64 / (int)C;
-    int spw = spw_env > 0 ? spw_env : 64;
-    if (spw < rpi) spw = rpi;
+  if (pow2c) {
+    const int spw = 64;                                    // slots per wave pass (32 and 16 measured slower at every C)
     int64_t wg = tt_cdiv(tt_cdiv(slots, spw), kThreads / 64);
     const int64_t cap = (int64_t)ctx->num_cus * 16;
     const int grid = (int)(wg < cap ? wg : cap);
-#define TT_LK2(CV, SV)                                                                                         \
-    if (variant == 2) lookup_wave_kernel<CV, SV, 1><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots);               \
-    else if (variant == 3) lookup_wave_kernel<CV, SV, 2><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots);          \
-    else if (variant == 4) lookup_wave_kernel<CV, SV, 4><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots);          \
-    else if (variant == 5) lookup_wave_kernel<CV, SV, 5><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots);          \
-    else lookup_wave_kernel<CV, SV, 0><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots);
-#define TT_LK(CV)                                                                                              \
-    if (spw >= 64 || 64 / CV > 32) { TT_LK2(CV, 64) }                                                             \
-    else if (spw >= 32 || 64 / CV > 16) { TT_LK2(CV, (64 / CV > 32 ? 64 : 32)) }                                   \
-    else { TT_LK2(CV, (64 / CV > 16 ? 32 : 16)) }
+#define TT_LK(CV) lookup_wave_kernel<CV, spw><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots)
     switch (C) {
-      case 1: TT_LK2(1, 64) break;
-      case 2: TT_LK2(2, 64) break;
-      case 4: TT_LK(4) break;
-      case 8: TT_LK(8) break;
-      case 16: TT_LK(16) break;
-      case 32: TT_LK(32) break;
-      default: TT_LK(64) break;
+      case 1: TT_LK(1); break;
+      case 2: TT_LK(2); break;
+      case 4: TT_LK(4); break;
+      case 8: TT_LK(8); break;
+      case 16: TT_LK(16); break;
+      case 32: TT_LK(32); break;
+      default: TT_LK(64); break;
     }
 #undef TT_LK
-#undef TT_LK2
     TT_LAUNCH_CHECK();
     return TT_OK;
   }
@@ -1948,10 +2009,9 @@ static int dedup_plan_keyed_impl(tt_ctx* ctx, const int32_t* rows, const int32_t
     const GradLayout gl = grad_layout(reinterpret_cast<char*>(grad_ws), slots, E);
     pl = PlanLong{gl.ws.counters, gl.ws.long_row, gl.ws.long_base, gl.ws.chunk_lo, gl.ws.chunk_hi};
   }
-  // workgroups per key (TT_KEYED_PARTS: A/B runs): the sort's scatter, ranking and output phases split P ways, the load and
+  // workgroups per key (TT_OPT_KEYED_PARTS overrides): the sort's scatter, ranking and output phases split P ways, the load and
   // histogram phases are repeated by every share; small batches are launch-bound anyway
-  const int parts_env = getenv("TT_KEYED_PARTS") ? atoi(getenv("TT_KEYED_PARTS")) : 0;      // (read per call: tests vary it)
-  int parts = parts_env > 0 ? parts_env : (B >= 2048 ? 6 : 1);                        // (38 keys: 4 shares 17.9 us, 5: 17.4, 6: 17.2)
+  int parts = ctx->keyed_parts > 0 ? ctx->keyed_parts : (B >= 2048 ? 6 : 1);                        // (38 keys: 4 shares 17.9 us, 5: 17.4, 6: 17.2)
   if (parts > kKeyedMaxParts) parts = kKeyedMaxParts;
   while (parts > 1 && (int64_t)n_keys * parts > (int64_t)ctx->num_cus) --parts;        // a workgroup needs a CU of its own (144 KB of LDS)
   a.parts = parts;
@@ -2380,6 +2440,60 @@ int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const*
   const int64_t tiles = tt_cdiv(B, 64) * n_sides;        // row 0 holds every tile (the copy rows stride over their segments)
   if (tiles > gx) gx = tiles;
   batch_ingest_kernel<<<dim3((unsigned)gx, (unsigned)(n + 1)), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
+                          const tt_store_side* stores, int32_t n_sides, int64_t B, const int64_t* order, int32_t* rows_km, tt_stream stream) {
+  TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest_store: bad copy arguments");
+  TT_CHECK_ARG(sides && stores && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest_store: bad side arguments");
+  StoreIngestArgs a{};
+  int64_t mx = 0, slots = 0, dense_pieces = 0;
+  bool vec = true;
+  for (int i = 0; i < n; ++i) {
+    TT_CHECK_ARG(bytes[i] >= 0 && (bytes[i] == 0 || (dst[i] && src[i])), "tt_batch_ingest_store: segment %d NULL", i);
+    TT_CHECK_ARG(tt_aligned(dst[i], 16) && tt_aligned(src[i], 16), "tt_batch_ingest_store: segment %d not 16-byte aligned", i);
+    a.g.c.dst[i] = reinterpret_cast<char*>(dst[i]);
+    a.g.c.src[i] = reinterpret_cast<const char*>(src[i]);
+    a.g.c.bytes[i] = bytes[i];
+    mx = bytes[i] > mx ? bytes[i] : mx;
+  }
+  a.g.n_copy = n;
+  a.g.n_sides = n_sides;
+  a.g.B = (int32_t)B;
+  a.g.rows_km = rows_km;
+  a.order = order;
+  for (int i = 0; i < n_sides; ++i) {
+    const tt_embed_side& s = sides[i];
+    const tt_store_side& t = stores[i];
+    TT_CHECK_ARG(s.K >= 1 && s.key_row_offset && s.key_vocab, "tt_batch_ingest_store: side %d NULL / no keys", i);
+    TT_CHECK_ARG(t.entity && t.entity_stride >= 1 && t.cat_store && t.ids_out && t.dense_dim >= 0 &&
+                 (t.dense_dim == 0 || (t.dense_store && t.dense_out)), "tt_batch_ingest_store: store %d NULL / bad shape", i);
+    if (s.K > kIngestMaxK) {
+      tt_set_error("tt_batch_ingest_store: side %d has %d keys (max %d)", i, s.K, kIngestMaxK);
+      return TT_ERR_UNSUPPORTED;
+    }
+    a.g.off[i] = s.key_row_offset; a.g.vocab[i] = s.key_vocab; a.g.K[i] = s.K;
+    a.g.side_base[i] = (int32_t)slots;
+    slots += B * s.K;
+    a.entity[i] = t.entity; a.entity_stride[i] = t.entity_stride; a.dense_store[i] = t.dense_store; a.cat_store[i] = t.cat_store;
+    a.dense_out[i] = t.dense_out; a.ids_out[i] = t.ids_out; a.dense_dim[i] = t.dense_dim;
+    vec = vec && t.dense_dim % 4 == 0 && tt_aligned(t.dense_store, 16) && tt_aligned(t.dense_out, 16);
+    const int64_t p = B * (int64_t)t.dense_dim;
+    dense_pieces = p > dense_pieces ? p : dense_pieces;
+  }
+  TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_batch_ingest_store: too many slots");
+  int64_t gx = tt_cdiv(mx / 16 + 1, kThreads);
+  const int64_t rows_wg = tt_cdiv(vec ? dense_pieces / 4 : dense_pieces, kThreads);
+  if (rows_wg > gx) gx = rows_wg;
+  const int64_t cap = (int64_t)ctx->num_cus * 8;
+  if (gx > cap) gx = cap;
+  const int64_t tiles = tt_cdiv(B, 64) * n_sides;        // row 0 holds every tile (the other rows stride over their work)
+  if (tiles > gx) gx = tiles;
+  const dim3 grid((unsigned)gx, (unsigned)(1 + n_sides + n));
+  if (vec) batch_ingest_store_kernel<true><<<grid, kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+  else batch_ingest_store_kernel<false><<<grid, kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

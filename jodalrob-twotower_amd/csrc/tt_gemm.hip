@@ -627,7 +627,7 @@ inline int tn_splits(int64_t M, int64_t N, int64_t R) {
   // ~2 workgroups per CU (TT_GEMM_TN_WGS: A/B runs).  More splits shorten each workgroup's batch range but every split
   // writes a 64 x 64 f32 slab: at 1024 workgroups the slabs of the block weight gradient (16.5 MB) were as large as its
   // operands; 512 measured 5 us per step faster than 1024, 384 and 256 slower again
-  static const int64_t target = getenv("TT_GEMM_TN_WGS") ? atoll(getenv("TT_GEMM_TN_WGS")) : 512;
+  const int64_t target = 512;
   int64_t s = target / (tiles > 0 ? tiles : 1);
   int64_t maxs = tt_cdiv(R, 128);
   if (maxs > 64) maxs = 64;
@@ -648,8 +648,7 @@ static int launch_gemm(hipStream_t st, const GemmBatch& b, int n, int zsplits, b
   dim3 grid((unsigned)mt, (unsigned)nt, (unsigned)(n * zsplits));
   if (bf16) {
     // shapes without edges and one element type per operand across the batch: the three-steps-ahead kernel
-    static const bool fast_off = getenv("TT_GEMM_FAST") && atoi(getenv("TT_GEMM_FAST")) == 0;
-    bool fast = vec && !fast_off;
+    bool fast = vec;
     for (int i = 0; i < n && fast; ++i) {
       const GemmArgs& g = b.a[i];
       fast = g.M % BM == 0 && g.N % BN == 0 && g.K % BK16 == 0 && g.kchunk % BK16 == 0 && g.a_bf16 == b.a[0].a_bf16 &&
@@ -692,7 +691,7 @@ static int launch_gemm(hipStream_t st, const GemmBatch& b, int n, int zsplits, b
 
 static int nt_splits(int64_t tiles_all, int64_t K) {
   if (tiles_all >= 512) return 1;                     // two workgroups per CU already: a slab pass (~7 us) costs more than it buys
-  static const int64_t target = getenv("TT_GEMM_NT_WGS") ? atoll(getenv("TT_GEMM_NT_WGS")) : 1024;
+  const int64_t target = 1024;
   int64_t sp = target / (tiles_all > 0 ? tiles_all : 1);
   const int64_t maxs = K / 128;                       // at least 128 of K per split
   if (sp > maxs) sp = maxs;
@@ -872,8 +871,7 @@ size_t tt_gemm_back_g_workspace_bytes(int64_t H, int64_t h0, int64_t din, int64_
 }
 
 bool tt_gemm_back_supported(const GemmBack* it, int n) {
-  static const bool off = getenv("TT_GEMM_FAST") && atoi(getenv("TT_GEMM_FAST")) == 0;
-  if (off || n < 1 || n > TT_MAX_SIDES) return false;
+  if (n < 1 || n > TT_MAX_SIDES) return false;
   for (int i = 0; i < n; ++i) {
     const GemmBack& g = it[i];
     if (g.B < 64 || g.B % 64 || g.H < 64 || g.H % 64 || g.H > kProjMaxH || g.kx % 64 || g.h0 % 64 || g.h0 < 64 || g.h0 >= g.kx || g.din % 64) return false;
@@ -901,10 +899,8 @@ int tt_gemm_back_batched(hipStream_t st, const GemmBack* it, int n, TnPending* p
   int ns = 0, wg = 0;
   int64_t maxtotal = 1;
   auto kchunk_of = [](int64_t R, int splits) { return (int)(tt_cdiv(tt_cdiv(R, splits), BK16) * BK16); };
-  static const int role_mask = getenv("TT_BACK_ROLE_MASK") ? atoi(getenv("TT_BACK_ROLE_MASK")) : 7;   // timing experiments only
   for (int role = 0; role < 3; ++role)                   // long problems first
     for (int i = 0; i < n; ++i) {
-      if (!((role_mask >> role) & 1)) continue;
       const GemmBack& g = it[i];
       const int s0 = tn_splits(g.H, g.kx, g.B), s1 = back_g_splits(g.H, g.din, g.B);
       float* slabs0 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(g.ws_dw) + 255) & ~uintptr_t(255));

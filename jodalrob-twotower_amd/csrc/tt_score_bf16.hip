@@ -1026,10 +1026,8 @@ int tt_score_fwd_bf16(tt_ctx* ctx, const tt_score_fwd_dir* dirs, int32_t n_dirs,
     else score_fwd_bf16_kernel<KS, AT, NW, false><<<grid, NW * 64, 0, st>>>(a);                                \
   } while (0)
   // D <= 64: 32 rows per wave (AT = 1), 8 waves, 2 workgroups per CU measured best (43.6 us; AT = 2: 48.0, 4 waves: 53.4,
-  // 16 waves: 48.7 at B = 8192); TT_SCORE_FWD_VARIANT = 2 selects the 64-row form
-  static const int fvar = getenv("TT_SCORE_FWD_VARIANT") ? atoi(getenv("TT_SCORE_FWD_VARIANT")) : 0;
+  // 16 waves: 48.7 at B = 8192)
   if (Dp == 32) TT_FWD(2, 2, 8);
-  else if (Dp == 64 && fvar == 2) TT_FWD(4, 2, 8);
   else if (Dp == 64) TT_FWD(4, 1, 8);
   else if (Dp == 128) TT_FWD(8, 2, 8);
   else TT_FWD(16, 1, 8);
@@ -1064,7 +1062,6 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
   a.D = D;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int Dp = padded_d(D);
-  static const int bvar = getenv("TT_SCORE_BWD_VARIANT") ? atoi(getenv("TT_SCORE_BWD_VARIANT")) : 0;
 #define TT_BWD(KS, AT, NW)                                                                                     \
   do {                                                                                                         \
     const dim3 grid((unsigned)tt_cdiv(maxRa, 32 * AT), (unsigned)n_dirs);                                      \
@@ -1072,18 +1069,17 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
     else score_bwd_bf16_kernel<KS, AT, NW, false><<<grid, NW * 64, 0, st>>>(a);                                \
   } while (0)
   // enough rows for every SIMD to own 64 of them: the workgroup-staged form (no split along b, operands shared through LDS)
-  const int rows_min = getenv("TT_SCORE_BWD_ROWS_MIN") ? atoi(getenv("TT_SCORE_BWD_ROWS_MIN")) : 32768;   // (read per call: tests switch forms)
-  if (maxRa >= rows_min && Dp >= 64) {
+  if (maxRa >= ctx->score_bwd_rows_min && Dp >= 64) {
 #define TT_BWD_ROWS(KS)                                                                                        \
   do {                                                                                                         \
     const dim3 grid((unsigned)tt_cdiv(maxRa, 256), (unsigned)n_dirs);                                          \
     const size_t lds = 2 * (size_t)(KS * 2048 + 256);                                                          \
     if (unit) {                                                                                                \
-      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, true, false, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      score_bwd_rows_kernel<KS, true, false, 2, 4><<<grid, 256, lds, st>>>(a);                                       \
+      TT_LDS_ONCE(lds, &score_bwd_rows_kernel<KS, true, false, 2, 4>);                                         \
+      score_bwd_rows_kernel<KS, true, false, 2, 4><<<grid, 256, lds, st>>>(a);                                 \
     } else {                                                                                                   \
-      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, false, false, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-      score_bwd_rows_kernel<KS, false, false, 2, 4><<<grid, 256, lds, st>>>(a);                                      \
+      TT_LDS_ONCE(lds, &score_bwd_rows_kernel<KS, false, false, 2, 4>);                                        \
+      score_bwd_rows_kernel<KS, false, false, 2, 4><<<grid, 256, lds, st>>>(a);                                \
     }                                                                                                          \
   } while (0)
     if (Dp == 64) TT_BWD_ROWS(4);
@@ -1094,19 +1090,14 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
     return TT_OK;
   }
   if (Dp == 32) TT_BWD(2, 2, 8);
-  else if (Dp == 64) {
-    if (bvar == 1) TT_BWD(4, 1, 8);
-    else if (bvar != 2) {                                 // one streamed image, transposing LDS reads (TT_SCORE_BWD_VARIANT=2: two images)
-      const dim3 grid((unsigned)tt_cdiv(maxRa, 64), (unsigned)n_dirs);
-      if (unit) score_bwd_tr_kernel<4, 2, true><<<grid, 512, 0, st>>>(a);
-      else score_bwd_tr_kernel<4, 2, false><<<grid, 512, 0, st>>>(a);
-    } else TT_BWD(4, 2, 8);
-  } else if (Dp == 128) {
-    if (bvar != 2) {                                      // D <= 128: the one-image form, one a tile per workgroup
-      const dim3 grid((unsigned)tt_cdiv(maxRa, 32), (unsigned)n_dirs);
-      if (unit) score_bwd_tr_kernel<8, 1, true><<<grid, 512, 0, st>>>(a);
-      else score_bwd_tr_kernel<8, 1, false><<<grid, 512, 0, st>>>(a);
-    } else TT_BWD(8, 1, 8);
+  else if (Dp == 64) {                                    // one streamed image, transposing LDS reads
+    const dim3 grid((unsigned)tt_cdiv(maxRa, 64), (unsigned)n_dirs);
+    if (unit) score_bwd_tr_kernel<4, 2, true><<<grid, 512, 0, st>>>(a);
+    else score_bwd_tr_kernel<4, 2, false><<<grid, 512, 0, st>>>(a);
+  } else if (Dp == 128) {                                 // the one-image form, one a tile per workgroup
+    const dim3 grid((unsigned)tt_cdiv(maxRa, 32), (unsigned)n_dirs);
+    if (unit) score_bwd_tr_kernel<8, 1, true><<<grid, 512, 0, st>>>(a);
+    else score_bwd_tr_kernel<8, 1, false><<<grid, 512, 0, st>>>(a);
   }
   else TT_BWD(16, 1, 4);
 #undef TT_BWD
@@ -1169,23 +1160,21 @@ int tt_score_bwd_fp8(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, 
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   const int Dp = padded_d8(D);
   // D = 256: two waves per SIMD, one a tile each (the 128 accumulator registers of a 32 x 256 block leave room for nothing
-  // more); narrower: one wave per SIMD with two a tiles.  TT_SCORE_BWD8_FORM = 1 | 2 forces a form (A/B runs).
-  const int form = getenv("TT_SCORE_BWD8_FORM") ? atoi(getenv("TT_SCORE_BWD8_FORM")) : 0;
+  // more); narrower: one wave per SIMD with two a tiles.
 #define TT_BWD8(KS, AT_, NWV_)                                                                                 \
   do {                                                                                                         \
     const dim3 grid((unsigned)tt_cdiv(maxRa, 32 * AT_ * NWV_), (unsigned)n_dirs);                              \
     const size_t lds = 2 * (size_t)(KS * 512 + KS * 1024 + 256);                                               \
     if (unit) {                                                                                                \
-      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, true, true, AT_, NWV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      TT_LDS_ONCE(lds, &score_bwd_rows_kernel<KS, true, true, AT_, NWV_>);                                     \
       score_bwd_rows_kernel<KS, true, true, AT_, NWV_><<<grid, NWV_ * 64, lds, st>>>(a);                       \
     } else {                                                                                                   \
-      TT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&score_bwd_rows_kernel<KS, false, true, AT_, NWV_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+      TT_LDS_ONCE(lds, &score_bwd_rows_kernel<KS, false, true, AT_, NWV_>);                                    \
       score_bwd_rows_kernel<KS, false, true, AT_, NWV_><<<grid, NWV_ * 64, lds, st>>>(a);                      \
     }                                                                                                          \
   } while (0)
   if (Dp == 64) TT_BWD8(4, 2, 4);
   else if (Dp == 128) TT_BWD8(8, 2, 4);
-  else if (form == 1) TT_BWD8(16, 2, 4);
   else TT_BWD8(16, 1, 8);
 #undef TT_BWD8
   TT_LAUNCH_CHECK();

@@ -455,8 +455,7 @@ inline SymLayout sym_layout(const tt_ctx* ctx, int64_t R, int D) {
   L.nT = (int)tt_cdiv(R, 32);
   L.n_groups = (int)tt_cdiv(L.nT, kSymWaves);
   // notice tiles per workgroup: enough workgroups for ~2 per CU, at least 4 tiles per sweep, at most 32 (LDS: 3 * 8 * NI * 128 B)
-  static const int ni_env = getenv("TT_SCORE_SYM_NI") ? atoi(getenv("TT_SCORE_SYM_NI")) : 0;
-  int ni = ni_env > 0 ? ni_env : (int)tt_cdiv((int64_t)L.nT * L.n_groups, 2 * (ctx ? ctx->num_cus : 256));
+  int ni = (int)tt_cdiv((int64_t)L.nT * L.n_groups, 2 * (ctx ? ctx->num_cus : 256));
   ni = ni < 4 ? 4 : (ni > 16 ? 16 : ni);                  // 16 tiles: 48 KB of LDS slots per workgroup
   ni = (ni + 3) / 4 * 4;                                  // whole stages (a stage is 1, 2 or 4 tiles)
   L.NI = ni;

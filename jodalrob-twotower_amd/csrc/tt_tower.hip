@@ -1697,11 +1697,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       // slabs (+ bias) -> pre with the chunk statistics in the same pass, then everything up to the unit rows in one kernel
       if (phase != 2) {
         if (front) {
-          static const bool lds_set = [] {
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(tower_front_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       kFrontLds) == hipSuccess;
-          }();
-          if (!lds_set) { tt_set_error("tt_towers_mlp_fwd: cannot reserve %d bytes of LDS for tower_front_kernel", kFrontLds); return TT_ERR_HIP; }
+          TT_LDS_ONCE(kFrontLds, tower_front_kernel);
           Batch<FrontArgs> fb{};
           for (int t = 0; t < n; ++t)
             fb.a[t] = FrontArgs{A[t]->dense, P[t]->din, P[t]->din, P[t]->w_proj, P[t]->b_proj, P[t]->h0,
@@ -1762,11 +1758,7 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
         }
       if (i == nh - 1 && !fused && wide_tail_ok(n, P, train)) {
         // statistics finish + BN apply + dropout + output Linear + L2 normalise + the score kernels' operand images in one launch
-        static const bool lds_set = [] {
-          return hipFuncSetAttribute(reinterpret_cast<const void*>(tail_fwd_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     kWideLds) == hipSuccess;
-        }();
-        if (!lds_set) { tt_set_error("tt_towers_mlp_fwd: cannot reserve %d bytes of LDS for tail_fwd_wide_kernel", kWideLds); return TT_ERR_HIP; }
+        TT_LDS_ONCE(kWideLds, tail_fwd_wide_kernel);
         Batch<TailFwdArgs> tf{};
         for (int t = 0; t < n; ++t) {
           tf.a[t] = TailFwdArgs{bs.a[t], P[t]->bn_w[i], P[t]->bn_b[i], ba.a[t].salt, A[t]->act[i], P[t]->w_out, P[t]->b_out, P[t]->d_out,

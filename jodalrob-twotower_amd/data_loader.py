@@ -27,8 +27,11 @@ class DeviceFeatureStore:
     def __init__(self, store: Dict, categorical_keys, device):
         self.device = torch.device(device)
         self.keys = list(categorical_keys)
-        self.dense = torch.as_tensor(np.ascontiguousarray(store["dense_projected"]), dtype=torch.float32).to(self.device)
-        self.categorical = torch.as_tensor(np.ascontiguousarray(store["categorical"]), dtype=torch.int64).to(self.device)
+        def resident(x, dtype):            # host arrays (the reference's stores: feature_store.py:76-79) or tensors already on a device
+            t = x if torch.is_tensor(x) else torch.as_tensor(np.ascontiguousarray(x))
+            return t.to(device=self.device, dtype=dtype).contiguous()
+        self.dense = resident(store["dense_projected"], torch.float32)
+        self.categorical = resident(store["categorical"], torch.int64)
         if self.dense.shape[0] != self.categorical.shape[0]:
             raise ValueError("dense_projected and categorical must have one row per entity")
 
@@ -57,16 +60,36 @@ class DevicePairLoader:
     def __len__(self) -> int:
         return (self.pairs.shape[0] + self.batch_size - 1) // self.batch_size
 
-    def __iter__(self) -> Iterator[Dict]:
+    def epoch_order(self) -> Optional[torch.Tensor]:
+        """This epoch's permutation of the pair list on the device (None when not shuffling); drawn from the loader's seeded CPU
+        generator, so an epoch iterated through __iter__ and one driven through step_batches() see the same batches."""
         n = self.pairs.shape[0]
-        order = torch.randperm(n, generator=self._gen).to(self.pairs.device) if self.shuffle else None
-        for lo in range(0, n, self.batch_size):
-            sel = self.pairs[lo:lo + self.batch_size] if order is None else self.pairs[order[lo:lo + self.batch_size]]
-            yield {"notice": self.notice.gather(sel[:, 0].contiguous()), "company": self.company.gather(sel[:, 1].contiguous())}
+        return torch.randperm(n, generator=self._gen).to(self.pairs.device) if self.shuffle else None
+
+    def batch(self, order: Optional[torch.Tensor], lo: int) -> Dict:
+        sel = self.pairs[lo:lo + self.batch_size] if order is None else self.pairs[order[lo:lo + self.batch_size]]
+        return {"notice": self.notice.gather(sel[:, 0].contiguous()), "company": self.company.gather(sel[:, 1].contiguous())}
+
+    def __iter__(self) -> Iterator[Dict]:
+        order = self.epoch_order()
+        for lo in range(0, self.pairs.shape[0], self.batch_size):
+            yield self.batch(order, lo)
+
+    def step_batches(self, graphed_step, eager_step=None):
+        """One epoch on the fast path: every full batch is gathered out of the stores by the captured step's own hand-over launch
+        (GraphedTrainStep.step_from_store) and replayed; the ragged last batch -- a captured step has one batch size -- goes
+        through `eager_step(batch)` (skipped when None).  Yields the step's result dict per batch."""
+        order = self.epoch_order()
+        n, B = self.pairs.shape[0], self.batch_size
+        for lo in range(0, n, B):
+            if lo + B <= n:
+                yield graphed_step.step_from_store(self.notice, self.company, self.pairs, order, lo)
+            elif eager_step is not None:
+                yield eager_step(self.batch(order, lo))
 
 
 def create_unified_bid_dataloaders(db_engine, schema: TorchRecSchema, batch_size: int = 32, limit: Optional[int] = None,
-                                   test_split: float = 0.1, shuffle_seed: int = 42, num_workers: int = 0, pin_memory: bool = False,
+                                   test_split: float = 0.1, shuffle_seed: int = 42, num_workers: int = 4, pin_memory: bool = False,
                                    prefetch_factor: int = 2, persistent_workers: bool = False, streaming: bool = False,
                                    chunk_size: int = 1000, load_all_features: bool = True, feature_chunksize: int = 5000,
                                    feature_limit: Optional[int] = None, use_preprocessor: bool = True, test_mode: bool = False,

@@ -286,8 +286,6 @@ class RowExchange:
             be.owner_accumulate(self.store, state["plan"], d_rows)
 
     def all_reduce_dense(self, flat_grads: Sequence[torch.Tensor]):
-        if self.world == 1 and __import__("os").environ.get("TT_DIST_FAKE_A2A"):     # fault hunting only
-            return
         for g in flat_grads:                                                     # one call per tower
             self.comm.all_reduce_sum(g)
 
@@ -323,8 +321,8 @@ class PaddedRowExchange(RowExchange):
         self._place_buf = None           # [G * C + 1, E] rows as received; the LAST row stays zero (target of rows that did not fit)
         self._flag_host, self._flag_event, self._flag_pending = None, None, False
         self.poll_lag = 2                # steps a raised overflow may lag behind the step that caused it
-        self.wire_bf16 = __import__("os").environ.get("TT_DIST_WIRE_F32", "0") != "1"      # TT_DIST_WIRE_F32=1: f32 rows on the wire (A/B)
-        self.grad_wire_bf16 = __import__("os").environ.get("TT_DIST_GRAD_WIRE_BF16", "0") == "1"
+        self.wire_bf16 = True            # looked-up rows travel as bf16 (the towers round them to bf16 anyway: bit-identical)
+        self.grad_wire_bf16 = False      # row gradients travel as f32
 
     def local_rows_of(self, g: int) -> int:
         R = self.store.global_rows
@@ -365,8 +363,6 @@ class PaddedRowExchange(RowExchange):
             self._flag_pending = True
 
     def _a2a_equal(self, send: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if self.world == 1 and __import__("os").environ.get("TT_DIST_FAKE_A2A"):     # fault hunting only
-            return send.clone() if out is None else out.copy_(send)
         if out is None:
             return self.comm.all_to_all_equal(send)
         if isinstance(self.comm, DistComm):

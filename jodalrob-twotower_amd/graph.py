@@ -22,15 +22,20 @@ import torch
 
 from . import _lib as L
 from . import ops
+from .config import settings
 from .kjt import KeyedJaggedTensor
 from .optim import FusedAdam
 
 
 class GraphedTrainStep:
-    def __init__(self, task, optimizer: FusedAdam, example_batch: Dict, return_metrics: bool = True, warmup: int = 3):
+    def __init__(self, task, optimizer: FusedAdam, example_batch: Dict, return_metrics: bool = True, warmup: int = 3,
+                 defer_long: bool = True, defer_slabs: bool = True):
+        """defer_long / defer_slabs: the long rows' finish rides in the optimiser's launch and the towers' slab reduction in the
+        embedding gradient's (both bit-identical to the separate launches; the arguments exist for that comparison)."""
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("GraphedTrainStep needs jodalrob_twotower_amd.optim.FusedAdam (device-side hyper-parameters)")
         self.task, self.opt, self.return_metrics = task, optimizer, return_metrics
+        self._defer_long, self._defer_slabs = bool(defer_long), bool(defer_slabs)
         dev = example_batch["notice"]["dense"].device
         self.static = {side: {"dense": example_batch[side]["dense"].clone(),
                               "kjt": KeyedJaggedTensor(example_batch[side]["kjt"].keys(), example_batch[side]["kjt"].values().clone())}
@@ -67,10 +72,6 @@ class GraphedTrainStep:
         for t in self._towers:
             t._seed_dev = self._seed_dev
         optimizer._hp_dev = self._hp_dev
-        self._no_capture = bool(int(__import__("os").environ.get("TT_GRAPH_DEBUG", "0")))   # fault hunting: same body, eager
-        if self._no_capture:
-            self.graph = None
-            return
         self.graph = torch.cuda.CUDAGraph()
         # With a process group alive, its watchdog thread polls events while we capture; under the default "global" capture
         # mode that poll is an error ("operation not permitted when stream is capturing") that aborts the process --
@@ -91,8 +92,7 @@ class GraphedTrainStep:
         """Key-major row hand-over (ops.batch_ingest) when the step looks the static ids up in ONE local fused table with the
         per-key plan: returns (store, embedders, rows_km, static id tensors, B) or None (then the batch is handed over by plain
         copies and the plan gathers its rows out of the lookup's slot-major array)."""
-        import os
-        if os.environ.get("TT_GRAPH_INGEST", "1") == "0" or getattr(self.task, "exchange", None) is not None:
+        if not settings.graph_ingest or getattr(self.task, "exchange", None) is not None:
             return None
         model = getattr(self.task, "two_tower_model", None)
         towers = [getattr(model, n, None) for n in ("notice_tower", "company_tower")]
@@ -122,14 +122,16 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         # backward and optimiser step are one unit here: the gradient reduction leaves its long rows to the optimiser's launch
         # (FusedAdam finishes them whichever of its paths it takes) -- one launch fewer in the dependent chain
-        defer = __import__("os").environ.get("TT_DEFER_LONG", "1") != "0"
+        defer = self._defer_long
         stores = list(getattr(self.opt, "_stores", ()))
         for st in stores:
             st.defer_long_finish = defer
         # likewise the slab reduction of the towers' weight gradients rides in the embedding gradient's launch (the two do not
         # depend on each other); whatever is still queued after the backward is launched on its own
         dev = self._dev.device
-        slabs = __import__("os").environ.get("TT_DEFER_SLABS", "1") != "0"
+        # (never with a dense-gradient all-reduce in the backward: it would read the tensors the queue still owes)
+        ex = getattr(self.task, "exchange", None)
+        slabs = self._defer_slabs and (ex is None or getattr(ex, "world", 1) == 1)
         try:
             res = self.task(self.static, return_metrics=self.return_metrics)
             loss = res["loss"] if isinstance(res, dict) else res
@@ -161,13 +163,10 @@ class GraphedTrainStep:
         host = self._host_ring[self._slot, :self._n_scalar]
         ng = len(self.opt.param_groups)
         step = self._base_step + self._steps_done + 1
-        if __import__("os").environ.get("TT_GRAPH_PUSH_SAME"):       # fault hunting: identical scalars every step
-            step = self._base_step + 1
         for gi, g in enumerate(self.opt.param_groups):
             hp = ops.adam_hparams(step, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])
             host[gi * 8: gi * 8 + 6] = torch.tensor(hp)
-        if not __import__("os").environ.get("TT_GRAPH_PUSH_SAME"):
-            host[ng * 8:].view(torch.int64).random_()
+        host[ng * 8:].view(torch.int64).random_()
         return (self._dev, host)
 
     def _mark_slot(self):
@@ -197,10 +196,7 @@ class GraphedTrainStep:
                     src_ids.append(sv)
         else:
             pairs = []
-        if __import__("os").environ.get("TT_GRAPH_SKIP_PUSH"):       # fault hunting
-            if pairs:
-                ops.copy_multi(pairs)
-        elif self._ingest is not None:
+        if self._ingest is not None:
             # ONE launch: the four batch buffers + the scalars + the key-major rows of this step's ids -- also when nobody handed a
             # batch over: the static id buffers may have been written to by means no version counter sees (`.data`), and the
             # replayed plan sorts whatever rows_km holds
@@ -209,10 +205,9 @@ class GraphedTrainStep:
         else:
             ops.copy_multi(pairs + [self._fill_slot()])         # ONE launch: the four batch buffers + the scalars
             self._mark_slot()
-        if self._no_capture:
-            self.result = self._body()
-            self._steps_done += 1
-            return self.result
+        return self._replay()
+
+    def _replay(self):
         self.graph.replay()
         self._steps_done += 1
         self.opt.advance_steps(1)
@@ -220,6 +215,35 @@ class GraphedTrainStep:
         if ex is not None and hasattr(ex, "poll_overflow"):
             ex.poll_overflow()                                  # sharded tables: a bucket overflow rejects the step (non-blocking)
         return self.result
+
+    def step_from_store(self, notice_store, company_store, pairs: torch.Tensor, order: Optional[torch.Tensor] = None, offset: int = 0):
+        """Train on the B pairs `pairs[order[offset : offset + B]]` (order None: `pairs[offset : offset + B]`) gathered straight
+        out of the device-resident feature stores into the static buffers -- ONE launch (tt_batch_ingest_store: dense rows, ids,
+        key-major fused rows, the step scalars) and the replay; nothing per step crosses PCIe and no batch tensors are built
+        (the reference assembles the batch on the host and copies it over: unified_bid_data_loader.py:461-504, :630-684;
+        scripts/train.py:261-273).  `pairs`: int64 [P, 2] on the device, (notice row, company row) per pair; the stores are
+        data_loader.DeviceFeatureStore objects (`.dense` f32 [N, D], `.categorical` int64 [N, K])."""
+        B = self.static["notice"]["dense"].shape[0]
+        if pairs.dtype != torch.int64 or pairs.dim() != 2 or pairs.shape[1] != 2 or not pairs.is_contiguous():
+            raise ValueError("step_from_store: pairs must be a contiguous int64 [P, 2] tensor")
+        if order is None and (offset < 0 or offset + B > pairs.shape[0]):
+            raise ValueError("step_from_store: the batch runs past the pair list")
+        flat = pairs.view(-1)
+        base = 0 if order is not None else 2 * offset
+        model = self.task.two_tower_model
+        embs = [model.notice_tower.categorical_embedder, model.company_tower.categorical_embedder]
+        sides, stores = [], []
+        for i, (side, fs, e) in enumerate(zip(("notice", "company"), (notice_store, company_store), embs)):
+            sd, sv = self.static[side]["dense"], self.static[side]["kjt"].values()
+            sides.append(ops.LookupSide(None, e._key_row_offset, e._key_vocab, None, len(e.keys)))
+            stores.append(ops.StoreSide(flat[base + i:], 2, fs.dense, fs.categorical, sd, sv))
+        rows_km = self._ingest[2] if self._ingest is not None else None
+        ops.batch_ingest_store([self._fill_slot()], sides, stores, B, order, rows_km, offset if order is not None else 0)
+        self._mark_slot()
+        if self._ingest is not None:
+            store, _, _, ids, _ = self._ingest
+            store.ingest = (ids, [v._version for v in ids], rows_km)
+        return self._replay()
 
     def close(self):
         """Final (synchronous) overflow check, then drop the captured graph and its private pool.  With a process group

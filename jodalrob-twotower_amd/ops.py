@@ -9,6 +9,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib as L
+from .config import settings
 from ._lib import TT_BF16, TT_F32, TT_GRAD_DENSE_ACC, TT_GRAD_DENSE_SET, TT_GRAD_SPARSE  # noqa: F401
 
 
@@ -29,7 +30,7 @@ class KernelTimer:
 
 
 _TIMER: Optional[KernelTimer] = None
-_SYNC_DEBUG = bool(int(__import__("os").environ.get("TT_SYNC_DEBUG", "0")))
+_SYNC_DEBUG = settings.sync_debug
 
 
 def set_timer(t: Optional[KernelTimer]):
@@ -152,7 +153,6 @@ class DedupPlan:
     n_unique: torch.Tensor        # int32 [1] on device
     M: int
     keep: object = None           # tensors that must outlive the plan's kernels
-    stream: object = None         # stream the plan was built on (joined before first use)
     grad_ws: object = None        # (uint8 workspace, E): the gradient reduction's workspace with the long-row list already in it
     finish_deferred: object = None  # grad_rows whose long rows embed_grad left unfinished (adam_fused / embed_grad_finish complete them)
 
@@ -203,7 +203,7 @@ def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int, key_majo
     nk = sum(side_K)
     ws = L.workspace(dev, lib.tt_dedup_keyed_workspace_bytes(M, nk))
     ks = (L.i32 * len(side_K))(*side_K)
-    if E > 0 and __import__("os").environ.get("TT_GRAD_PLANNED", "1") != "0":
+    if E > 0 and settings.grad_planned:
         gws = torch.empty(lib.tt_embed_grad_workspace_bytes(M, E), dtype=torch.uint8, device=dev)
         with _timed("tt_dedup_plan_keyed"):
             L.check(lib.tt_dedup_plan_keyed_long(L.ctx(dev), L.ptr(rows), int(key_major), ks, len(side_K), B, E, L.ptr(plan.sorted_src),
@@ -666,6 +666,52 @@ def batch_ingest(pairs, sides: Sequence[LookupSide], B: int, rows_km: torch.Tens
         raise ValueError("batch_ingest: rows_km must be a contiguous int32 tensor of sum(B*K) elements")
     with _timed("tt_batch_ingest"):
         L.check(L.load().tt_batch_ingest(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), L.stream(dev)), "tt_batch_ingest")
+
+
+@dataclass
+class StoreSide:
+    """One tower's device-resident feature store as the source of a batch (tt_store_side)."""
+    entity: torch.Tensor          # int64: entity index per pair, element [o * entity_stride] (a column of the [P, 2] pair list)
+    entity_stride: int
+    dense_store: torch.Tensor     # f32 [N, dense_dim]
+    cat_store: torch.Tensor       # int64 [N, K]
+    dense_out: torch.Tensor       # f32 [B, dense_dim]  (the step's static dense buffer)
+    ids_out: torch.Tensor         # int64 [B * K]       (the step's static id buffer)
+
+
+def batch_ingest_store(pairs, sides: Sequence[LookupSide], stores: Sequence[StoreSide], B: int, order: Optional[torch.Tensor],
+                       rows_km: Optional[torch.Tensor], order_offset: int = 0):
+    """tt_batch_ingest_store: the batch `order[order_offset : order_offset + B]` of the pair list gathered out of the device
+    stores straight into the step's static buffers (+ key-major fused rows, + the copy segments `pairs`), one launch."""
+    dev, n = stores[0].dense_out.device, len(pairs)
+    dst = (L.vp * max(n, 1))(*[d.data_ptr() for d, _ in pairs])
+    src = (L.vp * max(n, 1))(*[s.data_ptr() for _, s in pairs])
+    nb = (L.i64 * max(n, 1))(*[d.numel() * d.element_size() for d, _ in pairs])
+    arr = (L.EmbedSide * len(sides))()
+    st = (L.StoreSide * len(sides))()
+    M = 0
+    for i, (s, t) in enumerate(zip(sides, stores)):
+        dd = t.dense_store.shape[1]
+        if t.cat_store.dtype != torch.int64 or t.cat_store.shape[1] != s.K or not t.cat_store.is_contiguous() or \
+                t.dense_store.dtype != torch.float32 or not t.dense_store.is_contiguous() or t.entity.dtype != torch.int64:
+            raise ValueError(f"batch_ingest_store: store {i}: need contiguous f32 [N, D] features and int64 [N, {s.K}] ids")
+        if t.dense_out.shape != (B, dd) or not t.dense_out.is_contiguous() or t.dense_out.dtype != torch.float32 or \
+                t.ids_out.numel() != B * s.K or t.ids_out.dtype != torch.int64 or not t.ids_out.is_contiguous():
+            raise ValueError(f"batch_ingest_store: side {i}: static buffers must be contiguous f32 [{B}, {dd}] and int64 [{B * s.K}]")
+        arr[i] = L.EmbedSide(None, L.ptr(s.key_row_offset), L.ptr(s.key_vocab), None, 0, s.K, TT_F32)
+        st[i] = L.StoreSide(L.ptr(t.entity), t.entity_stride, L.ptr(t.dense_store), L.ptr(t.cat_store), L.ptr(t.dense_out), L.ptr(t.ids_out), dd, 0)
+        M += B * s.K
+    if rows_km is not None and (rows_km.dtype != torch.int32 or rows_km.numel() != M or not rows_km.is_contiguous()):
+        raise ValueError("batch_ingest_store: rows_km must be a contiguous int32 tensor of sum(B*K) elements")
+    if order is not None:
+        if order.dtype != torch.int64 or not order.is_contiguous() or order_offset < 0 or order_offset + B > order.numel():
+            raise ValueError("batch_ingest_store: order must be a contiguous int64 tensor holding the batch's B entries")
+        order_ptr = L.vp(order.data_ptr() + 8 * order_offset)
+    else:
+        order_ptr = L.vp(0)
+    with _timed("tt_batch_ingest_store"):
+        L.check(L.load().tt_batch_ingest_store(L.ctx(dev), n, dst, src, nb, arr, st, len(sides), B, order_ptr, L.ptr(rows_km), L.stream(dev)),
+                "tt_batch_ingest_store")
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU routing

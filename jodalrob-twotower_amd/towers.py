@@ -16,7 +16,6 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
-import os
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -25,6 +24,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
+from .config import settings
 from .cat_embed import CategoricalEmbedder, EmbeddingStore
 
 
@@ -48,19 +48,6 @@ def _al(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_streams(dev: torch.device, n: int):
-    """Cached side streams: independent towers and the duplicate-row plan run beside the main stream (every
-    kernel of a tower fills at most half of the 256 CUs); a captured graph keeps them as parallel branches."""
-    key = torch.device(dev).index
-    lst = _SIDE_STREAMS.setdefault(key, [])
-    while len(lst) < n:
-        lst.append(torch.cuda.Stream(device=dev))
-    return lst[:n]
-
-
 class BaseTower(nn.Module):
     def __init__(self, categorical_keys: List[str], metadata_path: str = "meta/metadata.csv", table_name: str = "notice",
                  categorical_embedding_dim: int = 64, dense_input_dim: int = 256,
@@ -70,25 +57,21 @@ class BaseTower(nn.Module):
         super().__init__()
         if tower_hidden_dims is None:
             tower_hidden_dims = [256, 128]
-        self.mlp_dtype = mlp_dtype or os.environ.get("TT_MLP_DTYPE", "fp32")
+        self.mlp_dtype = mlp_dtype or settings.mlp_dtype
         if self.mlp_dtype not in ("fp32", "bf16"):
             raise ValueError(f"mlp_dtype must be 'fp32' or 'bf16', got {self.mlp_dtype!r}")
         # bf16 MLP: the tower input x = [projection | embedding rows] lives in bf16 -- bit-identical results (the GEMMs
         # that read x round it to bf16 anyway) at half the bytes: lookup 15.7 -> 9.2 us, step -7 us at B = 8192.
-        # A bf16 d_x (TT_TOWER_IO_DTYPE = dx | both) is implemented but measures no faster (0.354 vs 0.352 ms per step: the
+        # A bf16 d_x (settings.tower_io_dtype = dx | both) is implemented but measures no faster (0.354 vs 0.352 ms per step: the
         # segmented reduction is bound by its dependent trips, not by bytes, and the data-gradient GEMM stores 2-byte
         # pieces) and rounds the per-slot row gradients, so it stays off.
-        io = os.environ.get("TT_TOWER_IO_DTYPE", "x") if self.mlp_dtype == "bf16" else "none"
+        io = settings.tower_io_dtype if self.mlp_dtype == "bf16" else "none"
         if io not in ("none", "x", "dx", "both"):
-            raise ValueError(f"TT_TOWER_IO_DTYPE must be none|x|dx|both, got {io!r}")
+            raise ValueError(f"settings.tower_io_dtype must be none|x|dx|both, got {io!r}")
         self.x_dtype = torch.bfloat16 if io in ("x", "both") else torch.float32
         self.dx_dtype = torch.bfloat16 if io in ("dx", "both") else torch.float32
-        # TT_TOWER_UNFUSED_TAIL=1: run the BN / output-Linear / L2-normalise tail as the separate kernels (A/B runs)
-        self.unfused_tail = os.environ.get("TT_TOWER_UNFUSED_TAIL", "0") == "1"
-        # TT_TOWER_UNFUSED_FRONT=1: projection GEMM, block GEMM and the slab / statistics pass as separate launches (A/B runs)
-        self.unfused_front = os.environ.get("TT_TOWER_UNFUSED_FRONT", "0") == "1"
-        # TT_TOWER_UNFUSED_BACK=1: first-block / projection gradient GEMMs as separate launches (A/B runs)
-        self.unfused_back = os.environ.get("TT_TOWER_UNFUSED_BACK", "0") == "1"
+        # the fused launches against the separate kernels they replaced (tests): config.Settings
+        self.unfused_tail, self.unfused_front, self.unfused_back = settings.tower_unfused_tail, settings.tower_unfused_front, settings.tower_unfused_back
         self.categorical_keys = list(categorical_keys)
         self.exchange = None            # set by the distributed task: sharded-table row exchange
         self.sync_comm = None           # set by the distributed task (sync_bn=True): BN statistics over all ranks' rows
@@ -348,27 +331,21 @@ class _TowersFn(torch.autograd.Function):
             for s in live:
                 tw = s.tower
                 ops.tower_fwd(tw._params(), s.acts_struct, s.B, s.train, s.p_drop, s.seed, s.emb.device, tw._seed_dev)
-        # duplicate-row plans: depend on ids only, first needed in the backward.  Default: in line on the launch
-        # stream.  A side stream (TT_DEDUP_STREAM=side) overlaps the 38-workgroup sort with the score kernels, but a
-        # captured graph with two streams is replayed node by node with cross-queue signals: 4-6 us gaps in front of
-        # eight kernels and 0.20 ms instead of 0.05 ms of host time per replay -- as much as the overlap saves.
+        # duplicate-row plans: depend on ids only, first needed in the backward; in line on the launch stream (a side stream
+        # overlapped the sort with the score kernels, but a captured graph with two streams is replayed node by node with
+        # cross-queue signals: 4-6 us gaps in front of eight kernels -- as much as the overlap saved)
         for pl in plans:
             if len(pl) == 6:
                 store, psides, _, rows, ev, key_major = pl
                 plan = None
                 if ev is not None:
-                    inline = os.environ.get("TT_DEDUP_STREAM", "inline") != "side"
-                    ds = torch.cuda.current_stream(store.device) if inline else _side_streams(store.device, len(sides) + 1)[-1]
-                    if not inline:
-                        ds.wait_event(ev)
-                    with torch.cuda.stream(ds):
-                        Bs = psides[0].B
-                        if 0 < Bs <= ops.KEYED_MAX_B:       # per-key LDS sorts (2 launches)
-                            plan = ops.dedup_plan_keyed(rows, [len(q.tower.categorical_embedder.keys) for q in psides], Bs, key_major,
-                                                        E=int(store.E))
-                        else:
-                            plan = ops.dedup_plan(rows, store.rows)
-                    plan.keep, plan.stream = rows, (None if inline else ds)   # keep the sort input alive until it has run
+                    Bs = psides[0].B
+                    if 0 < Bs <= ops.KEYED_MAX_B:       # per-key LDS sorts (2 launches)
+                        plan = ops.dedup_plan_keyed(rows, [len(q.tower.categorical_embedder.keys) for q in psides], Bs, key_major,
+                                                    E=int(store.E))
+                    else:
+                        plan = ops.dedup_plan(rows, store.rows)
+                    plan.keep = rows                    # keep the sort input alive until it has run
                 pl[:] = [store, psides, plan]
         for s in sides:
             s.tower._last_packed = None if s.packed is None else (s.packed, float(s.tower.pack_scale))
@@ -474,6 +451,9 @@ class _TowersFn(torch.autograd.Function):
         if exch is not None:
             if buf is not None and dense_total:
                 flat_grads.append(buf[:dense_total])
+                # a queued (deferred) slab reduction still owes w[0] / b[0] / w_proj / b_proj of this buffer: it must have run
+                # before anything outside the library reads the dense gradients (GraphedTrainStep sets the deferral)
+                L.flush_deferred(buf.device)
             exch.all_reduce_dense(flat_grads)
             if ctx.exch_state is not None:
                 srcs = []
@@ -495,8 +475,6 @@ class _TowersFn(torch.autograd.Function):
                 if d is None:       # this tower received no gradient: contribute zeros
                     d = torch.zeros((s.B, K * store.E), dtype=s.tower.dx_dtype, device=store.device)
                 srcs.append((d, K))
-            if plan.stream is not None:                                           # join the plan's side stream
-                torch.cuda.current_stream(store.device).wait_stream(plan.stream)
             store.accumulate_grad(plan, srcs, plan_sides[0].B)
         return (None, *grads)
 

@@ -17,13 +17,12 @@ from ._lib import no_dynamo as _no_dynamo
 import torch.nn as nn
 
 from . import ops
+from .config import settings
 from .two_tower_model import TwoTowerModel, create_two_tower_model
 
 LAZY_SIM_BATCH = 2048
 
 
-_PRESCALE = __import__("os").environ.get("TT_SCORE_PRESCALE", "1") != "0"      # TT_SCORE_PRESCALE=0: unscaled operand images (A/B)
-_SYM_FWD = __import__("os").environ.get("TT_SCORE_SYM_FWD", "1") != "0"        # TT_SCORE_SYM_FWD=0: the two-direction forward kernel (A/B)
 
 
 class _DenseLossFn(torch.autograd.Function):
@@ -43,7 +42,9 @@ class _DenseLossFn(torch.autograd.Function):
     def backward(ctx, d_loss, _d_out8):
         n, c, S, stats = ctx.saved_tensors
         inv_t, loss_type, label_smoothing = ctx.cfg
-        dN, dC = ops.score_dense_bwd(n, c, inv_t, loss_type, label_smoothing, S, stats, d_loss.reshape(1).contiguous().float())
+        # tt_score_dense_bwd overwrites its S argument with dS through a raw pointer (no version counter sees it): work on a copy,
+        # so a second backward over the same graph (retain_graph=True) starts from the scores again
+        dN, dC = ops.score_dense_bwd(n, c, inv_t, loss_type, label_smoothing, S.clone(), stats, d_loss.reshape(1).contiguous().float())
         return dN, dC, None, None, None
 
 
@@ -78,9 +79,9 @@ class _ScoreCEFn(torch.autograd.Function):
                 Np, Cp = packed_n, packed_c
                 scale_n = 1.0 if scale_n is None else scale_n
             else:
-                scale_n = ops.score_unit_scale(inv_t) if (scale_n is None and _PRESCALE) else (scale_n or 1.0)
+                scale_n = ops.score_unit_scale(inv_t) if scale_n is None else scale_n
                 Np, Cp = ops.score_pack2_bf16(n, c, scale_n, 1.0)
-            if not want_col_rank and not full_rank and _SYM_FWD:
+            if not want_col_rank and not full_rank:
                 # steady state of training: ONE sweep of the B x B tiles serves both softmax directions (tt_score_fwd_sym_bf16)
                 rowsum, colsum, diag, row_rank, inv, out8, loss = ops.score_fwd_sym(Np, Cp, B, D, inv_t, shift, scale_n, True)
                 ctx.packed = (Np, Cp, scale_n, inv)
@@ -166,15 +167,14 @@ class TwoTowerTrainTask(nn.Module):
     def __init__(self, two_tower_model: TwoTowerModel, temperature: float = 1.0, loss_type: str = "cross_entropy",
                  label_smoothing: float = 0.0, score_dtype: str = None):
         super().__init__()
-        import os
-        self.score_dtype = score_dtype or os.environ.get("TT_SCORE_DTYPE", "fp32")
+        self.score_dtype = score_dtype or settings.score_dtype
         if self.score_dtype not in ("fp32", "bf16", "fp8"):
             raise ValueError(f"score_dtype must be 'fp32', 'bf16' or 'fp8', got {self.score_dtype!r}")
-        if self.score_dtype == "bf16" and os.environ.get("TT_TOWER_PACK", "1") != "0":      # TT_TOWER_PACK=0: separate pack launch (A/B)
+        if self.score_dtype == "bf16" and settings.tower_pack:       # (settings.tower_pack = False: separate pack launch; tests)
             for tw in (two_tower_model.notice_tower, two_tower_model.company_tower):
                 tw.pack_for_score = True
-            if _PRESCALE:                    # the notice image carries the softmax's exponent scale (see _ScoreCEFn)
-                two_tower_model.notice_tower.pack_scale = ops.score_unit_scale(1.0 / float(temperature))
+            # the notice image carries the softmax's exponent scale (see _ScoreCEFn)
+            two_tower_model.notice_tower.pack_scale = ops.score_unit_scale(1.0 / float(temperature))
         self.two_tower_model = two_tower_model
         self.temperature = temperature
         self.loss_type = loss_type

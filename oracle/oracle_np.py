@@ -322,14 +322,18 @@ NT, CT = "two_tower_model.notice_tower.", "two_tower_model.company_tower."
 
 def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, train=True, backward=True,
               dtype=np.float32, rounding=None, table_grads="dense", keep_sim=True, proj_grad="direct",
-              loss_type="cross_entropy", label_smoothing=0.0):
+              loss_type="cross_entropy", label_smoothing=0.0, score_rounding=None):
     """One forward (+backward) of the task.  batch: dict with notice_ids/company_ids [B,K] (or flat
     values) and notice_dense/company_dense.  Returns dict(loss, metrics, sim, notice_emb, company_emb,
     grads{state key: array}, bn_updates).
-    rounding="bf16": the operand rounding of the measured mode (mlp_dtype = score_dtype = "bf16"), see q_bf16."""
+    rounding="bf16": the operand rounding of the measured mode (mlp_dtype = score_dtype = "bf16"), see q_bf16.
+    score_rounding="fp8" (with rounding="bf16"; BASELINE configs[4], score_dtype="fp8"): the score matrix is formed from e4m3
+    operands (score_operands_fp8), the two gradient products from the bf16 ones, the softmax weights rounded to bf16."""
     q = q_bf16 if rounding == "bf16" else None
     if rounding not in (None, "bf16"):
         raise ValueError(f"rounding must be None or 'bf16', got {rounding!r}")
+    if score_rounding not in (None, "fp8") or (score_rounding == "fp8" and q is None):
+        raise ValueError("score_rounding must be None, or 'fp8' together with rounding='bf16'")
     vals_n = np.asarray(batch["notice_ids"]).reshape(-1)
     vals_c = np.asarray(batch["company_ids"]).reshape(-1)
     if batch["notice_dense"].shape[0] != batch["company_dense"].shape[0]:
@@ -337,6 +341,10 @@ def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, t
     ne, cn, bn_n = tower_fwd(state, NT, keys_n, vocab_n, batch["notice_dense"], vals_n, train, dtype, q)
     ce, cc, bn_c = tower_fwd(state, CT, keys_c, vocab_c, batch["company_dense"], vals_c, train, dtype, q)
     sn, sc = score_operands_bf16(ne, ce, temperature) if q is not None else (ne, ce)
+    prod = None
+    if score_rounding == "fp8":
+        prod = (sn, sc)
+        sn, sc = score_operands_fp8(ne, ce, temperature)
     variant = loss_type != "cross_entropy" or label_smoothing != 0.0          # the dense loss path (f32 only)
     if variant:
         if q is not None:
@@ -348,7 +356,7 @@ def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, t
            "bn_updates": {**bn_n, **bn_c}}
     if backward:
         if not variant:
-            dN, dC = score_ce_bwd(sn, sc, S, lse, temperature, q=q)
+            dN, dC = score_ce_bwd(sn, sc, S, lse, temperature, q=q, prod_operands=prod)
         del S
         g = tower_bwd(cn, dN, NT, keys_n, vocab_n, table_grads, proj_grad)
         out["d_concat_notice"] = g.pop("_d_concat")
@@ -373,6 +381,15 @@ def diag_rank(S):
     equals the evaluator's argsort position when there are no ties with the diagonal)."""
     d = np.diagonal(S)[:, None]
     return (S > d).sum(axis=1)
+
+
+def diag_rank_stable(S):
+    """Position of column i in a STABLE descending sort of row i: ties with the diagonal count only when they sit at a lower
+    column index.  The reference ranks with torch.topk / torch.argsort (evaluator.py:34, :58), whose order among equal scores is
+    unspecified; the HIP path (tt_diag_rank_rows, the rank output of the score sweeps) fixes it to this rule.  Equal scores
+    are real in this workload: two pairs of a batch that share a company have identical company embeddings."""
+    order = np.argsort(-S, axis=1, kind="stable")
+    return (order == np.arange(S.shape[0])[:, None]).argmax(axis=1)
 
 
 def recall_at_k(S, k):

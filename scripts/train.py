@@ -4,7 +4,15 @@
 :444-452, checkpoints :497-551, results CSV :24-75).  The reference driver needs PostgreSQL
 (DatabaseConnector(), :159); this one takes the same config keys and a synthetic feature/pair source.
 
-    python scripts/train.py [--resume PATH] [--steps N] [--batch-size B]
+    python scripts/train.py [--resume PATH] [--steps N] [--batch-size B] [--fast]
+
+--fast: the loop the MI355X path is built for -- bf16 towers and score operands, row-sparse table gradients, FusedAdam, the
+whole step replayed from ONE captured HIP graph, every full batch gathered out of the device-resident feature stores by the
+step's own hand-over launch (DevicePairLoader.step_batches -> GraphedTrainStep.step_from_store -> tt_batch_ingest_store): no
+batch tensors, nothing per step over PCIe.  Without the flag the loop is the reference's own, statement for statement
+(eager forward / backward / optimiser step on the loader's batches, f32 parity kernels).  Either way the run ends like the
+reference driver: validation, evaluator report, prediction demo, checkpoints, a results-CSV row; and prints pairs/s over the
+whole epoch including evaluation.
 """
 from __future__ import annotations
 
@@ -61,11 +69,16 @@ def main():
     ap.add_argument("--pairs", type=int, default=100_000)
     ap.add_argument("--steps", type=int, default=None, help="stop after this many training steps")
     ap.add_argument("--output-dir", default="output/models")
+    ap.add_argument("--fast", action="store_true", help="captured step fed from the device stores, bf16 operands, sparse gradients")
+    ap.add_argument("--hidden", default="128,64", help="tower_hidden_dims (the reference driver trains 512,256: scripts/train.py:106)")
+    ap.add_argument("--final-dim", type=int, default=64)
+    ap.add_argument("--epochs", type=int, default=1)
     a = ap.parse_args()
     config = {"batch_size": a.batch_size, "test_split": 0.2, "shuffle_seed": 42, "pair_limit": a.pairs,
               "categorical_embedding_dim": 32, "notice_dense_input_dim": 256, "company_dense_input_dim": 128,
-              "tower_hidden_dims": [128, 64], "final_embedding_dim": 64, "dropout_rate": 0.1, "temperature": 1.0,
-              "loss_type": "cross_entropy", "learning_rate": 1e-3, "weight_decay": 1e-5, "num_epochs": 1, "warmup_ratio": 0.05,
+              "tower_hidden_dims": [int(h) for h in a.hidden.split(",")], "final_embedding_dim": a.final_dim, "dropout_rate": 0.1,
+              "temperature": 1.0, "loss_type": "cross_entropy", "learning_rate": 1e-3, "weight_decay": 1e-5, "num_epochs": a.epochs,
+              "warmup_ratio": 0.05,
               "log_interval": 20, "output_dir": a.output_dir}
     device = torch.device("cuda:0")
     real = synthetic.load_real_schema(ROOT / "jodalrob-twotower_amd" / "schema_real.json")
@@ -95,7 +108,8 @@ def main():
                                              company_dense_input_dim=config["company_dense_input_dim"],
                                              tower_hidden_dims=config["tower_hidden_dims"],
                                              final_embedding_dim=config["final_embedding_dim"], dropout_rate=config["dropout_rate"],
-                                             temperature=config["temperature"], loss_type=config["loss_type"], device=device)
+                                             temperature=config["temperature"], loss_type=config["loss_type"], device=device,
+                                             **(dict(embedding_grad="sparse", score_dtype="bf16", mlp_dtype="bf16") if a.fast else {}))
     optimizer = FusedAdam.for_task(train_task, lr=config["learning_rate"], weight_decay=config["weight_decay"])
     warmup_steps = max(1, int(len(train_loader) * config["warmup_ratio"]))
     scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lambda s: s / warmup_steps if s < warmup_steps else 1.0, last_epoch=-1)
@@ -109,15 +123,30 @@ def main():
     train_losses, train_accs, val = [], [], {}
     if start_epoch >= config["num_epochs"]:
         config["num_epochs"] = start_epoch + 1           # resumed after the last epoch: run one more
+
+    def eager_step(batch):
+        optimizer.zero_grad()
+        result = train_task(batch, return_metrics=True)
+        result["loss"].backward()
+        optimizer.step()
+        return result
+
+    graphed = None
+    if a.fast and len(train_loader) > 1:                 # (a loader of one ragged batch has nothing to capture)
+        from jodalrob_twotower_amd.graph import GraphedTrainStep
+        train_task.train()
+        state = train_loader._gen.get_state()
+        example = next(iter(train_loader))               # shapes + the capture's one eager warm-up step: runs at the schedule's
+        train_loader._gen.set_state(state)               # first learning rate, which is 0 (LambdaLR warm-up: scripts/train.py:236-240)
+        graphed = GraphedTrainStep(train_task, optimizer, example, warmup=1)
+    pairs_seen, t_loop = 0, time.time()
     for epoch in range(start_epoch, config["num_epochs"]):
         train_task.train()
-        for batch in train_loader:
-            optimizer.zero_grad()
-            result = train_task(batch, return_metrics=True)
-            result["loss"].backward()
-            optimizer.step()
+        results = train_loader.step_batches(graphed, eager_step) if graphed is not None else (eager_step(b) for b in train_loader)
+        for result in results:
             scheduler.step()
             steps += 1
+            pairs_seen += config["batch_size"]
             if steps % config["log_interval"] == 0:
                 train_losses.append(result["loss"].item())
                 train_accs.append(result["accuracy"].item())
@@ -125,12 +154,18 @@ def main():
                       f"pos {result['positive_similarity_mean'].item():.3f}  neg {result['negative_similarity_mean'].item():.3f}")
             if a.steps and steps >= a.steps:
                 break
-        val = evaluator.evaluate_comprehensive(train_task, test_loader, max_batches=50, verbose=True)
+        val = evaluator.evaluate_comprehensive(train_task, test_loader, verbose=True, max_batches=50)
         if val.get("loss", float("inf")) < best:
             best = val["loss"]
             save_checkpoint(train_task, optimizer, epoch, best, config["output_dir"], is_best=True)
         else:
             save_checkpoint(train_task, optimizer, epoch, val.get("loss", 0.0), config["output_dir"])
+    evaluator.demonstrate_predictions(train_task, next(iter(test_loader)), top_k=10)      # reference driver: scripts/train.py:450-452
+    if graphed is not None:
+        graphed.close()
+    torch.cuda.synchronize()
+    print(f"throughput: {pairs_seen / (time.time() - t_loop):,.0f} pairs/s over {steps} steps incl. evaluation "
+          f"({'fast: captured step fed from the device stores' if a.fast else 'eager reference loop'})")
     save_checkpoint(train_task, optimizer, config["num_epochs"] - 1, best, config["output_dir"], is_final=True)
     row = [time.strftime("%Y-%m-%d %H:%M:%S"), config["batch_size"], str(config["tower_hidden_dims"]), config["final_embedding_dim"],
            config["categorical_embedding_dim"], config["learning_rate"], config["num_epochs"], steps,

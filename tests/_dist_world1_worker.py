@@ -88,11 +88,77 @@ def main():
             for k, v in finals["exact"][1].items():
                 np.testing.assert_allclose(finals[mode][1][k], v, rtol=1e-6, atol=1e-7, err_msg=f"{mlp}:{mode}:{k}")
     resume_check(cfg, batches)
+    deferred_slabs_before_all_reduce()
     import gc
     gc.collect()
     torch.cuda.synchronize()
     dist.destroy_process_group()
     print("DIST_WORLD1_OK", flush=True)
+
+
+def deferred_slabs_before_all_reduce():
+    """GraphedTrainStep lets the towers' slab reduction (which writes the first block's and the
+    projection's weight gradients) ride in the embedding gradient's launch -- but on the sharded task the dense gradients are
+    all-reduced BEFORE that launch.  The queue must have run by then.  Two ranks cannot share this box's one GPU under RCCL
+    and a host-staged wire cannot be captured, so the order is pinned at world 1 with a communicator whose all-reduce also
+    doubles its argument (two ranks holding the same gradient): replayed and eager steps must then agree bit for bit on every
+    dense parameter, nothing may be pending when the all-reduce is issued, and the deferral must have been on (else the test
+    proves nothing).  Reference-shaped bf16 towers [128, 64] -> 64 on the real 32 + 6 key schema: the shapes that take the
+    one-launch first-block backward whose slabs are deferred."""
+    from jodalrob_twotower_amd import _lib as L
+    from jodalrob_twotower_amd.distributed import DistComm
+    real = json.load(open(GOLD / "schema_real.json"))
+    kn, kc = real["notice"]["categorical"], real["company"]["categorical"]
+    vn, vc = real["notice"]["vocab_sizes"], real["company"]["vocab_sizes"]
+    seen = {"pending": [], "defer_on": []}
+
+    class DoublingComm(DistComm):
+        def all_reduce_sum(self, t):
+            seen["pending"].append(int(L.load().tt_deferred_pending(L.ctx(t.device))))
+            seen["defer_on"].append(bool(L._defer_on))
+            super().all_reduce_sum(t)
+            return t.mul_(2.0)
+
+    def to_batch(b):
+        return {"notice": {"dense": torch.from_numpy(b["notice_dense"]).to(DEV), "kjt": tt.build_batch_kjt(torch.from_numpy(b["notice_ids"]), kn).to(DEV)},
+                "company": {"dense": torch.from_numpy(b["company_dense"]).to(DEV), "kjt": tt.build_batch_kjt(torch.from_numpy(b["company_ids"]), kc).to(DEV)}}
+
+    batches = [to_batch(synth_batch_numpy(256, vn, vc, 256, 128, 990 + i, oob=False)) for i in range(4)]
+    finals, state = {}, None
+    for mode in ("eager", "graph"):
+        t = create_distributed_train_task(kn, kc, metadata_path=str(GOLD / "real_vocab_metadata.csv"), categorical_embedding_dim=32,
+                                          notice_dense_input_dim=256, company_dense_input_dim=128, tower_hidden_dims=[128, 64],
+                                          final_embedding_dim=64, dropout_rate=0.0, temperature=1.0, device=DEV, embedding_grad="sparse",
+                                          mlp_dtype="bf16", score_dtype="bf16", exchange="padded", comm=DoublingComm())
+        if state is None:
+            shapes = {k: tuple(v.shape) for k, v in t.full_state_dict().items()}
+            state = {k: torch.from_numpy(np.asarray(v)) for k, v in init_state_numpy(shapes, 991).items()}
+        t.load_full_state_dict(state)
+        t.train()
+        o = FusedAdam.for_task(t, lr=1e-2, weight_decay=1e-5)
+        gs = None
+        if mode == "graph":
+            seen["pending"].clear(); seen["defer_on"].clear()
+            gs = GraphedTrainStep(t, o, batches[0], warmup=1)
+            assert any(seen["defer_on"]), "the slab deferral was never on while the dense all-reduce was issued: nothing tested"
+            assert not any(seen["pending"]), "a slab reduction was still queued when the dense gradients were all-reduced"
+            for bt in batches:
+                gs.step(bt)
+        else:
+            o.zero_grad(); t(batches[0], return_metrics=True)["loss"].backward(); o.step()       # the capture's warm-up step
+            for bt in batches:
+                o.zero_grad()
+                t(bt, return_metrics=True)["loss"].backward()
+                o.step()
+        torch.cuda.synchronize()
+        finals[mode] = {k: v.detach().cpu().clone() for k, v in t.full_state_dict().items()}
+        if gs is not None:
+            gs.close()
+        del gs, o, t
+    for k, v in finals["eager"].items():
+        if "embeddings" in k or "num_batches" in k:
+            continue
+        assert torch.equal(finals["graph"][k], v), (k, float((finals["graph"][k] - v).abs().max()))
 
 
 def resume_check(cfg, batches):

@@ -95,6 +95,10 @@ def main():
             # gradient is not a rounding-level number (its sign is then the same in both runs)
             assert float((a - v).abs().max()) <= 2.1e-2, (k, float((a - v).abs().max()))
             assert float(((a - v).abs() > 1e-4).float().mean()) < 0.02 + 2.0 / a.numel(), (k, float(((a - v).abs() > 1e-4).float().mean()))
+    del od, os_, td, ts
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()                             # ordinary teardown and interpreter exit, as the world-1 worker
     print("DIST_WORLD2_OK", flush=True)
 
 
@@ -105,6 +109,5 @@ if __name__ == "__main__":
         import traceback
         traceback.print_exc()
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(1)
+        os._exit(1)                                          # a failed rank must not wait in gloo's teardown for its peer
     sys.stdout.flush()
-    os._exit(0)

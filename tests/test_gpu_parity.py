@@ -14,9 +14,25 @@ import oracle_np as O
 from conftest import GOLD, load_case, split_prefix
 from params_init import init_state_numpy, synth_batch_numpy
 
+from jodalrob_twotower_amd import _lib as _L
+from jodalrob_twotower_amd import config as _cfg
+
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+
+
+@pytest.fixture
+def ctx_option():
+    """Sets a TT_OPT_* option on the device's context for one test: ctx_option(option, value, default)."""
+    changed = {}
+
+    def set_(option, value, default):
+        _L.set_option(torch.device(DEV), option, value)
+        changed[option] = default
+    yield set_
+    for option, default in changed.items():
+        _L.set_option(torch.device(DEV), option, default)
 
 
 @pytest.fixture(scope="module")
@@ -113,6 +129,24 @@ def test_loss_variants_match_reference_golden(tt, case):
             assert np.abs(got[k] - v).max() <= 5e-2 * gmax + 1e-6, (k, np.abs(got[k] - v).max(), gmax)
         else:
             np.testing.assert_allclose(got[k], v, rtol=3e-4, atol=3e-7, err_msg=k)
+
+
+def test_dense_loss_second_backward_over_retained_graph(tt):
+    """The dense loss node's backward leaves its saved score matrix alone: two backward passes over one retained graph
+    (gradient accumulation over several losses) give the same gradients -- tt_score_dense_bwd writes dS through a raw
+    pointer, which autograd's version counters cannot see."""
+    from jodalrob_twotower_amd.two_tower_train_task import _DenseLossFn
+    g = torch.Generator(device=DEV).manual_seed(11)
+    for loss_type, ls in ((0, 0.1), (1, 0.0)):
+        n = torch.nn.functional.normalize(torch.randn(70, 24, generator=g, device=DEV), dim=1).requires_grad_()
+        c = torch.nn.functional.normalize(torch.randn(70, 24, generator=g, device=DEV), dim=1).requires_grad_()
+        loss, _ = _DenseLossFn.apply(n, c, 2.0, loss_type, ls)
+        loss.backward(retain_graph=True)
+        g1n, g1c = n.grad.clone(), c.grad.clone()
+        n.grad = c.grad = None
+        loss.backward()
+        assert torch.equal(n.grad, g1n) and torch.equal(c.grad, g1c)
+        assert float(g1n.abs().max()) > 0
 
 
 def test_torch_compile_wrapper_survives(tt, manifest):
@@ -589,7 +623,7 @@ def test_graph_ingest_key_major_plan(tt, manifest, monkeypatch):
     batches = [synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 930 + i, oob=True) for i in range(5)]
     finals = {}
     for ingest in ("0", "1"):
-        monkeypatch.setenv("TT_GRAPH_INGEST", ingest)
+        monkeypatch.setattr(_cfg.settings, "graph_ingest", ingest == "1")
         task = make_task(tt, cfg, embedding_grad="sparse", score_dtype="bf16", mlp_dtype="bf16", dropout_rate=0.0)
         load_state(task, init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 56))
         task.train()
@@ -633,7 +667,7 @@ def test_planned_long_rows_equal_unplanned(tt, manifest, schema_real, monkeypatc
     b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 610, oob=True)
     outs, state = {}, None
     for planned in ("0", "1"):
-        monkeypatch.setenv("TT_GRAD_PLANNED", planned)
+        monkeypatch.setattr(_cfg.settings, "grad_planned", planned == "1")
         task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", embedding_grad=grad, mlp_dtype="bf16", score_dtype="bf16")
         if state is None:
             state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 611)
@@ -716,7 +750,7 @@ def test_deferred_slab_reduce_equals_immediate(tt, manifest, schema_real, monkey
     reduction's scratch is the buffer the slabs live in) == its own launch at the end of tt_towers_mlp_bwd, bit for bit: every
     dense gradient and the sparse gradient rows.  Real 32 + 6 key schema, bf16 towers (the one-launch first-block backward)."""
     from jodalrob_twotower_amd import _lib as L
-    monkeypatch.setenv("TT_GRAD_PLANNED", planned)
+    monkeypatch.setattr(_cfg.settings, "grad_planned", planned == "1")
     cfg = dict(manifest["cases"]["real_schema"])
     kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
     cfg.update(keys_n=kn, keys_c=kc)
@@ -788,17 +822,14 @@ def test_bf16_mlp_close_to_fp32(tt, manifest, schema_real):
                                                (8192, [6, 3], "hot", 0), (8192, [8], "mid", 0), (515, [7, 2], "mid", 0),
                                                (8192, [32, 6], None, 1), (8192, [32, 6], None, 2), (1000, [5, 2], None, 8), (515, [7, 2], "mid", 3),
                                                (8192, [6, 3], "hot", 8), (8192, [8], "mid", 5), (70, [4], None, 4), (33, [2, 2], "mid", 2)])
-def test_dedup_plan_keyed_equals_general(tt, monkeypatch, B, Ks, vocabs, parts):
+def test_dedup_plan_keyed_equals_general(tt, ctx_option, B, Ks, vocabs, parts):
     """Per-key LDS plan == the general radix-sort plan (and numpy's stable argsort), bit for bit.  Wide row ranges take the
     bucket + rank path, narrow ones and keys with hot rows ("hot": Zipf-like ids, a few rows holding most slots -- a bucket
     overflows) the stable LSD passes; "mid": vocabularies around the 9-bit switch and the per-bucket cap.  parts: workgroups
     per key (0 = the library's choice: 4 from B = 2048 up) -- shares of the key's row range, also odd counts, more shares than
     rows (a two-row key), the LSD fallback (share 0 sorts alone) and batches below the bucket path."""
     from jodalrob_twotower_amd import ops
-    if parts:
-        monkeypatch.setenv("TT_KEYED_PARTS", str(parts))
-    else:
-        monkeypatch.delenv("TT_KEYED_PARTS", raising=False)
+    ctx_option(_L.TT_OPT_KEYED_PARTS, parts, 0)
     rng = np.random.default_rng(B + len(Ks))
     rows_sides, off = [], 0
     for K in Ks:
@@ -823,7 +854,7 @@ def test_dedup_plan_keyed_equals_general(tt, monkeypatch, B, Ks, vocabs, parts):
 
 
 @pytest.mark.parametrize("seed", list(range(12)))
-def test_dedup_plan_keyed_random_shapes(tt, monkeypatch, seed):
+def test_dedup_plan_keyed_random_shapes(tt, ctx_option, seed):
     """Randomised shapes for the per-key plan: batch, key counts, vocabularies (two-row keys to millions of rows), id
     distributions (uniform, Zipf-like, constant), share counts, key-major or slot-major rows, with or without the gradient
     reduction's long-row list -- always the order numpy's stable argsort gives, and a chunk list that tiles every long row."""
@@ -834,10 +865,7 @@ def test_dedup_plan_keyed_random_shapes(tt, monkeypatch, seed):
     parts = int(rng.choice([0, 1, 2, 3, 4, 6, 8]))
     key_major = bool(rng.integers(0, 2))
     E = int(rng.choice([0, 16, 32]))
-    if parts:
-        monkeypatch.setenv("TT_KEYED_PARTS", str(parts))
-    else:
-        monkeypatch.delenv("TT_KEYED_PARTS", raising=False)
+    ctx_option(_L.TT_OPT_KEYED_PARTS, parts, 0)
     sides_sm, sides_km, off = [], [], 0
     for K in Ks:
         v = rng.choice([2, 3, 17, 300, 4096, 4097, 70000, 1_000_000], size=K)
@@ -927,9 +955,9 @@ def test_bf16_tower_input_is_bit_identical(tt, manifest, schema_real, monkeypatc
     state = init_state_numpy(shapes, 77)
     b = synth_batch_numpy(cfg["B"], vn, vc, cfg["din_n"], cfg["din_c"], 78, oob=False)
     outs = {}
-    monkeypatch.setenv("TT_TOWER_UNFUSED_FRONT", "1")      # storage type only: the one-launch front needs bf16 x and sums K in another order
+    monkeypatch.setattr(_cfg.settings, "tower_unfused_front", True)      # storage type only: the one-launch front needs bf16 x and sums K in another order
     for io in ("none", "x", "both"):
-        monkeypatch.setenv("TT_TOWER_IO_DTYPE", io)
+        monkeypatch.setattr(_cfg.settings, "tower_io_dtype", io)
         task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", mlp_dtype="bf16")
         load_state(task, state)
         task.train()
@@ -969,9 +997,9 @@ def test_fused_tower_tail_equals_separate_kernels(tt, manifest, schema_real, mon
     state = init_state_numpy(shapes, 91)
     b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 92, oob=False)
     outs = {}
-    monkeypatch.setenv("TT_TOWER_UNFUSED_FRONT", "1")      # the one-launch front sums K in another order: compared in its own test
+    monkeypatch.setattr(_cfg.settings, "tower_unfused_front", True)      # the one-launch front sums K in another order: compared in its own test
     for unfused in ("1", "0"):
-        monkeypatch.setenv("TT_TOWER_UNFUSED_TAIL", unfused)
+        monkeypatch.setattr(_cfg.settings, "tower_unfused_tail", unfused == "1")
         torch.manual_seed(1234)
         task = make_task(tt, cfg, meta=meta, mlp_dtype="bf16", dropout_rate=drop)
         load_state(task, state)
@@ -1009,7 +1037,7 @@ def test_tower_emits_packed_score_operands(tt, manifest, schema_real, monkeypatc
     b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 142, oob=False)
     outs = {}
     for pack in ("0", "1"):
-        monkeypatch.setenv("TT_TOWER_PACK", pack)
+        monkeypatch.setattr(_cfg.settings, "tower_pack", pack == "1")
         task = make_task(tt, cfg, meta=meta, mlp_dtype="bf16", score_dtype="bf16")
         assert task.two_tower_model.notice_tower.pack_for_score == (pack == "1")
         load_state(task, state)
@@ -1109,9 +1137,9 @@ def test_fused_tower_tail_odd_shapes(tt, manifest, monkeypatch, B, H, D, drop):
     outs = {}
     state = None
     b = synth_batch_numpy(B, cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 171, oob=True)
-    monkeypatch.setenv("TT_TOWER_UNFUSED_FRONT", "1")
+    monkeypatch.setattr(_cfg.settings, "tower_unfused_front", True)
     for unfused in ("1", "0"):
-        monkeypatch.setenv("TT_TOWER_UNFUSED_TAIL", unfused)
+        monkeypatch.setattr(_cfg.settings, "tower_unfused_tail", unfused == "1")
         task = make_task(tt, cfg, mlp_dtype="bf16", score_dtype="bf16", dropout_rate=drop)
         if state is None:
             state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 172)
@@ -1159,7 +1187,7 @@ def test_tower_front_one_launch_vs_separate(tt, manifest, monkeypatch, E, nk_n, 
     b = synth_batch_numpy(B, cfg["vocab_n"], cfg["vocab_c"], din_n, din_c, 181, oob=True)
     outs, state = {}, None
     for unfused in ("1", "0"):
-        monkeypatch.setenv("TT_TOWER_UNFUSED_FRONT", unfused)
+        monkeypatch.setattr(_cfg.settings, "tower_unfused_front", unfused == "1")
         task = make_task(tt, cfg, mlp_dtype="bf16", score_dtype="bf16", dropout_rate=drop)
         if state is None:
             state = init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 182)
@@ -1207,7 +1235,7 @@ def test_tower_first_block_backward_one_launch_vs_separate(tt, manifest, schema_
     b = synth_batch_numpy(B, vn, vc, cfg["din_n"], cfg["din_c"], 192, oob=False)
     outs = {}
     for unfused in ("1", "0"):
-        monkeypatch.setenv("TT_TOWER_UNFUSED_BACK", unfused)
+        monkeypatch.setattr(_cfg.settings, "tower_unfused_back", unfused == "1")
         task = make_task(tt, cfg, meta=GOLD / "real_vocab_metadata.csv", mlp_dtype="bf16", score_dtype="bf16", dropout_rate=drop)
         for tw in (task.two_tower_model.notice_tower, task.two_tower_model.company_tower):
             tw._seed_override = 7
@@ -1623,7 +1651,7 @@ def test_two_processes_equal_single_process(tt):
         outs = []
         try:
             for p in procs:
-                outs.append(p.communicate(timeout=240))
+                outs.append(p.communicate(timeout=240) + (p.returncode,))
         finally:
             for p in procs:
                 if p.poll() is None:
@@ -1635,7 +1663,7 @@ def test_two_processes_equal_single_process(tt):
     wide = run_pair({"TT_W2_WIDE": "1"})               # towers [48, 80] -> 72: SyncBN on the separate (unfused) kernels
     assert all("DIST_WORLD2_OK" in o[0] for o in wide) and len(wide) == 2, "\n".join(o[1][-1500:] for o in wide)
     outs = run_pair({})
-    ok = all("DIST_WORLD2_OK" in o[0] for o in outs) and len(outs) == 2
+    ok = all("DIST_WORLD2_OK" in o[0] and o[2] == 0 for o in outs) and len(outs) == 2       # rc 0: ordinary teardown, no os._exit escape
     if not ok:
         log = Path(__file__).resolve().parents[1] / "gpurun_out"
         log.mkdir(exist_ok=True)
@@ -1710,16 +1738,25 @@ BF16_STEP_BOUNDS = {
 }
 
 
-@pytest.mark.parametrize("rows_per_tower,B,T,hidden,D", [(1_000_000, 8192, 1.0, [128, 64], 64), (None, 1000, 0.5, [128, 64], 64),
-                                                         (None, 2240, 1.0, [512, 256], 128), (None, 4096, 0.7, [256, 128], 96)])
-def test_bf16_step_vs_rounded_oracle(tt, schema_real, tmp_path, rows_per_tower, B, T, hidden, D):
+# score_dtype="fp8" (BASELINE configs[4]): the same quantities against the oracle with e4m3 score operands.  Embeddings do not
+# depend on the score kernels; the loss sees e4m3 products accumulated in f32 over D = 256; gradients add nothing to the bf16
+# case (bf16 softmax weights and bf16 product operands in both)
+FP8_STEP_BOUNDS = dict(BF16_STEP_BOUNDS, loss_rtol=2e-5)
+
+
+@pytest.mark.parametrize("rows_per_tower,B,T,hidden,D,score_dtype", [(1_000_000, 8192, 1.0, [128, 64], 64, "bf16"), (None, 1000, 0.5, [128, 64], 64, "bf16"),
+                                                                     (None, 2240, 1.0, [512, 256], 128, "bf16"), (None, 4096, 0.7, [256, 128], 96, "bf16"),
+                                                                     (None, 2048, 1.0, [128, 64], 256, "fp8"), (None, 1000, 0.5, [128, 64], 256, "fp8")])
+def test_bf16_step_vs_rounded_oracle(tt, schema_real, tmp_path, rows_per_tower, B, T, hidden, D, score_dtype):
     """ONE step of exactly bench.py's task (real 32 + 6 key schema, vocabularies scaled to 1 M + 1 M rows, B = 8192, E = 32,
     towers [128, 64] -> 64, mlp_dtype = score_dtype = "bf16", embedding_grad = "sparse"; dropout 0 so that the oracle needs
     no mask) against the f64 oracle with the kernels' operand rounding: loss, both towers' embeddings, the metrics, every
     dense gradient and the sparse row gradients, each with its own stated bound.  Second case: the real (unscaled)
     vocabularies at a ragged batch and T = 0.5.  Third case: scripts/train.py's own towers ([512, 256] -> 128,
     /root/reference/scripts/train.py:106-107) -- the wide tail kernels and the separate fast GEMMs of the first block (the
-    one-launch front / first-block backward do not take h0 = 512), at a batch of 35 x 64 rows."""
+    one-launch front / first-block backward do not take h0 = 512), at a batch of 35 x 64 rows.  Last two cases: BASELINE
+    configs[4]'s step -- final_embedding_dim 256, score_dtype "fp8" (e4m3 operands for the score products) -- at batches the
+    f64 oracle can hold (the same step at B = 65536: test_configs4_whole_step_full_size)."""
     from jodalrob_twotower_amd import synthetic
     kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
     vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
@@ -1729,7 +1766,7 @@ def test_bf16_step_vs_rounded_oracle(tt, schema_real, tmp_path, rows_per_tower, 
     torch.manual_seed(1234)
     task = tt.create_two_tower_train_task(kn, kc, metadata_path=str(meta), categorical_embedding_dim=32, notice_dense_input_dim=256,
                                           company_dense_input_dim=128, tower_hidden_dims=hidden, final_embedding_dim=D,
-                                          dropout_rate=0.0, temperature=T, device=DEV, embedding_grad="sparse", score_dtype="bf16",
+                                          dropout_rate=0.0, temperature=T, device=DEV, embedding_grad="sparse", score_dtype=score_dtype,
                                           mlp_dtype="bf16")
     task.train()
     task._pair_check_done = True
@@ -1758,8 +1795,9 @@ def test_bf16_step_vs_rounded_oracle(tt, schema_real, tmp_path, rows_per_tower, 
     # B a multiple of 64 (the bench shape): the one-launch first-block backward forms the projection gradients as
     # W[:, :h0]^T . (d_pre^T . dense); other batch sizes take the separate GEMMs (d_proj^T . dense) -- the oracle follows
     ref = O.task_step(state, b, kn, kc, vn, vc, T, True, dtype=np.float64, rounding="bf16", table_grads="none", keep_sim=False,
-                      proj_grad="factored" if (B % 64 == 0 and (hidden[1] // 64) * hidden[0] <= 256) else "direct")
-    bd = BF16_STEP_BOUNDS
+                      proj_grad="factored" if (B % 64 == 0 and (hidden[1] // 64) * hidden[0] <= 256) else "direct",
+                      score_rounding="fp8" if score_dtype == "fp8" else None)
+    bd = FP8_STEP_BOUNDS if score_dtype == "fp8" else BF16_STEP_BOUNDS
     # measure everything first (the report is printed with -s and quoted in DESIGN.md section 4), then assert
     report = {"loss": abs(res["loss"].item() - ref["loss"]) / ref["loss"]}
     for name, got, want in (("notice_emb", ne, ref["notice_emb"]), ("company_emb", ce, ref["company_emb"])):
@@ -1777,7 +1815,7 @@ def test_bf16_step_vs_rounded_oracle(tt, schema_real, tmp_path, rows_per_tower, 
     rc, gc = O.embed_grad_sparse(ref["d_concat_company"], ref["ids_company"], offs_c, 32)
     rows_equal = np.array_equal(got_rows, np.concatenate([rn, rc]))
     report["row_grads"] = _rel(got_grad, np.concatenate([gn, gc])) if rows_equal else float("inf")
-    print("\n[bf16 step vs rounded oracle]", json.dumps({k: (v if not isinstance(v, tuple) else list(v)) for k, v in report.items()}))
+    print(f"\n[{score_dtype} step vs rounded oracle]", json.dumps({k: (v if not isinstance(v, tuple) else list(v)) for k, v in report.items()}))
     assert report["loss"] <= bd["loss_rtol"], report
     for name in ("notice_emb", "company_emb"):
         assert report[name][0] <= bd["emb_norm"] and report[name][1] <= bd["emb_maxabs"], (name, report[name])
@@ -1842,7 +1880,7 @@ def test_score_sym_forward(tt, B, D, T, prescale):
 
 
 @pytest.mark.parametrize("B,D,T", [(300, 64, 1.0), (1000, 128, 1.0), (257, 200, 2.0), (2048, 64, 0.5), (70, 256, 1.0), (513, 256, 1.0)])
-def test_score_backward_large_batch_form(tt, monkeypatch, B, D, T):
+def test_score_backward_large_batch_form(tt, ctx_option, B, D, T):
     """The workgroup-staged backward kernel (waves own rows a, every b tile staged once through LDS: the form used from
     32768 rows up) against the b-split form on the same operands -- the two sum over b in different orders: 2e-5 norm-wise
     -- and against the f64 oracle with the kernels' rounding (operands and softmax weights in bf16): 3e-4 norm-wise."""
@@ -1859,9 +1897,9 @@ def test_score_backward_large_batch_form(tt, monkeypatch, B, D, T):
     rs, cs, dg, rk, inv, out8, loss = ops.score_fwd_sym(Np, Cp, B, D, inv_t, abs(inv_t), sn, True)
     one = torch.ones(1, device=DEV)
     scale = inv_t / (2.0 * B)
-    monkeypatch.setenv("TT_SCORE_BWD_ROWS_MIN", "1000000000")
+    ctx_option(_L.TT_OPT_SCORE_BWD_ROWS_MIN, 1000000000, 32768)
     dN0, dC0 = ops.score_bwd_bf16(Np, Cp, B, D, inv_t, abs(inv_t), rs, cs, one, scale, sn, inv)
-    monkeypatch.setenv("TT_SCORE_BWD_ROWS_MIN", "1")
+    ctx_option(_L.TT_OPT_SCORE_BWD_ROWS_MIN, 1, 32768)
     dN1, dC1 = ops.score_bwd_bf16(Np, Cp, B, D, inv_t, abs(inv_t), rs, cs, one, scale, sn, inv)
     dN2, dC2 = ops.score_bwd_bf16(Np, Cp, B, D, inv_t, abs(inv_t), rs, cs, one, scale, sn, None)     # reciprocals taken in the kernel
     for a, b in ((dN1, dN0), (dC1, dC0), (dN2, dN0), (dC2, dC0)):
@@ -1930,6 +1968,84 @@ def test_score_fp8_vs_rounded_oracle(tt, B, D, T):
 
 
 # ------------------------------------------------------------------ BASELINE configs[2] / [3] / [4] at their own sizes
+def test_configs4_whole_step_full_size(tt, schema_real, tmp_path):
+    """BASELINE configs[4] as ONE WHOLE STEP at its own size -- batch 65536, final_embedding_dim 256, score_dtype "fp8", row-sparse
+    table gradients, FusedAdam (fused sparse Adam on the looked-up rows), 1 M + 1 M-row tables -- eagerly and replayed from the
+    captured graph: lookup of 2.5 M slots, the global radix duplicate-row plan (the keyed plan stops at B = 8192), segmented
+    reduction, both towers, fp8 score forward / backward, fused Adam and the graph's copy hand-over (tt_copy_multi).  The oracle
+    cannot hold B = 65536, so the step is checked through size-independent properties: the loss of a fresh initialisation is
+    ln(B); two passes from the same state give the same bits (loss, touched rows, row gradients); the touched-row set IS the
+    set of clamped ids of the batch (numpy on the ids: bit-exact); one optimiser step moves exactly those rows and every dense
+    parameter; and the replayed steps reproduce the eager ones bit for bit over three different batches.  (The same step
+    against the rounded f64 oracle, at B = 2048 / 1000: test_bf16_step_vs_rounded_oracle[...-256-fp8].)"""
+    from jodalrob_twotower_amd import synthetic
+    from jodalrob_twotower_amd.graph import GraphedTrainStep
+    from jodalrob_twotower_amd.optim import FusedAdam
+    B = 65536
+    dev = torch.device(DEV)
+    torch.manual_seed(17)
+    task, (kn, kc, vn, vc) = _config_task(tt, schema_real, tmp_path, 1_000_000, 1_000_000, False, final_embedding_dim=256, score_dtype="fp8")
+    state0 = {k: v.detach().clone() for k, v in task.state_dict().items()}
+    batches = [synthetic.make_batch(B, vn, vc, kn, kc, 256, 128, dev, seed=700 + i) for i in range(3)]
+    store = task.two_tower_model.embedding_store
+    store = store() if callable(store) else store
+    opt = FusedAdam.for_task(task, lr=1e-3, weight_decay=1e-5)
+    runs = []
+    for rep in range(2):
+        opt.zero_grad()
+        r = task(batches[0], return_metrics=True)
+        r["loss"].backward()
+        plan, grad_rows = store.sparse_grad
+        U = int(plan.n_unique.item())
+        runs.append((r["loss"].item(), plan.unique_rows[:U].clone(), grad_rows[:U].clone()))
+    assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]) and torch.equal(runs[0][2], runs[1][2])
+    assert abs(runs[0][0] - np.log(B)) < 0.25, runs[0][0]                 # ln(65536) = 11.09 at a random initialisation
+    assert bool(torch.isfinite(runs[0][2]).all())
+    # the touched rows are the batch's ids, clamped and offset into the fused row space (cat_embed.py:114-117): bit-exact
+    want = []
+    off = 0
+    for side, keys, vocab in (("notice", kn, vn), ("company", kc, vc)):
+        ids = batches[0][side]["kjt"].values().view(B, len(keys))
+        offs = off + torch.tensor(np.concatenate([[0], np.cumsum(vocab)[:-1]]), device=dev)
+        hi = torch.tensor(vocab, device=dev) - 1
+        want.append((torch.minimum(ids.clamp(min=0), hi) + offs).reshape(-1))
+        off += sum(vocab)
+    want_rows = torch.unique(torch.cat(want)).int()
+    assert torch.equal(runs[0][1].int(), want_rows)
+    before_tab = store.weight.detach().clone()
+    before_dense = {n: p.detach().clone() for n, p in task.named_parameters() if "categorical_embedder" not in n}
+    opt.step()
+    torch.cuda.synchronize()
+    changed = (store.weight.detach() != before_tab).any(dim=1).nonzero().flatten().int()
+    assert torch.equal(changed, want_rows)                                  # exactly the touched rows moved
+    del before_tab
+    for n, p in task.named_parameters():
+        if "categorical_embedder" not in n:
+            assert not torch.equal(p.detach(), before_dense[n]), n
+    # eager steps 2, 3 on new batches, then the same three steps replayed from a captured graph on a task reset to the same state
+    losses_e = [runs[1][0]]
+    for b in batches[1:]:
+        opt.zero_grad()
+        r = task(b, return_metrics=True)
+        r["loss"].backward()
+        opt.step()
+        losses_e.append(r["loss"].item())
+    torch.cuda.synchronize()
+    final_e = {k: v.detach().clone() for k, v in task.state_dict().items()}
+    del opt, runs, r
+    task.load_state_dict(state0)
+    opt = FusedAdam.for_task(task, lr=1e-3, weight_decay=1e-5)
+    gs = GraphedTrainStep(task, opt, batches[0], warmup=1)                  # its one eager warm-up step IS step 1
+    losses_g = [None] + [gs.step(b)["loss"].item() for b in batches[1:]]
+    torch.cuda.synchronize()
+    assert losses_g[1:] == losses_e[1:], (losses_g, losses_e)
+    for k, v in final_e.items():
+        assert torch.equal(task.state_dict()[k], v), k
+    gs.close()
+    del gs, opt, task, final_e, state0
+    torch.cuda.empty_cache()
+
+
 def _config_task(tt, schema_real, tmp_path, rows_n, rows_c, sharded, **kw):
     from jodalrob_twotower_amd import synthetic
     kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]

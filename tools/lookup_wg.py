@@ -1,4 +1,4 @@
-"""Per-workgroup anatomy of the lookup launch from bench.py's stamp ring: TT_LOOKUP_WG_DUMP=path python bench.py ...; then
+"""Per-workgroup anatomy of the lookup launch from bench.py's stamp ring: python bench.py --lookup-wg-dump path.npy ...; then
 python tools/lookup_wg.py path.npy"""
 import sys, numpy as np
 r = np.load(sys.argv[1]).astype(np.int64)
