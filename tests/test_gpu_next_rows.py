@@ -262,6 +262,7 @@ def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
                                                 pair_notice_id_cols=["bidntceno", "bidntceord"], pair_company_id_cols=["bizno"], metadata_path=str(meta))
     finals = {}
     for mode in ("tensors", "store"):
+        torch.manual_seed(123)                                           # the preprocessor's frozen random projectors draw from it
         src = synthetic.SyntheticSource(900, 700, 1200, vn, vc)
         train_loader, _ = create_unified_bid_dataloaders(src, schema, batch_size=256, test_split=0.0, shuffle_seed=7, test_mode=True, pair_limit=1200, device=DEV)
         assert len(train_loader) == 5                                    # 4 full batches + 176 pairs

@@ -356,8 +356,7 @@ def test_score_bf16_path_vs_oracle(tt):
         c[5] = c[3]
         n[7] = n[2]
         # the notice image is packed times inv_t * log2(e) (the kernels' unit form): bf16(scale * n) / scale is the operand
-        from jodalrob_twotower_amd.two_tower_train_task import _PRESCALE
-        sn = ops.score_unit_scale(1.0 / T) if _PRESCALE else 1.0
+        sn = ops.score_unit_scale(1.0 / T)
         nb = (torch.from_numpy(n) * np.float32(sn)).bfloat16().float().numpy().astype(np.float64) / float(np.float32(sn))
         cb = torch.from_numpy(c).bfloat16().float().numpy().astype(np.float64)
         loss, met, S, lse = O.score_ce_fwd(nb, cb, T)
@@ -1741,7 +1740,9 @@ BF16_STEP_BOUNDS = {
 # score_dtype="fp8" (BASELINE configs[4]): the same quantities against the oracle with e4m3 score operands.  Embeddings do not
 # depend on the score kernels; the loss sees e4m3 products accumulated in f32 over D = 256; gradients add nothing to the bf16
 # case (bf16 softmax weights and bf16 product operands in both)
-FP8_STEP_BOUNDS = dict(BF16_STEP_BOUNDS, loss_rtol=2e-5)
+# (measured at B = 2048 / T = 1 and B = 1000 / T = 0.5: loss 1e-7 / 4e-7, metrics <= 2.7e-6 -- the diagonal is a sum of D = 256
+# e4m3 products in f32, twice as large at T = 0.5 --, dense gradients <= 1.0e-3, rows 5.3e-4)
+FP8_STEP_BOUNDS = dict(BF16_STEP_BOUNDS, loss_rtol=2e-5, metric_atol=6e-6)
 
 
 @pytest.mark.parametrize("rows_per_tower,B,T,hidden,D,score_dtype", [(1_000_000, 8192, 1.0, [128, 64], 64, "bf16"), (None, 1000, 0.5, [128, 64], 64, "bf16"),
@@ -2012,6 +2013,13 @@ def test_configs4_whole_step_full_size(tt, schema_real, tmp_path):
         off += sum(vocab)
     want_rows = torch.unique(torch.cat(want)).int()
     assert torch.equal(runs[0][1].int(), want_rows)
+    # back to the initial state (the two passes above moved the BatchNorm running statistics twice), then step 1 for real
+    task.load_state_dict(state0)
+    opt = FusedAdam.for_task(task, lr=1e-3, weight_decay=1e-5)
+    opt.zero_grad()
+    r = task(batches[0], return_metrics=True)
+    r["loss"].backward()
+    assert r["loss"].item() == runs[0][0]
     before_tab = store.weight.detach().clone()
     before_dense = {n: p.detach().clone() for n, p in task.named_parameters() if "categorical_embedder" not in n}
     opt.step()
@@ -2023,7 +2031,7 @@ def test_configs4_whole_step_full_size(tt, schema_real, tmp_path):
         if "categorical_embedder" not in n:
             assert not torch.equal(p.detach(), before_dense[n]), n
     # eager steps 2, 3 on new batches, then the same three steps replayed from a captured graph on a task reset to the same state
-    losses_e = [runs[1][0]]
+    losses_e = [runs[0][0]]
     for b in batches[1:]:
         opt.zero_grad()
         r = task(b, return_metrics=True)
