@@ -75,6 +75,24 @@ class DevicePairLoader:
         for lo in range(0, self.pairs.shape[0], self.batch_size):
             yield self.batch(order, lo)
 
+    def eval_batches(self, graphed_eval, eager_eval=None, max_batches: Optional[int] = None) -> int:
+        """One pass over the pairs in order (no shuffling is applied here: the reference's test loader does not shuffle) through a
+        GraphedEvalStep: full batches from the stores, the ragged last one through `eager_eval(batch) -> metrics dict` (skipped
+        when None).  Returns the number of batches evaluated; the sums sit in `graphed_eval`."""
+        n, B, done = self.pairs.shape[0], self.batch_size, 0
+        order = self.epoch_order()
+        for lo in range(0, n, B):
+            if max_batches is not None and done >= max_batches:
+                break
+            if lo + B <= n:
+                graphed_eval.step_from_store(self.notice, self.company, self.pairs, order, lo)
+            elif eager_eval is not None:
+                graphed_eval.add_eager(eager_eval(self.batch(order, lo)))
+            else:
+                continue
+            done += 1
+        return done
+
     def step_batches(self, graphed_step, eager_step=None):
         """One epoch on the fast path: every full batch is gathered out of the stores by the captured step's own hand-over launch
         (GraphedTrainStep.step_from_store) and replayed; the ragged last batch -- a captured step has one batch size -- goes

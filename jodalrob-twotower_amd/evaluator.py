@@ -66,6 +66,20 @@ class TwoTowerEvaluator:
         """Mean of the per-batch metrics over `dataloader` (every key of the reference's result -- loss, accuracy, recall@5,
         recall@10, mrr, similarity_gap, num_batches -- plus the means of the other per-batch figures).  `max_batches` (not in
         the reference) stops early; `num_batches` is the number of batches evaluated."""
+        fast = self._fast_eval(model, dataloader)
+        if fast is not None:
+            fast.reset()
+            n = dataloader.eval_batches(fast, lambda b: self.evaluate_single_batch(model, b, verbose=False), max_batches)
+            out = fast.means() if n else {}
+            if n:                                            # the figures every batch shares (evaluate_single_batch's other keys)
+                b = dataloader.batch_size
+                out.update({"batch_size": float(b), "random_accuracy": 1.0 / b, "random_recall@5": min(5.0 / b, 1.0),
+                            "random_recall@10": min(10.0 / b, 1.0)})
+            out["num_batches"] = n
+            model.eval()
+            if verbose and n:
+                self.print_comprehensive_results(out)
+            return out
         agg, n = {}, 0
         for i, batch in enumerate(dataloader):
             if max_batches is not None and i >= max_batches:
@@ -80,6 +94,26 @@ class TwoTowerEvaluator:
         if verbose and n:
             self.print_comprehensive_results(out)
         return out
+
+    def _fast_eval(self, model, dataloader):
+        """A GraphedEvalStep for (model, loader batch size) when the loader is a device-resident DevicePairLoader with at least one
+        full batch and the model is this package's task on a GPU; cached on the evaluator.  None: the batch-by-batch loop."""
+        if not (hasattr(dataloader, "eval_batches") and hasattr(model, "forward_with_ranks") and getattr(model, "exchange", None) is None):
+            return None
+        B = dataloader.batch_size
+        if dataloader.pairs.shape[0] < B or dataloader.shuffle or not dataloader.pairs.is_cuda:
+            return None
+        key = (id(model), B)
+        cache = self.__dict__.setdefault("_eval_graphs", {})
+        if key not in cache:
+            from .graph import GraphedEvalStep
+            cache[key] = GraphedEvalStep(model, dataloader.batch(None, 0))
+        return cache[key]
+
+    def close(self):
+        """Drops the captured evaluation graphs (and their private memory pools)."""
+        for g in self.__dict__.pop("_eval_graphs", {}).values():
+            g.close()
 
     # ---- printers (:211-267): same lines on stdout as the reference, driven by tables ---------------------------------
     _ROWS_SINGLE = (("Loss", "loss", 4), ("Top-1 Accuracy", "accuracy", 3), ("Recall@5", "recall@5", 3), ("Recall@10", "recall@10", 3),

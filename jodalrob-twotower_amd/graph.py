@@ -266,3 +266,81 @@ class GraphedTrainStep:
             import gc
             gc.collect()
             torch.cuda.synchronize(dev)
+
+
+class GraphedEvalStep:
+    """The evaluation pass of one batch -- towers in eval mode, loss and metrics, the rank of every positive in its row, and from
+    the ranks Recall@5 / Recall@10 / MRR (src/evaluation/evaluator.py:20-71, :123-155) -- captured once and replayed per batch,
+    fed like GraphedTrainStep.step_from_store from the device-resident feature stores.  Per batch the eager evaluator costs ~30
+    launches from Python and a dozen `.item()` round trips; here it is one hand-over launch, one replay and NO host sync: the
+    eight per-batch figures are added into a device accumulator, read once at the end (`means()`).
+    metrics order: loss, accuracy, similarity_gap, positive_similarity_mean, negative_similarity_mean, recall@5, recall@10, mrr."""
+
+    KEYS = ("loss", "accuracy", "similarity_gap", "positive_similarity_mean", "negative_similarity_mean", "recall@5", "recall@10", "mrr")
+
+    def __init__(self, task, example_batch: Dict, warmup: int = 2):
+        self.task = task
+        dev = example_batch["notice"]["dense"].device
+        self.static = {side: {"dense": example_batch[side]["dense"].clone(),
+                              "kjt": KeyedJaggedTensor(example_batch[side]["kjt"].keys(), example_batch[side]["kjt"].values().clone())}
+                       for side in ("notice", "company")}
+        self.B = self.static["notice"]["dense"].shape[0]
+        self.acc = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.batches = 0
+        was_training = task.training
+        task.eval()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.acc.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        import torch.distributed as _dist
+        mode = "thread_local" if (_dist.is_available() and _dist.is_initialized()) else "global"
+        with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=mode):
+            self._body()
+        task.train(was_training)
+
+    def _body(self):
+        res, ranks = self.task.forward_with_ranks(self.static)
+        k5, k10 = min(5, self.B), min(10, self.B)
+        r = ranks.float()
+        per = torch.stack([res["loss"].reshape(()), res["accuracy"].reshape(()), res["similarity_gap"].reshape(()),
+                           res["positive_similarity_mean"].reshape(()), res["negative_similarity_mean"].reshape(()),
+                           (ranks < k5).float().mean(), (ranks < k10).float().mean(), (1.0 / (r + 1.0)).mean()])
+        self.acc.add_(per)
+
+    def reset(self):
+        self.acc.zero_()
+        self.batches = 0
+
+    def step_from_store(self, notice_store, company_store, pairs: torch.Tensor, order: Optional[torch.Tensor] = None, offset: int = 0):
+        flat = pairs.view(-1)
+        base = 0 if order is not None else 2 * offset
+        model = self.task.two_tower_model
+        embs = [model.notice_tower.categorical_embedder, model.company_tower.categorical_embedder]
+        sides, stores = [], []
+        for i, (side, fs, e) in enumerate(zip(("notice", "company"), (notice_store, company_store), embs)):
+            sides.append(ops.LookupSide(None, e._key_row_offset, e._key_vocab, None, len(e.keys)))
+            stores.append(ops.StoreSide(flat[base + i:], 2, fs.dense, fs.categorical, self.static[side]["dense"], self.static[side]["kjt"].values()))
+        ops.batch_ingest_store([], sides, stores, self.B, order, None, offset if order is not None else 0)
+        self.graph.replay()
+        self.batches += 1
+
+    def add_eager(self, metrics: Dict):
+        """A batch evaluated outside the graph (the ragged last one) joins the sums."""
+        self.acc.add_(torch.tensor([float(metrics[k]) for k in self.KEYS], dtype=torch.float32, device=self.acc.device))
+        self.batches += 1
+
+    def means(self) -> Dict[str, float]:
+        vals = (self.acc / max(self.batches, 1)).cpu().tolist()          # the one host sync of the evaluation
+        return dict(zip(self.KEYS, vals))
+
+    def close(self):
+        torch.cuda.synchronize(self.acc.device)
+        if self.graph is not None:
+            self.graph.reset()
+            self.graph = None

@@ -139,8 +139,12 @@ def main():
         example = next(iter(train_loader))               # shapes + the capture's one eager warm-up step: runs at the schedule's
         train_loader._gen.set_state(state)               # first learning rate, which is 0 (LambdaLR warm-up: scripts/train.py:236-240)
         graphed = GraphedTrainStep(train_task, optimizer, example, warmup=1)
-    pairs_seen, t_loop = 0, time.time()
+    if a.fast:                                           # one-off: capture the evaluation pass too (outside the epoch clock, like the step's capture)
+        evaluator._fast_eval(train_task, test_loader)
+    torch.cuda.synchronize()
+    pairs_seen, t_loop, t_train, t_eval = 0, time.time(), 0.0, 0.0
     for epoch in range(start_epoch, config["num_epochs"]):
+        t_e0 = time.time()
         train_task.train()
         results = train_loader.step_batches(graphed, eager_step) if graphed is not None else (eager_step(b) for b in train_loader)
         for result in results:
@@ -154,18 +158,27 @@ def main():
                       f"pos {result['positive_similarity_mean'].item():.3f}  neg {result['negative_similarity_mean'].item():.3f}")
             if a.steps and steps >= a.steps:
                 break
+        torch.cuda.synchronize()
+        t_e1 = time.time()
         val = evaluator.evaluate_comprehensive(train_task, test_loader, verbose=True, max_batches=50)
+        torch.cuda.synchronize()
+        t_train, t_eval = t_train + (t_e1 - t_e0), t_eval + (time.time() - t_e1)
         if val.get("loss", float("inf")) < best:
             best = val["loss"]
             save_checkpoint(train_task, optimizer, epoch, best, config["output_dir"], is_best=True)
         else:
             save_checkpoint(train_task, optimizer, epoch, val.get("loss", 0.0), config["output_dir"])
+    torch.cuda.synchronize()
+    t_epochs = time.time() - t_loop
+    print(f"throughput: {pairs_seen / t_epochs:,.0f} pairs/s over {steps} steps incl. evaluation "
+          f"({'fast: captured step fed from the device stores' if a.fast else 'eager reference loop'}); "
+          f"training {t_train * 1e3:.1f} ms = {pairs_seen / max(t_train, 1e-9):,.0f} pairs/s, evaluation {t_eval * 1e3:.1f} ms "
+          f"({val.get('num_batches', 0)} batches), checkpoints {max(t_epochs - t_train - t_eval, 0.0) * 1e3:.1f} ms")
     evaluator.demonstrate_predictions(train_task, next(iter(test_loader)), top_k=10)      # reference driver: scripts/train.py:450-452
     if graphed is not None:
         graphed.close()
+    evaluator.close()                                    # (captured evaluation graphs)
     torch.cuda.synchronize()
-    print(f"throughput: {pairs_seen / (time.time() - t_loop):,.0f} pairs/s over {steps} steps incl. evaluation "
-          f"({'fast: captured step fed from the device stores' if a.fast else 'eager reference loop'})")
     save_checkpoint(train_task, optimizer, config["num_epochs"] - 1, best, config["output_dir"], is_final=True)
     row = [time.strftime("%Y-%m-%d %H:%M:%S"), config["batch_size"], str(config["tower_hidden_dims"]), config["final_embedding_dim"],
            config["categorical_embedding_dim"], config["learning_rate"], config["num_epochs"], steps,

@@ -302,3 +302,37 @@ def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
     assert finals["tensors"][0] == finals["store"][0] and len(set(finals["store"][0])) == 10
     for k, v in finals["tensors"][1].items():
         assert torch.equal(v, finals["store"][1][k]), k
+
+
+def test_fast_evaluation_equals_batch_loop(tt, tmp_path):
+    """evaluate_comprehensive over a device-resident loader (GraphedEvalStep: every full batch gathered from the stores and
+    replayed, metrics summed on the device, ragged last batch eager) == the reference-shaped loop over the loader's batches
+    (evaluate_single_batch per batch, Python means): every key of the reference's result, 1e-6."""
+    from jodalrob_twotower_amd import synthetic
+    from jodalrob_twotower_amd.data_loader import create_unified_bid_dataloaders
+    vn, vc = [12, 400, 7, 90], [9, 50]
+    meta = synthetic.write_metadata(tmp_path / "metadata.csv", {"notice": {f"n{i}": v for i, v in enumerate(vn)}, "company": {f"c{i}": v for i, v in enumerate(vc)}})
+    with open(meta, "a", encoding="utf-8") as f:
+        f.write("notice,bidntceno,text,Y,,,,0,,Y,Y,,\nnotice,bidntceord,text,Y,,,,0,,Y,Y,,\ncompany,bizno,text,Y,,,,0,,Y,Y,,\n"
+                "notice,amount,numeric,Y,,,,0,,,,,\ncompany,size,numeric,Y,,,,0,,,,,\n")
+    schema = tt.build_torchrec_schema_from_meta(notice_table="notice", company_table="company", pair_table="bid_two_tower",
+                                                pair_notice_id_cols=["bidntceno", "bidntceord"], pair_company_id_cols=["bizno"], metadata_path=str(meta))
+    torch.manual_seed(5)
+    src = synthetic.SyntheticSource(900, 700, 2000, vn, vc)
+    _, test_loader = create_unified_bid_dataloaders(src, schema, batch_size=256, test_split=0.5, shuffle_seed=7, test_mode=True, pair_limit=2000, device=DEV)
+    assert len(test_loader) == 4                                          # 3 full batches + 232 pairs
+    first = next(iter(test_loader))
+    task = tt.create_two_tower_train_task(schema.notice.categorical, schema.company.categorical, metadata_path=str(meta), categorical_embedding_dim=16,
+                                          notice_dense_input_dim=first["notice"]["dense"].shape[1], company_dense_input_dim=first["company"]["dense"].shape[1],
+                                          tower_hidden_dims=[64, 32], final_embedding_dim=32, dropout_rate=0.1, device=DEV, score_dtype="bf16", mlp_dtype="bf16")
+    task._pair_check_done = True
+    ev = tt.TwoTowerEvaluator(device=DEV)
+    fast = ev.evaluate_comprehensive(task, test_loader, verbose=False)
+    assert ev._fast_eval(task, test_loader) is not None and fast["num_batches"] == 4
+    per = [ev.evaluate_single_batch(task, b, verbose=False) for b in test_loader]
+    for k in ("loss", "accuracy", "recall@5", "recall@10", "mrr", "similarity_gap", "positive_similarity_mean", "negative_similarity_mean"):
+        want = sum(m[k] for m in per) / len(per)
+        assert fast[k] == pytest.approx(want, rel=1e-6, abs=1e-7), (k, fast[k], want)
+    two = ev.evaluate_comprehensive(task, test_loader, verbose=False, max_batches=2)           # the cached graph again, two batches
+    assert two["num_batches"] == 2 and two["loss"] == pytest.approx(sum(m["loss"] for m in per[:2]) / 2, rel=1e-6)
+    ev.close()
