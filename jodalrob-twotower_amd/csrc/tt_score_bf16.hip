@@ -710,6 +710,9 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows_kernel(BwdArgs args) 
   constexpr int kRowsB = FP8 ? KS * 512 : KS * 1024, kFragB = KS * 1024, kIvB = 256, kStageB = kRowsB + kFragB + kIvB;
   constexpr int kPieces = (kRowsB + kFragB) / 16, kPPT = (kPieces + NTH - 1) / NTH;   // 16-byte pieces per thread per stage (last one ragged)
   static_assert(!FP8 || KS % 4 == 0, "fp8 operands come in K = 64 steps");
+  // bf16 operands at D = 256: the wave's own A fragments are 64 registers beside 128 of accumulators -- they live in LDS behind
+  // the two stages ([wave][k-step][lane] 16-byte pieces: 8 KB per wave) and are read back four k-steps at a time
+  constexpr bool ALDS = !FP8 && KS == 16;
   extern __shared__ __attribute__((aligned(16))) char lds_raw[];
   const bool d1 = blockIdx.y != 0;
   DirBwd dr;
@@ -730,14 +733,19 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows_kernel(BwdArgs args) 
   const int nT = (Rb + 31) / 32, nTa_img = (int)(rup(Ra, 64) / 32);
   const int at0 = ((int)blockIdx.x * NWV + wave) * AT;                      // this wave's first a tile
   if ((int)blockIdx.x * NWV * AT * 32 >= Ra) return;                        // (whole workgroup)
-  bf16x8 ares[AT][FP8 ? 1 : KS];
+  bf16x8 ares[AT][(FP8 || ALDS) ? 1 : KS];
   i32x8 ares8[AT][K64];
+  bf16x8* const a_lds = reinterpret_cast<bf16x8*>(lds_raw + 2 * kStageB) + (size_t)wave * AT * KS * 64 + lane;   // (ALDS) [a tile][k-step][lane]
   float ia[AT];
   int pos[AT];
 #pragma unroll
   for (int i = 0; i < AT; ++i) {
     if (FP8) load_f8frag<K64>(reinterpret_cast<const char*>(dr.a_rows), min(at0 + i, nTa_img - 1), c, h, ares8[i]);
-    else load_bfrag<(FP8 ? 1 : KS)>(dr.a_rows, min(at0 + i, nTa_img - 1), c, h, ares[i]);
+    else if (ALDS) {
+      const __bf16* pa = dr.a_rows + (((int64_t)min(at0 + i, nTa_img - 1) * KS * 2 + h) * 32 + c) * 8;
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) a_lds[(i * KS + s2) * 64] = *reinterpret_cast<const bf16x8*>(pa + s2 * 512);    // (wave-private: no barrier)
+    } else load_bfrag<((FP8 || ALDS) ? 1 : KS)>(dr.a_rows, min(at0 + i, nTa_img - 1), c, h, ares[i]);
     const int a = 32 * (at0 + i) + c;
     ia[i] = a < Ra ? (inv_a ? inv_a[a] : __builtin_amdgcn_rcpf(dr.sumexp_a[a]) * kx) : 0.f;
     pos[i] = a + off;
@@ -752,43 +760,35 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows_kernel(BwdArgs args) 
       for (int r = 0; r < 16; ++r) dacc[i][d][r] = 0.f;
   const bool have_inv = inv_b != nullptr;
   const float* const ivsrc = have_inv ? inv_b : dr.sumexp_b;
-  // stage loader: pieces p = tid + 256 q of the tile's [rows image | fragment image]; both images are contiguous per tile.
-  // ONE load site inside the loop (iteration -1 only loads), plain unrolled loops over the register array: behind lambdas or
-  // a macro hipcc kept the array in scratch memory (a store, a reload and a vmcnt(0) drain per stage)
-  // The copy runs in TWO halves so that only kPPT / 2 pieces are live in registers at a time (at D = 256 the A fragments
-  // alone are 128 registers): half 0 (the rows image's share) is loaded while the previous tile's second product runs and
-  // stored before this tile's barrier; half 1 is loaded before the S products and stored behind them.  Named registers, one
-  // load site each: behind lambdas / arrays hipcc kept them in scratch memory (a store, a reload and a vmcnt(0) drain per stage).
-  constexpr int kHalf = (kPPT + 1) / 2;                    // half 0: pieces [0, kHalf), half 1: [kHalf, kPPT) (a piece index past kPieces is skipped)
-  static_assert(kHalf >= 1 && kHalf <= 4, "stage loader: at most eight pieces per thread");
-  uint4 p0 = make_uint4(0, 0, 0, 0), p1 = p0, p2 = p0, p3 = p0;
-  float4 ivreg = make_float4(0.f, 0.f, 0.f, 0.f);
-#define TT_PIECE_SRC(q, tn)                                                                                                      \
-  ((tid + NTH * (q)) < kRowsB / 16 ? reinterpret_cast<const char*>(dr.b_rows) + (int64_t)(tn) * kRowsB + (tid + NTH * (q)) * 16  \
-                                   : reinterpret_cast<const char*>(dr.b_frag) + (int64_t)(tn) * kFragB + ((tid + NTH * (q)) - kRowsB / 16) * 16)
-#define TT_PIECE_OK(j, q0) (kHalf > (j) && (q0) + (j) < kPPT && (((q0) + (j) + 1) * NTH <= kPieces || tid + NTH * ((q0) + (j)) < kPieces))
-#define TT_PIECE_ST(j, var, q0) if (TT_PIECE_OK(j, q0)) *reinterpret_cast<uint4*>(base + (tid + NTH * ((q0) + (j))) * 16) = var
-#define TT_PIECE_LD(j, var, q0, tn) if (TT_PIECE_OK(j, q0)) var = *reinterpret_cast<const uint4*>(TT_PIECE_SRC((q0) + (j), tn))
-#define TT_HALF_LOAD(q0, tn) do { TT_PIECE_LD(0, p0, q0, tn); TT_PIECE_LD(1, p1, q0, tn); TT_PIECE_LD(2, p2, q0, tn); TT_PIECE_LD(3, p3, q0, tn); } while (0)
-#define TT_HALF_STORE(q0, buf)                                                                        \
-  do {                                                                                                \
-    char* base = lds_raw + (buf) * kStageB;                                                           \
-    TT_PIECE_ST(0, p0, q0); TT_PIECE_ST(1, p1, q0); TT_PIECE_ST(2, p2, q0); TT_PIECE_ST(3, p3, q0);   \
-  } while (0)
-  // prologue: tile 0 completely into buffer 0, then half 0 of tile 1 into registers
-  TT_HALF_LOAD(0, 0);
-  TT_HALF_STORE(0, 0);
-  TT_HALF_LOAD(kHalf, 0);
-  if (tid < 8) ivreg = *reinterpret_cast<const float4*>(ivsrc + 4 * tid);
-  TT_HALF_STORE(kHalf, 0);
-  if (tid < 8) *reinterpret_cast<float4*>(lds_raw + kRowsB + kFragB + tid * 16) = ivreg;
-  TT_HALF_LOAD(0, min(1, nT - 1));
+  // stage loader: the tile's [rows image | fragment image | 32 reciprocals] (contiguous per tile in global memory) go STRAIGHT into
+  // the LDS stage by LDS-DMA (global_load_lds_dwordx4: lane l of a wave writes 16 bytes at the wave's base + 16 l), piece
+  // p = tid + NTH q at offset 16 p.  Round 3: the copy used to pass through registers (up to eight 16-byte pieces per thread,
+  // loaded a tile ahead and stored before the barrier): at D = 256 those 16-20 registers were the difference between 256
+  // registers and 8-36 dwords of scratch per lane in the tile loop.  The DMA of tile t + 1 is issued right behind the barrier that
+  // frees its buffer and has the whole tile to land; a wave waits for its own pieces (vmcnt(0)) before the next barrier.
+  const char* const g_rows = reinterpret_cast<const char*>(dr.b_rows);
+  const char* const g_frag = reinterpret_cast<const char*>(dr.b_frag);
+  auto stage_dma = [&](int tn, int buf) {
+    char* const base = lds_raw + buf * kStageB;
+#pragma unroll
+    for (int q = 0; q < kPPT; ++q) {
+      const int p = tid + NTH * q;
+      if ((q + 1) * NTH <= kPieces || p < kPieces) {
+        const char* src = p < kRowsB / 16 ? g_rows + (int64_t)tn * kRowsB + p * 16 : g_frag + (int64_t)tn * kFragB + (p - kRowsB / 16) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(base + (wave * 64 + NTH * q) * 16), 16, 0, 0);
+      }
+    }
+    if (wave == 0 && lane < 8)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ivsrc + 32 * tn + 4 * lane),
+                                       (__attribute__((address_space(3))) void*)(base + kRowsB + kFragB), 16, 0, 0);
+  };
+  stage_dma(0, 0);
   for (int t = 0; t < nT; ++t) {
-    const int tn = min(t + 1, nT - 1), nb = (t + 1) & 1;
-    __syncthreads();                                       // buffer t & 1 complete; buffer nb no longer read by anyone
-    TT_HALF_STORE(0, nb);                                  // half 0 of tile t + 1 (loaded during the previous tile)
-    TT_HALF_LOAD(kHalf, tn);                               // half 1 of tile t + 1: in flight during the S products
-    if (tid < 8) ivreg = *reinterpret_cast<const float4*>(ivsrc + 32 * tn + 4 * tid);
+    const int nb = (t + 1) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of tile t have landed ...
+    __syncthreads();                                       // ... and everybody's; buffer nb is no longer read by anyone
+    if (t + 1 < nT) stage_dma(t + 1, nb);
     const char* rb = lds_raw + (t & 1) * kStageB;
     const char* fb = rb + kRowsB;
     const float* ivp = reinterpret_cast<const float*>(fb + kFragB);
@@ -821,15 +821,20 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows_kernel(BwdArgs args) 
         bf16x8 bf[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const bf16x8*>(rb + (((s0 + j) * 2 + h) * 32 + c) * 16);
+        bf16x8 af[AT][4];
+        if (ALDS) {
+#pragma unroll
+          for (int i = 0; i < AT; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[i][j] = a_lds[(i * KS + s0 + j) * 64];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int i = 0; i < AT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], ares[i][FP8 ? 0 : s0 + j], acc[i], 0, 0, 0);
+          for (int i = 0; i < AT; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], ALDS ? af[i][j] : ares[i][(FP8 || ALDS) ? 0 : s0 + j], acc[i], 0, 0, 0);
       }
     }
-    TT_HALF_STORE(kHalf, nb);                              // half 1 of tile t + 1 has had the S products' time to land
-    if (tid < 8) *reinterpret_cast<float4*>(lds_raw + nb * kStageB + kRowsB + kFragB + tid * 16) = ivreg;
-    TT_HALF_LOAD(0, min(t + 2, nT - 1));                   // half 0 of tile t + 2: in flight during the second products
     float ib[16];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -866,23 +871,25 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows_kernel(BwdArgs args) 
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int j = 0; j < 8; ++j) wf[s][j] = (__bf16)w[8 * s + j];
-      // second product, software-pipelined over batches of (up to) four fragment reads: batch k + 1 is in flight while
-      // batch k's MFMAs issue -- with one wave per SIMD nobody else covers an LDS round trip
-      constexpr int NBATCH = 2 * ((DT + 3) / 4);
-      bf16x8 bmq[2][4];
-      auto bm_read = [&](int k, bf16x8 (&dst)[4]) {
-        const int s = k / ((DT + 3) / 4), d0 = 4 * (k % ((DT + 3) / 4));
+      // second product, software-pipelined over batches of BQ fragment reads: batch k + 1 is in flight while batch k's MFMAs
+      // issue -- with one wave per SIMD nobody else covers an LDS round trip.  (BQ = 2 for the bf16 D = 256 form: its two a
+      // tiles' A fragments alone are 128 registers, and batches of four left 20 bytes of scratch per lane)
+      constexpr int BQ = (KS == 16 && !FP8) ? 2 : 4;
+      constexpr int NB1 = (DT + BQ - 1) / BQ, NBATCH = 2 * NB1;
+      bf16x8 bmq[2][BQ];
+      auto bm_read = [&](int k, bf16x8 (&dst)[BQ]) {
+        const int s = k / NB1, d0 = BQ * (k % NB1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < BQ; ++j)
           if (d0 + j < DT) dst[j] = *reinterpret_cast<const bf16x8*>(fb + (((s * 2 + h) * Dp + 32 * (d0 + j) + c) * 16));
       };
       bm_read(0, bmq[0]);
 #pragma unroll
       for (int k = 0; k < NBATCH; ++k) {
         if (k + 1 < NBATCH) bm_read(k + 1, bmq[(k + 1) & 1]);
-        const int s = k / ((DT + 3) / 4), d0 = 4 * (k % ((DT + 3) / 4));
+        const int s = k / NB1, d0 = BQ * (k % NB1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < BQ; ++j)
           if (d0 + j < DT) dacc[i][d0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s], bmq[k & 1][j], dacc[i][d0 + j], 0, 0, 0);
       }
     }
@@ -899,12 +906,6 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows_kernel(BwdArgs args) 
         if (a < Ra && dd < args.D) dr.dA[(int64_t)a * args.D + dd] = dacc[i][d][r] * g;
       }
 }
-#undef TT_PIECE_SRC
-#undef TT_PIECE_OK
-#undef TT_PIECE_ST
-#undef TT_PIECE_LD
-#undef TT_HALF_LOAD
-#undef TT_HALF_STORE
 
 // ---- fp8 pack: [fp8 rows image | bf16 fragment image] (tt_score_bf16.h) -------------------------------------
 __global__ __launch_bounds__(256) void pack_fp8_kernel(PackBatch batch, int D, int Dp) {
@@ -1070,21 +1071,24 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
   } while (0)
   // enough rows for every SIMD to own 64 of them: the workgroup-staged form (no split along b, operands shared through LDS)
   if (maxRa >= ctx->score_bwd_rows_min && Dp >= 64) {
-#define TT_BWD_ROWS(KS)                                                                                        \
+#define TT_BWD_ROWS(KS, AT_, NWV_)                                                                             \
   do {                                                                                                         \
-    const dim3 grid((unsigned)tt_cdiv(maxRa, 256), (unsigned)n_dirs);                                          \
-    const size_t lds = 2 * (size_t)(KS * 2048 + 256);                                                          \
+    const dim3 grid((unsigned)tt_cdiv(maxRa, 32 * AT_ * NWV_), (unsigned)n_dirs);                              \
+    const size_t lds = 2 * (size_t)(KS * 2048 + 256) + (KS == 16 ? (size_t)NWV_ * AT_ * KS * 1024 : 0);        \
     if (unit) {                                                                                                \
-      TT_LDS_ONCE(lds, &score_bwd_rows_kernel<KS, true, false, 2, 4>);                                         \
-      score_bwd_rows_kernel<KS, true, false, 2, 4><<<grid, 256, lds, st>>>(a);                                 \
+      TT_LDS_ONCE(lds, &score_bwd_rows_kernel<KS, true, false, AT_, NWV_>);                                    \
+      score_bwd_rows_kernel<KS, true, false, AT_, NWV_><<<grid, NWV_ * 64, lds, st>>>(a);                      \
     } else {                                                                                                   \
-      TT_LDS_ONCE(lds, &score_bwd_rows_kernel<KS, false, false, 2, 4>);                                        \
-      score_bwd_rows_kernel<KS, false, false, 2, 4><<<grid, 256, lds, st>>>(a);                                \
+      TT_LDS_ONCE(lds, &score_bwd_rows_kernel<KS, false, false, AT_, NWV_>);                                   \
+      score_bwd_rows_kernel<KS, false, false, AT_, NWV_><<<grid, NWV_ * 64, lds, st>>>(a);                     \
     }                                                                                                          \
   } while (0)
-    if (Dp == 64) TT_BWD_ROWS(4);
-    else if (Dp == 128) TT_BWD_ROWS(8);
-    else TT_BWD_ROWS(16);
+    // D = 256: one a tile per wave with its A fragments in LDS (16 KB per wave: four waves beside the two 33-KB stages) -- with
+    // two a tiles per wave the A fragments (128 registers) and the accumulators (256) filled the whole file and hipcc shuttled
+    // hundreds of values between AGPRs, VGPRs and scratch (20-116 bytes of scratch per lane in the tile loop)
+    if (Dp == 64) TT_BWD_ROWS(4, 2, 4);
+    else if (Dp == 128) TT_BWD_ROWS(8, 2, 4);
+    else TT_BWD_ROWS(16, 1, 4);
 #undef TT_BWD_ROWS
     TT_LAUNCH_CHECK();
     return TT_OK;
