@@ -70,6 +70,7 @@ def parse(argv=None):
     ap.add_argument("--sync-bn", action="store_true", help="multi-GPU: BatchNorm statistics over all ranks' rows also in the weak leg")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-to-device-inclusive leg")
     ap.add_argument("--breakdown", action="store_true", help="extra instrumented pass: per-kernel HIP-event times")
+    ap.add_argument("--no-riders", action="store_true", help="plan compaction / loss reduction as launches of their own (A/B of TT_OPT_DEFER_RIDERS)")
     ap.add_argument("--dist-eager", action="store_true", help="sharded path launched from Python instead of replayed (analysis)")
     ap.add_argument("--no-lookup-profile", action="store_true", help="do not stamp the lookup launches (no `roofline` object then)")
     ap.add_argument("--lookup-wg-dump", default=None, help="write the lookup's per-workgroup stamps to this .npy (tools/lookup_wg.py)")
@@ -185,7 +186,7 @@ class Leg:
         if self.use_graph:
             from jodalrob_twotower_amd.graph import GraphedTrainStep
             try:
-                self.gstep = GraphedTrainStep(task, self.opt, self.pool[0], return_metrics=True, warmup=3)
+                self.gstep = GraphedTrainStep(task, self.opt, self.pool[0], return_metrics=True, warmup=3, defer_riders=not args.no_riders)
             except Exception as e:                      # a capture that fails on some RCCL / world size must not lose the run
                 if not sharded:
                     raise

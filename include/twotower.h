@@ -62,8 +62,18 @@ int tt_ctx_num_cus(const tt_ctx* ctx);
  * force either form). */
 #define TT_OPT_KEYED_PARTS 2
 #define TT_OPT_SCORE_BWD_ROWS_MIN 3
+/* TT_OPT_DEFER_RIDERS (default 0): tt_dedup_plan_keyed* leaves the plan's compaction, and tt_score_fwd_sym_* its last reduction
+ * (loss_out / out8), QUEUED in the context instead of launching them: tt_towers_mlp_fwd / tt_towers_mlp_bwd run them in an extra
+ * grid row of their fused tail kernels (two launches fewer in the step's dependent chain; same bodies: bit-identical), and
+ * tt_flush_deferred, tt_embed_grad_bwd, tt_embed_grad_finish and the tt_adam_* entries launch whatever is still queued.  Until
+ * then the plan's unique_rows / seg_offsets / n_unique and the forward's loss_out / out8 are NOT written: for callers that run
+ * the whole step back to back (GraphedTrainStep); tt_deferred_pending() covers the queue. */
+#define TT_OPT_DEFER_RIDERS 4
 int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value);
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream);
+/* only the queued slab reduction (the one thing that lives in the caller's shared scratch buffer) */
+int tt_flush_deferred_slabs(tt_ctx* ctx, tt_stream stream);
+/* bit 0: a slab reduction is queued; bit 1: riders (TT_OPT_DEFER_RIDERS) are queued */
 int tt_deferred_pending(const tt_ctx* ctx);
 
 /* ------------------------------------------------------------------------------------------------

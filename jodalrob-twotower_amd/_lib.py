@@ -108,6 +108,7 @@ SIGNATURES = {
     "tt_ctx_set_option": (C.c_int, [vp, i32, i32]),
     "tt_flush_deferred": (C.c_int, [vp, vp]),
     "tt_deferred_pending": (C.c_int, [vp]),
+    "tt_flush_deferred_slabs": (C.c_int, [vp, vp]),
     "tt_tower_workspace_bytes": (sz, [C.POINTER(TowerParams), i64]),
     "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, vp, sz, vp]),
     "tt_tower_mlp_bwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), vp, C.POINTER(TowerGrads), i64, i32,
@@ -153,6 +154,7 @@ SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 _ctxs: dict = {}
 _defer_on: set = set()       # devices whose context queues the towers' slab reduction (set_defer_slab_reduce)
+_riders_on: set = set()      # devices whose context queues the plan compaction / loss reduction (set_defer_riders)
 _workspaces: dict = {}
 
 
@@ -206,6 +208,7 @@ def ptr(t: Optional[torch.Tensor]) -> vp:
 TT_OPT_DEFER_SLAB_REDUCE = 1
 TT_OPT_KEYED_PARTS = 2
 TT_OPT_SCORE_BWD_ROWS_MIN = 3
+TT_OPT_DEFER_RIDERS = 4
 
 
 def set_option(device: torch.device, option: int, value: int):
@@ -222,6 +225,21 @@ def set_defer_slab_reduce(device: torch.device, on: bool):
         flush_deferred(device)
 
 
+def set_defer_riders(device: torch.device, on: bool):
+    """tt_dedup_plan_keyed* / tt_score_fwd_sym_* leave the plan's compaction and the loss reduction queued in the context; the towers'
+    fused tail launches run them (include/twotower.h: TT_OPT_DEFER_RIDERS).  Switching it off launches what is still queued."""
+    check(load().tt_ctx_set_option(ctx(device), TT_OPT_DEFER_RIDERS, 1 if on else 0), "tt_ctx_set_option")
+    idx = torch.device(device).index
+    (_riders_on.add if on else _riders_on.discard)(idx if idx is not None else torch.cuda.current_device())
+    if not on:
+        flush_deferred(device)
+
+
+def riders_deferred(device: torch.device) -> bool:
+    idx = torch.device(device).index
+    return (idx if idx is not None else torch.cuda.current_device()) in _riders_on
+
+
 def flush_deferred(device: torch.device):
     """Launch a queued slab reduction now (no-op when nothing is queued)."""
     lib = load()
@@ -233,8 +251,10 @@ def flush_deferred(device: torch.device):
 def workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     """Stream-ordered scratch: one growable buffer per (device, stream).  The slabs of a queued (deferred) reduction live in
     it: they are reduced before the buffer is handed to anybody else."""
-    if _defer_on:
-        flush_deferred(device)
+    if _defer_on:                     # (only the slabs live in this buffer: queued riders keep their own)
+        lib, c = load(), ctx(device)
+        if lib.tt_deferred_pending(c) & 1:
+            check(lib.tt_flush_deferred_slabs(c, stream(device)), "tt_flush_deferred_slabs")
     key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:

@@ -20,6 +20,8 @@ struct tt_ctx {
   struct TnPending* deferred;
   int keyed_parts;          // TT_OPT_KEYED_PARTS: workgroups per key of the keyed dedup plan (0 = chosen from the batch)
   int score_bwd_rows_min;   // TT_OPT_SCORE_BWD_ROWS_MIN: rows from which tt_score_bwd_bf16 takes the workgroup-staged form
+  int defer_riders;         // TT_OPT_DEFER_RIDERS: plan compaction / score loss reduction queue in `riders` (tt_riders.h)
+  struct tt_riders* riders;
 };
 
 void tt_set_error(const char* fmt, ...);

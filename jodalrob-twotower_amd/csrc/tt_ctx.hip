@@ -1,10 +1,26 @@
 // Context, error string, ABI version.
 #include "tt_common.h"
 #include "tt_gemm.h"
+#include "tt_riders.h"
 
 #include <string.h>
 
 static thread_local char g_err[512] = "";
+
+namespace {
+__global__ __launch_bounds__(kRiderThreads) void riders_kernel(tt_riders r) {
+  if ((int)blockIdx.x < r.c_wg) compact_body(r.c, blockIdx.x);
+  else finish2_body(r.f);
+}
+}  // namespace
+
+int tt_riders_flush(tt_ctx* ctx, hipStream_t st) {
+  if (!ctx || !ctx->riders || (ctx->riders->c_wg == 0 && ctx->riders->f_wg == 0)) return TT_OK;
+  riders_kernel<<<ctx->riders->c_wg + ctx->riders->f_wg, kRiderThreads, 0, st>>>(*ctx->riders);
+  ctx->riders->c_wg = ctx->riders->f_wg = 0;
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
 
 void tt_set_error(const char* fmt, ...) {
   va_list ap;
@@ -41,12 +57,16 @@ int tt_ctx_create(int device, tt_ctx** out) {
   c->deferred = nullptr;
   c->keyed_parts = 0;
   c->score_bwd_rows_min = 32768;
+  c->defer_riders = 0;
+  c->riders = new tt_riders();
+  c->riders->c_wg = c->riders->f_wg = 0;
   *out = c;
   return TT_OK;
 }
 
 int tt_ctx_destroy(tt_ctx* ctx) {
   if (ctx && ctx->deferred) tt_gemm_tn_pending_destroy(ctx->deferred);
+  if (ctx) delete ctx->riders;
   delete ctx;
   return TT_OK;
 }
@@ -63,6 +83,7 @@ int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value) {
       TT_CHECK_ARG(value >= 1, "tt_ctx_set_option: TT_OPT_SCORE_BWD_ROWS_MIN needs a value >= 1");
       ctx->score_bwd_rows_min = value;
       break;
+    case TT_OPT_DEFER_RIDERS: ctx->defer_riders = value != 0; break;
     default: tt_set_error("tt_ctx_set_option: unknown option %d", option); return TT_ERR_INVALID_ARG;
   }
   return TT_OK;
@@ -70,10 +91,19 @@ int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value) {
 
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream) {
   TT_CHECK_ARG(ctx != nullptr, "tt_flush_deferred: NULL context");
+  if (int rc = tt_riders_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;
   return tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream));
 }
 
-int tt_deferred_pending(const tt_ctx* ctx) { return ctx && ctx->deferred && ctx->deferred->n > 0 ? 1 : 0; }
+int tt_flush_deferred_slabs(tt_ctx* ctx, tt_stream stream) {
+  TT_CHECK_ARG(ctx != nullptr, "tt_flush_deferred_slabs: NULL context");
+  return tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream));
+}
+
+int tt_deferred_pending(const tt_ctx* ctx) {
+  if (!ctx) return 0;
+  return ((ctx->deferred && ctx->deferred->n > 0) ? 1 : 0) | ((ctx->riders && (ctx->riders->c_wg > 0 || ctx->riders->f_wg > 0)) ? 2 : 0);
+}
 
 int tt_ctx_num_cus(const tt_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
 

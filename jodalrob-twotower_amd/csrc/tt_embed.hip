@@ -4,6 +4,7 @@
 // grids capped at 8 workgroups per CU with grid-stride loops.
 #include "tt_common.h"
 #include "tt_gemm.h"
+#include "tt_riders.h"
 
 #include <stdlib.h>
 
@@ -449,13 +450,7 @@ struct KeyedArgs {
   int32_t parts;                         // workgroups per key (range partition of the key's rows)
 };
 constexpr int kKeyedMaxParts = 8;
-// the long-row list of the segmented gradient reduction (rows with more than kPlanLongSeg slots are summed chunk by chunk), built
-// by the plan's compaction instead of by the reduction itself: the reduction's row and chunk passes then run as ONE launch
-constexpr int kPlanLongSeg = 64;
-struct PlanLong {
-  int32_t* counters;     // [0] chunks, [1] long rows (zeroed by keyed_sort_kernel, filled by keyed_compact_kernel)
-  int32_t* long_row; int32_t* long_base; int32_t* chunk_lo; int32_t* chunk_hi;
-};
+// (PlanLong, the long-row list the compaction builds for the gradient reduction: tt_riders.h)
 
 __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, const int32_t* __restrict__ rows,
                                                                   int32_t* __restrict__ sorted_src, int32_t* __restrict__ uniq_stage,
@@ -794,57 +789,7 @@ __global__ __launch_bounds__(kKeyedThreads) void keyed_sort_kernel(KeyedArgs a, 
   }
 }
 
-__global__ __launch_bounds__(kKeyedThreads) void keyed_compact_kernel(const int32_t* __restrict__ uniq_stage, const int32_t* __restrict__ seg_stage,
-                                                                const int32_t* __restrict__ ucount, const int32_t* __restrict__ ubase,
-                                                                const int32_t* __restrict__ uend, PlanLong pl,
-                                                                int n_keys, int64_t M,
-                                                                int32_t* __restrict__ unique_rows, int32_t* __restrict__ seg_offsets,
-                                                                int32_t* __restrict__ n_unique) {
-  const int ki = blockIdx.x;                           // (key, share) in ascending row order
-  // head counts of all (key, share) pairs -- a few dozen to a few hundred -- added up in parallel (integer sums: any order)
-  __shared__ int sred[2][kKeyedThreads / 64];
-  int before = 0, all = 0;
-  for (int q = threadIdx.x; q < n_keys; q += kKeyedThreads) {
-    const int v = ucount[q];
-    all += v;
-    if (q < ki) before += v;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    before += __shfl_xor(before, o);
-    all += __shfl_xor(all, o);
-  }
-  if ((threadIdx.x & 63) == 0) { sred[0][threadIdx.x >> 6] = before; sred[1][threadIdx.x >> 6] = all; }
-  __syncthreads();
-  before = 0; all = 0;
-#pragma unroll
-  for (int w = 0; w < kKeyedThreads / 64; ++w) { before += sred[0][w]; all += sred[1][w]; }
-  const int U = ucount[ki];
-  const int64_t gbase = ubase[ki];
-  for (int u = threadIdx.x; u < U; u += kKeyedThreads) {
-    unique_rows[before + u] = uniq_stage[gbase + u];
-    const int32_t s0 = seg_stage[gbase + u];
-    seg_offsets[before + u] = s0;
-    if (pl.counters) {                                   // long rows -> chunk list (what seg_reduce_kernel registers otherwise)
-      const int32_t s1 = u + 1 < U ? seg_stage[gbase + u + 1] : uend[ki];
-      if (s1 - s0 > kPlanLongSeg) {
-        const int32_t nch = (s1 - s0 + kPlanLongSeg - 1) / kPlanLongSeg;
-        const int32_t cb = atomicAdd(&pl.counters[0], nch);
-        const int32_t li = atomicAdd(&pl.counters[1], 1);
-        pl.long_row[li] = before + u;
-        pl.long_base[li] = cb;
-        for (int32_t c = 0; c < nch; ++c) {
-          pl.chunk_lo[cb + c] = s0 + c * kPlanLongSeg;
-          pl.chunk_hi[cb + c] = min(s1, s0 + (c + 1) * kPlanLongSeg);
-        }
-      }
-    }
-  }
-  if (ki == 0 && threadIdx.x == 0) {
-    n_unique[0] = all;
-    seg_offsets[all] = (int32_t)M;
-  }
-}
+__global__ __launch_bounds__(kKeyedThreads) void keyed_compact_kernel(CompactRider cr) { compact_body(cr, blockIdx.x); }
 
 // ------------------------------------------------------------------------------------------------
 // a16: segmented gradient reduction.  A lane-group of LG lanes owns one distinct row and walks its
@@ -2018,8 +1963,15 @@ static int dedup_plan_keyed_impl(tt_ctx* ctx, const int32_t* rows, const int32_t
   keyed_sort_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(a, rows, sorted_src, uniq_stage, seg_stage, ucount, ubase, uend, key_major,
                                                               pl.counters);
   TT_LAUNCH_CHECK();
-  keyed_compact_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(uniq_stage, seg_stage, ucount, ubase, uend, pl, n_keys * parts, slots,
-                                                                 unique_rows, seg_offsets, n_unique);
+  const CompactRider cr{uniq_stage, seg_stage, ucount, ubase, uend, pl, n_keys * parts, slots, unique_rows, seg_offsets, n_unique};
+  if (ctx->defer_riders) {                               // rides beside the towers' tail_fwd (tt_riders.h); a second plan before that
+    if (ctx->riders->c_wg > 0)                           // launch takes the queue's place, the older one is launched now
+      if (int rc = tt_riders_flush(ctx, st)) return rc;
+    ctx->riders->c = cr;
+    ctx->riders->c_wg = n_keys * parts;
+    return TT_OK;
+  }
+  keyed_compact_kernel<<<n_keys * parts, kKeyedThreads, 0, st>>>(cr);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }
@@ -2093,6 +2045,7 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
   const int dt = srcs[0].dtype;
   GradLayout gl = grad_layout(reinterpret_cast<char*>(workspace), M, E);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (int rc = tt_riders_flush(ctx, st)) return rc;      // a plan compaction nobody hosted: this reduction reads its output
   if (planned) {
     // counters and lists were written into THIS workspace by tt_dedup_plan_keyed_long: nothing to zero, nothing to register
   } else if (counters) {
@@ -2170,6 +2123,7 @@ void tt_adam_hparams(int64_t step, float lr, float beta1, float beta2, float eps
 
 int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v, int64_t n, int64_t step, float lr, float beta1,
                        float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream) {
+  if (int rc = tt_riders_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;       // (a queued plan compaction: its rows are read here)
   if (ctx && ctx->deferred && ctx->deferred->n > 0)      // a queued slab reduction: the gradients are not complete before it
     if (int rc = tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;
   TT_CHECK_ARG(ctx && (n == 0 || (p && g && m && v)), "tt_adam_dense_step: NULL argument");
@@ -2189,6 +2143,7 @@ int tt_adam_dense_step(tt_ctx* ctx, float* p, const float* g, float* m, float* v
 
 int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_tensors, int64_t step, float lr, float beta1,
                        float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream) {
+  if (int rc = tt_riders_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;       // (a queued plan compaction: its rows are read here)
   if (ctx && ctx->deferred && ctx->deferred->n > 0)      // a queued slab reduction: the gradients are not complete before it
     if (int rc = tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;
   TT_CHECK_ARG(ctx && (n_tensors == 0 || tensors), "tt_adam_multi_step: NULL argument");
@@ -2216,6 +2171,7 @@ int tt_adam_multi_step(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n_ten
 int tt_sparse_adam_step(tt_ctx* ctx, float* table, float* m, float* v, int64_t table_rows, int32_t E, const int32_t* unique_rows,
                         const float* grad_rows, const int32_t* n_unique, int64_t M, int64_t step, float lr, float beta1, float beta2, float eps,
                         float weight_decay, const float* hparams_dev, tt_stream stream) {
+  if (int rc = tt_riders_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;       // (a queued plan compaction: its rows are read here)
   if (ctx && ctx->deferred && ctx->deferred->n > 0)      // a queued slab reduction: the gradients are not complete before it
     if (int rc = tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;
   TT_CHECK_ARG(ctx && table && m && v, "tt_sparse_adam_step: NULL state");
@@ -2239,6 +2195,7 @@ static int adam_fused_impl(tt_ctx* ctx, const tt_adam_tensor* tensors, int32_t n
                            const int32_t* seg_offsets, void* grad_workspace, size_t grad_workspace_bytes, int64_t step, float lr,
                            float beta1, float beta2, float eps, float weight_decay, const float* hparams_dev, tt_stream stream,
                            const char* who) {
+  if (int rc = tt_riders_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;       // (a queued plan compaction: its rows are read here)
   if (ctx && ctx->deferred && ctx->deferred->n > 0)      // a queued slab reduction: the gradients are not complete before it
     if (int rc = tt_gemm_deferred_flush(ctx, reinterpret_cast<hipStream_t>(stream))) return rc;
   TT_CHECK_ARG(ctx && tensors && table && m && v && unique_rows && grad_rows && n_unique, "%s: NULL argument", who);

@@ -19,6 +19,7 @@
 // sum of all scores (negative_similarity_mean): sum_ab n_a . c_b = (sum_a n_a) . (sum_b c_b) -- finish1 adds the operand
 // images' columns instead of the kernel adding 67 M products.
 #include "tt_score_bf16.h"
+#include "tt_riders.h"
 
 #include <stdlib.h>
 
@@ -390,58 +391,7 @@ __global__ __launch_bounds__(256) void score_sym_finish1_kernel(Fin1Args f) {
   for (int d = t; d < 2 * Dp; d += 256) part[4 + d] = cols[d / Dp][d % Dp];
 }
 
-// finish2: one workgroup adds the partial records in a fixed order (thread (j, q): records q, q + 4, ... of entry j, the four
-// partial sums in order); loss and metrics (out8 as tt_score_loss_finish)
-__global__ __launch_bounds__(1024) void score_sym_finish2_kernel(const float* __restrict__ part, int n_wg, int Dp, float fb, float unscale,
-                                                                float* __restrict__ out, float* __restrict__ loss_out) {
-  __shared__ float red[4][4 + 2 * 256];
-  __shared__ float prod[256];
-  const int t = threadIdx.x, q = t >> 8, j0 = t & 255, stride = 4 + 2 * Dp;
-  for (int j = j0; j < stride; j += 256) {
-    float s = 0.f;
-    for (int w0 = q; w0 < n_wg; w0 += 32) {
-      float v[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = w0 + 4 * k < n_wg ? part[(int64_t)(w0 + 4 * k) * stride + j] : 0.f;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) s += v[k];
-    }
-    red[q][j] = s;
-  }
-  __syncthreads();
-  if (t < 256) {
-    float p = 0.f;
-    if (t < Dp) {
-      const float u = (red[0][4 + t] + red[1][4 + t]) + (red[2][4 + t] + red[3][4 + t]);
-      const float v = (red[0][4 + Dp + t] + red[1][4 + Dp + t]) + (red[2][4 + Dp + t] + red[3][4 + Dp + t]);
-      p = u * v;
-    }
-    prod[t] = p;
-  }
-  __syncthreads();
-  if (t < 64) {
-    float p = (prod[t] + prod[t + 64]) + (prod[t + 128] + prod[t + 192]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
-    if (t == 0) {
-      const float tot = p * unscale;                       // sum of all s_ab / T = (sum_a n_a) . (sum_b c_b) / T
-      const float l = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-      const float hit = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
-      const float dsum = (red[0][2] + red[1][2]) + (red[2][2] + red[3][2]);
-      const float pos = dsum / fb;
-      const float neg = (tot - dsum) / (fb * fb - fb);     // mean over the off-diagonal (nan for B == 1, as torch)
-      out[0] = 0.5f * l / fb;
-      out[1] = hit / fb;
-      out[2] = pos;
-      out[3] = neg;
-      out[4] = pos - neg;
-      out[5] = 0.f;                                        // column-direction top-1 rate: first-call diagnostic only (two-direction kernel)
-      out[6] = tot;
-      out[7] = 0.f;
-      if (loss_out) loss_out[0] = out[0];
-    }
-  }
-}
+__global__ __launch_bounds__(kRiderThreads) void score_sym_finish2_kernel(Finish2Rider fr) { finish2_body(fr); }
 
 struct SymLayout {
   int nT, NI, n_groups, n_chunks, n_wg, Dp;
@@ -541,7 +491,15 @@ static int sym_forward(tt_ctx* ctx, const void* N_packed, const void* C_packed, 
   f.part = reinterpret_cast<float*>(ws + L.off_part);
   score_sym_finish1_kernel<<<(unsigned)L.n_wg, 256, 0, st>>>(f);
   TT_LAUNCH_CHECK();
-  score_sym_finish2_kernel<<<1, 1024, 0, st>>>(f.part, L.n_wg, L.Dp, (float)B, f.unscale, out8, loss_out);
+  const Finish2Rider fr{f.part, L.n_wg, L.Dp, (float)B, f.unscale, out8, loss_out};
+  if (ctx->defer_riders) {                               // rides beside the towers' tail_bwd (tt_riders.h): nothing on the device reads it
+    if (ctx->riders->f_wg > 0)
+      if (int rc = tt_riders_flush(ctx, st)) return rc;
+    ctx->riders->f = fr;
+    ctx->riders->f_wg = 1;
+    return TT_OK;
+  }
+  score_sym_finish2_kernel<<<1, kRiderThreads, 0, st>>>(fr);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

@@ -2,6 +2,7 @@
 // GEMM tiles of tt_gemm.hip, BatchNorm1d statistics as deterministic two-stage column reductions,
 // ReLU / BN / dropout / L2-normalise as fused elementwise and row-wise kernels.
 #include "tt_gemm.h"
+#include "tt_riders.h"
 
 namespace {
 
@@ -618,9 +619,16 @@ struct TailFwdArgs {
   __bf16* pk_rows; __bf16* pk_frag; int Dp; float pk_scale;   // optional: the score kernels' two operand images of emb (tt_score_pack_bf16)
 };
 
+static_assert(kTailThreads == kRiderThreads, "the riders run in the tail kernels' workgroups");
+// (cr_wg > 0: the FIRST grid row -- dispatched first: not every workgroup of the launch is resident at once -- is the keyed plan's
+// compaction riding in this launch: tt_riders.h)
 __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed0,
-                                                               const uint64_t* __restrict__ seed_dev) {
-  const TailFwdArgs& f = batch.a[blockIdx.y];
+                                                               const uint64_t* __restrict__ seed_dev, CompactRider cr, int cr_wg) {
+  if (cr_wg > 0 && blockIdx.y == 0) {
+    if ((int)blockIdx.x < cr_wg) compact_body(cr, blockIdx.x);
+    return;
+  }
+  const TailFwdArgs& f = batch.a[blockIdx.y - (cr_wg > 0 ? 1 : 0)];
   const BnStatArgs& a = f.s;
   const int H = a.H, D = f.D, B = a.B;
   const int m0 = blockIdx.x * 64;
@@ -957,9 +965,14 @@ struct TailBwdArgs {
   float* w_slab; float* b_slab;      // [nchunks][D * H], [nchunks][D]
 };
 
+// (fr_on: the FIRST grid row is one workgroup running the symmetric score forward's loss reduction -- tt_riders.h)
 __global__ __launch_bounds__(kTailThreads) void tail_bwd_kernel(Batch<TailBwdArgs> batch, bool drop, float p, uint64_t seed0,
-                                                               const uint64_t* __restrict__ seed_dev) {
-  const TailBwdArgs& f = batch.a[blockIdx.y];
+                                                               const uint64_t* __restrict__ seed_dev, Finish2Rider fr, int fr_on) {
+  if (fr_on && blockIdx.y == 0) {
+    if (blockIdx.x == 0) finish2_body(fr);
+    return;
+  }
+  const TailBwdArgs& f = batch.a[blockIdx.y - fr_on];
   const ColArgs& a = f.col;
   const int H = a.H, D = f.D;
   if ((int)blockIdx.x >= a.nchunks) return;
@@ -1736,7 +1749,11 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
           tf.a[t].Dp = Dp;
           tf.a[t].pk_scale = A[t]->emb_pack_scale == 0.f ? 1.f : A[t]->emb_pack_scale;
         }
-      tail_fwd_kernel<<<dim3((unsigned)tt_cdiv(B, 64), (unsigned)n), kTailThreads, 0, st>>>(tf, drop, dropout_p, seed, seed_dev);
+      const int cr_wg = ctx->riders->c_wg;               // a queued plan compaction rides in one extra grid row
+      const int64_t gx = tt_cdiv(B, 64) > cr_wg ? tt_cdiv(B, 64) : cr_wg;
+      tail_fwd_kernel<<<dim3((unsigned)gx, (unsigned)(n + (cr_wg > 0 ? 1 : 0))), kTailThreads, 0, st>>>(tf, drop, dropout_p, seed, seed_dev,
+                                                                                                       ctx->riders->c, cr_wg);
+      ctx->riders->c_wg = 0;
       TT_LAUNCH_CHECK();
       return TT_OK;
     }
@@ -1889,7 +1906,10 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       cmax = nchunks > cmax ? nchunks : cmax;
     }
     if (phase != 2) {
-      tail_bwd_kernel<<<dim3((unsigned)cmax, (unsigned)n), kTailThreads, 0, st>>>(tb, drop, dropout_p, seed, seed_dev);
+      const int fr_on = ctx->riders->f_wg > 0 ? 1 : 0;    // a queued loss reduction rides in one extra grid row
+      tail_bwd_kernel<<<dim3((unsigned)cmax, (unsigned)(n + fr_on)), kTailThreads, 0, st>>>(tb, drop, dropout_p, seed, seed_dev, ctx->riders->f,
+                                                                                           fr_on);
+      ctx->riders->f_wg = 0;
       TT_LAUNCH_CHECK();
     }
     if (phase == 1) {                                   // SyncBN: hand this rank's column sums to the caller and stop

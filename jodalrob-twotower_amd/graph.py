@@ -29,13 +29,13 @@ from .optim import FusedAdam
 
 class GraphedTrainStep:
     def __init__(self, task, optimizer: FusedAdam, example_batch: Dict, return_metrics: bool = True, warmup: int = 3,
-                 defer_long: bool = True, defer_slabs: bool = True):
+                 defer_long: bool = True, defer_slabs: bool = True, defer_riders: bool = True):
         """defer_long / defer_slabs: the long rows' finish rides in the optimiser's launch and the towers' slab reduction in the
         embedding gradient's (both bit-identical to the separate launches; the arguments exist for that comparison)."""
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("GraphedTrainStep needs jodalrob_twotower_amd.optim.FusedAdam (device-side hyper-parameters)")
         self.task, self.opt, self.return_metrics = task, optimizer, return_metrics
-        self._defer_long, self._defer_slabs = bool(defer_long), bool(defer_slabs)
+        self._defer_long, self._defer_slabs, self._defer_riders = bool(defer_long), bool(defer_slabs), bool(defer_riders)
         dev = example_batch["notice"]["dense"].device
         self.static = {side: {"dense": example_batch[side]["dense"].clone(),
                               "kjt": KeyedJaggedTensor(example_batch[side]["kjt"].keys(), example_batch[side]["kjt"].values().clone())}
@@ -132,7 +132,12 @@ class GraphedTrainStep:
         # (never with a dense-gradient all-reduce in the backward: it would read the tensors the queue still owes)
         ex = getattr(self.task, "exchange", None)
         slabs = self._defer_slabs and (ex is None or getattr(ex, "world", 1) == 1)
+        # the keyed plan's compaction and the score forward's loss reduction ride in the towers' tail launches (two launches fewer
+        # in the chain; only where nothing reads the plan before the embedding gradient does: one local store)
+        riders = self._defer_riders and self._ingest is not None
         try:
+            if riders:
+                L.set_defer_riders(dev, True)
             res = self.task(self.static, return_metrics=self.return_metrics)
             loss = res["loss"] if isinstance(res, dict) else res
             if slabs:
@@ -147,6 +152,8 @@ class GraphedTrainStep:
                 if st.sparse_grad is not None:
                     ops.embed_grad_finish(st.sparse_grad[0])
         finally:
+            if riders:
+                L.set_defer_riders(dev, False)         # (launches what nobody hosted: e.g. the loss reduction of a forward-only pass)
             for st in stores:
                 st.defer_long_finish = False
         return res

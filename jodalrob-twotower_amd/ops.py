@@ -153,6 +153,7 @@ class DedupPlan:
     n_unique: torch.Tensor        # int32 [1] on device
     M: int
     keep: object = None           # tensors that must outlive the plan's kernels
+    staging: object = None        # the keyed sort's staging arrays when the compaction is deferred (TT_OPT_DEFER_RIDERS)
     grad_ws: object = None        # (uint8 workspace, E): the gradient reduction's workspace with the long-row list already in it
     finish_deferred: object = None  # grad_rows whose long rows embed_grad left unfinished (adam_fused / embed_grad_finish complete them)
 
@@ -201,7 +202,11 @@ def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int, key_majo
     plan = DedupPlan(buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:], M)
     lib = L.load()
     nk = sum(side_K)
-    ws = L.workspace(dev, lib.tt_dedup_keyed_workspace_bytes(M, nk))
+    if L.riders_deferred(dev):       # the compaction runs later, inside the towers' launch: its staging arrays must outlive whatever
+        ws = torch.empty(lib.tt_dedup_keyed_workspace_bytes(M, nk), dtype=torch.uint8, device=dev)      # takes the shared scratch meanwhile
+    else:
+        ws = L.workspace(dev, lib.tt_dedup_keyed_workspace_bytes(M, nk))
+    plan.staging = ws
     ks = (L.i32 * len(side_K))(*side_K)
     if E > 0 and settings.grad_planned:
         gws = torch.empty(lib.tt_embed_grad_workspace_bytes(M, E), dtype=torch.uint8, device=dev)
@@ -498,7 +503,11 @@ def score_fwd_sym(Np, Cp, B, D, inv_t, shift, scale_n: float = 1.0, want_rank: b
     out8 = torch.empty(8, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     lib = L.load()
-    ws = L.workspace(dev, lib.tt_score_fwd_sym_workspace_bytes(B, D))
+    if L.riders_deferred(dev):       # the last reduction runs later (inside the towers' backward launch): its partial records must
+        ws = torch.empty(lib.tt_score_fwd_sym_workspace_bytes(B, D), dtype=torch.uint8, device=dev)     # outlive the shared scratch's next user
+        out8._tt_keep = ws
+    else:
+        ws = L.workspace(dev, lib.tt_score_fwd_sym_workspace_bytes(B, D))
     fn, name = (lib.tt_score_fwd_sym_fp8, "tt_score_fwd_sym_fp8") if fp8 else (lib.tt_score_fwd_sym_bf16, "tt_score_fwd_sym_bf16")
     with _timed(name):
         L.check(fn(L.ctx(dev), L.ptr(Np), L.ptr(Cp), B, D, inv_t, shift, scale_n, int(want_rank), L.ptr(f[0]), L.ptr(f[1]),

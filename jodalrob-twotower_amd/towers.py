@@ -286,11 +286,24 @@ class _TowersFn(torch.autograd.Function):
             # tensors in key-major order: the plan sorts those, the lookup need not write its slot-major copy
             km = store.rows_km_for([g[1].ids for g in group]) if (grad_on and 0 < B <= ops.KEYED_MAX_B) else None
             rows = ops.embed_lookup(store.weight, [g[1] for g in group], B, want_rows=grad_on and km is None)
-            ev = None
-            if grad_on:
-                ev = torch.cuda.Event()
-                ev.record()                                        # rows are ready here
-            plans.append([store, [g[0] for g in group], None, rows if km is None else km, ev, km is not None])
+            plans.append([store, [g[0] for g in group], None, rows if km is None else km, grad_on, km is not None])
+        # duplicate-row plans: depend on ids only, first needed in the backward.  In line on the launch stream (a side stream
+        # overlapped the sort with the score kernels, but a captured graph with two streams is replayed node by node with
+        # cross-queue signals: 4-6 us gaps in front of eight kernels -- as much as the overlap saved), and BEFORE the towers'
+        # forward: with TT_OPT_DEFER_RIDERS the plan's compaction then rides in the towers' tail launch
+        for pl in plans:
+            if len(pl) == 6:
+                store, psides, _, rows, want_plan, key_major = pl
+                plan = None
+                if want_plan:
+                    Bs = psides[0].B
+                    if 0 < Bs <= ops.KEYED_MAX_B:       # per-key LDS sorts (2 launches)
+                        plan = ops.dedup_plan_keyed(rows, [len(q.tower.categorical_embedder.keys) for q in psides], Bs, key_major,
+                                                    E=int(store.E))
+                    else:
+                        plan = ops.dedup_plan(rows, store.rows)
+                    plan.keep = rows                    # keep the sort input alive until it has run
+                pl[:] = [store, psides, plan]
         live = [s for s in sides if s.B]
         fused = len(live) > 1 and len({s.B for s in live}) == 1 and len({s.tower.n_hidden for s in live}) == 1 and \
             len({(s.train, s.p_drop) for s in live}) == 1
@@ -331,22 +344,6 @@ class _TowersFn(torch.autograd.Function):
             for s in live:
                 tw = s.tower
                 ops.tower_fwd(tw._params(), s.acts_struct, s.B, s.train, s.p_drop, s.seed, s.emb.device, tw._seed_dev)
-        # duplicate-row plans: depend on ids only, first needed in the backward; in line on the launch stream (a side stream
-        # overlapped the sort with the score kernels, but a captured graph with two streams is replayed node by node with
-        # cross-queue signals: 4-6 us gaps in front of eight kernels -- as much as the overlap saved)
-        for pl in plans:
-            if len(pl) == 6:
-                store, psides, _, rows, ev, key_major = pl
-                plan = None
-                if ev is not None:
-                    Bs = psides[0].B
-                    if 0 < Bs <= ops.KEYED_MAX_B:       # per-key LDS sorts (2 launches)
-                        plan = ops.dedup_plan_keyed(rows, [len(q.tower.categorical_embedder.keys) for q in psides], Bs, key_major,
-                                                    E=int(store.E))
-                    else:
-                        plan = ops.dedup_plan(rows, store.rows)
-                    plan.keep = rows                    # keep the sort input alive until it has run
-                pl[:] = [store, psides, plan]
         for s in sides:
             s.tower._last_packed = None if s.packed is None else (s.packed, float(s.tower.pack_scale))
         ctx.sides, ctx.plans, ctx.spans, ctx.n_flat = sides, plans, spans, len(flat)

@@ -742,6 +742,48 @@ def test_deferred_long_finish_equals_immediate(tt, manifest, schema_real, B, con
         assert np.array_equal(v, outs[True][4][k]), k
 
 
+@pytest.mark.parametrize("hidden,D,B", [([128, 64], 64, 2048), ([512, 256], 128, 1024), ([128, 64], 64, 1000)])
+def test_riders_in_tail_launches_equal_own_launches(tt, schema_real, hidden, D, B):
+    """TT_OPT_DEFER_RIDERS (what GraphedTrainStep replays): the keyed plan's compaction rides in the towers' tail_fwd launch and the
+    symmetric score forward's loss reduction in tail_bwd's == both as launches of their own, bit for bit over three replayed steps:
+    losses, metrics, every parameter.  Real 32 + 6 key schema; the reference-shaped towers take the fused tail (riders hosted), the
+    [512, 256] -> 128 ones do not (the queue is launched by the embedding gradient / at the end of the step), B = 1000 has a
+    ragged last tile."""
+    from jodalrob_twotower_amd.graph import GraphedTrainStep
+    from jodalrob_twotower_amd.optim import FusedAdam
+    from jodalrob_twotower_amd import synthetic
+    kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
+    vn, vc = schema_real["notice"]["vocab_sizes"], schema_real["company"]["vocab_sizes"]
+    dev = torch.device(DEV)
+    batches = [synthetic.make_batch(B, vn, vc, kn, kc, 256, 128, dev, seed=310 + i) for i in range(4)]
+    finals, state = {}, None
+    for riders in (False, True):
+        torch.manual_seed(9)
+        task = tt.create_two_tower_train_task(kn, kc, metadata_path=str(GOLD / "real_vocab_metadata.csv"), categorical_embedding_dim=32,
+                                              notice_dense_input_dim=256, company_dense_input_dim=128, tower_hidden_dims=hidden,
+                                              final_embedding_dim=D, dropout_rate=0.1, device=DEV, embedding_grad="sparse",
+                                              score_dtype="bf16", mlp_dtype="bf16")
+        task._pair_check_done = True
+        if state is None:
+            state = {k: v.detach().clone() for k, v in task.state_dict().items()}
+        task.load_state_dict(state)
+        task.train()
+        for tw in (task.two_tower_model.notice_tower, task.two_tower_model.company_tower):
+            tw._seed_override = 77
+        opt = FusedAdam.for_task(task, lr=1e-2, weight_decay=1e-5)
+        gs = GraphedTrainStep(task, opt, batches[0], warmup=1, defer_riders=riders)
+        outs = []
+        for b in batches[1:]:
+            r = gs.step(b)
+            outs.append([r[k].item() for k in ("loss", "accuracy", "positive_similarity_mean", "negative_similarity_mean", "similarity_gap")])
+        torch.cuda.synchronize()
+        finals[riders] = (outs, {k: v.detach().cpu().clone() for k, v in task.state_dict().items()})
+        gs.close()
+    assert finals[False][0] == finals[True][0] and len({o[0] for o in finals[True][0]}) == 3
+    for k, v in finals[False][1].items():
+        assert torch.equal(v, finals[True][1][k]), k
+
+
 @pytest.mark.parametrize("B,planned,hidden", [(2048, "1", None), (8192, "1", None), (2048, "0", None), (2048, "1", [512, 256]), (1000, "1", None)])
 def test_deferred_slab_reduce_equals_immediate(tt, manifest, schema_real, monkeypatch, B, planned, hidden):
     """The slab reduction of the towers' weight gradients run by the first workgroups of the embedding gradient's launch
