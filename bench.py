@@ -409,6 +409,8 @@ def config_of(args, leg, world, ctx, B_global, workload):
            "launch": "hip graph replay" if leg.gstep is not None else "eager",
            "batch_handover": ("one launch: copies + key-major rows for the dedup plan (tt_batch_ingest)"
                               if getattr(leg.gstep, "_ingest", None) is not None else "one launch: copies (tt_copy_multi)") if leg.gstep is not None else "none"}
+    if leg.gstep is not None and hasattr(leg.gstep, "library_launches"):
+        cfg["launches_per_step"] = leg.gstep.library_launches      # kernels of libtwotower_hip.so per step (RCCL's own kernels come on top)
     if leg.sharded and ex is not None and hasattr(ex, "C"):
         cfg.update({"exchange_capacity_rows_per_peer": ex.C,
                     "exchange_bytes_per_rank_fwd": world * ex.C * leg.E * (2 if (x_bf16 and ex.wire_bf16) else 4),
@@ -516,7 +518,9 @@ def bench_multi(args, ctx):
                 leg.run()
                 ref = {"value": Bg * args.steps / leg.dt, "unit": "pairs/s", "ms_per_step": leg.dt / args.steps * 1e3,
                        "device_ms_per_step_median": leg.device_ms_median,
-                       "config": f"the same {rows_n} + {rows_c}-row tables UNSHARDED on one GPU, batch {Bg}, measured by rank 0 in this run"}
+                       "config": f"the same {rows_n} + {rows_c}-row tables UNSHARDED on one GPU, batch {Bg}, measured by rank 0 in this run",
+                       "roofline": roofline_of(args, leg, 1),           # the lookup over tables the Infinity Cache cannot hold
+                       "launches_per_step": getattr(leg.gstep, "library_launches", None)}
                 leg.close()
             except Exception as e:
                 ref = {"error": f"{type(e).__name__}: {e}"}

@@ -49,6 +49,9 @@ int tt_ctx_destroy(tt_ctx* ctx);
 const char* tt_last_error_string(void);
 /* number of compute units of the context's device (used by callers to size synthetic work) */
 int tt_ctx_num_cus(const tt_ctx* ctx);
+/* kernels this library has launched (or recorded into a stream capture) so far in the process: the difference across one
+ * captured step is the step's launch count (collectives and the caller's own kernels are not in it); a measurement aid */
+uint64_t tt_launch_count(void);
 
 /* Options of a context.  TT_OPT_DEFER_SLAB_REDUCE (default 0): tt_towers_mlp_bwd's one-launch first-block backward leaves the
  * split-K slab reduction of its weight gradients queued in the context instead of launching it; the next tt_embed_grad_bwd

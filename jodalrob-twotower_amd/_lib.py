@@ -108,6 +108,7 @@ SIGNATURES = {
     "tt_ctx_set_option": (C.c_int, [vp, i32, i32]),
     "tt_flush_deferred": (C.c_int, [vp, vp]),
     "tt_deferred_pending": (C.c_int, [vp]),
+    "tt_launch_count": (C.c_uint64, []),
     "tt_flush_deferred_slabs": (C.c_int, [vp, vp]),
     "tt_tower_workspace_bytes": (sz, [C.POINTER(TowerParams), i64]),
     "tt_tower_mlp_fwd": (C.c_int, [vp, C.POINTER(TowerParams), C.POINTER(TowerActs), i64, i32, f32, u64, vp, vp, sz, vp]),

@@ -43,7 +43,13 @@ void tt_set_error(const char* fmt, ...);
     }                                                                                  \
   } while (0)
 
-#define TT_LAUNCH_CHECK() TT_HIP(hipGetLastError())
+// (every kernel launch of the library is followed by this check: it also counts them -- tt_launch_count(), a measurement aid)
+extern std::atomic<uint64_t> tt_launches;
+#define TT_LAUNCH_CHECK()                                    \
+  do {                                                       \
+    tt_launches.fetch_add(1, std::memory_order_relaxed);     \
+    TT_HIP(hipGetLastError());                               \
+  } while (0)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize of one kernel instantiation, set once per device (a static per expansion site; the
 // kernel goes last because its template arguments carry commas).  Needs `ctx` in scope.

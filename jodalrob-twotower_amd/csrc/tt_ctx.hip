@@ -6,6 +6,7 @@
 #include <string.h>
 
 static thread_local char g_err[512] = "";
+std::atomic<uint64_t> tt_launches{0};
 
 namespace {
 __global__ __launch_bounds__(kRiderThreads) void riders_kernel(tt_riders r) {
@@ -106,5 +107,7 @@ int tt_deferred_pending(const tt_ctx* ctx) {
 }
 
 int tt_ctx_num_cus(const tt_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+
+uint64_t tt_launch_count(void) { return tt_launches.load(std::memory_order_relaxed); }
 
 }  // extern "C"

@@ -148,11 +148,12 @@ class HipBackend:
         store.accumulate_grad(plan, [(d_rows, 1)], d_rows.shape[0], short_segments=0 < max_per_row <= 64)
 
     # ---- steps of the fixed-capacity exchange (PaddedRowExchange) --------------------------------------------
-    def local_plan(self, rows: torch.Tensor, side_K: Sequence[int], B: int, table_rows: int = 0):
+    def local_plan(self, rows: torch.Tensor, side_K: Sequence[int], B: int, table_rows: int = 0, key_major: bool = False, E: int = 0):
         """duplicate-row plan of this rank's slots over the GLOBAL row space (table_rows = its size: sets the sort's digit
-        count; nothing is read back from the device)"""
+        count; nothing is read back from the device).  key_major: `rows` are batch_ingest's [key][sample] rows; E > 0: the plan
+        also prepares the local gradient reduction's long-row list (row and chunk passes then run as one launch)"""
         if 0 < B <= ops.KEYED_MAX_B:
-            return ops.dedup_plan_keyed(rows, list(side_K), B)
+            return ops.dedup_plan_keyed(rows, list(side_K), B, key_major, E=E)
         if table_rows <= 0:
             raise ValueError("local_plan: table_rows (the global row count) is required above the keyed plan's batch limit")
         return ops.dedup_plan(rows, table_rows)
@@ -391,8 +392,15 @@ class PaddedRowExchange(RowExchange):
 
     def forward(self, sides: Sequence[ops.LookupSide], B: int, want_grad: bool):
         G, be, E = self.world, self.backend, self.E
-        rows = be.global_rows(sides, B, E, self.store.global_rows)               # int32 [M], slot order
-        plan = be.local_plan(rows, [s.K for s in sides], B, self.store.global_rows)
+        # a graph-replayed step hands the batch over with ops.batch_ingest, which leaves the GLOBAL fused rows of exactly these id
+        # tensors in key-major order (the same id -> row rule): the plan sorts those and the rows-only lookup is not needed
+        km = self.store.rows_km_for([s.ids for s in sides]) if (want_grad and 0 < B <= ops.KEYED_MAX_B and hasattr(be, "global_rows")
+                                                               and isinstance(be, HipBackend)) else None
+        rows = km if km is not None else be.global_rows(sides, B, E, self.store.global_rows)    # int32 [M], slot order (or key-major)
+        if isinstance(be, HipBackend):
+            plan = be.local_plan(rows, [s.K for s in sides], B, self.store.global_rows, key_major=km is not None, E=E if want_grad else 0)
+        else:
+            plan = be.local_plan(rows, [s.K for s in sides], B, self.store.global_rows)
         if self.C is None:
             self._calibrate(plan, rows.device)
         pads = [self.local_rows_of(g) for g in range(G)]

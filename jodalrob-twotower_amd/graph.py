@@ -78,10 +78,12 @@ class GraphedTrainStep:
         # now and then, depending on timing.  "thread_local" restricts the check to the capturing thread.
         import torch.distributed as _dist
         mode = "thread_local" if (_dist.is_available() and _dist.is_initialized()) else "global"
+        n0 = L.load().tt_launch_count()
         try:
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.result = self._body()
         finally:
+            self.library_launches = int(L.load().tt_launch_count() - n0) + 1       # (+ the hand-over launch in front of every replay)
             optimizer._hp_dev = None
             for t in self._towers:
                 t._seed_dev = None
@@ -92,13 +94,25 @@ class GraphedTrainStep:
         """Key-major row hand-over (ops.batch_ingest) when the step looks the static ids up in ONE local fused table with the
         per-key plan: returns (store, embedders, rows_km, static id tensors, B) or None (then the batch is handed over by plain
         copies and the plan gathers its rows out of the lookup's slot-major array)."""
-        if not settings.graph_ingest or getattr(self.task, "exchange", None) is not None:
+        if not settings.graph_ingest:
             return None
         model = getattr(self.task, "two_tower_model", None)
         towers = [getattr(model, n, None) for n in ("notice_tower", "company_tower")]
-        if model is None or any(t is None or getattr(t, "exchange", None) is not None for t in towers):
+        if model is None or any(t is None for t in towers):
             return None
         embs = [t.categorical_embedder for t in towers]
+        ex = getattr(self.task, "exchange", None)
+        if ex is not None:
+            # row-wise sharded tables: the key-major rows are GLOBAL fused rows (the embedders' offsets span the global row space);
+            # the fixed-capacity exchange sorts them in place of its rows-only lookup
+            store = getattr(ex, "store", None)
+            ids = [self.static[side]["kjt"].values() for side in ("notice", "company")]
+            B = self.static["notice"]["dense"].shape[0]
+            if store is None or not hasattr(ex, "poll_overflow") or not (0 < B <= ops.KEYED_MAX_B) or \
+                    any(len(e.keys) == 0 or len(e.keys) > 64 or v.dtype != torch.int64 or not v.is_contiguous() for e, v in zip(embs, ids)):
+                return None
+            rows_km = torch.empty(sum(v.numel() for v in ids), dtype=torch.int32, device=ids[0].device)
+            return store, embs, rows_km, ids, B
         store = embs[0].store
         ids = [self.static[side]["kjt"].values() for side in ("notice", "company")]
         B = self.static["notice"]["dense"].shape[0]
@@ -134,7 +148,7 @@ class GraphedTrainStep:
         slabs = self._defer_slabs and (ex is None or getattr(ex, "world", 1) == 1)
         # the keyed plan's compaction and the score forward's loss reduction ride in the towers' tail launches (two launches fewer
         # in the chain; only where nothing reads the plan before the embedding gradient does: one local store)
-        riders = self._defer_riders and self._ingest is not None
+        riders = self._defer_riders and self._ingest is not None and ex is None      # (the exchange reads the plan at once)
         try:
             if riders:
                 L.set_defer_riders(dev, True)

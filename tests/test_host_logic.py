@@ -102,7 +102,7 @@ def test_scale_vocabs(schema_real):
 
 def test_c_abi_library_exports_every_declared_symbol():
     header = (ROOT / "include" / "twotower.h").read_text()
-    declared = set(re.findall(r"^\s*(?:int|size_t|void|float|const char\*)\s+(tt_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|size_t|uint64_t|void|float|const char\*)\s+(tt_\w+)\s*\(", header, flags=re.M))
     assert declared, "no declarations parsed"
     lib = _lib.load()                                          # dlopen + resolve (no GPU needed)
     for name in sorted(declared):
