@@ -72,6 +72,10 @@ uint64_t tt_launch_count(void);
  * then the plan's unique_rows / seg_offsets / n_unique and the forward's loss_out / out8 are NOT written: for callers that run
  * the whole step back to back (GraphedTrainStep); tt_deferred_pending() covers the queue. */
 #define TT_OPT_DEFER_RIDERS 4
+/* TT_OPT_FP8_GRAD (default 1): tt_score_bwd_fp8 forms the gradient products dA = W B from e4m3 operands as well (softmax weights
+ * block-scaled per row and 32 consecutive b rows, the diagonal weight kept apart in f32: tt_score_bwd_fp8 below); 0 = bf16 weights and bf16
+ * B rows for those products (round 2's arithmetic, 1.5 x the matrix-pipe time). */
+#define TT_OPT_FP8_GRAD 5
 int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value);
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream);
 /* only the queued slab reduction (the one thing that lives in the caller's shared scratch buffer) */
@@ -460,14 +464,19 @@ int tt_score_fwd_sym_bf16(tt_ctx* ctx, const void* N_packed, const void* C_packe
                           float* inv_col, float* diag, int32_t* row_rank, float* out8, float* loss_out, void* workspace,
                           size_t workspace_bytes, tt_stream stream);
 /* fp8 (OCP e4m3) form of the score kernels -- BASELINE.json configs[4] (final_embedding_dim 256, batch 65536): the S products
- * run on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 MFMA rate), f32 accumulate; softmax, loss and the gradient
- * products (softmax weights x bf16 operand images) as on the bf16 path.  Per-tensor scale: the images hold
- * fp8(64 * scale * x), the factor 2^6 leaves again through the instruction's block scales, so ab_scale / b_scale mean what
- * they mean in the bf16 calls.  tt_score_pack2_fp8 writes, per operand, the fp8 rows image followed by the bf16
- * fragment image (tt_score_pack_fp8_bytes(R, D) bytes, 16-byte aligned).  tt_score_fwd_sym_fp8 = tt_score_fwd_sym_bf16
- * on such operands (same workspace); tt_score_bwd_fp8 = tt_score_bwd_bf16 on such operands (always the workgroup-staged
- * form).  Tolerance: tests/test_gpu_parity.py::test_score_fp8_vs_rounded_oracle (the f64 oracle fed the same e4m3-rounded
- * operands). */
+ * run on v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 MFMA rate), f32 accumulate; softmax and loss as on the bf16 path.
+ * Per-tensor scale: the images hold fp8(64 * scale * x), the factor 2^6 leaves again through the instruction's block scales,
+ * so ab_scale / b_scale mean what they mean in the bf16 calls.  tt_score_pack2_fp8 writes, per operand, the fp8 rows image,
+ * the bf16 fragment image and the fp8 fragment image (tt_score_pack_fp8_bytes(R, D) bytes, 16-byte aligned).
+ * tt_score_fwd_sym_fp8 = tt_score_fwd_sym_bf16 on such operands (same workspace).  tt_score_bwd_fp8 = tt_score_bwd_bf16 on such
+ * operands, always in the workgroup-staged form, with the gradient products dA = W B
+ *   TT_OPT_FP8_GRAD 1 (default): on the fp8 MFMA as well, K = 64 b rows per instruction.  The softmax weights
+ *     w_ab = e_ab (1/rowsum_a + 1/colsum_b) of row a and of one BLOCK of 32 consecutive b rows (32 k .. 32 k + 31) are divided
+ *     by 2^(floor(log2 m) - 7), m the block's largest weight, and rounded to e4m3 (nearest even); the power of two goes into
+ *     the instruction as the block's scale.  The diagonal's weight w_aa - 2 stays out of the block (f32) and multiplies the
+ *     bf16 image's row: dA[a] = sum_b q(w_ab) B8[b] + (w_aa - 2) B16[pos_a].
+ *   TT_OPT_FP8_GRAD 0: bf16 weights x bf16 operand images, as tt_score_bwd_bf16.
+ * Tolerance: tests/test_gpu_parity.py::test_score_fp8_vs_rounded_oracle (the f64 oracle with the same roundings). */
 size_t tt_score_pack_fp8_bytes(int64_t R, int32_t D);
 int tt_score_pack2_fp8(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0, const float* X1, int64_t R1,
                        void* packed1, int32_t D, float scale0, float scale1, tt_stream stream);

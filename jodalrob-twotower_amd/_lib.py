@@ -210,6 +210,7 @@ TT_OPT_DEFER_SLAB_REDUCE = 1
 TT_OPT_KEYED_PARTS = 2
 TT_OPT_SCORE_BWD_ROWS_MIN = 3
 TT_OPT_DEFER_RIDERS = 4
+TT_OPT_FP8_GRAD = 5
 
 
 def set_option(device: torch.device, option: int, value: int):

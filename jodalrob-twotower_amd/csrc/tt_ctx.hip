@@ -59,6 +59,7 @@ int tt_ctx_create(int device, tt_ctx** out) {
   c->keyed_parts = 0;
   c->score_bwd_rows_min = 32768;
   c->defer_riders = 0;
+  c->fp8_grad = 1;
   c->riders = new tt_riders();
   c->riders->c_wg = c->riders->f_wg = 0;
   *out = c;
@@ -85,6 +86,7 @@ int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value) {
       ctx->score_bwd_rows_min = value;
       break;
     case TT_OPT_DEFER_RIDERS: ctx->defer_riders = value != 0; break;
+    case TT_OPT_FP8_GRAD: ctx->fp8_grad = value != 0; break;
     default: tt_set_error("tt_ctx_set_option: unknown option %d", option); return TT_ERR_INVALID_ARG;
   }
   return TT_OK;

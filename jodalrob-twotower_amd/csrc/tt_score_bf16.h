@@ -50,6 +50,7 @@ __device__ __forceinline__ void load_bfrag(const __bf16* __restrict__ b_rows, in
 // exactly as on the bf16 path.
 using i32x8 = __attribute__((ext_vector_type(8))) int;
 using i32x4 = __attribute__((ext_vector_type(4))) int;
+using v2s16 = __attribute__((ext_vector_type(2))) short;
 constexpr float kFp8Up = 64.f;
 constexpr int kFp8ScaleE8M0 = 0x79797979;               // 2^-6 in every byte
 
@@ -80,17 +81,22 @@ inline PackedView view(const void* packed, int64_t R, int D) {
   const __bf16* base = reinterpret_cast<const __bf16*>(packed);
   return PackedView{base, base + Rp * Dp};
 }
-// fp8 packing: [fp8 rows image: Rp * Dp bytes | bf16 fragment image: Rp * Dp * 2 bytes]; Dp is a multiple of 64 here
+// fp8 packing: [fp8 rows image: Rp * Dp bytes | bf16 fragment image: Rp * Dp * 2 bytes | fp8 fragment image: Rp * Dp bytes];
+// Dp is a multiple of 64 here.  The fp8 fragment image is the second operand of the gradient products with K = 64 rows per
+// MFMA: [pair of 32-row tiles P][32-column block d][part 0..1][half h][column c][16 bytes], byte j of part p = element
+// (row 64 P + 32 p + rowmap(j, h), column 32 d + c) -- the order in which a lane of the S accumulators holds the rows of the pair
+// -- as fp8(64 * scale * x), like the rows image.
 struct PackedView8 {
   const char* rows8;
   const __bf16* frag;
+  const char* frag8;
 };
 inline int padded_d8(int D) { return D <= 64 ? 64 : (D <= 128 ? 128 : 256); }
 inline PackedView8 view8(const void* packed, int64_t R, int D) {
   const int64_t Rp = rup(R, 64);
   const int Dp = padded_d8(D);
   const char* base = reinterpret_cast<const char*>(packed);
-  return PackedView8{base, reinterpret_cast<const __bf16*>(base + Rp * Dp)};
+  return PackedView8{base, reinterpret_cast<const __bf16*>(base + Rp * Dp), base + 3 * Rp * Dp};
 }
 
 }  // namespace ttscore

@@ -92,6 +92,7 @@ struct DirBwd {
   float out_scale;     // scale / (the B image's scale)
   const float* inv_a;  // optional: DirFwd::inv_sumexp of the A rows / of the B rows (then no reciprocals in the tile loop)
   const float* inv_b;
+  const char* b_frag8;  // fp8 packing only: the B rows' fp8 fragment image (score_bwd_rows8_kernel)
 };
 struct BwdArgs {
   DirBwd d[2];
@@ -907,7 +908,266 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows_kernel(BwdArgs args) 
       }
 }
 
-// ---- fp8 pack: [fp8 rows image | bf16 fragment image] (tt_score_bf16.h) -------------------------------------
+// ---- backward, large-batch form, fp8 operands for BOTH products ------------------------------------------
+// score_bwd_rows_kernel<.., FP8> halves the matrix-pipe time of the S products only; two thirds of that kernel's MFMA cycles
+// are the gradient products dA += W B (K = the b rows), still bf16.  Here they run on v_mfma_scale_f32_32x32x64_f8f6f4 too:
+// K = 64 b rows per instruction, so the sweep goes over PAIRS of 32-row tiles, the softmax weights of a pair are converted
+// to e4m3 and the b rows come from a third image of the packing (fp8 fragment image: tt_score_bf16.h).
+// What makes 3 mantissa bits usable for weights that span 2^-20 .. 1 along a row is the instruction's block scale.  A lane
+// (row a = c, half h) of the first operand holds 32 bytes = here: 16 weights of the pair's first tile, then 16 of its second;
+// the hardware's blocks are [bytes 0..15 of both halves] scaled by lane (c, 0)'s scale register and [bytes 16..31 of both
+// halves] scaled by lane (c, 1)'s (probe: tools/probe/fp8_block_scale.hip) -- i.e. one block = row a x the 32 rows of ONE b
+// tile, and its two lanes meet through v_permlane32_swap.  Per block: m = largest weight, scale = 2^(floor(log2 m) - 7)
+// (m / scale in [128, 256): the top of e4m3's range, 448), conversion with v_cvt_scalef32_pk_fp8_f32 (divides by the scale's
+// power of two, round-to-nearest-even: same probe), the scale's exponent goes into the MFMA: MX-style dynamic block scaling,
+// no a-priori bound on the weights.  Weights more than 2^16 below their block's largest flush to zero -- at most 32 x 2^-17
+// of that largest one per block.
+// The diagonal's weight (e_aa (1/rowsum + 1/colsum) - 2, the one weight of a row that is O(1) and carries the positive
+// pair's pull) never goes through e4m3: the lane that meets it keeps it in f32, zeroes it in the block, and the epilogue
+// adds (w_aa - 2) * b[pos_a] from the bf16 fragment image.
+// Oracle model of this arithmetic: oracle_np.score_ce_bwd(..., block_fp8=True).
+template <int KS, bool UNIT, int AT, int NWV>
+__global__ __launch_bounds__(NWV * 64) void score_bwd_rows8_kernel(BwdArgs args) {
+  constexpr int NTH = NWV * 64, DT = KS / 2, Dp = KS * 16, K64 = KS / 4;
+  constexpr int kRowsB = KS * 1024, kFragB = KS * 1024, kIvB = 256, kStageB = kRowsB + kFragB + kIvB;   // one PAIR of tiles
+  constexpr int kPieces = (kRowsB + kFragB) / 16, kPPT = kPieces / NTH;
+  static_assert(KS % 4 == 0 && kPieces % NTH == 0, "fp8 operands come in K = 64 steps; whole 16-byte pieces per thread");
+  // D = 256, two waves per SIMD (256 registers each): the wave's own A fragments (32 registers) live in LDS behind the two
+  // stages, [wave][k64-step][part][lane] 16-byte pieces (8 KB per wave), and are read back beside the b fragments
+  constexpr bool ALDS = KS == 16;
+  extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+  const bool d1 = blockIdx.y != 0;
+  const char* const a_rows = reinterpret_cast<const char*>(d1 ? args.d[1].a_rows : args.d[0].a_rows);
+  const char* const g_rows = reinterpret_cast<const char*>(d1 ? args.d[1].b_rows : args.d[0].b_rows);
+  const char* const g_frag = d1 ? args.d[1].b_frag8 : args.d[0].b_frag8;
+  const __bf16* const b_frag16 = d1 ? args.d[1].b_frag : args.d[0].b_frag;
+  const float* const sumexp_a = d1 ? args.d[1].sumexp_a : args.d[0].sumexp_a;
+  const float* const sumexp_b = d1 ? args.d[1].sumexp_b : args.d[0].sumexp_b;
+  float* const dA = d1 ? args.d[1].dA : args.d[0].dA;
+  const float c1 = d1 ? args.d[1].c1 : args.d[0].c1, out_scale = d1 ? args.d[1].out_scale : args.d[0].out_scale;
+  const float* const inv_a = d1 ? args.d[1].inv_a : args.d[0].inv_a;
+  const float* const inv_b = d1 ? args.d[1].inv_b : args.d[0].inv_b;
+  const float c2 = args.c2, kx = UNIT ? args.kexp : 1.f;
+  const int Ra = (int)(d1 ? args.d[1].Ra : args.d[0].Ra), Rb = (int)(d1 ? args.d[1].Rb : args.d[0].Rb);
+  const int off = (int)(d1 ? args.d[1].off : args.d[0].off);
+  const int tid = threadIdx.x, lane = tid & 63, c = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nP = (Rb + 63) / 64, nTa_img = (int)(rup(Ra, 64) / 32);
+  const int at0 = ((int)blockIdx.x * NWV + wave) * AT;
+  if ((int)blockIdx.x * NWV * AT * 32 >= Ra) return;                        // (whole workgroup)
+  i32x8 ares8[AT][ALDS ? 1 : K64];
+  i32x4* const a_lds = reinterpret_cast<i32x4*>(lds_raw + 2 * kStageB) + (size_t)wave * AT * K64 * 128 + lane;
+  float ia[AT], wd[AT];
+  int pos[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+    if (ALDS) {
+      const char* pa = a_rows + ((int64_t)min(at0 + i, nTa_img - 1) * K64 * 4 + h) * 512 + c * 16;
+#pragma unroll
+      for (int s2 = 0; s2 < K64; ++s2) {                                    // (wave-private: no barrier)
+        a_lds[((i * K64 + s2) * 2) * 64] = *reinterpret_cast<const i32x4*>(pa + (s2 * 4) * 512);
+        a_lds[((i * K64 + s2) * 2 + 1) * 64] = *reinterpret_cast<const i32x4*>(pa + (s2 * 4 + 2) * 512);
+      }
+    } else load_f8frag<(ALDS ? 1 : K64)>(a_rows, min(at0 + i, nTa_img - 1), c, h, ares8[i]);
+    const int a = 32 * (at0 + i) + c;
+    ia[i] = a < Ra ? (inv_a ? inv_a[a] : __builtin_amdgcn_rcpf(sumexp_a[a]) * kx) : 0.f;
+    pos[i] = a + off;
+    wd[i] = 0.f;                                                            // stays 0 in the lanes that never meet the diagonal
+  }
+  const int posmin = 32 * at0 + off, posmax = 32 * (at0 + AT) - 1 + off;
+  f32x16 dacc[AT][DT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i)
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dacc[i][d][r] = 0.f;
+  const bool have_inv = inv_b != nullptr;
+  const float* const ivsrc = have_inv ? inv_b : sumexp_b;
+  const int iv_last = (int)rup(Rb, 32) - 4;                                  // the per-row arrays are readable up to a multiple of 32 rows
+  // stage = the pair's [two rows-image tiles | fp8 fragment image | 64 reciprocals], by LDS-DMA as in score_bwd_rows_kernel
+  auto stage_dma = [&](int pn, int buf) {
+    char* const base = lds_raw + buf * kStageB;
+#pragma unroll
+    for (int q = 0; q < kPPT; ++q) {
+      const int p = tid + NTH * q;
+      const char* src = p < kRowsB / 16 ? g_rows + (int64_t)pn * kRowsB + p * 16 : g_frag + (int64_t)pn * kFragB + (p - kRowsB / 16) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(base + (wave * 64 + NTH * q) * 16), 16, 0, 0);
+    }
+    if (wave == 0 && lane < 16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ivsrc + min(64 * pn + 4 * lane, iv_last)),
+                                       (__attribute__((address_space(3))) void*)(base + kRowsB + kFragB), 16, 0, 0);
+  };
+  stage_dma(0, 0);
+  for (int p = 0; p < nP; ++p) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (p + 1 < nP) stage_dma(p + 1, (p + 1) & 1);
+    const char* rb = lds_raw + (p & 1) * kStageB;
+    const char* fb = rb + kRowsB;
+    const float* ivp = reinterpret_cast<const float*>(fb + kFragB);
+    const int b_lo = 64 * p;
+    f32x16 acc[AT][2];
+#pragma unroll
+    for (int i = 0; i < AT; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+    // S products, software-pipelined by hand: k-step s + 1's fragments are in flight while step s's MFMAs issue (left to
+    // itself hipcc hoists all 24 reads of the phase in front of the first MFMA: 96 registers, and spills accumulators)
+    i32x8 bf8[2][2], af8[2][AT];
+    auto s_read = [&](int s, i32x8 (&bdst)[2], i32x8 (&adst)[AT]) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const char* q = rb + t * (kRowsB / 2) + (s * 4 + h) * 512 + c * 16;
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(q);
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(q + 1024);
+        bdst[t] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+      if (ALDS) {
+#pragma unroll
+        for (int i = 0; i < AT; ++i) {
+          const i32x4 lo = a_lds[((i * K64 + s) * 2) * 64], hi = a_lds[((i * K64 + s) * 2 + 1) * 64];
+          adst[i] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+      }
+    };
+    s_read(0, bf8[0], af8[0]);
+#pragma unroll
+    for (int s = 0; s < K64; ++s) {
+      if (s + 1 < K64) s_read(s + 1, bf8[(s + 1) & 1], af8[(s + 1) & 1]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int i = 0; i < AT; ++i) acc[i][t] = mfma_f8(bf8[s & 1][t], ALDS ? af8[s & 1][i] : ares8[i][ALDS ? 0 : s], acc[i][t]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // (pins the MFMAs to this block: their results are first read behind the branches below, and the machine sinker otherwise
+    // moves the whole chain there, behind all of the phase's reads)
+#pragma unroll
+    for (int i = 0; i < AT; ++i)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(acc[i][t]));
+    const bool ragged = b_lo + 63 >= Rb;
+    const bool band = !(b_lo + 63 < posmin || b_lo > posmax);
+    i32x8 wA[AT];
+    int e8[AT];
+    // softmax weights of the pair, in place in the S accumulators, and the largest one this lane holds of either tile
+    float wmax[AT][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float ib[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(ivp + 32 * t + 4 * h + 8 * q);
+        ib[4 * q] = v.x; ib[4 * q + 1] = v.y; ib[4 * q + 2] = v.z; ib[4 * q + 3] = v.w;
+      }
+      if (!have_inv) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ib[r] = __builtin_amdgcn_rcpf(ib[r]) * kx;
+      }
+#pragma unroll
+      for (int i = 0; i < AT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[i][t][r] = (UNIT ? __builtin_amdgcn_exp2f(acc[i][t][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i][t][r], c1, c2))) * (ia[i] + ib[r]);
+        if (ragged) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][t][r] = b_lo + 32 * t + rowmap(r, h) < Rb ? acc[i][t][r] : 0.f;
+        }
+        if (band) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (b_lo + 32 * t + rowmap(r, h) == pos[i]) {
+              wd[i] = acc[i][t][r] - 2.f;
+              acc[i][t][r] = 0.f;
+            }
+        }
+        wmax[i][t] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) wmax[i][t] = max3_asm(wmax[i][t], acc[i][t][r], acc[i][t][r + 1]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < AT; ++i) {
+      // the block's two lanes: after the swap lane (c, 0) holds both halves' maxima of tile 0, lane (c, 1) those of tile 1 --
+      // the tile whose scale the MFMA takes from that lane
+      const auto mm = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, wmax[i][0]), __builtin_bit_cast(unsigned, wmax[i][1]), false, false);
+      const unsigned m_own = max(mm[0], mm[1]);                            // (non-negative floats order like their bit patterns)
+      // scale = 2^(floor(log2 m) - 7), floored at 2^-110 (an all-zero block converts to zeros at any scale)
+      const unsigned sb_own = (max(m_own, 0x0C000000u) & 0x7F800000u) - (7u << 23);
+      e8[i] = (int)(sb_own >> 23);
+      // tile 0's scale in every lane / tile 1's.  (Elements taken out by constant index: indexed with the unrolled loop's
+      // variable, sb[t], hipcc 7.2 folds both reads to element 0 and converts both tiles with tile 0's scale.)
+      const auto sb = __builtin_amdgcn_permlane32_swap(sb_own, sb_own, false, false);
+      const unsigned sb0 = sb[0], sb1 = sb[1];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float scale = __builtin_bit_cast(float, t ? sb1 : sb0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v2s16 u = {0, 0};
+          u = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(u, acc[i][t][4 * q], acc[i][t][4 * q + 1], scale, false);
+          u = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(u, acc[i][t][4 * q + 2], acc[i][t][4 * q + 3], scale, true);
+          wA[i][4 * t + q] = __builtin_bit_cast(int, u);
+        }
+      }
+    }
+    // gradient products: one MFMA per 32 columns of d and a tile, K = the pair's 64 b rows
+    constexpr int BQ = 2;
+#pragma unroll
+    for (int d0 = 0; d0 < DT; d0 += BQ) {
+      i32x8 bm8[BQ];
+#pragma unroll
+      for (int j = 0; j < BQ && d0 + j < DT; ++j) {
+        const char* q = fb + ((d0 + j) * 4 + h) * 512 + c * 16;
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(q);
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(q + 1024);
+        bm8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int j = 0; j < BQ && d0 + j < DT; ++j)
+#pragma unroll
+        for (int i = 0; i < AT; ++i)
+          dacc[i][d0 + j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wA[i], bm8[j], dacc[i][d0 + j], 0, 0, 0, e8[i], 0, kFp8ScaleE8M0);
+    }
+  }
+  // epilogue: + (w_aa - 2) b[pos_a] with the bf16 image's row (a lane holds the diagonal weight of row a = its column index c,
+  // the accumulators are laid out by row: one cross-lane read per register)
+  const float g = args.d_loss[0] * out_scale;
+  const int nTb_img = (int)(rup(Rb, 64) / 32);
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+    const float wd_row = wd[i] + __shfl_xor(wd[i], 32);                    // one of the two halves met it (or neither: 0)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int arow = rowmap(r, h);
+      const float wv = __shfl(wd_row, arow);
+      const int pb = 32 * (at0 + i) + arow + off;
+      const int a = 32 * (at0 + i) + arow;
+      const bool diag_ok = pb >= 0 && pb < 32 * nTb_img;
+      const int pbc = diag_ok ? pb : 0;
+      const int t = pbc >> 5, rr = pbc & 31, s = rr >> 4, r16 = rr & 15, hh = (r16 >> 2) & 1, j = ((r16 >> 3) << 2) | (r16 & 3);
+      const __bf16* prow = b_frag16 + ((((int64_t)t * 2 + s) * 2 + hh) * Dp) * 8 + j;
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const int dd = 32 * d + c;
+        if (a < Ra && dd < args.D) {
+          const float bv = diag_ok ? (float)prow[dd * 8] : 0.f;
+          dA[(int64_t)a * args.D + dd] = __builtin_fmaf(wv, bv, dacc[i][d][r]) * g;
+        }
+      }
+    }
+  }
+}
+
+// ---- fp8 pack: [fp8 rows image | bf16 fragment image | fp8 fragment image] (tt_score_bf16.h) ----------------
+// saturating: past e4m3's largest finite value the conversion would give NaN (64 * scale * x reaches 448 once |x| / T > 4.85,
+// e.g. a row with one dominant coordinate at T = 0.2)
+__device__ __forceinline__ float fp8_clamp(float v) { return __builtin_fminf(__builtin_fmaxf(v, -448.f), 448.f); }
+
 __global__ __launch_bounds__(256) void pack_fp8_kernel(PackBatch batch, int D, int Dp) {
   const PackArgs& pa = batch.a[blockIdx.y];
   const float* __restrict__ X = pa.X;
@@ -915,18 +1175,38 @@ __global__ __launch_bounds__(256) void pack_fp8_kernel(PackBatch batch, int D, i
   char* __restrict__ rows8 = reinterpret_cast<char*>(pa.rows);
   __bf16* __restrict__ frag = pa.frag;
   const float sc = pa.scale;
-  const int64_t n8 = Rp * Dp / 16, nfr = Rp * Dp / 8;      // 16-byte chunks of the two images
+  const int64_t n8 = Rp * Dp / 16, nfr = Rp * Dp / 8;      // 16-byte chunks of the rows image / of the bf16 fragment image
+  char* __restrict__ frag8 = reinterpret_cast<char*>(frag) + Rp * Dp * 2;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   const int cpt = Dp * 2;                                   // fp8 chunks per 32-row tile
-  for (int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ci < n8 + nfr; ci += stride) {
-    if (ci < n8) {
+  for (int64_t ci = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ci < 2 * n8 + nfr; ci += stride) {
+    if (ci >= n8 + nfr) {                                   // fp8 fragment image [P][d][part][h][c][16]
+      const int64_t f = ci - n8 - nfr;
+      const int64_t P = f / (Dp * 4);
+      const int w = (int)(f - P * (Dp * 4)), c = w & 31, h = (w >> 5) & 1, part = (w >> 6) & 1, d = w >> 7;
+      const int col = 32 * d + c;
+      i32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t row = 64 * P + 32 * part + rowmap(4 * q + j, h);
+          v[j] = (row < R && col < D) ? fp8_clamp(X[row * D + col] * sc * kFp8Up) : 0.f;
+        }
+        int u = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+        u = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], u, true);
+        o[q] = u;
+      }
+      *reinterpret_cast<i32x4*>(frag8 + f * 16) = o;
+    } else if (ci < n8) {
       const int64_t t = ci / cpt;
       const int w = (int)(ci - t * cpt), row_in = w & 31, g5 = w >> 5;
       const int d0 = 64 * (g5 >> 2) + 32 * (g5 & 1) + 16 * ((g5 >> 1) & 1);
       const int64_t row = 32 * t + row_in;
       float v[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = (row < R && d0 + j < D) ? X[row * D + d0 + j] * sc * kFp8Up : 0.f;
+      for (int j = 0; j < 16; ++j) v[j] = (row < R && d0 + j < D) ? fp8_clamp(X[row * D + d0 + j] * sc * kFp8Up) : 0.f;
       i32x4 o;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -1111,7 +1391,7 @@ int tt_score_bwd_bf16(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs,
 
 size_t tt_score_pack_fp8_bytes(int64_t R, int32_t D) {
   if (R < 0 || D < 1 || D > 256) return 0;
-  return (size_t)(3 * rup(R > 0 ? R : 1, 64) * padded_d8(D));
+  return (size_t)(4 * rup(R > 0 ? R : 1, 64) * padded_d8(D));
 }
 
 int tt_score_pack2_fp8(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0, const float* X1, int64_t R1, void* packed1,
@@ -1128,7 +1408,7 @@ int tt_score_pack2_fp8(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0, 
     char* base = reinterpret_cast<char*>(i ? packed1 : packed0);
     const float sc = i ? scale1 : scale0;
     b.a[i] = PackArgs{i ? X1 : X0, R, Rp, reinterpret_cast<__bf16*>(base), reinterpret_cast<__bf16*>(base + Rp * Dp), sc == 0.f ? 1.f : sc};
-    const int64_t chunks = Rp * Dp / 16 + Rp * Dp / 8;
+    const int64_t chunks = 2 * (Rp * Dp / 16) + Rp * Dp / 8;
     maxchunks = chunks > maxchunks ? chunks : maxchunks;
   }
   int64_t grid = tt_cdiv(maxchunks, 256);
@@ -1153,7 +1433,7 @@ int tt_score_bwd_fp8(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, 
     const PackedView8 va = view8(d.A_packed, d.Ra, D), vb = view8(d.B_packed, d.Rb, D);
     const float ab = d.ab_scale == 0.f ? 1.f : d.ab_scale, bs = d.b_scale == 0.f ? 1.f : d.b_scale;
     a.d[i] = DirBwd{reinterpret_cast<const __bf16*>(va.rows8), reinterpret_cast<const __bf16*>(vb.rows8), vb.frag, d.Ra, d.Rb, d.diag_offset,
-                    d.sumexp_a, d.sumexp_b, d.dA, inv_t * kLog2e / ab, scale / bs, d.inv_a, d.inv_b};
+                    d.sumexp_a, d.sumexp_b, d.dA, inv_t * kLog2e / ab, scale / bs, d.inv_a, d.inv_b, vb.frag8};
     unit = unit && ab == inv_t * kLog2e;
     maxRa = d.Ra > maxRa ? d.Ra : maxRa;
   }
@@ -1165,6 +1445,26 @@ int tt_score_bwd_fp8(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, 
   const int Dp = padded_d8(D);
   // D = 256: two waves per SIMD, one a tile each (the 128 accumulator registers of a 32 x 256 block leave room for nothing
   // more); narrower: one wave per SIMD with two a tiles.
+  if (ctx->fp8_grad) {                                     // TT_OPT_FP8_GRAD (default): e4m3 gradient products, block-scaled weights
+#define TT_BWD88(KS, AT_, NWV_)                                                                                \
+  do {                                                                                                         \
+    const dim3 grid((unsigned)tt_cdiv(maxRa, 32 * AT_ * NWV_), (unsigned)n_dirs);                              \
+    const size_t lds = 2 * (size_t)(KS * 2048 + 256) + (KS == 16 ? (size_t)NWV_ * AT_ * KS * 512 : 0);         \
+    if (unit) {                                                                                                \
+      TT_LDS_ONCE(lds, &score_bwd_rows8_kernel<KS, true, AT_, NWV_>);                                          \
+      score_bwd_rows8_kernel<KS, true, AT_, NWV_><<<grid, NWV_ * 64, lds, st>>>(a);                            \
+    } else {                                                                                                   \
+      TT_LDS_ONCE(lds, &score_bwd_rows8_kernel<KS, false, AT_, NWV_>);                                         \
+      score_bwd_rows8_kernel<KS, false, AT_, NWV_><<<grid, NWV_ * 64, lds, st>>>(a);                           \
+    }                                                                                                          \
+  } while (0)
+    if (Dp == 64) TT_BWD88(4, 2, 4);
+    else if (Dp == 128) TT_BWD88(8, 2, 4);
+    else TT_BWD88(16, 1, 8);
+#undef TT_BWD88
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+  }
 #define TT_BWD8(KS, AT_, NWV_)                                                                                 \
   do {                                                                                                         \
     const dim3 grid((unsigned)tt_cdiv(maxRa, 32 * AT_ * NWV_), (unsigned)n_dirs);                              \

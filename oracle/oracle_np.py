@@ -246,22 +246,51 @@ def score_ce_fwd(N, C, temperature=1.0):
                   "similarity_gap": pos - neg}, S, (lse_r, lse_c)
 
 
-def score_ce_bwd(N, C, S, lse, temperature=1.0, dloss=1.0, q=None, prod_operands=None):
+def q_block_e4m3(W, axis):
+    """Block-scaled e4m3 rounding of the softmax weights along `axis` (score_bwd_rows8_kernel, include/twotower.h
+    TT_OPT_FP8_GRAD): blocks of 32 consecutive indices (one 32-row tile of the summed operand = one scale block of
+    v_mfma_scale_f32_32x32x64_f8f6f4); per block and per position on the other axis, scale = 2^(floor(log2 m) - 7) with m
+    the block's largest entry (floored at 2^-103), and the entries become scale * e4m3_rne(w / scale).  W >= 0."""
+    W = np.moveaxis(np.asarray(W, dtype=np.float64), axis, -1)
+    A, B = W.shape
+    Bp = (B + 31) // 32 * 32
+    Wp = np.zeros((A, Bp))
+    Wp[:, :B] = W
+    Wb = Wp.reshape(A, Bp // 32, 32)
+    m = np.maximum(Wb.max(axis=2, keepdims=True), 2.0 ** -103)
+    scale = np.ldexp(1.0, np.frexp(m)[1] - 1 - 7)             # frexp: m = f * 2^e with f in [0.5, 1)
+    Q = (q_e4m3(Wb / scale) * scale).reshape(A, Bp)[:, :B]
+    return np.moveaxis(Q, -1, axis)
+
+
+def score_ce_bwd(N, C, S, lse, temperature=1.0, dloss=1.0, q=None, prod_operands=None, block_fp8=False):
     """dS = (softmax_rows + softmax_cols - 2I)/(2B) ; dN = dS C / T ; dC = dS^T N / T.
     q: the bf16 score kernels round the weight matrix (softmax_rows + softmax_cols - 2I) once more before the
     gradient products (it is the second MFMA's operand).  prod_operands = (N', C'): the operands of the two gradient
-    products when they differ from those S was formed from (fp8 score kernels: S from e4m3 operands, products from bf16 ones)."""
-    if prod_operands is not None:
-        N, C = prod_operands
+    products when they differ from those S was formed from (fp8 score kernels with bf16 gradient products: S from e4m3
+    operands, products from bf16 ones).
+    block_fp8 (the fp8 score kernels' default, TT_OPT_FP8_GRAD 1): the gradient products take the e4m3 operands N, C that S was
+    formed from and block-scaled e4m3 weights (q_block_e4m3: blocks run along the summed index, i.e. along b for dN and along
+    a for dC); the diagonal's weight w_aa - 2 stays exact and multiplies prod_operands' (bf16) row."""
     B = S.shape[0]
     W = np.exp(S - lse[0][:, None])
     W += np.exp(S - lse[1][None, :])
+    k = dloss / (2 * B)
+    if temperature != 1.0:
+        k = k / S.dtype.type(temperature)
+    if block_fp8:
+        N16, C16 = prod_operands
+        wd = np.diagonal(W).copy() - 2
+        W[np.arange(B), np.arange(B)] = 0
+        dN = q_block_e4m3(W, 1) @ C + wd[:, None] * C16
+        dC = q_block_e4m3(W, 0).T @ N + wd[:, None] * N16
+        return dN * k, dC * k
+    if prod_operands is not None:
+        N, C = prod_operands
     W[np.arange(B), np.arange(B)] -= 2
     if q is not None:
         W = q(W)
-    W *= dloss / (2 * B)
-    if temperature != 1.0:
-        W /= S.dtype.type(temperature)
+    W *= k
     return W @ C, W.T @ N
 
 
@@ -327,13 +356,15 @@ def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, t
     values) and notice_dense/company_dense.  Returns dict(loss, metrics, sim, notice_emb, company_emb,
     grads{state key: array}, bn_updates).
     rounding="bf16": the operand rounding of the measured mode (mlp_dtype = score_dtype = "bf16"), see q_bf16.
-    score_rounding="fp8" (with rounding="bf16"; BASELINE configs[4], score_dtype="fp8"): the score matrix is formed from e4m3
-    operands (score_operands_fp8), the two gradient products from the bf16 ones, the softmax weights rounded to bf16."""
+    score_rounding="fp8" (with rounding="bf16"; BASELINE configs[4], score_dtype="fp8"): the score matrix AND the two gradient
+    products are formed from e4m3 operands (score_operands_fp8), the softmax weights block-scaled e4m3 (q_block_e4m3), the
+    diagonal's weight exact on the bf16 operand's row.  score_rounding="fp8_s" (TT_OPT_FP8_GRAD 0): only the score matrix from
+    e4m3 operands; gradient products from the bf16 ones with bf16 weights."""
     q = q_bf16 if rounding == "bf16" else None
     if rounding not in (None, "bf16"):
         raise ValueError(f"rounding must be None or 'bf16', got {rounding!r}")
-    if score_rounding not in (None, "fp8") or (score_rounding == "fp8" and q is None):
-        raise ValueError("score_rounding must be None, or 'fp8' together with rounding='bf16'")
+    if score_rounding not in (None, "fp8", "fp8_s") or (score_rounding is not None and q is None):
+        raise ValueError("score_rounding must be None, or 'fp8' / 'fp8_s' together with rounding='bf16'")
     vals_n = np.asarray(batch["notice_ids"]).reshape(-1)
     vals_c = np.asarray(batch["company_ids"]).reshape(-1)
     if batch["notice_dense"].shape[0] != batch["company_dense"].shape[0]:
@@ -342,7 +373,7 @@ def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, t
     ce, cc, bn_c = tower_fwd(state, CT, keys_c, vocab_c, batch["company_dense"], vals_c, train, dtype, q)
     sn, sc = score_operands_bf16(ne, ce, temperature) if q is not None else (ne, ce)
     prod = None
-    if score_rounding == "fp8":
+    if score_rounding is not None:
         prod = (sn, sc)
         sn, sc = score_operands_fp8(ne, ce, temperature)
     variant = loss_type != "cross_entropy" or label_smoothing != 0.0          # the dense loss path (f32 only)
@@ -356,7 +387,7 @@ def task_step(state, batch, keys_n, keys_c, vocab_n, vocab_c, temperature=1.0, t
            "bn_updates": {**bn_n, **bn_c}}
     if backward:
         if not variant:
-            dN, dC = score_ce_bwd(sn, sc, S, lse, temperature, q=q, prod_operands=prod)
+            dN, dC = score_ce_bwd(sn, sc, S, lse, temperature, q=q, prod_operands=prod, block_fp8=score_rounding == "fp8")
         del S
         g = tower_bwd(cn, dN, NT, keys_n, vocab_n, table_grads, proj_grad)
         out["d_concat_notice"] = g.pop("_d_concat")

@@ -1,0 +1,50 @@
+# one-hot company rows: dN[a][j] = q(w_aj) (+ the diagonal term at j = a), so the kernel's quantised weights can be read off directly
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from oracle import oracle_np as O
+from jodalrob_twotower_amd import ops, _lib as L
+from jodalrob_twotower_amd.two_tower_train_task import _ScoreCEFn
+B, D, T = int(sys.argv[1]), 256, 1.0
+rng = np.random.default_rng(5)
+n = rng.standard_normal((B, D)).astype(np.float32)
+n /= np.linalg.norm(n, axis=1, keepdims=True)
+c = np.zeros((B, D), dtype=np.float32)
+c[np.arange(min(B, D)), np.arange(min(B, D))] = 1.0
+tn, tc = torch.from_numpy(n).cuda(), torch.from_numpy(c).cuda()
+n8, c8 = O.score_operands_fp8(n.astype(np.float64), c.astype(np.float64), T)
+nb, cb = O.score_operands_bf16(n.astype(np.float64), c.astype(np.float64), T)
+_, _, S, lse = O.score_ce_fwd(n8, c8, T)
+outs = []
+for rep in range(2):
+    a, b = tn.clone().requires_grad_(True), tc.clone().requires_grad_(True)
+    l2, _, _ = _ScoreCEFn.apply(a, b, 1.0 / T, "fp8", False, False)
+    l2.backward()
+    outs.append(a.grad.cpu().numpy().astype(np.float64) * 2 * B * T)
+print("two runs identical:", np.array_equal(outs[0], outs[1]))
+W = np.exp(S - lse[0][:, None]) + np.exp(S - lse[1][None, :])
+wd = np.diagonal(W).copy() - 2
+W[np.arange(B), np.arange(B)] = 0
+Q = O.q_block_e4m3(W, 1)
+want = Q @ c8 + wd[:, None] * cb
+g = outs[0]
+bad = np.argwhere(np.abs(g - want) > 1e-6 * np.abs(want).max())
+print("mismatching (a, j):", len(bad))
+rows = sorted(set(int(x) for x in bad[:, 0]))
+print("rows:", rows[:40])
+for a_ in rows[:6]:
+    js = bad[bad[:, 0] == a_][:, 1]
+    print(" row", a_, "n_bad", len(js), "cols", js[:40].tolist())
+    print("     ratio got/want", np.round(g[a_, js[:16]] / want[a_, js[:16]], 3).tolist())
+a_ = rows[0]
+js = bad[bad[:, 0] == a_][:, 1]
+P = int(js[0]) // 64
+blk = np.arange(64 * P, 64 * P + 64)
+np.set_printoptions(linewidth=200, precision=5)
+print("row", a_, "pair", P)
+print(" W      ", W[a_, blk])
+print(" oracle ", Q[a_, blk])
+print(" gpu    ", g[a_, blk])
+for hh in range(2):
+    sel = blk[(blk % 8) // 4 == hh]
+    m = W[a_, sel].max()
+    print("  h", hh, "max", m, "log2", np.log2(m), "f32 max", np.float32(m), " oracle scale 2^", np.frexp(m)[1] - 8)
