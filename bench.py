@@ -70,6 +70,8 @@ def parse(argv=None):
     ap.add_argument("--sync-bn", action="store_true", help="multi-GPU: BatchNorm statistics over all ranks' rows also in the weak leg")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-to-device-inclusive leg")
     ap.add_argument("--breakdown", action="store_true", help="extra instrumented pass: per-kernel HIP-event times")
+    ap.add_argument("--fp8-grad", type=int, default=1, choices=[0, 1], help="TT_OPT_FP8_GRAD with --score-dtype fp8: 1 e4m3 gradient products "
+                    "(default), 0 bf16 gradient products")
     ap.add_argument("--no-riders", action="store_true", help="plan compaction / loss reduction as launches of their own (A/B of TT_OPT_DEFER_RIDERS)")
     ap.add_argument("--dist-eager", action="store_true", help="sharded path launched from Python instead of replayed (analysis)")
     ap.add_argument("--no-lookup-profile", action="store_true", help="do not stamp the lookup launches (no `roofline` object then)")
@@ -156,6 +158,9 @@ class Leg:
         task = self.task
         task.train()
         task._pair_check_done = True            # skip the first-call diagnostic printout (host sync)
+        if args.fp8_grad != 1:
+            from jodalrob_twotower_amd import _lib
+            _lib.set_option(dev, _lib.TT_OPT_FP8_GRAD, args.fp8_grad)
         if args.optimizer == "torch_adam":
             self.opt = torch.optim.Adam(task.parameters(), lr=1e-3, weight_decay=1e-5)
         else:
@@ -405,7 +410,7 @@ def config_of(args, leg, world, ctx, B_global, workload):
     x_bf16 = args.mlp_dtype == "bf16" and _tower_io_dtype() in ("x", "both")
     cfg = {"workload": workload, "batch_per_gpu": leg.B, "global_batch": B_global, "rows_notice": sum(leg.vocab_n),
            "rows_company": sum(leg.vocab_c), "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})",
-           "optimizer": args.optimizer, "score_dtype": args.score_dtype, "mlp_dtype": args.mlp_dtype,
+           "optimizer": args.optimizer, "score_dtype": args.score_dtype, **({"fp8_grad": args.fp8_grad} if args.score_dtype == "fp8" else {}), "mlp_dtype": args.mlp_dtype,
            "launch": "hip graph replay" if leg.gstep is not None else "eager",
            "batch_handover": ("one launch: copies + key-major rows for the dedup plan (tt_batch_ingest)"
                               if getattr(leg.gstep, "_ingest", None) is not None else "one launch: copies (tt_copy_multi)") if leg.gstep is not None else "none"}

@@ -926,12 +926,18 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows_kernel(BwdArgs args) 
 // pair's pull) never goes through e4m3: the lane that meets it keeps it in f32, zeroes it in the block, and the epilogue
 // adds (w_aa - 2) * b[pos_a] from the bf16 fragment image.
 // Oracle model of this arithmetic: oracle_np.score_ce_bwd(..., block_fp8=True).
+// Measured and not kept: running the gradient products of the second wave of every SIMD one pair late (at the top of the
+// next pair's interval, fragment image triple-buffered) so that one wave's weights phase faces the other's MFMAs -- bit-identical,
+// configs[4] step 7.88 against 7.77 ms: as in the bf16 kernels the two pipes' times add up whatever the waves' phases
+// (profiles/NOTES.md).
 template <int KS, bool UNIT, int AT, int NWV>
 __global__ __launch_bounds__(NWV * 64) void score_bwd_rows8_kernel(BwdArgs args) {
-  constexpr int NTH = NWV * 64, DT = KS / 2, Dp = KS * 16, K64 = KS / 4;
-  constexpr int kRowsB = KS * 1024, kFragB = KS * 1024, kIvB = 256, kStageB = kRowsB + kFragB + kIvB;   // one PAIR of tiles
-  constexpr int kPieces = (kRowsB + kFragB) / 16, kPPT = kPieces / NTH;
-  static_assert(KS % 4 == 0 && kPieces % NTH == 0, "fp8 operands come in K = 64 steps; whole 16-byte pieces per thread");
+  constexpr int NTH = NWV * 64, DT = KS / 2, Dp = KS * 16, K64 = KS / 4, NF = 2;
+  // LDS: [rows-image tiles of a PAIR x 2 | fp8 fragment image of a pair x NF | 64 reciprocals x 2 | A fragments (ALDS)]
+  constexpr int kRowsB = KS * 1024, kFragB = KS * 1024, kIvB = 256;
+  constexpr int kFragOff = 2 * kRowsB, kIvOff = kFragOff + NF * kFragB, kALdsOff = kIvOff + 2 * kIvB;
+  constexpr int kPieces = (kRowsB + kFragB) / 16, kPPT = kPieces / NTH, kRowQ = kRowsB / 16 / NTH;
+  static_assert(KS % 4 == 0 && kPieces % NTH == 0 && (kRowsB / 16) % NTH == 0, "fp8 operands come in K = 64 steps; whole 16-byte pieces per thread");
   // D = 256, two waves per SIMD (256 registers each): the wave's own A fragments (32 registers) live in LDS behind the two
   // stages, [wave][k64-step][part][lane] 16-byte pieces (8 KB per wave), and are read back beside the b fragments
   constexpr bool ALDS = KS == 16;
@@ -956,7 +962,7 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows8_kernel(BwdArgs args)
   const int at0 = ((int)blockIdx.x * NWV + wave) * AT;
   if ((int)blockIdx.x * NWV * AT * 32 >= Ra) return;                        // (whole workgroup)
   i32x8 ares8[AT][ALDS ? 1 : K64];
-  i32x4* const a_lds = reinterpret_cast<i32x4*>(lds_raw + 2 * kStageB) + (size_t)wave * AT * K64 * 128 + lane;
+  i32x4* const a_lds = reinterpret_cast<i32x4*>(lds_raw + kALdsOff) + (size_t)wave * AT * K64 * 128 + lane;
   float ia[AT], wd[AT];
   int pos[AT];
 #pragma unroll
@@ -986,27 +992,52 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows8_kernel(BwdArgs args)
   const float* const ivsrc = have_inv ? inv_b : sumexp_b;
   const int iv_last = (int)rup(Rb, 32) - 4;                                  // the per-row arrays are readable up to a multiple of 32 rows
   // stage = the pair's [two rows-image tiles | fp8 fragment image | 64 reciprocals], by LDS-DMA as in score_bwd_rows_kernel
-  auto stage_dma = [&](int pn, int buf) {
-    char* const base = lds_raw + buf * kStageB;
+  auto stage_dma = [&](int pn, int rbuf, int fbuf) {
 #pragma unroll
     for (int q = 0; q < kPPT; ++q) {
-      const int p = tid + NTH * q;
-      const char* src = p < kRowsB / 16 ? g_rows + (int64_t)pn * kRowsB + p * 16 : g_frag + (int64_t)pn * kFragB + (p - kRowsB / 16) * 16;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(base + (wave * 64 + NTH * q) * 16), 16, 0, 0);
+      const char* src = q < kRowQ ? g_rows + (int64_t)pn * kRowsB + (tid + NTH * q) * 16 : g_frag + (int64_t)pn * kFragB + (tid + NTH * (q - kRowQ)) * 16;
+      char* dst = q < kRowQ ? lds_raw + rbuf * kRowsB + (wave * 64 + NTH * q) * 16 : lds_raw + kFragOff + fbuf * kFragB + (wave * 64 + NTH * (q - kRowQ)) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
     if (wave == 0 && lane < 16)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ivsrc + min(64 * pn + 4 * lane, iv_last)),
-                                       (__attribute__((address_space(3))) void*)(base + kRowsB + kFragB), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(lds_raw + kIvOff + rbuf * kIvB), 16, 0, 0);
   };
-  stage_dma(0, 0);
+  i32x8 wA[AT];
+  int e8[AT];
+#pragma unroll
+  for (int i = 0; i < AT; ++i) {
+    wA[i] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+    e8[i] = 0;
+  }
+  // gradient products of one pair: one MFMA per 32 columns of d and a tile, K = the pair's 64 b rows; fragment d + 1 is in
+  // flight while fragment d's MFMAs issue
+  auto grad = [&](const char* fb) {
+    i32x8 bm8[2];
+    auto bm_read = [&](int d, i32x8& dst) {
+      const char* q = fb + (d * 4 + h) * 512 + c * 16;
+      const i32x4 lo = *reinterpret_cast<const i32x4*>(q);
+      const i32x4 hi = *reinterpret_cast<const i32x4*>(q + 1024);
+      dst = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    bm_read(0, bm8[0]);
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      if (d + 1 < DT) bm_read(d + 1, bm8[(d + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < AT; ++i)
+        dacc[i][d] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wA[i], bm8[d & 1], dacc[i][d], 0, 0, 0, e8[i], 0, kFp8ScaleE8M0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  stage_dma(0, 0, 0);
   for (int p = 0; p < nP; ++p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (p + 1 < nP) stage_dma(p + 1, (p + 1) & 1);
-    const char* rb = lds_raw + (p & 1) * kStageB;
-    const char* fb = rb + kRowsB;
-    const float* ivp = reinterpret_cast<const float*>(fb + kFragB);
+    if (p + 1 < nP) stage_dma(p + 1, (p + 1) & 1, (p + 1) & 1);
+    const char* rb = lds_raw + (p & 1) * kRowsB;
+    const char* fb = lds_raw + kFragOff + (p & 1) * kFragB;
+    const float* ivp = reinterpret_cast<const float*>(lds_raw + kIvOff + (p & 1) * kIvB);
     const int b_lo = 64 * p;
     f32x16 acc[AT][2];
 #pragma unroll
@@ -1052,8 +1083,6 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows8_kernel(BwdArgs args)
       for (int t = 0; t < 2; ++t) asm volatile("" : "+v"(acc[i][t]));
     const bool ragged = b_lo + 63 >= Rb;
     const bool band = !(b_lo + 63 < posmin || b_lo > posmax);
-    i32x8 wA[AT];
-    int e8[AT];
     // softmax weights of the pair, in place in the S accumulators, and the largest one this lane holds of either tile
     float wmax[AT][2];
 #pragma unroll
@@ -1115,24 +1144,7 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows8_kernel(BwdArgs args)
         }
       }
     }
-    // gradient products: one MFMA per 32 columns of d and a tile, K = the pair's 64 b rows
-    constexpr int BQ = 2;
-#pragma unroll
-    for (int d0 = 0; d0 < DT; d0 += BQ) {
-      i32x8 bm8[BQ];
-#pragma unroll
-      for (int j = 0; j < BQ && d0 + j < DT; ++j) {
-        const char* q = fb + ((d0 + j) * 4 + h) * 512 + c * 16;
-        const i32x4 lo = *reinterpret_cast<const i32x4*>(q);
-        const i32x4 hi = *reinterpret_cast<const i32x4*>(q + 1024);
-        bm8[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      }
-#pragma unroll
-      for (int j = 0; j < BQ && d0 + j < DT; ++j)
-#pragma unroll
-        for (int i = 0; i < AT; ++i)
-          dacc[i][d0 + j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wA[i], bm8[j], dacc[i][d0 + j], 0, 0, 0, e8[i], 0, kFp8ScaleE8M0);
-    }
+    grad(fb);
   }
   // epilogue: + (w_aa - 2) b[pos_a] with the bf16 image's row (a lane holds the diagonal weight of row a = its column index c,
   // the accumulators are laid out by row: one cross-lane read per register)
@@ -1449,7 +1461,7 @@ int tt_score_bwd_fp8(tt_ctx* ctx, const tt_score_bwd_dir* dirs, int32_t n_dirs, 
 #define TT_BWD88(KS, AT_, NWV_)                                                                                \
   do {                                                                                                         \
     const dim3 grid((unsigned)tt_cdiv(maxRa, 32 * AT_ * NWV_), (unsigned)n_dirs);                              \
-    const size_t lds = 2 * (size_t)(KS * 2048 + 256) + (KS == 16 ? (size_t)NWV_ * AT_ * KS * 512 : 0);         \
+    const size_t lds = (size_t)4 * KS * 1024 + 512 + (KS == 16 ? (size_t)NWV_ * AT_ * KS * 512 : 0);           \
     if (unit) {                                                                                                \
       TT_LDS_ONCE(lds, &score_bwd_rows8_kernel<KS, true, AT_, NWV_>);                                          \
       score_bwd_rows8_kernel<KS, true, AT_, NWV_><<<grid, NWV_ * 64, lds, st>>>(a);                            \
