@@ -15,11 +15,12 @@ batch whose ids and dense features are already resident in HBM.
   N = 1 : BASELINE.json configs[1] -- real 32+6 key schema, per-key vocabularies scaled to 1 M rows per tower, E=32, towers
           [128,64], final 64, batch 8192, in-batch negatives.
   N > 1 : BASELINE.json configs[2] -- 100 M notice + 10 M company rows, sharded row-wise over the N GPUs (--zipf 1.2:
-          configs[3]).  `value` is the BASELINE metric: GLOBAL batch 8192 (8192/N pairs per GPU, in-batch negatives over the
-          global batch, SyncBN: the single-process job at batch 8192 split over N GPUs; "scaling": "strong").  The line
-          also carries `weak_scaling` (8192 pairs per GPU, per-rank negatives and BN statistics: the usual data-parallel
-          job whose global batch grows with N) and `one_gpu_same_tables` (the unsharded single-GPU step on the SAME
-          100 M + 10 M-row tables, measured by rank 0 in the same run: the like-for-like denominator of a speed-up).
+          configs[3]).  `value`: every GPU keeps the N = 1 job's batch (8192 pairs PER GPU, per-rank in-batch negatives and
+          BN statistics: the data-parallel job whose global batch grows with N; per-GPU work fixed, "scaling": "weak" -- the
+          leg in which north_star's 1 -> 8 scaling on 100 M-row tables is defined).  The line also carries `strong_scaling`
+          (GLOBAL batch 8192 = 8192/N pairs per GPU, global in-batch negatives + SyncBN: the single-process job at batch 8192
+          split over N GPUs; latency-bound) and `one_gpu_same_tables` (the unsharded single-GPU step on the SAME 100 M +
+          10 M-row tables, measured by rank 0 in the same run: the like-for-like denominator of a speed-up).
 
 Prints ONE JSON line (rank 0).  `roofline` is the embedding-lookup kernel (the kernel BASELINE.json's metric names);
 `mfma` the score GEMMs; `value_with_h2d` the same step fed from pinned host batches through a staging stream;
@@ -487,31 +488,34 @@ def bench_multi(args, ctx):
     cname = "configs[3]" if args.zipf is not None else "configs[2]"
     desc = (f"32+6 real keys, {rows_n}-row notice + {rows_c}-row company tables sharded row-wise over {world} GPUs (row r on GPU r mod {world}), "
             f"E=32, towers [{args.hidden}], final {args.final_dim}, dropout 0.1")
-    out, results = None, {}
-    if "strong" in legs:
-        # the BASELINE metric: the batch-8192 job split over N GPUs -- global in-batch negatives + SyncBN make it the
-        # single-process job at the global batch (tests: test_two_processes_equal_single_process)
-        neg = args.negatives or "global"
-        leg = Leg(args, ctx, Bg // world, rows_n, rows_c, True, negatives=neg, sync_bn=(neg == "global") or args.sync_bn, label="strong")
+    out, strong = None, None
+    if "weak" in legs:
+        # `value` at N > 1: every GPU keeps the N = 1 job's batch (8192 pairs PER GPU; per-GPU work fixed: "scaling": "weak"),
+        # tables sharded row-wise -- the data-parallel job whose global batch grows with N
+        leg = Leg(args, ctx, Bg, rows_n, rows_c, True, negatives=args.negatives or "local", sync_bn=args.sync_bn, label="weak")
         leg.run()
-        out = base_line(args, leg, world, "strong", Bg)
-        out["config"] = config_of(args, leg, world, ctx, Bg, f"{cname}: {desc}; GLOBAL batch {Bg} ({Bg // world} pairs per GPU)")
+        out = base_line(args, leg, world, "weak", Bg * world)
+        out["config"] = config_of(args, leg, world, ctx, Bg * world, f"{cname}: {desc}; {Bg} pairs PER GPU (global batch {Bg * world}), "
+                                  "per-rank in-batch negatives and BatchNorm statistics (data-parallel semantics)")
         out["roofline"] = roofline_of(args, leg, world)
         out["final_loss"] = leg.loss
         leg.close()
-    if "weak" in legs:
-        leg = Leg(args, ctx, Bg, rows_n, rows_c, True, negatives=args.negatives or "local", sync_bn=args.sync_bn, label="weak")
+    if "strong" in legs:
+        # the batch-8192 job split over N GPUs -- global in-batch negatives + SyncBN make it the single-process job at the
+        # global batch (tests: test_two_processes_equal_single_process); latency-bound at 8192 / N pairs per GPU
+        neg = args.negatives or "global"
+        leg = Leg(args, ctx, Bg // world, rows_n, rows_c, True, negatives=neg, sync_bn=(neg == "global") or args.sync_bn, label="strong")
         leg.run()
-        w = base_line(args, leg, world, "weak", Bg * world)
-        w = {k: w[k] for k in ("value", "unit", "ms_per_step", "device_ms_per_step_median", "host_enqueue_ms_per_step", "scaling")}
-        w["config"] = config_of(args, leg, world, ctx, Bg * world, f"{cname} tables; {Bg} pairs PER GPU (global batch {Bg * world}), "
-                                "per-rank in-batch negatives and BatchNorm statistics (data-parallel semantics)")
-        w["roofline"] = roofline_of(args, leg, world)
+        st = base_line(args, leg, world, "strong", Bg)
+        cfg = config_of(args, leg, world, ctx, Bg, f"{cname}: {desc}; GLOBAL batch {Bg} ({Bg // world} pairs per GPU), global in-batch negatives + SyncBN")
         if out is None:
-            out = base_line(args, leg, world, "weak", Bg * world)
-            out["config"], out["roofline"], out["final_loss"] = w["config"], w["roofline"], leg.loss
+            out = st
+            out["config"], out["roofline"], out["final_loss"] = cfg, roofline_of(args, leg, world), leg.loss
         else:
-            out["weak_scaling"] = w
+            strong = {k: st[k] for k in ("value", "unit", "ms_per_step", "device_ms_per_step_median", "host_enqueue_ms_per_step", "scaling")}
+            strong["config"] = cfg
+            strong["roofline"] = roofline_of(args, leg, world)
+            out["strong_scaling"] = strong
         leg.close()
     if "one_gpu" in legs:
         # like-for-like denominator: the unsharded single-GPU step on the SAME tables and batch, rank 0 only
@@ -534,8 +538,8 @@ def bench_multi(args, ctx):
             out["one_gpu_same_tables"] = ref
             if "value" in ref:
                 out["speedup_vs_one_gpu_same_tables"] = out["value"] / ref["value"]
-                if "weak_scaling" in out:
-                    out["weak_scaling"]["speedup_vs_one_gpu_same_tables"] = out["weak_scaling"]["value"] / ref["value"]
+                if "strong_scaling" in out:
+                    out["strong_scaling"]["speedup_vs_one_gpu_same_tables"] = out["strong_scaling"]["value"] / ref["value"]
     return out
 
 

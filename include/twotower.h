@@ -65,7 +65,8 @@ uint64_t tt_launch_count(void);
  * force either form). */
 #define TT_OPT_KEYED_PARTS 2
 #define TT_OPT_SCORE_BWD_ROWS_MIN 3
-/* TT_OPT_DEFER_RIDERS (default 0): tt_dedup_plan_keyed* leaves the plan's compaction, and tt_score_fwd_sym_* its last reduction
+/* TT_OPT_DEFER_RIDERS (default 0; 1 or 3 = both riders, 2 = only the loss reduction -- a caller that reads the plan right after
+ * building it, as the sharded exchange does): tt_dedup_plan_keyed* leaves the plan's compaction, and tt_score_fwd_sym_* its last reduction
  * (loss_out / out8), QUEUED in the context instead of launching them: tt_towers_mlp_fwd / tt_towers_mlp_bwd run them in an extra
  * grid row of their fused tail kernels (two launches fewer in the step's dependent chain; same bodies: bit-identical), and
  * tt_flush_deferred, tt_embed_grad_bwd, tt_embed_grad_finish and the tt_adam_* entries launch whatever is still queued.  Until

@@ -155,7 +155,7 @@ SIGNATURES = {
 _lib: Optional[C.CDLL] = None
 _ctxs: dict = {}
 _defer_on: set = set()       # devices whose context queues the towers' slab reduction (set_defer_slab_reduce)
-_riders_on: set = set()      # devices whose context queues the plan compaction / loss reduction (set_defer_riders)
+_riders_on: dict = {}        # device -> mask of what its context queues: 1 plan compaction, 2 loss reduction (set_defer_riders)
 _workspaces: dict = {}
 
 
@@ -227,19 +227,25 @@ def set_defer_slab_reduce(device: torch.device, on: bool):
         flush_deferred(device)
 
 
-def set_defer_riders(device: torch.device, on: bool):
+def set_defer_riders(device: torch.device, on, loss_only: bool = False):
     """tt_dedup_plan_keyed* / tt_score_fwd_sym_* leave the plan's compaction and the loss reduction queued in the context; the towers'
-    fused tail launches run them (include/twotower.h: TT_OPT_DEFER_RIDERS).  Switching it off launches what is still queued."""
-    check(load().tt_ctx_set_option(ctx(device), TT_OPT_DEFER_RIDERS, 1 if on else 0), "tt_ctx_set_option")
+    fused tail launches run them (include/twotower.h: TT_OPT_DEFER_RIDERS).  loss_only: the plan is compacted at once (somebody
+    reads it before the towers run).  Switching it off launches what is still queued."""
+    mask = (2 if loss_only else 3) if on else 0
+    check(load().tt_ctx_set_option(ctx(device), TT_OPT_DEFER_RIDERS, mask), "tt_ctx_set_option")
     idx = torch.device(device).index
-    (_riders_on.add if on else _riders_on.discard)(idx if idx is not None else torch.cuda.current_device())
-    if not on:
+    idx = idx if idx is not None else torch.cuda.current_device()
+    if mask:
+        _riders_on[idx] = mask
+    else:
+        _riders_on.pop(idx, None)
         flush_deferred(device)
 
 
-def riders_deferred(device: torch.device) -> bool:
+def riders_deferred(device: torch.device, which: int = 3) -> bool:
+    """which: 1 the plan compaction, 2 the loss reduction"""
     idx = torch.device(device).index
-    return (idx if idx is not None else torch.cuda.current_device()) in _riders_on
+    return bool(_riders_on.get(idx if idx is not None else torch.cuda.current_device(), 0) & which)
 
 
 def flush_deferred(device: torch.device):

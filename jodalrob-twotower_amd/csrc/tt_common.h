@@ -20,7 +20,7 @@ struct tt_ctx {
   struct TnPending* deferred;
   int keyed_parts;          // TT_OPT_KEYED_PARTS: workgroups per key of the keyed dedup plan (0 = chosen from the batch)
   int score_bwd_rows_min;   // TT_OPT_SCORE_BWD_ROWS_MIN: rows from which tt_score_bwd_bf16 takes the workgroup-staged form
-  int defer_riders;         // TT_OPT_DEFER_RIDERS: plan compaction / score loss reduction queue in `riders` (tt_riders.h)
+  int defer_riders;         // TT_OPT_DEFER_RIDERS, as a mask: 1 plan compaction, 2 score loss reduction queue in `riders` (tt_riders.h)
   int fp8_grad;             // TT_OPT_FP8_GRAD: tt_score_bwd_fp8 forms the gradient products from e4m3 operands too (default 1)
   struct tt_riders* riders;
 };

@@ -85,7 +85,10 @@ int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value) {
       TT_CHECK_ARG(value >= 1, "tt_ctx_set_option: TT_OPT_SCORE_BWD_ROWS_MIN needs a value >= 1");
       ctx->score_bwd_rows_min = value;
       break;
-    case TT_OPT_DEFER_RIDERS: ctx->defer_riders = value != 0; break;
+    case TT_OPT_DEFER_RIDERS:
+      TT_CHECK_ARG(value >= 0 && value <= 3, "tt_ctx_set_option: TT_OPT_DEFER_RIDERS takes 0 .. 3");
+      ctx->defer_riders = value == 1 ? 3 : value;      // 1 = both riders (as 3), 2 = the loss reduction only
+      break;
     case TT_OPT_FP8_GRAD: ctx->fp8_grad = value != 0; break;
     default: tt_set_error("tt_ctx_set_option: unknown option %d", option); return TT_ERR_INVALID_ARG;
   }

@@ -1964,7 +1964,7 @@ static int dedup_plan_keyed_impl(tt_ctx* ctx, const int32_t* rows, const int32_t
                                                               pl.counters);
   TT_LAUNCH_CHECK();
   const CompactRider cr{uniq_stage, seg_stage, ucount, ubase, uend, pl, n_keys * parts, slots, unique_rows, seg_offsets, n_unique};
-  if (ctx->defer_riders) {                               // rides beside the towers' tail_fwd (tt_riders.h); a second plan before that
+  if (ctx->defer_riders & 1) {                           // rides beside the towers' tail_fwd (tt_riders.h); a second plan before that
     if (ctx->riders->c_wg > 0)                           // launch takes the queue's place, the older one is launched now
       if (int rc = tt_riders_flush(ctx, st)) return rc;
     ctx->riders->c = cr;

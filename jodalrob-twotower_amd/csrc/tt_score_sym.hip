@@ -492,7 +492,7 @@ static int sym_forward(tt_ctx* ctx, const void* N_packed, const void* C_packed, 
   score_sym_finish1_kernel<<<(unsigned)L.n_wg, 256, 0, st>>>(f);
   TT_LAUNCH_CHECK();
   const Finish2Rider fr{f.part, L.n_wg, L.Dp, (float)B, f.unscale, out8, loss_out};
-  if (ctx->defer_riders) {                               // rides beside the towers' tail_bwd (tt_riders.h): nothing on the device reads it
+  if (ctx->defer_riders & 2) {                           // rides beside the towers' tail_bwd (tt_riders.h): nothing on the device reads it
     if (ctx->riders->f_wg > 0)
       if (int rc = tt_riders_flush(ctx, st)) return rc;
     ctx->riders->f = fr;

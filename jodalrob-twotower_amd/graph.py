@@ -143,15 +143,17 @@ class GraphedTrainStep:
         # likewise the slab reduction of the towers' weight gradients rides in the embedding gradient's launch (the two do not
         # depend on each other); whatever is still queued after the backward is launched on its own
         dev = self._dev.device
-        # (never with a dense-gradient all-reduce in the backward: it would read the tensors the queue still owes)
+        # (a sharded task's dense-gradient all-reduce comes BEHIND the exchange's backward, whose first launch hosts the queue, and
+        # flushes whatever is still queued before it reads the gradients: towers.py)
         ex = getattr(self.task, "exchange", None)
-        slabs = self._defer_slabs and (ex is None or getattr(ex, "world", 1) == 1)
+        slabs = self._defer_slabs
         # the keyed plan's compaction and the score forward's loss reduction ride in the towers' tail launches (two launches fewer
-        # in the chain; only where nothing reads the plan before the embedding gradient does: one local store)
-        riders = self._defer_riders and self._ingest is not None and ex is None      # (the exchange reads the plan at once)
+        # in the chain).  A sharded task's exchange reads the plan at once: only the loss reduction rides there (and not under SyncBN,
+        # whose tail kernels run in two phases with a collective between them)
+        riders = self._defer_riders and self._ingest is not None and (ex is None or not getattr(self.task, "sync_bn", False))
         try:
             if riders:
-                L.set_defer_riders(dev, True)
+                L.set_defer_riders(dev, True, loss_only=ex is not None)
             res = self.task(self.static, return_metrics=self.return_metrics)
             loss = res["loss"] if isinstance(res, dict) else res
             if slabs:

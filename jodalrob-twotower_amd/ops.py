@@ -202,7 +202,7 @@ def dedup_plan_keyed(rows: torch.Tensor, side_K: Sequence[int], B: int, key_majo
     plan = DedupPlan(buf[:M], buf[M:2 * M], buf[2 * M:3 * M + 1], buf[3 * M + 1:], M)
     lib = L.load()
     nk = sum(side_K)
-    if L.riders_deferred(dev):       # the compaction runs later, inside the towers' launch: its staging arrays must outlive whatever
+    if L.riders_deferred(dev, 1):    # the compaction runs later, inside the towers' launch: its staging arrays must outlive whatever
         ws = torch.empty(lib.tt_dedup_keyed_workspace_bytes(M, nk), dtype=torch.uint8, device=dev)      # takes the shared scratch meanwhile
     else:
         ws = L.workspace(dev, lib.tt_dedup_keyed_workspace_bytes(M, nk))
@@ -503,7 +503,7 @@ def score_fwd_sym(Np, Cp, B, D, inv_t, shift, scale_n: float = 1.0, want_rank: b
     out8 = torch.empty(8, dtype=torch.float32, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
     lib = L.load()
-    if L.riders_deferred(dev):       # the last reduction runs later (inside the towers' backward launch): its partial records must
+    if L.riders_deferred(dev, 2):    # the last reduction runs later (inside the towers' backward launch): its partial records must
         ws = torch.empty(lib.tt_score_fwd_sym_workspace_bytes(B, D), dtype=torch.uint8, device=dev)     # outlive the shared scratch's next user
         out8._tt_keep = ws
     else:

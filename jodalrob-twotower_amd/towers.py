@@ -446,12 +446,7 @@ class _TowersFn(torch.autograd.Function):
                 ops.tower_bwd(s.tower._params(), s.acts_struct, d_emb, g, s.B, s.train, s.p_drop, s.seed, s.emb.device,
                               s.tower._seed_dev)
         if exch is not None:
-            if buf is not None and dense_total:
-                flat_grads.append(buf[:dense_total])
-                # a queued (deferred) slab reduction still owes w[0] / b[0] / w_proj / b_proj of this buffer: it must have run
-                # before anything outside the library reads the dense gradients (GraphedTrainStep sets the deferral)
-                L.flush_deferred(buf.device)
-            exch.all_reduce_dense(flat_grads)
+            # the exchange's backward first: its local reduction is the launch that hosts a queued (deferred) slab reduction
             if ctx.exch_state is not None:
                 srcs = []
                 for s in ctx.exch_sides:
@@ -461,6 +456,12 @@ class _TowersFn(torch.autograd.Function):
                         d = torch.zeros((s.B, K * exch.E), dtype=s.tower.dx_dtype, device=s.emb.device)
                     srcs.append((d, K))
                 exch.backward(ctx.exch_state, srcs, ctx.exch_sides[0].B)
+            if buf is not None and dense_total:
+                flat_grads.append(buf[:dense_total])
+                # a slab reduction that is STILL queued owes w[0] / b[0] / w_proj / b_proj of this buffer: it must have run before
+                # anything outside the library reads the dense gradients (GraphedTrainStep sets the deferral)
+                L.flush_deferred(buf.device)
+            exch.all_reduce_dense(flat_grads)
         # table gradients: one fused segmented reduction per store
         for store, plan_sides, plan in ctx.plans:
             if plan is None:
