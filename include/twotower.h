@@ -77,6 +77,11 @@ uint64_t tt_launch_count(void);
  * block-scaled per row and 32 consecutive b rows, the diagonal weight kept apart in f32: tt_score_bwd_fp8 below); 0 = bf16 weights and bf16
  * B rows for those products (round 2's arithmetic, 1.5 x the matrix-pipe time). */
 #define TT_OPT_FP8_GRAD 5
+/* TT_OPT_CHAINED (default 1): the segment-head pass of tt_dedup_plan / tt_dedup_plan_runs runs as ONE launch, its cross-workgroup
+ * prefix sum chained through a small context-owned buffer (a tile publishes its head count with a ready bit and sums its
+ * predecessors'; the last one through clears the buffer); 0 = count and write as separate launches.  Same results bit for bit
+ * (tests compare the two). */
+#define TT_OPT_CHAINED 6
 int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value);
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream);
 /* only the queued slab reduction (the one thing that lives in the caller's shared scratch buffer) */
@@ -544,6 +549,7 @@ int tt_batch_gather(tt_ctx* ctx, const int64_t* entity, int64_t B, const float* 
  *   counts   [G]    int32  entries wanted per owner; overflow[0] is set to 1 when any count exceeds C (sticky: never
  *                          cleared here, the caller owns the flag)
  * tt_route_expand: idx_slot[slot] = pos_u[u] for every slot of plan row u (int64: ids of the placing lookup).
+ * tt_route_bucket_expand: both in one call.
  * ---------------------------------------------------------------------------------------------- */
 #define TT_MAX_RANKS 64
 size_t tt_route_workspace_bytes(int64_t M, int32_t G);
@@ -552,6 +558,10 @@ int tt_route_bucket(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_un
                     int32_t* counts, int32_t* overflow, void* workspace, size_t workspace_bytes, tt_stream stream);
 int tt_route_expand(tt_ctx* ctx, const int32_t* sorted_src, const int32_t* seg_offsets, const int32_t* n_unique,
                     const int32_t* pos_u, int64_t M, int64_t* idx_slot, tt_stream stream);
+int tt_route_bucket_expand(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t G, int32_t C,
+                           const int32_t* pad_id, int32_t pad_u, int32_t* send_ids, int32_t* send_u, int32_t* pos_u,
+                           int32_t* counts, int32_t* overflow, void* workspace, size_t workspace_bytes,
+                           const int32_t* sorted_src, const int32_t* seg_offsets, int64_t* idx_slot, tt_stream stream);
 /* Duplicate-row plan of G ASCENDING runs of C row ids each (what an owner receives: every source sends its distinct rows in
  * ascending order, pads -- the largest value -- at the end): a stable merge by binary searches instead of radix passes.
  * Same outputs as tt_dedup_plan over the concatenated runs; workspace tt_dedup_workspace_bytes(G * C).

@@ -143,6 +143,7 @@ SIGNATURES = {
     "tt_route_workspace_bytes": (sz, [i64, i32]),
     "tt_route_bucket": (C.c_int, [vp, vp, vp, i64, i32, i32, C.POINTER(i32), i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "tt_route_expand": (C.c_int, [vp, vp, vp, vp, vp, i64, vp, vp]),
+    "tt_route_bucket_expand": (C.c_int, [vp, vp, vp, i64, i32, i32, C.POINTER(i32), i32, vp, vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]),
     "tt_dedup_plan_runs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_gather_rows": (C.c_int, [vp, vp, i64, i32, vp, i64, vp, i32, vp]),
     "tt_copy_multi": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]),
@@ -211,6 +212,7 @@ TT_OPT_KEYED_PARTS = 2
 TT_OPT_SCORE_BWD_ROWS_MIN = 3
 TT_OPT_DEFER_RIDERS = 4
 TT_OPT_FP8_GRAD = 5
+TT_OPT_CHAINED = 6
 
 
 def set_option(device: torch.device, option: int, value: int):

@@ -23,7 +23,21 @@ struct tt_ctx {
   int defer_riders;         // TT_OPT_DEFER_RIDERS, as a mask: 1 plan compaction, 2 score loss reduction queue in `riders` (tt_riders.h)
   int fp8_grad;             // TT_OPT_FP8_GRAD: tt_score_bwd_fp8 forms the gradient products from e4m3 operands too (default 1)
   struct tt_riders* riders;
+  // chained single-launch scans (segment heads, owner routing): small device buffers that are all-zero between launches -- word 0
+  // a ticket, the rest per-workgroup aggregates with a ready bit; the last workgroup through clears what it used.  One slice
+  // per stream that calls in (launches of different streams may overlap: the test rigs that run several virtual ranks on one
+  // GPU do), handed out from a pool allocated with the context -- nothing is allocated at call time (stream capture)
+  uint32_t* chain;
+  int chain_words;          // per slice
+  void* chain_stream[16];
+  int chain_used;
+  int chained;              // TT_OPT_CHAINED: use them (default 1); 0 = the multi-launch forms (same results; tests compare)
 };
+
+constexpr uint32_t kChainReady = 0x80000000u;
+constexpr int kChainWords = 1 << 16, kChainSlices = 16;
+// the calling stream's slice, or nullptr (pool exhausted / chaining off): the caller then takes its multi-launch form
+uint32_t* tt_chain_for(tt_ctx* ctx, hipStream_t stream);
 
 void tt_set_error(const char* fmt, ...);
 

@@ -3,6 +3,8 @@
 #include "tt_gemm.h"
 #include "tt_riders.h"
 
+#include <mutex>
+
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -14,6 +16,17 @@ __global__ __launch_bounds__(kRiderThreads) void riders_kernel(tt_riders r) {
   else finish2_body(r.f);
 }
 }  // namespace
+
+uint32_t* tt_chain_for(tt_ctx* ctx, hipStream_t stream) {
+  static std::mutex mu;
+  if (!ctx || !ctx->chained || !ctx->chain) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < ctx->chain_used; ++i)
+    if (ctx->chain_stream[i] == static_cast<void*>(stream)) return ctx->chain + (size_t)i * kChainWords;
+  if (ctx->chain_used == kChainSlices) return nullptr;
+  ctx->chain_stream[ctx->chain_used] = static_cast<void*>(stream);
+  return ctx->chain + (size_t)(ctx->chain_used++) * kChainWords;
+}
 
 int tt_riders_flush(tt_ctx* ctx, hipStream_t st) {
   if (!ctx || !ctx->riders || (ctx->riders->c_wg == 0 && ctx->riders->f_wg == 0)) return TT_OK;
@@ -62,6 +75,25 @@ int tt_ctx_create(int device, tt_ctx** out) {
   c->fp8_grad = 1;
   c->riders = new tt_riders();
   c->riders->c_wg = c->riders->f_wg = 0;
+  c->chain = nullptr;
+  c->chain_words = 0;
+  c->chain_used = 0;
+  c->chained = 1;
+  {
+    int prev = 0;
+    TT_HIP(hipGetDevice(&prev));
+    TT_HIP(hipSetDevice(device));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->chain), sizeof(uint32_t) * kChainWords * kChainSlices);
+    if (e == hipSuccess) e = hipMemset(c->chain, 0, sizeof(uint32_t) * kChainWords * kChainSlices);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+      tt_set_error("tt_ctx_create: %s", hipGetErrorString(e));
+      delete c->riders;
+      delete c;
+      return TT_ERR_HIP;
+    }
+    c->chain_words = kChainWords;
+  }
   *out = c;
   return TT_OK;
 }
@@ -69,6 +101,7 @@ int tt_ctx_create(int device, tt_ctx** out) {
 int tt_ctx_destroy(tt_ctx* ctx) {
   if (ctx && ctx->deferred) tt_gemm_tn_pending_destroy(ctx->deferred);
   if (ctx) delete ctx->riders;
+  if (ctx && ctx->chain) (void)hipFree(ctx->chain);
   delete ctx;
   return TT_OK;
 }
@@ -90,6 +123,7 @@ int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value) {
       ctx->defer_riders = value == 1 ? 3 : value;      // 1 = both riders (as 3), 2 = the loss reduction only
       break;
     case TT_OPT_FP8_GRAD: ctx->fp8_grad = value != 0; break;
+    case TT_OPT_CHAINED: ctx->chained = value != 0; break;
     default: tt_set_error("tt_ctx_set_option: unknown option %d", option); return TT_ERR_INVALID_ARG;
   }
   return TT_OK;

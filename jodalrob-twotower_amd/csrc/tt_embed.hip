@@ -435,6 +435,83 @@ __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __
   }
 }
 
+// chained aggregates (tt_common.h: tt_ctx::chain): a workgroup's value with the ready bit; a reader polls until the bit shows.
+// All workgroups of these grids are resident at once (<= 2048 of 256 threads) and dispatched in index order, so a predecessor is
+// always running or done; the poll is bounded all the same -- a buffer left dirty by an aborted launch must not hang the device
+// (`stuck` then makes the caller-visible result invalid instead: n_unique = -1).
+__device__ __forceinline__ void chain_publish(uint32_t* slot, uint32_t v) {
+  __hip_atomic_store(slot, v | kChainReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t chain_wait(const uint32_t* slot, bool& stuck) {
+  for (int spin = 0; spin < (1 << 22); ++spin) {
+    const uint32_t v = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    if (v & kChainReady) return v & ~kChainReady;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  stuck = true;
+  return 0u;
+}
+
+// head_count_kernel + head_write_kernel as ONE launch: a tile publishes its head count in chain[1 + tile] and adds up the tiles before
+// it; the last tile also writes the totals.  chain[0] counts the tiles that are through with their reads: the last one clears.
+__global__ __launch_bounds__(kThreads) void head_chained_kernel(const uint32_t* __restrict__ keys, uint32_t M, uint32_t* __restrict__ chain,
+                                                               int32_t* __restrict__ n_unique, int32_t* __restrict__ unique_rows,
+                                                               int32_t* __restrict__ seg_offsets, uint32_t drop_from) {
+  __shared__ uint32_t wsum[4], wbefore[4];
+  __shared__ uint32_t s_stuck, s_last;
+  constexpr uint32_t PER = kSortTile / kThreads;
+  const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nblk = gridDim.x;
+  const uint32_t lo = blockIdx.x * kSortTile + tid * PER;
+  if (tid == 0) s_stuck = 0;
+  uint32_t flags = 0, c = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < PER; ++j) {
+    const uint32_t idx = lo + j;
+    if (idx < M && is_head(keys, idx)) { flags |= 1u << j; ++c; }
+  }
+  uint32_t x = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o);
+    if (lane >= (uint32_t)o) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  const uint32_t total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  if (tid == 0) chain_publish(chain + 1 + blockIdx.x, total);
+  uint32_t before = 0;
+  bool stuck = false;
+  for (uint32_t b = tid; b < blockIdx.x; b += kThreads) before += chain_wait(chain + 1 + b, stuck);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+  if (lane == 0) wbefore[wave] = before;
+  if (stuck) s_stuck = 1;
+  __syncthreads();
+  before = wbefore[0] + wbefore[1] + wbefore[2] + wbefore[3];
+  uint32_t u = before + x - c;
+  for (uint32_t w = 0; w < wave; ++w) u += wsum[w];
+#pragma unroll
+  for (uint32_t j = 0; j < PER; ++j) {
+    if (flags & (1u << j)) {
+      unique_rows[u] = (int32_t)keys[lo + j];
+      seg_offsets[u] = (int32_t)(lo + j);
+      ++u;
+    }
+  }
+  if (blockIdx.x == nblk - 1 && tid == 0) {              // (drop_from: see head_write_kernel)
+    const uint32_t all = before + total;
+    n_unique[0] = s_stuck ? -1 : (int32_t)(all - ((M > 0 && keys[M - 1] >= drop_from) ? 1u : 0u));
+    seg_offsets[all] = (int32_t)M;
+  }
+  // everybody's reads of the chain are done once every tile has been here: the last one leaves the buffer all-zero
+  if (tid == 0) s_last = atomicAdd(chain, 1u) == nblk - 1 ? 1u : 0u;
+  __syncthreads();
+  if (s_last) {
+    for (uint32_t b = tid; b < nblk; b += kThreads) chain[1 + b] = 0u;
+    if (tid == 0) chain[0] = 0u;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Keyed dedup plan: one 1024-thread workgroup per (side, key) sorts that key's B slot rows in LDS.
 // ------------------------------------------------------------------------------------------------
@@ -1567,46 +1644,43 @@ __global__ __launch_bounds__(kThreads) void route_count_kernel(const int32_t* __
   if (lane < G) seg_counts[((size_t)blockIdx.x * kRouteWaves + wave) * G + lane] = cnt[wave][lane];
 }
 
-// one workgroup: per owner an exclusive prefix over the (block, wave) segments; totals, overflow flag, pad fill
-__global__ __launch_bounds__(1024) void route_scan_kernel(uint32_t* __restrict__ seg_counts, uint32_t nseg, uint32_t G, uint32_t C,
-                                                         int32_t* __restrict__ counts, int32_t* __restrict__ overflow) {
-  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t g = wave; g < G; g += 16) {             // a wave per owner, 64 segments per trip
-    uint32_t carry = 0;
-    for (uint32_t s0 = 0; s0 < nseg; s0 += 64) {
-      const uint32_t s = s0 + lane;
-      const uint32_t c = s < nseg ? seg_counts[(size_t)s * G + g] : 0u;
-      uint32_t x = c;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(x, o);
-        if (lane >= (uint32_t)o) x += y;
-      }
-      if (s < nseg) seg_counts[(size_t)s * G + g] = carry + x - c;
-      carry += __shfl(x, 63);
-    }
-    if (lane == 0) {
-      counts[g] = (int32_t)carry;
-      if (carry > C) overflow[0] = 1;                   // sticky: the caller owns (and clears) the flag
-    }
-  }
-}
-
+// Every workgroup adds up the (block, wave) segment counts itself -- all of them for the totals (pads, counts, overflow flag), those
+// in front of its own block for its starting offsets: nseg * G words from L2 per workgroup instead of a one-workgroup scan launch
+// between the two passes (round 3: 6.4 us of the sharded step for 152 x 4 numbers).  Chaining the three passes through a ready-flag
+// buffer in ONE launch was measured too: 19.7 us against 19.0 for the three -- the last workgroup's serial tail ate the launches saved.
 __global__ __launch_bounds__(kThreads) void route_scatter_kernel(const int32_t* __restrict__ unique_rows, const int32_t* __restrict__ n_unique,
-                                                                uint32_t G, uint32_t C, const uint32_t* __restrict__ seg_base,
-                                                                const int32_t* __restrict__ counts, RoutePads pads, int32_t pad_u,
-                                                                int32_t* __restrict__ send_ids, int32_t* __restrict__ send_u,
+                                                                uint32_t G, uint32_t C, const uint32_t* __restrict__ seg_counts,
+                                                                int32_t* __restrict__ counts, int32_t* __restrict__ overflow, RoutePads pads,
+                                                                int32_t pad_u, int32_t* __restrict__ send_ids, int32_t* __restrict__ send_u,
                                                                 int32_t* __restrict__ pos_u) {
-  // unused tail of every bucket: pad entries, written by the whole grid
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G * C; i += gridDim.x * blockDim.x) {
-    const uint32_t g = i / C, p = i - g * C;
-    if (p >= (uint32_t)counts[g]) { send_ids[i] = pads.id[g]; send_u[i] = pad_u; }
-  }
+  __shared__ uint32_t tot[TT_MAX_RANKS], pre[TT_MAX_RANKS];
   __shared__ uint32_t off[kRouteWaves][TT_MAX_RANKS];
   __shared__ unsigned long long pm[kRouteWaves][TT_MAX_RANKS];
   const uint32_t U = (uint32_t)*n_unique, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t nseg = gridDim.x * kRouteWaves, my_first = blockIdx.x * kRouteWaves;
+  if (threadIdx.x < G) { tot[threadIdx.x] = 0; pre[threadIdx.x] = 0; }
+  __syncthreads();
+  for (uint32_t e = threadIdx.x; e < nseg * G; e += kThreads) {
+    const uint32_t v = seg_counts[e];
+    if (v) {
+      atomicAdd(&tot[e % G], v);
+      if (e / G < my_first) atomicAdd(&pre[e % G], v);
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < G) {
+    counts[threadIdx.x] = (int32_t)tot[threadIdx.x];
+    if (tot[threadIdx.x] > C) overflow[0] = 1;          // sticky: the caller owns (and clears) the flag
+  }
+  // unused tail of every bucket: pad entries, written by the whole grid
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < G * C; i += gridDim.x * blockDim.x) {
+    const uint32_t g = i / C, p = i - g * C;
+    if (p >= tot[g]) { send_ids[i] = pads.id[g]; send_u[i] = pad_u; }
+  }
   if (lane < G) {
-    off[wave][lane] = seg_base[((size_t)blockIdx.x * kRouteWaves + wave) * G + lane];
+    uint32_t o = pre[lane];
+    for (uint32_t w = 0; w < wave; ++w) o += seg_counts[((size_t)my_first + w) * G + lane];
+    off[wave][lane] = o;
     pm[wave][lane] = 0ull;
   }
   __builtin_amdgcn_wave_barrier();
@@ -1639,7 +1713,7 @@ __global__ __launch_bounds__(kThreads) void route_scatter_kernel(const int32_t* 
         send_u[(size_t)g * C + pos] = (int32_t)u;
         pos_u[u] = (int32_t)(g * C + pos);
       } else {
-        pos_u[u] = (int32_t)(G * C);                    // did not fit (flagged by route_scan_kernel): the row AFTER the buckets,
+        pos_u[u] = (int32_t)(G * C);                    // did not fit (flagged in the prologue): the row AFTER the buckets,
       }                                                 // which the caller keeps all-zero -- never another row's embedding
     }
   }
@@ -1715,6 +1789,22 @@ inline DedupWs dedup_layout(char* base, int64_t M) {
   w.blockcount = reinterpret_cast<uint32_t*>(take(sizeof(uint32_t) * (size_t)(nblk + 1)));
   w.bytes = o;
   return w;
+}
+
+// segment heads of the sorted keys: unique rows, segment offsets, their number -- one chained launch, or count + write
+static int launch_heads(tt_ctx* ctx, hipStream_t st, const DedupWs& w, int64_t M, uint32_t nblk, int32_t* n_unique, int32_t* unique_rows,
+                        int32_t* seg_offsets, uint32_t drop_from) {
+  uint32_t* chain = (int64_t)nblk + 1 <= ctx->chain_words && nblk <= 2048 ? tt_chain_for(ctx, st) : nullptr;
+  if (chain) {
+    head_chained_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, chain, n_unique, unique_rows, seg_offsets, drop_from);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
+  }
+  head_count_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount);
+  TT_LAUNCH_CHECK();
+  head_write_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount, n_unique, unique_rows, seg_offsets, drop_from);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
 }
 
 struct GradLayout {
@@ -1867,11 +1957,7 @@ int tt_dedup_plan(tt_ctx* ctx, const int32_t* rows, int64_t M, int64_t table_row
     kin = kout;
     vin = vout;
   }
-  head_count_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount);
-  TT_LAUNCH_CHECK();
-  head_write_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount, n_unique, unique_rows, seg_offsets);
-  TT_LAUNCH_CHECK();
-  return TT_OK;
+  return launch_heads(ctx, st, w, M, nblk, n_unique, unique_rows, seg_offsets, 0xFFFFFFFFu);
 }
 
 int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, int64_t row_limit, int32_t* sorted_src,
@@ -1889,12 +1975,8 @@ int tt_dedup_plan_runs(tt_ctx* ctx, const int32_t* rows, int32_t G, int64_t C, i
   const uint32_t nblk = (uint32_t)tt_cdiv(M, kSortTile);
   merge_runs_kernel<<<grid_for(ctx, M), kThreads, 0, st>>>(rows, (uint32_t)G, (uint32_t)C, w.keysA, sorted_src);
   TT_LAUNCH_CHECK();
-  head_count_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount);
-  TT_LAUNCH_CHECK();
-  head_write_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, w.blockcount, n_unique, unique_rows, seg_offsets,
-                                               row_limit > 0 && row_limit < (int64_t)0xFFFFFFFFll ? (uint32_t)row_limit : 0xFFFFFFFFu);
-  TT_LAUNCH_CHECK();
-  return TT_OK;
+  return launch_heads(ctx, st, w, M, nblk, n_unique, unique_rows, seg_offsets,
+                      row_limit > 0 && row_limit < (int64_t)0xFFFFFFFFll ? (uint32_t)row_limit : 0xFFFFFFFFu);
 }
 
 size_t tt_dedup_keyed_workspace_bytes(int64_t M, int32_t n_keys) {
@@ -2288,13 +2370,15 @@ size_t tt_route_workspace_bytes(int64_t M, int32_t G) {
   return align256(sizeof(uint32_t) * (size_t)nb * kRouteWaves * (size_t)(G > 0 ? G : 1));
 }
 
-int tt_route_bucket(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t G, int32_t C,
-                    const int32_t* pad_id, int32_t pad_u, int32_t* send_ids, int32_t* send_u, int32_t* pos_u, int32_t* counts,
-                    int32_t* overflow, void* workspace, size_t workspace_bytes, tt_stream stream) {
+static int route_bucket_impl(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t G, int32_t C,
+                             const int32_t* pad_id, int32_t pad_u, int32_t* send_ids, int32_t* send_u, int32_t* pos_u, int32_t* counts,
+                             int32_t* overflow, void* workspace, size_t workspace_bytes, const int32_t* sorted_src,
+                             const int32_t* seg_offsets, int64_t* idx_slot, tt_stream stream) {
   TT_CHECK_ARG(ctx && unique_rows && n_unique && pad_id && send_ids && send_u && pos_u && counts && overflow && workspace,
                "tt_route_bucket: NULL argument");
   TT_CHECK_ARG(M >= 1 && M < ((int64_t)1 << 31) && G >= 1 && G <= TT_MAX_RANKS && C >= 1 && (int64_t)G * C < ((int64_t)1 << 31),
                "tt_route_bucket: bad M / G / C");
+  TT_CHECK_ARG(idx_slot == nullptr || (sorted_src && seg_offsets), "tt_route_bucket_expand: NULL plan arrays");
   if (workspace_bytes < tt_route_workspace_bytes(M, G)) {
     tt_set_error("tt_route_bucket: workspace %zu < required %zu", workspace_bytes, tt_route_workspace_bytes(M, G));
     return TT_ERR_WORKSPACE;
@@ -2306,12 +2390,30 @@ int tt_route_bucket(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_un
   for (int g = 0; g < G; ++g) pads.id[g] = pad_id[g];
   route_count_kernel<<<nb, kThreads, 0, st>>>(unique_rows, n_unique, (uint32_t)G, seg);
   TT_LAUNCH_CHECK();
-  route_scan_kernel<<<1, 1024, 0, st>>>(seg, nb * kRouteWaves, (uint32_t)G, (uint32_t)C, counts, overflow);
+  route_scatter_kernel<<<nb, kThreads, 0, st>>>(unique_rows, n_unique, (uint32_t)G, (uint32_t)C, seg, counts, overflow, pads, pad_u, send_ids,
+                                                send_u, pos_u);
   TT_LAUNCH_CHECK();
-  route_scatter_kernel<<<nb, kThreads, 0, st>>>(unique_rows, n_unique, (uint32_t)G, (uint32_t)C, seg, counts, pads, pad_u, send_ids, send_u,
-                                                pos_u);
-  TT_LAUNCH_CHECK();
+  if (idx_slot != nullptr) {
+    route_expand_kernel<<<grid_for(ctx, M * 8), kThreads, 0, st>>>(sorted_src, seg_offsets, n_unique, pos_u, idx_slot);
+    TT_LAUNCH_CHECK();
+  }
   return TT_OK;
+}
+
+int tt_route_bucket(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t G, int32_t C,
+                    const int32_t* pad_id, int32_t pad_u, int32_t* send_ids, int32_t* send_u, int32_t* pos_u, int32_t* counts,
+                    int32_t* overflow, void* workspace, size_t workspace_bytes, tt_stream stream) {
+  return route_bucket_impl(ctx, unique_rows, n_unique, M, G, C, pad_id, pad_u, send_ids, send_u, pos_u, counts, overflow, workspace,
+                           workspace_bytes, nullptr, nullptr, nullptr, stream);
+}
+
+int tt_route_bucket_expand(tt_ctx* ctx, const int32_t* unique_rows, const int32_t* n_unique, int64_t M, int32_t G, int32_t C,
+                           const int32_t* pad_id, int32_t pad_u, int32_t* send_ids, int32_t* send_u, int32_t* pos_u, int32_t* counts,
+                           int32_t* overflow, void* workspace, size_t workspace_bytes, const int32_t* sorted_src,
+                           const int32_t* seg_offsets, int64_t* idx_slot, tt_stream stream) {
+  TT_CHECK_ARG(idx_slot != nullptr, "tt_route_bucket_expand: NULL idx_slot");
+  return route_bucket_impl(ctx, unique_rows, n_unique, M, G, C, pad_id, pad_u, send_ids, send_u, pos_u, counts, overflow, workspace,
+                           workspace_bytes, sorted_src, seg_offsets, idx_slot, stream);
 }
 
 int tt_gather_rows(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const int32_t* rows, int64_t n, void* out,

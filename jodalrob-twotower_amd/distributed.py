@@ -158,8 +158,8 @@ class HipBackend:
             raise ValueError("local_plan: table_rows (the global row count) is required above the keyed plan's batch limit")
         return ops.dedup_plan(rows, table_rows)
 
-    def route_bucket(self, plan, G: int, C: int, pad_id: Sequence[int], pad_u: int, overflow: torch.Tensor):
-        return ops.route_bucket(plan, G, C, pad_id, pad_u, overflow)
+    def route_bucket(self, plan, G: int, C: int, pad_id: Sequence[int], pad_u: int, overflow: torch.Tensor, expand: bool = False):
+        return ops.route_bucket(plan, G, C, pad_id, pad_u, overflow, expand)
 
     def new_flag(self, device) -> torch.Tensor:
         return torch.zeros(1, dtype=torch.int32, device=device)
@@ -406,7 +406,11 @@ class PaddedRowExchange(RowExchange):
         pads = [self.local_rows_of(g) for g in range(G)]
         if self._overflow is None:
             self._overflow = be.new_flag(rows.device)
-        send_ids, send_u, pos_u, _counts = be.route_bucket(plan, G, self.C, pads, -1, self._overflow)
+        idx_slot = None
+        if isinstance(be, HipBackend):       # routing and the slots' bucket positions from one launch
+            send_ids, send_u, pos_u, _counts, idx_slot = be.route_bucket(plan, G, self.C, pads, -1, self._overflow, expand=True)
+        else:
+            send_ids, send_u, pos_u, _counts = be.route_bucket(plan, G, self.C, pads, -1, self._overflow)
         recv_ids = self._a2a_equal(send_ids)                                     # [G*C] local row ids, pad = my local_rows
         # bf16 tower inputs (mlp_dtype="bf16"): the rows are rounded where they are gathered instead of where they are
         # placed -- the same bits in x, half the bytes on the wire
@@ -414,7 +418,7 @@ class PaddedRowExchange(RowExchange):
         pooled_local = be.gather_rows(self.store.weight, recv_ids, wire)         # pads clamp to the last row (unused)
         buf = self._rows_buffer(pooled_local)
         self._a2a_equal(pooled_local, buf[:G * self.C])                          # [G*C, E] in my send order (+ the zero row)
-        be.place_rows(buf, be.route_expand(plan, pos_u), sides, B)
+        be.place_rows(buf, idx_slot if idx_slot is not None else be.route_expand(plan, pos_u), sides, B)
         if not want_grad:
             return None
         return {"plan": plan, "send_u": send_u, "owner_plan": be.owner_plan(recv_ids, self.store.local_rows, G), "padded": True}

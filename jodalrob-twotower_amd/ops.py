@@ -724,10 +724,11 @@ def batch_ingest_store(pairs, sides: Sequence[LookupSide], stores: Sequence[Stor
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU routing
-def route_bucket(plan: DedupPlan, G: int, C: int, pad_id: Sequence[int], pad_u: int, overflow: torch.Tensor):
+def route_bucket(plan: DedupPlan, G: int, C: int, pad_id: Sequence[int], pad_u: int, overflow: torch.Tensor, expand: bool = False):
     """Distinct rows of `plan` -> fixed-capacity owner buckets.  Returns (send_ids [G*C] i32, send_u [G*C] i32,
     pos_u [M] i32, counts [G] i32) -- all on the device, no host sync; `overflow` (int32 [1], caller-owned, sticky)
-    is set to 1 when a bucket needed more than C entries."""
+    is set to 1 when a bucket needed more than C entries.  expand: also idx_slot [M] int64 = pos_u[u(slot)] as a fifth
+    result (tt_route_bucket_expand: route_expand's output from the same launch)."""
     dev, M = plan.unique_rows.device, plan.M
     buf = torch.empty(2 * G * C + M + G, dtype=torch.int32, device=dev)
     send_ids, send_u = buf[:G * C], buf[G * C:2 * G * C]
@@ -735,6 +736,14 @@ def route_bucket(plan: DedupPlan, G: int, C: int, pad_id: Sequence[int], pad_u: 
     lib = L.load()
     ws = L.workspace(dev, lib.tt_route_workspace_bytes(M, G))
     pads = (L.i32 * G)(*[int(p) for p in pad_id])
+    if expand:
+        idx = torch.empty(M, dtype=torch.int64, device=dev)
+        with _timed("tt_route_bucket_expand"):
+            L.check(lib.tt_route_bucket_expand(L.ctx(dev), L.ptr(plan.unique_rows), L.ptr(plan.n_unique), M, G, C, pads, pad_u, L.ptr(send_ids),
+                                               L.ptr(send_u), L.ptr(pos_u), L.ptr(counts), L.ptr(overflow), L.ptr(ws), ws.numel(),
+                                               L.ptr(plan.sorted_src), L.ptr(plan.seg_offsets), L.ptr(idx), L.stream(dev)),
+                    "tt_route_bucket_expand")
+        return send_ids, send_u, pos_u, counts, idx
     with _timed("tt_route_bucket"):
         L.check(lib.tt_route_bucket(L.ctx(dev), L.ptr(plan.unique_rows), L.ptr(plan.n_unique), M, G, C, pads, pad_u, L.ptr(send_ids),
                                     L.ptr(send_u), L.ptr(pos_u), L.ptr(counts), L.ptr(overflow), L.ptr(ws), ws.numel(), L.stream(dev)),

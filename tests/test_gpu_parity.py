@@ -238,8 +238,12 @@ def test_lookup_bit_exact(tt, E, B, out_dtype):
 @pytest.mark.parametrize("M,table_rows,dist", [(1, 10, "uniform"), (4096, 200, "uniform"), (4097, 70000, "uniform"),
                                                 (100000, 2_000_000, "uniform"), (50000, 14_000_000, "zipf"),
                                                 (30000, 3, "uniform"), (20000, 1 << 25, "zipf")])
-def test_dedup_plan_bit_exact(tt, M, table_rows, dist):
+@pytest.mark.parametrize("chained", [1, 0])
+def test_dedup_plan_bit_exact(tt, ctx_option, M, table_rows, dist, chained):
+    """chained: the segment heads as one launch whose tiles chain their counts through the context's buffer (TT_OPT_CHAINED,
+    default) / as count + write launches."""
     from jodalrob_twotower_amd import ops
+    ctx_option(_L.TT_OPT_CHAINED, chained, 1)
     rng = np.random.default_rng(M + table_rows)
     if dist == "uniform":
         rows = rng.integers(0, table_rows, M)
@@ -1365,11 +1369,13 @@ def test_adam_fused_equals_separate_launches(tt, manifest, monkeypatch):
         assert np.array_equal(v, finals[1][k]), k
 
 
+@pytest.mark.parametrize("chained", [1, 0])
 @pytest.mark.parametrize("G,C,rows_max", [(1, 5000, 100000), (3, 777, 2000), (8, 12345, 250000), (4, 1, 3)])
-def test_dedup_plan_runs_equals_general(tt, G, C, rows_max):
+def test_dedup_plan_runs_equals_general(tt, ctx_option, G, C, rows_max, chained):
     """tt_dedup_plan_runs (stable merge of G ascending runs, as an owner receives them: distinct ascending ids, pads = the
     largest value at the end) == tt_dedup_plan over the concatenation == numpy's stable argsort, bit for bit."""
     from jodalrob_twotower_amd import ops
+    ctx_option(_L.TT_OPT_CHAINED, chained, 1)
     rng = np.random.default_rng(G * 1000 + C)
     runs = []
     for g in range(G):
@@ -1492,15 +1498,21 @@ def test_full_size_step_is_reproducible(tt, schema_real, tmp_path):
 
 
 @pytest.mark.parametrize("G,M,U,C", [(1, 5000, 4000, 4096), (2, 70000, 65000, 40000), (3, 10000, 9999, 3000), (8, 311296, 65731, 12288),
-                                     (64, 9000, 9000, 256), (5, 4097, 0, 16), (4, 6000, 6000, 1000)])
-def test_route_bucket_and_expand(tt, G, M, U, C):
+                                     (64, 9000, 9000, 256), (5, 4097, 0, 16), (4, 6000, 6000, 1000), (8, 400000, 200000, 30000)])
+@pytest.mark.parametrize("chained", [1, 0])
+def test_route_bucket_and_expand(tt, ctx_option, G, M, U, C, chained):
     """tt_route_bucket / tt_route_expand against a plain numpy routing: stable order inside every owner's bucket, pads,
-    counts, the overflow flag (last case: capacity too small), and the slot -> bucket-position map."""
+    counts, the overflow flag (capacity too small in one case), and the slot -> bucket-position map; tt_route_bucket_expand gives
+    all of it from one call (run twice).  One synthetic plan row has 3000 slots (a hot row).  (chained: TT_OPT_CHAINED only
+    concerns the plans' head pass; the routing launches are the same.)"""
     from jodalrob_twotower_amd import ops
+    ctx_option(_L.TT_OPT_CHAINED, chained, 1)
     rng = np.random.default_rng(G * 7 + M)
     uniq = np.sort(rng.choice(5_000_000, size=U, replace=False)).astype(np.int32)
     # a synthetic plan: U distinct ascending rows, every slot assigned to one of them
     slot_u = np.concatenate([np.arange(U), rng.integers(0, max(U, 1), M - U)]) if U else np.zeros(0, np.int64)
+    if U and M - U > 3000:
+        slot_u[U:U + 3000] = U // 2                                        # a hot row
     if U:
         rng.shuffle(slot_u)
         order = np.argsort(slot_u, kind="stable").astype(np.int32)
@@ -1528,6 +1540,11 @@ def test_route_bucket_and_expand(tt, G, M, U, C):
     if U:
         idx = ops.route_expand(plan, pos_u).cpu().numpy()
         assert np.array_equal(idx, e_pos[slot_u].astype(np.int64))
+        for _ in range(2):
+            flag2 = torch.zeros(1, dtype=torch.int32, device=DEV)
+            s2, u2, p2, c2, idx2 = ops.route_bucket(plan, G, C, pads, -1, flag2, expand=True)
+            assert torch.equal(s2, send_ids) and torch.equal(u2, send_u) and torch.equal(p2[:U], pos_u[:U]) and torch.equal(c2, counts)
+            assert flag2.item() == flag.item() and np.array_equal(idx2.cpu().numpy(), idx)
 
 
 class _ThreadComm:
