@@ -176,6 +176,13 @@ class HipBackend:
         order); the pad value `local_rows` groups into one (last) row that is left out of the plan's row count"""
         return ops.dedup_plan_runs(recv_ids, G, recv_ids.numel() // G, local_rows)
 
+    def reduce_into_buckets(self, plan, pos_u: torch.Tensor, srcs, B: int, E: int, n_rows: int, counters=None) -> torch.Tensor:
+        """[n_rows, E] f32: row pos_u[u] = summed gradient of plan row u; the other rows are not written"""
+        import dataclasses
+        out = torch.empty((n_rows, E), dtype=torch.float32, device=pos_u.device)
+        ops.embed_grad(dataclasses.replace(plan, unique_rows=pos_u), srcs, B, E, ops.TT_GRAD_DENSE_SET, out, counters=counters)
+        return out
+
     def reduce_local(self, plan, srcs, B: int, E: int, counters=None) -> torch.Tensor:
         """[M, E]: row u = summed gradient of plan row u (unused bucket entries carry u = -1: gather_rows gives them zeros)"""
         out = torch.empty((max(plan.M, 1), E), dtype=torch.float32, device=plan.unique_rows.device)
@@ -352,15 +359,21 @@ class PaddedRowExchange(RowExchange):
             return
         if self._flag_host is None:
             self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-            self._flag_event = torch.cuda.Event()
+            self._flag_event, self._flag_mark = torch.cuda.Event(), torch.cuda.Event()
+            self._flag_stream = torch.cuda.Stream(device=self._overflow.device)
         if self._flag_pending and self._flag_event.query():
             self._flag_pending = False
             if int(self._flag_host[0]) != 0:
                 raise ExchangeOverflowError(f"fixed-capacity exchange: a bucket needed more than C = {self.C} rows (rank {self.rank}) "
                                             f"within the last {self.poll_lag} steps")
         if not self._flag_pending:
-            self._flag_host.copy_(self._overflow, non_blocking=True)
-            self._flag_event.record()
+            # the copy runs on its own stream behind a marker of the work issued so far: the next step's launches do not queue
+            # behind a device-to-host transfer (5 us per step on the training stream before round 3)
+            self._flag_mark.record()
+            with torch.cuda.stream(self._flag_stream):
+                self._flag_stream.wait_event(self._flag_mark)
+                self._flag_host.copy_(self._overflow, non_blocking=True)
+                self._flag_event.record()
             self._flag_pending = True
 
     def _a2a_equal(self, send: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -421,15 +434,23 @@ class PaddedRowExchange(RowExchange):
         be.place_rows(buf, idx_slot if idx_slot is not None else be.route_expand(plan, pos_u), sides, B)
         if not want_grad:
             return None
-        return {"plan": plan, "send_u": send_u, "owner_plan": be.owner_plan(recv_ids, self.store.local_rows, G), "padded": True}
+        return {"plan": plan, "send_u": send_u, "pos_u": pos_u, "owner_plan": be.owner_plan(recv_ids, self.store.local_rows, G), "padded": True}
 
     def backward(self, state, srcs, B: int):
         be = self.backend
-        grad_u = be.reduce_local(state["plan"], srcs, B, self.E, self.store.grad_counters())      # one row per distinct row (+ a zero row)
-        # opt-in (TT_DIST_GRAD_WIRE_BF16=1 / grad_wire_bf16): the per-rank row sums travel as bf16 and are added in f32 by
-        # their owner -- half the bytes of the step's largest message, at 2^-9 relative rounding per contribution
+        # opt-in (grad_wire_bf16): the per-rank row sums travel as bf16 and are added in f32 by their owner -- half the bytes of
+        # the step's largest message, at 2^-9 relative rounding per contribution
         wire = torch.bfloat16 if (self.grad_wire_bf16 and self.E % 8 == 0) else torch.float32
-        d_rows = self._a2a_equal(be.gather_rows(grad_u, state["send_u"], wire))  # to the owners, pads carry zeros
+        if isinstance(be, HipBackend) and wire == torch.float32 and state.get("pos_u") is not None:
+            # the local reduction writes every distinct row's sum straight at its bucket position (the reduction's dense-set mode
+            # with the bucket positions as its row indices): no [M, E] intermediate, no gather launch.  Unused bucket entries keep
+            # whatever the buffer held: their ids are pads, which the owner's plan leaves out of its row count -- never read.
+            # Rows that did not fit all land on the spare row behind the buckets (the step is rejected anyway).
+            send = be.reduce_into_buckets(state["plan"], state["pos_u"], srcs, B, self.E, self.world * self.C + 1, self.store.grad_counters())
+            d_rows = self._a2a_equal(send[:self.world * self.C])
+        else:
+            grad_u = be.reduce_local(state["plan"], srcs, B, self.E, self.store.grad_counters())  # one row per distinct row (+ a zero row)
+            d_rows = self._a2a_equal(be.gather_rows(grad_u, state["send_u"], wire))               # to the owners, pads carry zeros
         be.owner_accumulate(self.store, state["owner_plan"], d_rows, self.world)
 
 
