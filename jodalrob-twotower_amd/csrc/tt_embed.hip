@@ -439,12 +439,14 @@ __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __
 // All workgroups of these grids are resident at once (<= 2048 of 256 threads) and dispatched in index order, so a predecessor is
 // always running or done; the poll is bounded all the same -- a buffer left dirty by an aborted launch must not hang the device
 // (`stuck` then makes the caller-visible result invalid instead: n_unique = -1).
+// (relaxed agent-scope atomics: the word itself is all that travels, and nothing else has to become visible with it -- an acquire
+//  load per poll invalidates the XCD's caches every time: 72 us for 608 tiles against 24 us for the two launches it replaced)
 __device__ __forceinline__ void chain_publish(uint32_t* slot, uint32_t v) {
-  __hip_atomic_store(slot, v | kChainReady, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(slot, v | kChainReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ uint32_t chain_wait(const uint32_t* slot, bool& stuck) {
   for (int spin = 0; spin < (1 << 22); ++spin) {
-    const uint32_t v = __hip_atomic_load(slot, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v & kChainReady) return v & ~kChainReady;
     __builtin_amdgcn_s_sleep(1);
   }

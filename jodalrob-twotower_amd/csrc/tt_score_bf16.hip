@@ -1244,6 +1244,84 @@ __global__ __launch_bounds__(256) void pack_fp8_kernel(PackBatch batch, int D, i
   }
 }
 
+
+// The same three images from ONE read of X: a workgroup stages 64 rows (a tile pair) in LDS -- coalesced, 16 bytes per lane -- and
+// every thread then assembles 16-byte chunks of the images from there.  pack_fp8_kernel reads X once per image, the rows image
+// with 64 different rows per wave-instruction (536 MB of traffic for 134 MB of input at B = 65536, D = 256: 179 us).  Same
+// arithmetic per element: bit-identical images (tests compare the packed buffers with torch's conversion).
+constexpr int kPackTileRows = 64, kPackPad = 4;
+__global__ __launch_bounds__(256) void pack_fp8_tile_kernel(PackBatch batch, int D, int Dp) {
+  extern __shared__ __attribute__((aligned(16))) float xt[];          // [64][Dp + 4]
+  const PackArgs& pa = batch.a[blockIdx.y];
+  const float* __restrict__ X = pa.X;
+  const int64_t R = pa.R, Rp = pa.Rp;
+  const int64_t P = blockIdx.x;
+  if (P * kPackTileRows >= Rp) return;
+  char* __restrict__ rows8 = reinterpret_cast<char*>(pa.rows);
+  __bf16* __restrict__ frag = pa.frag;
+  char* __restrict__ frag8 = reinterpret_cast<char*>(frag) + Rp * Dp * 2;
+  const float sc = pa.scale;
+  const int ld = Dp + kPackPad, tid = threadIdx.x;
+  // stage: rows 64 P .. 64 P + 63, columns [0, Dp); zero outside [0, R) x [0, D)
+  if (D == Dp && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    const int per_row = Dp / 4;
+    for (int e = tid; e < kPackTileRows * per_row; e += 256) {
+      const int r = e / per_row, c4 = e - r * per_row;
+      const int64_t row = P * kPackTileRows + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < R) v = reinterpret_cast<const float4*>(X + row * D)[c4];
+      *reinterpret_cast<float4*>(xt + r * ld + 4 * c4) = v;
+    }
+  } else {
+    for (int e = tid; e < kPackTileRows * Dp; e += 256) {
+      const int r = e / Dp, c = e - r * Dp;
+      const int64_t row = P * kPackTileRows + r;
+      xt[r * ld + c] = (row < R && c < D) ? X[row * D + c] : 0.f;
+    }
+  }
+  __syncthreads();
+  // fp8 rows image: tiles 2 P, 2 P + 1; chunk w of a tile = (row w & 31, group w >> 5)
+  const int cpt = Dp * 2;
+  for (int e = tid; e < 2 * cpt; e += 256) {
+    const int t = e / cpt, w = e - t * cpt, row_in = w & 31, g5 = w >> 5;
+    const int d0 = 64 * (g5 >> 2) + 32 * (g5 & 1) + 16 * ((g5 >> 1) & 1);
+    const float* src = xt + (32 * t + row_in) * ld + d0;
+    i32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+      int u = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(v.x * sc * kFp8Up), fp8_clamp(v.y * sc * kFp8Up), 0, false);
+      u = __builtin_amdgcn_cvt_pk_fp8_f32(fp8_clamp(v.z * sc * kFp8Up), fp8_clamp(v.w * sc * kFp8Up), u, true);
+      o[q] = u;
+    }
+    *reinterpret_cast<i32x4*>(rows8 + ((2 * P + t) * cpt + w) * 16) = o;
+  }
+  // bf16 fragment image [t][s][h][d][8]
+  for (int e = tid; e < 8 * Dp; e += 256) {
+    const int d = e % Dp, rest = e / Dp, h = rest & 1, s2 = (rest >> 1) & 1, t = rest >> 2;
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(xt[(32 * t + 16 * s2 + 8 * (j >> 2) + 4 * h + (j & 3)) * ld + d] * sc);
+    *reinterpret_cast<bf16x8*>(frag + ((((2 * P + t) * 2 + s2) * 2 + h) * Dp + d) * 8) = v;
+  }
+  // fp8 fragment image [P][d][part][h][c][16]
+  for (int e = tid; e < 4 * Dp; e += 256) {
+    const int c = e & 31, h = (e >> 5) & 1, part = (e >> 6) & 1, d = e >> 7;
+    const int col = 32 * d + c;
+    i32x4 o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fp8_clamp(xt[(32 * part + rowmap(4 * q + j, h)) * ld + col] * sc * kFp8Up);
+      int u = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+      u = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], u, true);
+      o[q] = u;
+    }
+    *reinterpret_cast<i32x4*>(frag8 + (P * (Dp * 4) + e) * 16) = o;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1422,6 +1500,15 @@ int tt_score_pack2_fp8(tt_ctx* ctx, const float* X0, int64_t R0, void* packed0, 
     b.a[i] = PackArgs{i ? X1 : X0, R, Rp, reinterpret_cast<__bf16*>(base), reinterpret_cast<__bf16*>(base + Rp * Dp), sc == 0.f ? 1.f : sc};
     const int64_t chunks = 2 * (Rp * Dp / 16) + Rp * Dp / 8;
     maxchunks = chunks > maxchunks ? chunks : maxchunks;
+  }
+  int64_t maxRp = 0;
+  for (int i = 0; i < n; ++i) maxRp = b.a[i].Rp > maxRp ? b.a[i].Rp : maxRp;
+  if (maxRp >= 4096) {                                   // enough tile pairs to fill the chip: one read of X through LDS
+    const size_t lds = (size_t)kPackTileRows * (Dp + kPackPad) * sizeof(float);
+    TT_LDS_ONCE(lds, &pack_fp8_tile_kernel);
+    pack_fp8_tile_kernel<<<dim3((unsigned)(maxRp / kPackTileRows), (unsigned)n), 256, lds, reinterpret_cast<hipStream_t>(stream)>>>(b, D, Dp);
+    TT_LAUNCH_CHECK();
+    return TT_OK;
   }
   int64_t grid = tt_cdiv(maxchunks, 256);
   const int64_t cap = (int64_t)ctx->num_cus * 4;

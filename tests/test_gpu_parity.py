@@ -2002,6 +2002,36 @@ def _unpack_fp8_frag(buf, R, D):
     return out[:R]
 
 
+def _unpack_bf16_frag(buf, R, D):
+    """[R, Dp] float32 view of the bf16 fragment image of the fp8 packing: [tile][s][h][d][8], element j of a chunk = row
+    32 t + 16 s + 8 (j >> 2) + 4 h + (j & 3), column d"""
+    Rp, Dp = (R + 63) // 64 * 64, (64 if D <= 64 else (128 if D <= 128 else 256))
+    raw = buf[Rp * Dp:3 * Rp * Dp].view(torch.bfloat16).float().cpu().numpy().reshape(Rp // 32, 2, 2, Dp, 2, 4)
+    # axes: t, s, h, d, j >> 2, j & 3  ->  row = 32 t + 16 s + 8 (j >> 2) + 4 h + (j & 3)
+    return raw.transpose(0, 1, 4, 2, 5, 3).reshape(Rp, Dp)[:R]
+
+
+@pytest.mark.parametrize("B,D", [(4096, 256), (4100, 200), (5000, 64), (8192, 128)])
+def test_fp8_pack_large_batches(tt, B, D):
+    """tt_score_pack2_fp8 from 4096 rows on (pack_fp8_tile_kernel: 64 rows staged in LDS, ONE read of the operand for the three
+    images): every image == torch's conversion of the same scaled values, element for element -- rows image and fp8 fragment
+    image against float8_e4m3fn of clamp(64 s x), bf16 fragment image against bfloat16 of s x; ragged row count, a width that is
+    not its padded width (zero columns), two operands with different scales in one launch."""
+    from jodalrob_twotower_amd import ops
+    g = torch.Generator().manual_seed(B + D)
+    x0 = torch.randn(B, D, generator=g) * 0.3
+    x1 = torch.randn(B, D, generator=g) * 0.1
+    s0, s1 = 1.4375, 1.0
+    p0, p1 = ops.score_pack2_fp8(x0.to(DEV), x1.to(DEV), s0, s1)
+    for x, sc, p in ((x0, s0, p0), (x1, s1, p1)):
+        w8 = (x * np.float32(sc) * 64.0).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).float().numpy()
+        w16 = (x * np.float32(sc)).to(torch.bfloat16).float().numpy()
+        Dp = 64 if D <= 64 else (128 if D <= 128 else 256)
+        r8, f8, f16 = _unpack_fp8_rows(p, B, D), _unpack_fp8_frag(p, B, D), _unpack_bf16_frag(p, B, D)
+        assert np.array_equal(r8[:, :D], w8) and np.array_equal(f8[:, :D], w8) and np.array_equal(f16[:, :D], w16)
+        assert not r8[:, D:Dp].any() and not f8[:, D:Dp].any() and not f16[:, D:Dp].any()
+
+
 @pytest.mark.parametrize("fp8_grad", [1, 0])
 @pytest.mark.parametrize("B,D,T", [(300, 64, 1.0), (513, 256, 1.0), (1000, 128, 0.5), (70, 200, 2.0), (2048, 256, 1.0), (1000, 256, 0.05)])
 def test_score_fp8_vs_rounded_oracle(tt, ctx_option, B, D, T, fp8_grad):
