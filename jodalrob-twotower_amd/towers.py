@@ -403,7 +403,7 @@ class _TowersFn(torch.autograd.Function):
             g.d_x = d_x.data_ptr()
             g.d_y = base + 4 * offs[len(dps) + 1 + len(hid)]
             prepared.append((s, d_emb, g))
-            if _DEBUG_KEEP is not None:      # tools/tail_diff.py: keep the backward scratch for inspection
+            if _DEBUG_KEEP is not None:      # tests/debug/tail_diff.py: keep the backward scratch for inspection
                 _DEBUG_KEEP.append({"buf": buf, "offs": offs, "n_dense": len(dps), "hidden": hid, "B": B, "acts": s.buf, "emb": s.emb,
                                     "d_emb": d_emb})
             for i, v in enumerate(views):

@@ -3,7 +3,7 @@ kernel that reads memory nobody wrote shows up as a wrong / NaN result.  POISON_
 import os, sys, json, faulthandler, traceback
 from pathlib import Path
 faulthandler.enable()
-root = Path(__file__).resolve().parents[2]
+root = Path(__file__).resolve().parents[2]   # tests/debug/ -> the repository
 sys.path.insert(0, str(root)); sys.path.insert(0, str(root / "tests")); sys.path.insert(0, str(root / "oracle"))
 import torch
 import numpy as np

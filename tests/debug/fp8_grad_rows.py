@@ -1,3 +1,4 @@
+# Debugging aid (round 3, fp8 gradient products): per-row error of the fp8 score backward against its oracle model.  Run from the repository root on the GPU box.
 import sys, numpy as np, torch
 sys.path.insert(0, '.')
 import importlib

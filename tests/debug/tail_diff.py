@@ -4,7 +4,7 @@ import json, os, sys
 from pathlib import Path
 import numpy as np
 import torch
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "oracle"))   # params_init: seeded test inputs only
 import jodalrob_twotower_amd as tt
 from params_init import init_state_numpy, synth_batch_numpy
