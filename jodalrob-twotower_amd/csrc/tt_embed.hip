@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __
 // chained aggregates (tt_common.h: tt_ctx::chain): a workgroup's value with the ready bit; a reader polls until the bit shows.
 // All workgroups of these grids are resident at once (<= 2048 of 256 threads) and dispatched in index order, so a predecessor is
 // always running or done; the poll is bounded all the same -- a buffer left dirty by an aborted launch must not hang the device
-// (`stuck` then makes the caller-visible result invalid instead: n_unique = -1).
+// (`stuck` then leaves an EMPTY plan, n_unique = 0: wrong results, but no consumer indexes anything with it).
 // (relaxed agent-scope atomics: the word itself is all that travels, and nothing else has to become visible with it -- an acquire
 //  load per poll invalidates the XCD's caches every time: 72 us for 608 tiles against 24 us for the two launches it replaced)
 __device__ __forceinline__ void chain_publish(uint32_t* slot, uint32_t v) {
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(kThreads) void head_chained_kernel(const uint32_t* 
   }
   if (blockIdx.x == nblk - 1 && tid == 0) {              // (drop_from: see head_write_kernel)
     const uint32_t all = before + total;
-    n_unique[0] = s_stuck ? -1 : (int32_t)(all - ((M > 0 && keys[M - 1] >= drop_from) ? 1u : 0u));
+    n_unique[0] = s_stuck ? 0 : (int32_t)(all - ((M > 0 && keys[M - 1] >= drop_from) ? 1u : 0u));   // (stuck: an empty plan reads nothing)
     seg_offsets[all] = (int32_t)M;
   }
   // everybody's reads of the chain are done once every tile has been here: the last one leaves the buffer all-zero
