@@ -77,7 +77,12 @@ struct SymStage {
   static_assert(LPT >= 1 && LPT * kSymThreads * 16 == kBytes, "stage must be whole 16-byte loads");
 };
 
-template <int KS, bool UNIT, bool FP8>
+// JT company tiles per wave (fp8, D = 256: 2).  With one tile per wave and one notice tile per stage a wave meets a workgroup
+// barrier every 32 x 32 tile and waits 35 % of its life (profiles/r03_pmc_configs4_fp8.json); with two, a stage's fragments feed two
+// MFMA chains, the barriers and stage copies per score halve, and the slab of row partials has half the rows.  The two tiles'
+// row partials are added (and their maxima joined) in registers before the slot is written: tiles J0, J0 + 1 lie on the same
+// side of the positives of every notice tile but their own.
+template <int KS, bool UNIT, bool FP8, int JT>
 __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
   using ST = SymStage<KS, FP8>;
   constexpr int TS = ST::TS, LPT = ST::LPT, kTileB = ST::kTileB, K64 = FP8 ? KS / 4 : 1;
@@ -91,22 +96,30 @@ __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
   float* s_mb = lds + (1 * kSymWaves + wave) * slots;
   float* s_ma = lds + (2 * kSymWaves + wave) * slots;
   char* stage = reinterpret_cast<char*>(lds + 3 * kSymWaves * slots);
-  const int J = (int)blockIdx.x * kSymWaves + wave;        // this wave's company tile
+  const int J0 = ((int)blockIdx.x * kSymWaves + wave) * JT;  // this wave's company tiles J0 .. J0 + JT - 1
   const int I0 = (int)blockIdx.y * NI, I1 = min(I0 + NI, nT);
-  const bool active = J < nT;
+  const bool active = J0 < nT;
   for (int i = lane; i < slots; i += 64) { s_sum[i] = 0.f; s_mb[i] = kNegBig; s_ma[i] = kNegBig; }
   const float c1 = g.c1, c2 = g.c2;
   auto ex = [&](float x) { return UNIT ? __builtin_amdgcn_exp2f(x) : __builtin_amdgcn_exp2f(__builtin_fmaf(x, c1, c2)); };
-  float colacc[16];
+  float colacc[JT][16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) colacc[r] = 0.f;
-  bf16x8 bres[FP8 ? 1 : KS];
-  i32x8 bres8[K64];
-  if (FP8) load_f8frag<K64>(reinterpret_cast<const char*>(g.b_rows), active ? J : 0, c, h, bres8);
-  else load_bfrag<(FP8 ? 1 : KS)>(reinterpret_cast<const __bf16*>(g.b_rows), active ? J : 0, c, h, bres);
+  for (int j = 0; j < JT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) colacc[j][r] = 0.f;
+  bf16x8 bres[JT][FP8 ? 1 : KS];
+  i32x8 bres8[JT][K64];
   const int n_full = R / 32;                               // tiles below n_full hold 32 valid rows
-  const bool jfull = active && J < n_full;
-  float dg_keep = kNegBig;                                 // the positives of tile J (met once per wave, if J is in this chunk)
+  bool jact[JT], jfull[JT];
+  float dg_keep[JT];                                       // the positives of tile J (met once per wave, if J is in this chunk)
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    jact[j] = J0 + j < nT;
+    jfull[j] = jact[j] && J0 + j < n_full;
+    dg_keep[j] = kNegBig;
+    if (FP8) load_f8frag<K64>(reinterpret_cast<const char*>(g.b_rows), jact[j] ? J0 + j : 0, c, h, bres8[j]);
+    else load_bfrag<(FP8 ? 1 : KS)>(reinterpret_cast<const __bf16*>(g.b_rows), jact[j] ? J0 + j : 0, c, h, bres[j]);
+  }
   // stage loader: thread t copies bytes [16 t, 16 t + 16) (+ 8 KB per further load) of the stage's tiles; tiles past the
   // image's end are clamped to its last tile (their results are never used)
   const int nst = (I1 - I0 + TS - 1) / TS;
@@ -139,78 +152,95 @@ __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
       for (int tl = 0; tl < TS; ++tl) {
         const int I = I0 + st * TS + tl;
         // the tile's fragments in one burst of LDS reads (left to itself hipcc reads two, waits, issues two MFMAs, reads two
-        // ...: at D = 256 every second MFMA then pays a full LDS round trip), the MFMA chain behind counted lgkmcnt waits
-        f32x16 acc;
+        // ...: at D = 256 every second MFMA then pays a full LDS round trip), the MFMA chains behind counted lgkmcnt waits
+        f32x16 acc[JT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int j = 0; j < JT; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         if (FP8) {
           i32x8 af8[K64];
           load_f8frag<K64>(sb, tl, c, h, af8);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int s = 0; s < K64; ++s) acc = mfma_f8(bres8[s], af8[s], acc);
+          for (int s = 0; s < K64; ++s)
+#pragma unroll
+            for (int j = 0; j < JT; ++j) acc[j] = mfma_f8(bres8[j][s], af8[s], acc[j]);
         } else {
           bf16x8 af[FP8 ? 1 : KS];
 #pragma unroll
           for (int s = 0; s < (FP8 ? 1 : KS); ++s) af[s] = *reinterpret_cast<const bf16x8*>(sb + (((tl * KS + s) * 2 + h) * 32 + c) * 16);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int s = 0; s < (FP8 ? 1 : KS); ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bres[s], af[s], acc, 0, 0, 0);
+          for (int s = 0; s < (FP8 ? 1 : KS); ++s)
+#pragma unroll
+            for (int j = 0; j < JT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bres[j][s], af[s], acc[j], 0, 0, 0);
         }
         const int il = (I - I0) * 32 + c;
-        if (I < I1 && I != J && I < n_full && jfull) {     // plain tile: 32 x 32 valid scores, all on one side of the positives
-          float e[16];
+        float rs_tot = 0.f, xb_tot = kNegBig, xa_tot = kNegBig;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) e[r] = ex(acc[r]);
+        for (int j = 0; j < JT; ++j) {
+          const int J = J0 + j;
+          if (I < I1 && I != J && I < n_full && jfull[j]) {  // plain tile: 32 x 32 valid scores, all on one side of the positives
+            float e[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) colacc[r] = add_asm(colacc[r], e[r]);
-          float t0 = (e[0] + e[1]) + (e[2] + e[3]), t1 = (e[4] + e[5]) + (e[6] + e[7]);
-          float t2 = (e[8] + e[9]) + (e[10] + e[11]), t3 = (e[12] + e[13]) + (e[14] + e[15]);
-          const float rsum = half_sum((t0 + t1) + (t2 + t3));
-          if (g.want_rank) {
-            float m = max3_asm(acc[0], acc[1], acc[2]);
+            for (int r = 0; r < 16; ++r) e[r] = ex(acc[j][r]);
 #pragma unroll
-            for (int r = 3; r < 15; r += 2) m = max3_asm(m, acc[r], acc[r + 1]);
-            m = half_max(fmaxf(m, acc[15]));
-            if (h == 0) (J < I ? s_mb : s_ma)[il] = m;     // every b of tile J lies before (J < I) / after the positive of every a of tile I
+            for (int r = 0; r < 16; ++r) colacc[j][r] = add_asm(colacc[j][r], e[r]);
+            float t0 = (e[0] + e[1]) + (e[2] + e[3]), t1 = (e[4] + e[5]) + (e[6] + e[7]);
+            float t2 = (e[8] + e[9]) + (e[10] + e[11]), t3 = (e[12] + e[13]) + (e[14] + e[15]);
+            rs_tot += half_sum((t0 + t1) + (t2 + t3));
+            if (g.want_rank) {
+              float m = max3_asm(acc[j][0], acc[j][1], acc[j][2]);
+#pragma unroll
+              for (int r = 3; r < 15; r += 2) m = max3_asm(m, acc[j][r], acc[j][r + 1]);
+              m = half_max(fmaxf(m, acc[j][15]));
+              // every b of tile J lies before (J < I) / after the positive of every a of tile I
+              if (J < I) xb_tot = fmaxf(xb_tot, m);
+              else xa_tot = fmaxf(xa_tot, m);
+            }
+          } else if (I < I1 && jact[j]) {                  // the diagonal tile and the ragged last tiles: per element
+            const int a = 32 * I + c;
+            float rsum = 0.f, xb = kNegBig, xa = kNegBig, dg = kNegBig;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int b = 32 * J + rowmap(r, h);
+              const float x = acc[j][r];
+              const bool valid = b < R && a < R;
+              const float e = valid ? ex(x) : 0.f;
+              colacc[j][r] += e;
+              rsum += e;
+              xb = (valid && b < a) ? fmaxf(xb, x) : xb;
+              xa = (valid && b > a) ? fmaxf(xa, x) : xa;
+              dg = (b == a) ? x : dg;
+            }
+            rs_tot += half_sum(rsum);
+            xb_tot = fmaxf(xb_tot, half_max(xb));
+            xa_tot = fmaxf(xa_tot, half_max(xa));
+            dg = half_max(dg);
+            if (I == J) dg_keep[j] = dg;                   // taken from the MFMA result itself, so ties compare bit for bit
           }
-          if (h == 0) s_sum[il] = rsum;
-        } else if (I < I1) {                               // the diagonal tile and the ragged last tiles: per element
-          const int a = 32 * I + c;
-          float rsum = 0.f, xb = kNegBig, xa = kNegBig, dg = kNegBig;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int b = 32 * J + rowmap(r, h);
-            const float x = acc[r];
-            const bool valid = b < R && a < R;
-            const float e = valid ? ex(x) : 0.f;
-            colacc[r] += e;
-            rsum += e;
-            xb = (valid && b < a) ? fmaxf(xb, x) : xb;
-            xa = (valid && b > a) ? fmaxf(xa, x) : xa;
-            dg = (b == a) ? x : dg;
-          }
-          rsum = half_sum(rsum);
-          xb = half_max(xb);
-          xa = half_max(xa);
-          dg = half_max(dg);
-          if (h == 0) { s_sum[il] = rsum; s_mb[il] = xb; s_ma[il] = xa; }
-          if (I == J) dg_keep = dg;                        // taken from the MFMA result itself, so ties compare bit for bit
         }
+        if (I < I1 && h == 0) { s_sum[il] = rs_tot; s_mb[il] = xb_tot; s_ma[il] = xa_tot; }
       }
     }
   }
   if (active) {
-    if (J >= I0 && J < I1 && h == 0 && 32 * J + c < R) g.diag_raw[32 * J + c] = dg_keep;
-    // column direction: one cross-lane reduction per sweep (fixed butterfly order), lanes c == 0 hold the 32 sums
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1)
+    for (int j = 0; j < JT; ++j) {
+      const int J = J0 + j;
+      if (!jact[j]) continue;
+      if (J >= I0 && J < I1 && h == 0 && 32 * J + c < R) g.diag_raw[32 * J + c] = dg_keep[j];
+      // column direction: one cross-lane reduction per sweep (fixed butterfly order), lanes c == 0 hold the 32 sums
 #pragma unroll
-      for (int r = 0; r < 16; ++r) colacc[r] += __shfl_xor(colacc[r], o);
-    if (c == 0) {
-      float* dst = g.cs + (int64_t)blockIdx.y * g.Rp + 32 * J;
+      for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dst[rowmap(r, h)] = colacc[r];      // (rows beyond R: slab padding, never read)
+        for (int r = 0; r < 16; ++r) colacc[j][r] += __shfl_xor(colacc[j][r], o);
+      if (c == 0) {
+        float* dst = g.cs + (int64_t)blockIdx.y * g.Rp + 32 * J;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[rowmap(r, h)] = colacc[j][r];  // (rows beyond R: slab padding, never read)
+      }
     }
   }
   __syncthreads();
@@ -461,29 +491,32 @@ static int sym_forward(tt_ctx* ctx, const void* N_packed, const void* C_packed, 
   g.diag_raw = reinterpret_cast<float*>(ws + L.off_diag);
   g.want_rank = want_rank ? 1 : 0;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  const dim3 grid((unsigned)L.n_groups, (unsigned)L.n_chunks);
+  // fp8, D = 256: two company tiles per wave (half the workgroups along J, half the slab rows)
+  const int jt = (fp8 && L.Dp == 256) ? 2 : 1;
+  const int n_groups = (int)tt_cdiv(L.nT, kSymWaves * jt);
+  const dim3 grid((unsigned)n_groups, (unsigned)L.n_chunks);
   const size_t slot_bytes = sizeof(float) * 3 * kSymWaves * L.NI * 32;
-#define TT_SYM(KS, F8)                                                                                                  \
+#define TT_SYM(KS, F8, JT_)                                                                                             \
   do {                                                                                                                  \
     const size_t lds = slot_bytes + 2 * SymStage<KS, F8>::kBytes;                                                       \
-    if (unit) score_fwd_sym_kernel<KS, true, F8><<<grid, kSymThreads, lds, st>>>(g);                                    \
-    else score_fwd_sym_kernel<KS, false, F8><<<grid, kSymThreads, lds, st>>>(g);                                        \
+    if (unit) score_fwd_sym_kernel<KS, true, F8, JT_><<<grid, kSymThreads, lds, st>>>(g);                               \
+    else score_fwd_sym_kernel<KS, false, F8, JT_><<<grid, kSymThreads, lds, st>>>(g);                                   \
   } while (0)
   if (fp8) {
-    if (L.Dp == 64) TT_SYM(4, true);
-    else if (L.Dp == 128) TT_SYM(8, true);
-    else TT_SYM(16, true);
+    if (L.Dp == 64) TT_SYM(4, true, 1);
+    else if (L.Dp == 128) TT_SYM(8, true, 1);
+    else TT_SYM(16, true, 2);
   } else {
-    if (L.Dp == 32) TT_SYM(2, false);
-    else if (L.Dp == 64) TT_SYM(4, false);
-    else if (L.Dp == 128) TT_SYM(8, false);
-    else TT_SYM(16, false);
+    if (L.Dp == 32) TT_SYM(2, false, 1);
+    else if (L.Dp == 64) TT_SYM(4, false, 1);
+    else if (L.Dp == 128) TT_SYM(8, false, 1);
+    else TT_SYM(16, false, 1);
   }
 #undef TT_SYM
   TT_LAUNCH_CHECK();
   Fin1Args f{};
   f.rs = g.rs; f.mb = g.mb; f.ma = g.ma; f.cs = g.cs; f.diag_raw = g.diag_raw;
-  f.n_groups = L.n_groups; f.n_chunks = L.n_chunks; f.R = (int)B; f.KS = L.Dp / 16; f.Rp = L.Rp;
+  f.n_groups = n_groups; f.n_chunks = L.n_chunks; f.R = (int)B; f.KS = L.Dp / 16; f.Rp = L.Rp;
   f.kexp = exp2f(g.c2); f.unscale = inv_t / ab; f.shift = shift; f.unit = unit ? 1 : 0; f.want_rank = g.want_rank;
   f.rowsum = rowsum; f.colsum = colsum; f.inv_row = inv_row; f.inv_col = inv_col; f.diag = diag; f.row_rank = row_rank;
   f.a_rows = g.a_rows; f.b_rows = g.b_rows;
