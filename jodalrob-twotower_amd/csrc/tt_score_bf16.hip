@@ -1137,10 +1137,13 @@ __global__ __launch_bounds__(NWV * 64) void score_bwd_rows8_kernel(BwdArgs args)
         const float scale = __builtin_bit_cast(float, t ? sb1 : sb0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          v2s16 u = {0, 0};
-          u = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(u, acc[i][t][4 * q], acc[i][t][4 * q + 1], scale, false);
-          u = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(u, acc[i][t][4 * q + 2], acc[i][t][4 * q + 3], scale, true);
-          wA[i][4 * t + q] = __builtin_bit_cast(int, u);
+          // (the conversion writes one 16-bit half of its destination and keeps the other.  Through the builtin the first of
+          //  a word's two conversions needs a defined `old` value -- a v_mov per word, 8 of the pair's ~144 vector instructions;
+          //  as inline asm its destination is write-only and the second conversion fills the other half)
+          int u;
+          asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3" : "=v"(u) : "v"(acc[i][t][4 * q]), "v"(acc[i][t][4 * q + 1]), "v"(scale));
+          asm("v_cvt_scalef32_pk_fp8_f32 %0, %1, %2, %3 op_sel:[0,0,0,1]" : "+v"(u) : "v"(acc[i][t][4 * q + 2]), "v"(acc[i][t][4 * q + 3]), "v"(scale));
+          wA[i][4 * t + q] = u;
         }
       }
     }

@@ -71,7 +71,9 @@ struct SymArgs {
 template <int KS, bool FP8>
 struct SymStage {
   static constexpr int kTileB = FP8 ? KS * 512 : KS * 1024;                 // bytes of one 32-row tile of the rows image
-  static constexpr int TS = kTileB <= 4096 ? 4 : 1;                         // tiles per stage (D = 64: 2 -> 4 tiles, half the barriers: sweep 22.2 -> 20.8 us)
+  // tiles per stage (D = 64: 2 -> 4 tiles, half the barriers: sweep 22.2 -> 20.8 us).  8-KB tiles: 2 for bf16 D = 128; the fp8
+  // D = 256 kernel holds two company tiles per wave and has no registers left for a second staged piece (256 VGPRs + scratch)
+  static constexpr int TS = kTileB <= 4096 ? 4 : ((kTileB <= 8192 && !FP8) ? 2 : 1);
   static constexpr int kBytes = TS * kTileB;
   static constexpr int LPT = kBytes / (kSymThreads * 16);                   // 16-byte loads per thread per stage
   static_assert(LPT >= 1 && LPT * kSymThreads * 16 == kBytes, "stage must be whole 16-byte loads");
