@@ -72,11 +72,11 @@ template <int KS, bool FP8>
 struct SymStage {
   static constexpr int kTileB = FP8 ? KS * 512 : KS * 1024;                 // bytes of one 32-row tile of the rows image
   // tiles per stage (D = 64: 2 -> 4 tiles, half the barriers: sweep 22.2 -> 20.8 us).  8-KB tiles: 2 for bf16 D = 128; the fp8
-  // D = 256 kernel holds two company tiles per wave and has no registers left for a second staged piece (256 VGPRs + scratch)
+  // D = 256 kernel holds two company tiles per wave and spills with two notice tiles' fragments in flight (256 VGPRs + scratch)
   static constexpr int TS = kTileB <= 4096 ? 4 : ((kTileB <= 8192 && !FP8) ? 2 : 1);
   static constexpr int kBytes = TS * kTileB;
-  static constexpr int LPT = kBytes / (kSymThreads * 16);                   // 16-byte loads per thread per stage
-  static_assert(LPT >= 1 && LPT * kSymThreads * 16 == kBytes, "stage must be whole 16-byte loads");
+  static constexpr int LPT = kBytes / (kSymThreads * 16);                   // 16-byte pieces per thread per stage
+  static_assert(LPT >= 1 && LPT * kSymThreads * 16 == kBytes && kTileB % 1024 == 0, "stage must be whole 16-byte pieces, a wave's 64 inside one tile");
 };
 
 // JT company tiles per wave (fp8, D = 256: 2).  With one tile per wave and one notice tile per stage a wave meets a workgroup
@@ -122,32 +122,27 @@ __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
     if (FP8) load_f8frag<K64>(reinterpret_cast<const char*>(g.b_rows), jact[j] ? J0 + j : 0, c, h, bres8[j]);
     else load_bfrag<(FP8 ? 1 : KS)>(reinterpret_cast<const __bf16*>(g.b_rows), jact[j] ? J0 + j : 0, c, h, bres[j]);
   }
-  // stage loader: thread t copies bytes [16 t, 16 t + 16) (+ 8 KB per further load) of the stage's tiles; tiles past the
-  // image's end are clamped to its last tile (their results are never used)
+  // stage loader: the stage's tiles go STRAIGHT into the LDS buffer by LDS-DMA (global_load_lds_dwordx4: lane l of a wave writes
+  // 16 bytes at the wave's base + 16 l), piece p = tid + 512 q of the stage at byte 16 p; tiles past the image's end are clamped
+  // to its last tile (their results are never used).  Round 3: the copy used to pass through two named registers per thread and a
+  // ds_write; the DMA of stage st + 1 is issued right behind the barrier that frees its buffer and has the whole stage to land.
   const int nst = (I1 - I0 + TS - 1) / TS;
-  // (two named registers, not an array behind the lambdas: at LPT = 2 hipcc kept the array in scratch memory and every stage
-  //  paid a store, a reload and a full vmcnt(0) drain -- two thirds of the D = 256 kernel's wave time was that wait)
-  static_assert(LPT <= 2, "stage loader holds at most two 16-byte pieces per thread");
-  uint4 sreg0 = make_uint4(0, 0, 0, 0), sreg1 = make_uint4(0, 0, 0, 0);
-  auto stage_addr = [&](int st, int q) -> const uint4* {
-    const int off = (q * kSymThreads + (int)threadIdx.x) * 16;             // byte offset inside the stage
-    const int tl = off / kTileB;                                           // tile of the stage this piece belongs to
-    const int tile = min(I0 + st * TS + tl, nT - 1);
-    return reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g.a_rows) + (int64_t)tile * kTileB + (off - tl * kTileB));
+  auto stage_dma = [&](int st, int buf) {
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) {
+      const int off = (q * kSymThreads + (int)threadIdx.x) * 16;           // byte offset inside the stage
+      const int tl = off / kTileB;                                         // tile of the stage this piece belongs to (wave-uniform)
+      const int tile = min(I0 + st * TS + tl, nT - 1);
+      const char* src = reinterpret_cast<const char*>(g.a_rows) + (int64_t)tile * kTileB + (off - tl * kTileB);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + buf * ST::kBytes + (q * kSymThreads + wave * 64) * 16), 16, 0, 0);
+    }
   };
-  auto stage_load = [&](int st) {
-    sreg0 = *stage_addr(st, 0);
-    if (LPT > 1) sreg1 = *stage_addr(st, 1);
-  };
-  auto stage_store = [&](int buf) {
-    *reinterpret_cast<uint4*>(stage + buf * ST::kBytes + (int)threadIdx.x * 16) = sreg0;
-    if (LPT > 1) *reinterpret_cast<uint4*>(stage + buf * ST::kBytes + (kSymThreads + (int)threadIdx.x) * 16) = sreg1;
-  };
-  stage_load(0);
+  stage_dma(0, 0);
   for (int st = 0; st < nst; ++st) {
-    stage_store(st & 1);
-    stage_load(min(st + 1, nst - 1));                      // unconditional: the compiler's vmcnt waits stay exact
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of stage st have landed ...
+    __syncthreads();                                       // ... and everybody's; the other buffer is no longer read by anyone
+    if (st + 1 < nst) stage_dma(st + 1, (st + 1) & 1);
     if (active) {
       const char* sb = stage + (st & 1) * ST::kBytes;
 #pragma unroll
