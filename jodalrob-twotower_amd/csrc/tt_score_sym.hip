@@ -28,6 +28,7 @@ namespace {
 using namespace ttscore;
 
 constexpr int kSymWaves = 8;           // tiles J per workgroup
+constexpr int kFin2Fold = 32;          // partial records a workgroup of the pre-reduction (score_sym_fold_kernel) folds into one
 constexpr int kSymThreads = kSymWaves * 64;
 
 // x[lane] + x[lane ^ 32] in every lane: v_permlane32_swap exchanges the upper half of one register with the lower half of the
@@ -257,6 +258,22 @@ __global__ __launch_bounds__(kSymThreads) void score_fwd_sym_kernel(SymArgs g) {
   }
 }
 
+// finish2 reads every workgroup's partial record in ONE workgroup: 4.6 us for 128 records (B = 8192), 50 us for 1024 (B = 65536:
+// 2 MB through one CU).  From 256 records on, this launch folds them 32 to one first (fixed order: record k of the fold after
+// record k - 1), and finish2 adds the folded ones.
+__global__ __launch_bounds__(1024) void score_sym_fold_kernel(const float* __restrict__ part, int n_wg, int stride, float* __restrict__ part2) {
+  const int j = threadIdx.x;
+  if (j >= stride) return;
+  const int r0 = (int)blockIdx.x * kFin2Fold, r1 = min(r0 + kFin2Fold, n_wg);
+  float v[kFin2Fold];
+#pragma unroll
+  for (int k = 0; k < kFin2Fold; ++k) v[k] = r0 + k < r1 ? part[(int64_t)(r0 + k) * stride + j] : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < kFin2Fold; ++k) s += v[k];
+  part2[(int64_t)blockIdx.x * stride + j] = s;
+}
+
 // ---- finish1: slabs -> per-row sums, reciprocals, top-1 flags; per-workgroup partial sums of the loss terms; column sums
 // of both operand images (for the sum of all scores).  64 rows per workgroup: wave q adds the slab rows g = q, q + 4, ...
 // (independent loads, 8 in flight), the four partial results are combined in wave order.
@@ -423,7 +440,7 @@ __global__ __launch_bounds__(kRiderThreads) void score_sym_finish2_kernel(Finish
 struct SymLayout {
   int nT, NI, n_groups, n_chunks, n_wg, Dp;
   int64_t Rp;
-  size_t off_rs, off_mb, off_ma, off_cs, off_diag, off_part, bytes;
+  size_t off_rs, off_mb, off_ma, off_cs, off_diag, off_part, off_part2, bytes;
 };
 
 inline SymLayout sym_layout(const tt_ctx* ctx, int64_t R, int D) {
@@ -447,6 +464,7 @@ inline SymLayout sym_layout(const tt_ctx* ctx, int64_t R, int D) {
   L.off_cs = take(sizeof(float) * L.n_chunks * L.Rp);
   L.off_diag = take(sizeof(float) * L.Rp);
   L.off_part = take(sizeof(float) * L.n_wg * (4 + 2 * 256));   // (sized for the widest record: fp8 operands pad D up to 64)
+  L.off_part2 = take(sizeof(float) * tt_cdiv(L.n_wg, kFin2Fold) * (4 + 2 * 256));
   L.bytes = o + 256;
   return L;
 }
@@ -521,7 +539,15 @@ static int sym_forward(tt_ctx* ctx, const void* N_packed, const void* C_packed, 
   f.part = reinterpret_cast<float*>(ws + L.off_part);
   score_sym_finish1_kernel<<<(unsigned)L.n_wg, 256, 0, st>>>(f);
   TT_LAUNCH_CHECK();
-  const Finish2Rider fr{f.part, L.n_wg, L.Dp, (float)B, f.unscale, out8, loss_out};
+  Finish2Rider fr{f.part, L.n_wg, L.Dp, (float)B, f.unscale, out8, loss_out};
+  if (L.n_wg >= 256) {                                   // large batches: fold the records 32 to one before the one-workgroup reduction
+    float* part2 = reinterpret_cast<float*>(ws + L.off_part2);
+    const int n2 = (int)tt_cdiv(L.n_wg, kFin2Fold);
+    score_sym_fold_kernel<<<n2, 1024, 0, st>>>(f.part, L.n_wg, 4 + 2 * L.Dp, part2);
+    TT_LAUNCH_CHECK();
+    fr.part = part2;
+    fr.n_wg = n2;
+  }
   if (ctx->defer_riders & 2) {                           // rides beside the towers' tail_bwd (tt_riders.h): nothing on the device reads it
     if (ctx->riders->f_wg > 0)
       if (int rc = tt_riders_flush(ctx, st)) return rc;
