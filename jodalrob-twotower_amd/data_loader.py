@@ -54,17 +54,19 @@ class DevicePairLoader:
         if len(pairs) and (pairs[:, 0].max() >= len(notice) or pairs[:, 1].max() >= len(company) or pairs.min() < 0):
             raise KeyError("pair refers to an entity that is not in the feature store")      # reference raises KeyError: :495-498
         self.pairs = torch.from_numpy(pairs).to(notice.device)
-        self._gen = torch.Generator(device="cpu")
+        # the epoch permutation is drawn where it is used: a host randperm of 1.6 M pairs + its upload cost ~20 ms per epoch,
+        # a third of a 68-ms epoch at batch 8192 (profiles/NOTES.md, round 4)
+        self._gen = torch.Generator(device=self.pairs.device)
         self._gen.manual_seed(seed)
 
     def __len__(self) -> int:
         return (self.pairs.shape[0] + self.batch_size - 1) // self.batch_size
 
     def epoch_order(self) -> Optional[torch.Tensor]:
-        """This epoch's permutation of the pair list on the device (None when not shuffling); drawn from the loader's seeded CPU
+        """This epoch's permutation of the pair list on the device (None when not shuffling); drawn from the loader's seeded
         generator, so an epoch iterated through __iter__ and one driven through step_batches() see the same batches."""
         n = self.pairs.shape[0]
-        return torch.randperm(n, generator=self._gen).to(self.pairs.device) if self.shuffle else None
+        return torch.randperm(n, generator=self._gen, device=self.pairs.device) if self.shuffle else None
 
     def batch(self, order: Optional[torch.Tensor], lo: int) -> Dict:
         sel = self.pairs[lo:lo + self.batch_size] if order is None else self.pairs[order[lo:lo + self.batch_size]]
@@ -93,17 +95,47 @@ class DevicePairLoader:
             done += 1
         return done
 
-    def step_batches(self, graphed_step, eager_step=None):
+    def step_batches(self, graphed_step, eager_step=None, ragged_step=None):
         """One epoch on the fast path: every full batch is gathered out of the stores by the captured step's own hand-over launch
         (GraphedTrainStep.step_from_store) and replayed; the ragged last batch -- a captured step has one batch size -- goes
-        through `eager_step(batch)` (skipped when None).  Yields the step's result dict per batch."""
+        through `ragged_step` (a second GraphedTrainStep captured at the remainder's size, sharing task and optimiser) or, without
+        one, through `eager_step(batch)` (skipped when None).  Yields the step's result dict per batch."""
         order = self.epoch_order()
         n, B = self.pairs.shape[0], self.batch_size
         for lo in range(0, n, B):
             if lo + B <= n:
                 yield graphed_step.step_from_store(self.notice, self.company, self.pairs, order, lo)
+            elif ragged_step is not None and ragged_step.static["notice"]["dense"].shape[0] == n - lo:
+                yield ragged_step.step_from_store(self.notice, self.company, self.pairs, order, lo)
             elif eager_step is not None:
                 yield eager_step(self.batch(order, lo))
+
+    def ragged_example(self) -> Optional[Dict]:
+        """A batch of the remainder's size (pairs % batch_size), or None when the epoch has no ragged batch: the example a second
+        captured step is built from."""
+        n, B = self.pairs.shape[0], self.batch_size
+        r = n % B
+        if r == 0 or n < B:
+            return None
+        sel = self.pairs[:r]
+        return {"notice": self.notice.gather(sel[:, 0].contiguous()), "company": self.company.gather(sel[:, 1].contiguous())}
+
+
+def sklearn_split_indices(n: int, test_size: float, seed: int) -> Tuple[np.ndarray, np.ndarray]:
+    """(train, test) index arrays -- membership AND order -- of `sklearn.model_selection.train_test_split(range(n),
+    test_size=test_size, random_state=seed)`, which is how the reference's test-mode loader splits its pair list
+    (unified_bid_data_loader.py:1222-1226; scripts/train.py: test_split 0.2, shuffle_seed 42).  scikit-learn's ShuffleSplit draws
+    `RandomState(seed).permutation(n)`, takes the first n_test = ceil(test_size * n) entries as the test set and the following
+    n - n_test as the training set.  Index work: bit-exact against tests/golden/split_indices.json (generated with scikit-learn
+    itself by oracle/gen_split_fixture.py); scikit-learn is not needed at run time."""
+    if not (0.0 < test_size < 1.0):
+        return np.arange(n, dtype=np.int64), np.empty(0, dtype=np.int64)        # reference: test_split == 0 keeps every pair (:1227-1228)
+    n_test = int(np.ceil(test_size * n))
+    n_train = n - n_test
+    if n_train <= 0:
+        raise ValueError(f"With n_samples={n}, test_size={test_size} the resulting train set will be empty")     # sklearn's ValueError
+    perm = np.random.RandomState(seed).permutation(n)
+    return perm[n_test:n_test + n_train].astype(np.int64), perm[:n_test].astype(np.int64)
 
 
 def create_unified_bid_dataloaders(db_engine, schema: TorchRecSchema, batch_size: int = 32, limit: Optional[int] = None,
@@ -127,10 +159,8 @@ def create_unified_bid_dataloaders(db_engine, schema: TorchRecSchema, batch_size
         if str(ck) not in c2i:
             raise KeyError(f"Company ID not found in features: {ck}")
         idx[i] = (n2i[tuple(nk)], c2i[str(ck)])
-    rng = np.random.default_rng(shuffle_seed)
-    perm = rng.permutation(len(idx))
-    n_test = int(len(idx) * test_split) if test_split > 0 else 0      # floor, as the reference (:207)
-    test_idx, train_idx = idx[perm[:n_test]], idx[perm[n_test:]]
+    train_sel, test_sel = sklearn_split_indices(len(idx), test_split, shuffle_seed)
+    test_idx, train_idx = idx[test_sel], idx[train_sel]
     ns = DeviceFeatureStore(stores["notice"], schema.notice.categorical, device)
     cs = DeviceFeatureStore(stores["company"], schema.company.categorical, device)
     return (DevicePairLoader(ns, cs, train_idx, batch_size, shuffle=True, seed=shuffle_seed),

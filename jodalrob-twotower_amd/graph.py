@@ -29,9 +29,17 @@ from .optim import FusedAdam
 
 class GraphedTrainStep:
     def __init__(self, task, optimizer: FusedAdam, example_batch: Dict, return_metrics: bool = True, warmup: int = 3,
-                 defer_long: bool = True, defer_slabs: bool = True, defer_riders: bool = True):
+                 defer_long: bool = True, defer_slabs: bool = True, defer_riders: bool = True, preserve_state: bool = True,
+                 accumulate_metrics: bool = False):
         """defer_long / defer_slabs: the long rows' finish rides in the optimiser's launch and the towers' slab reduction in the
-        embedding gradient's (both bit-identical to the separate launches; the arguments exist for that comparison)."""
+        embedding gradient's (both bit-identical to the separate launches; the arguments exist for that comparison).
+        preserve_state: the eager warm-up steps (allocator + first-call paths) are REAL steps on the example batch; with this flag
+        everything they change -- weights, Adam moments and step counts, BatchNorm running statistics -- is put back before the
+        capture, so a captured loop starts from the state an eager loop starts from (row-sparse tables: only the example batch's
+        rows move and only those are saved; dense-gradient tables are saved whole).
+        accumulate_metrics: `metric_sums` (device, 8 floats: loss, accuracy, positive mean, negative mean, gap, ...: twotower.h
+        tt_score_loss_finish) += the step's figures inside the replay -- an epoch's mean loss / accuracy (the reference driver's
+        avg_train_loss: scripts/train.py:357-358) without a host sync per step."""
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("GraphedTrainStep needs jodalrob_twotower_amd.optim.FusedAdam (device-side hyper-parameters)")
         self.task, self.opt, self.return_metrics = task, optimizer, return_metrics
@@ -55,11 +63,12 @@ class GraphedTrainStep:
         self._seed_dev = self._dev[ng * 8:].view(torch.int64)          # 2 floats = one 64-bit word
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
         self._towers = [m for m in task.modules() if hasattr(m, "_seed_dev") and hasattr(m, "dense_parameters")]
-        self._steps_done = 0
+        self.metric_sums = torch.zeros(8, dtype=torch.float32, device=dev) if (accumulate_metrics and return_metrics) else None
         self._ingest = self._setup_ingest()
         if self._ingest is not None:
             self._run_ingest([], None)                           # rows_km of the example batch: warm-up and capture see it
         # eager warm-up on a side stream (allocator + first-call paths), then capture
+        snap = self._snapshot_state() if (preserve_state and warmup > 0) else None
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -67,7 +76,10 @@ class GraphedTrainStep:
                 self._eager_once()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        self._base_step = optimizer.current_step()
+        if snap is not None:
+            self._restore_state(snap)
+        if self.metric_sums is not None:
+            self.metric_sums.zero_()
         self._push_scalars()
         for t in self._towers:
             t._seed_dev = self._seed_dev
@@ -167,6 +179,8 @@ class GraphedTrainStep:
             for st in stores:                          # a store this optimiser did not step: nobody else will finish its gradient
                 if st.sparse_grad is not None:
                     ops.embed_grad_finish(st.sparse_grad[0])
+            if self.metric_sums is not None:           # (behind the backward: a riding loss reduction has written out8 by now)
+                self.metric_sums.add_(res.out8)
         finally:
             if riders:
                 L.set_defer_riders(dev, False)         # (launches what nobody hosted: e.g. the loss reduction of a forward-only pass)
@@ -177,6 +191,77 @@ class GraphedTrainStep:
     def _eager_once(self):
         self._body()
 
+    # ---- warm-up without side effects ---------------------------------------------------------------------------------
+    def _touched_rows(self, store):
+        """Fused rows (sorted, distinct) the example batch looks up in `store`, or None when they cannot be told from here
+        (row-wise sharded tables: the rows this rank updates come from every rank's batch)."""
+        model = getattr(self.task, "two_tower_model", None)
+        if model is None or getattr(self.task, "exchange", None) is not None:
+            return None
+        rows = []
+        for name, side in (("notice_tower", "notice"), ("company_tower", "company")):
+            tw = getattr(model, name, None)
+            if tw is None:
+                return None
+            e = tw.categorical_embedder
+            if e.store is not store or not e.keys:
+                continue
+            ids = self.static[side]["kjt"].values().view(-1, len(e.keys))
+            rows.append((ids.clamp(min=0).minimum(e._key_vocab - 1) + e._key_row_offset).reshape(-1))      # cat_embed.py:114-117
+        return torch.unique(torch.cat(rows)) if rows else None
+
+    def _snapshot_state(self):
+        opt = self.opt
+        opt._flush_pending()
+        table_ids = opt._table_param_ids()
+        snap = {"buffers": [(b, b.detach().clone()) for b in self.task.buffers()], "dense": [], "stores": [], "steps": []}
+        for group in opt.param_groups:
+            for p in group["params"]:
+                if id(p) in table_ids:
+                    continue
+                st = opt.state.get(p) or {}
+                snap["dense"].append((p, p.detach().clone(), None if "exp_avg" not in st else
+                                      (st["exp_avg"].clone(), st["exp_avg_sq"].clone(), st["step"].clone())))
+        for store in getattr(opt, "_stores", ()):
+            if store.weight is None or not store.optim_parameters():
+                continue
+            st = opt._state_of(store)
+            rows = self._touched_rows(store) if store.grad_mode == "sparse" else None
+            if rows is None and 3 * store.weight.numel() * 4 > (8 << 30):
+                rows = torch.empty(0, dtype=torch.int64, device=store.weight.device)     # too large to copy whole: left as the warm-up leaves it
+            pick = (lambda t: t[rows].clone()) if rows is not None else (lambda t: t.clone())
+            snap["stores"].append((store, rows, pick(store.weight), pick(st["m"]), pick(st["v"]), st["step"]))
+        snap["steps"] = [(st, st["step"].clone()) for st in opt.state.values() if "step" in st]
+        return snap
+
+    @torch.no_grad()
+    def _restore_state(self, snap):
+        opt = self.opt
+        opt._flush_pending()
+        for b, saved in snap["buffers"]:
+            b.copy_(saved)
+        for p, w, st0 in snap["dense"]:
+            p.copy_(w)
+            st = opt.state.get(p)
+            if st and "exp_avg" in st:
+                if st0 is None:                        # the state came into being during the warm-up: back to Adam's initial state
+                    st["exp_avg"].zero_(); st["exp_avg_sq"].zero_(); st["step"] = torch.tensor(0.0)
+                else:
+                    st["exp_avg"].copy_(st0[0]); st["exp_avg_sq"].copy_(st0[1]); st["step"] = st0[2].clone()
+        for store, rows, w, m, v, step in snap["stores"]:
+            st = opt._state_of(store)
+            if rows is None:
+                store.weight.copy_(w); st["m"].copy_(m); st["v"].copy_(v)
+            elif rows.numel():
+                store.weight[rows] = w; st["m"][rows] = m; st["v"][rows] = v
+            st["step"] = step
+        known = {id(st): val for st, val in snap["steps"]}
+        for st in opt.state.values():
+            if "step" in st:
+                st["step"] = known[id(st)].clone() if id(st) in known else torch.tensor(0.0)
+        opt._step_cache = None
+        opt.zero_grad(set_to_none=True)
+
     def _fill_slot(self):
         """Writes this step's scalars into the next ring slot; returns the (dst, src) copy pair."""
         self._slot = (self._slot + 1) % self._ring
@@ -185,7 +270,9 @@ class GraphedTrainStep:
             ev.synchronize()                                        # the copy that last read this slot has run
         host = self._host_ring[self._slot, :self._n_scalar]
         ng = len(self.opt.param_groups)
-        step = self._base_step + self._steps_done + 1
+        # the optimiser's own count: eager steps taken between replays (a ragged last batch, another captured step sharing
+        # the optimiser) advance the bias corrections exactly as they do in an all-eager loop
+        step = self.opt.peek_step() + 1
         for gi, g in enumerate(self.opt.param_groups):
             hp = ops.adam_hparams(step, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])
             host[gi * 8: gi * 8 + 6] = torch.tensor(hp)
@@ -232,7 +319,6 @@ class GraphedTrainStep:
 
     def _replay(self):
         self.graph.replay()
-        self._steps_done += 1
         self.opt.advance_steps(1)
         ex = getattr(self.task, "exchange", None)
         if ex is not None and hasattr(ex, "poll_overflow"):

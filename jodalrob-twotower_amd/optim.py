@@ -32,6 +32,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._stores: List[EmbeddingStore] = list(stores)
         self._store_state: Dict[int, dict] = {}
         self._hp_dev = None             # [n_groups, 8] device floats while a captured graph owns the step
+        self._step_cache = None         # current_step() as of the last eager change (peek_step)
 
     @classmethod
     def for_task(cls, task, **kw):
@@ -67,6 +68,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         self._flush_pending()
+        self._step_cache = None
         table_ids = self._table_param_ids()
         group_of = {}
         for group in self.param_groups:
@@ -161,6 +163,8 @@ class FusedAdam(torch.optim.Optimizer):
         n = getattr(self, "_pending_steps", 0)
         if n:
             self._pending_steps = 0
+            if self._step_cache is not None:
+                self._step_cache += n
             for st in self._store_state.values():
                 st["step"] += n
             for st in self.state.values():
@@ -171,6 +175,14 @@ class FusedAdam(torch.optim.Optimizer):
         self._flush_pending()
         steps = [int(float(st["step"])) for st in self.state.values() if "step" in st]
         return max(steps) if steps else 0
+
+    def peek_step(self) -> int:
+        """Number of optimiser steps taken so far -- eager step() calls AND graph replays accounted through advance_steps() --
+        without walking the per-parameter state on every call: a captured step asks for it at every hand-over (its bias
+        corrections must follow the optimiser's own count when eager steps and replays interleave: GraphedTrainStep._fill_slot)."""
+        if self._step_cache is None:
+            self._step_cache = self.current_step()                 # (flushes the pending replays into the state)
+        return self._step_cache + getattr(self, "_pending_steps", 0)
 
     def state_dict(self):
         self._flush_pending()
@@ -183,6 +195,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._step_cache = None
         # re-point the table parameters' moments at store-level buffers (the kernels update those; self.state holds views)
         for store in self._stores:
             shard = getattr(store, "shard_param", None)

@@ -23,8 +23,6 @@ from .two_tower_model import TwoTowerModel, create_two_tower_model
 LAZY_SIM_BATCH = 2048
 
 
-
-
 class _DenseLossFn(torch.autograd.Function):
     """The loss variants the fused kernels do not cover, on the materialised score matrix (tt_score_dense_fwd / _bwd):
     loss_type 0 = cross-entropy with label smoothing (:114-133), 1 = cosine-embedding loss (:135-158).  O(B^2) memory."""
@@ -127,9 +125,10 @@ class _ScoreCEFn(torch.autograd.Function):
 class _Result(dict):
     """Result dict whose 'similarity_matrix' entry is computed on first access (large batches)."""
 
-    def __init__(self, *a, sim_thunk=None, **k):
+    def __init__(self, *a, sim_thunk=None, out8=None, **k):
         super().__init__(*a, **k)
         self._sim_thunk = sim_thunk
+        self.out8 = out8          # the finish kernel's 8 floats (loss, accuracy, pos, neg, gap, ...): the entries above are views of it
 
     def _materialise(self):
         if self._sim_thunk is not None and not dict.__contains__(self, "similarity_matrix"):
@@ -205,7 +204,7 @@ class TwoTowerTrainTask(nn.Module):
         n_det, c_det, inv_t = notice_embeddings.detach(), company_embeddings.detach(), 1.0 / float(self.temperature)
         res = _Result({"loss": loss, "accuracy": out8[1], "positive_similarity_mean": out8[2],
                        "negative_similarity_mean": out8[3], "similarity_gap": out8[4]},
-                      sim_thunk=lambda: ops.score_matrix(n_det, c_det, inv_t))
+                      sim_thunk=lambda: ops.score_matrix(n_det, c_det, inv_t), out8=out8)
         if nb <= LAZY_SIM_BATCH:
             res._materialise()
         return res

@@ -150,9 +150,40 @@ def scan_definitions(path: str, names):
     return out
 
 
+def scan_harness(path: str = "scripts/train.py"):
+    """The driver's own output contracts ("the results-CSV columns (:37-57)", "checkpoint dict keys (:506-511)", "config
+    keys (:84-134)"): keys of the dict literals named result_row / hyperparams / final_metrics / config / checkpoint, in source
+    order, and for result_row which dict and key each column is read from."""
+    tree = ast.parse((REF / path).read_text(encoding="utf-8"))
+    want = {"result_row": "results_csv", "hyperparams": "hyperparams_keys", "final_metrics": "final_metrics_keys", "config": "config_keys",
+            "checkpoint": "checkpoint_keys"}
+    out = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name) \
+                and node.targets[0].id in want and isinstance(node.value, ast.Dict):
+            name = node.targets[0].id
+            keys = [k.value for k in node.value.keys if isinstance(k, ast.Constant)]
+            if name == "result_row":
+                cols = []
+                for k, v in zip(node.value.keys, node.value.values):
+                    src = None
+                    for sub in ast.walk(v):                  # hyperparams.get("batch_size", "N/A") -> ["hyperparams", "batch_size"]
+                        if isinstance(sub, ast.Call) and isinstance(sub.func, ast.Attribute) and sub.func.attr == "get" \
+                                and isinstance(sub.func.value, ast.Name) and sub.args and isinstance(sub.args[0], ast.Constant):
+                            src = [sub.func.value.id, sub.args[0].value]
+                    cols.append({"column": k.value, "read_from": src})
+                out["results_csv"] = {"columns": cols}
+            else:
+                out.setdefault(want[name], keys)
+        if isinstance(node, ast.FunctionDef) and node.name == "save_training_results":
+            a = node.args
+            out["results_csv_default_file"] = ast.literal_eval(a.defaults[-1]) if a.defaults else None
+    return out
+
+
 def main():
     surface = {"generated_by": "oracle/gen_api_surface.py (ast walk of the reference; nothing imported)", "uses": {}, "imports": {},
-               "signatures": {}}
+               "signatures": {}, "harness": {"scripts/train.py": scan_harness()}}
     for path, roles in CALLERS.items():
         uses, imports = scan_uses(path, roles)
         surface["uses"][path] = uses

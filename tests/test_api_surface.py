@@ -187,3 +187,50 @@ def test_printers_and_demo_run_and_say_what_the_reference_says():
                  "유사도 구분: 양호 (0.5 이상)", "Top-1 정확도: 우수 (0.3 이상)", "Recall@10: 부족 (0.4 미만)", "유사도 구분: 개선 필요 (0.5 미만)",
                  "--- 추론 예제 ---", "유사도 행렬 크기: torch.Size([12, 12])"):
         assert line in text, line
+
+
+def test_driver_writes_the_references_results_csv_and_checkpoint(tmp_path):
+    """scripts/train.py's own output contracts: the results CSV has the reference's columns in the reference's order and
+    default file name (scripts/train.py:24-57), its hyper-parameter / metric dicts carry the reference's keys (:458-485), the
+    checkpoint dict its four keys (:506-511).  The reference side comes from the `ast` walk in tests/golden/api_surface.json
+    ("harness"); this side from importing this repository's driver (no GPU is touched at import) and writing one row."""
+    import ast
+    import csv
+    import importlib.util
+    import inspect
+    from conftest import ROOT
+    h = SURFACE["harness"]["scripts/train.py"]
+    spec = importlib.util.spec_from_file_location("_tt_train_driver", ROOT / "scripts" / "train.py")
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    cols = [c["column"] for c in h["results_csv"]["columns"]]
+    assert drv.RESULT_COLUMNS == cols
+    sig = inspect.signature(drv.save_training_results)
+    assert list(sig.parameters) == ["hyperparams", "metrics", "output_file"] and sig.parameters["output_file"].default == h["results_csv_default_file"]
+    from_hp = {c["column"] for c in h["results_csv"]["columns"] if c["read_from"] and c["read_from"][0] == "hyperparams"}
+    assert drv._FROM_HYPERPARAMS == from_hp
+    out = tmp_path / "r.csv"
+    hp = {k: i for i, k in enumerate(h["hyperparams_keys"])}
+    hp["hidden_dims"] = [512, 256]
+    fm = {k: 0.5 + i for i, k in enumerate(h["final_metrics_keys"])}           # the reference's keys: "recall@5", not "recall_at_5"
+    drv.save_training_results(hp, fm, str(out))
+    drv.save_training_results(hp, {}, str(out))
+    with open(out, newline="", encoding="utf-8") as f:
+        rows = list(csv.reader(f))
+    assert rows[0] == cols and len(rows) == 3
+    first = dict(zip(cols, rows[1]))
+    assert first["hidden_dims"] == "[512, 256]" and first["recall_at_5"] == str(fm["recall@5"]) and first["train_loss"] == str(fm["train_loss"])
+    assert dict(zip(cols, rows[2]))["val_loss"] == "N/A"                       # the reference's `.get(key, "N/A")`
+    # the dict literals the driver builds carry the reference's keys
+    src = ast.parse((ROOT / "scripts" / "train.py").read_text(encoding="utf-8"))
+    lits = {}
+    for node in ast.walk(src):
+        if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name) and isinstance(node.value, ast.Dict):
+            lits[node.targets[0].id] = [k.value for k in node.value.keys if isinstance(k, ast.Constant)]
+    assert lits["hyperparams"] == h["hyperparams_keys"] and lits["final_metrics"] == h["final_metrics_keys"]
+    assert lits["ckpt"] == h["checkpoint_keys"]
+    missing = [k for k in ("batch_size", "test_split", "shuffle_seed", "pair_limit", "categorical_embedding_dim", "notice_dense_input_dim",
+                           "company_dense_input_dim", "tower_hidden_dims", "final_embedding_dim", "dropout_rate", "temperature", "loss_type",
+                           "learning_rate", "weight_decay", "num_epochs", "warmup_ratio", "log_interval", "output_dir", "gpu_optimization")
+               if k not in lits["config"] or k not in h["config_keys"]]
+    assert not missing, missing

@@ -89,9 +89,14 @@ def test_evaluator_golden(tt):
 
 
 def test_train_driver_smoke(tmp_path):
-    out = tmp_path / "models"
-    r = subprocess.run([sys.executable, str(ROOT / "scripts" / "train.py"), "--entities", "2000", "--pairs", "8192", "--batch-size", "256",
-                        "--steps", "12", "--output-dir", str(out)], capture_output=True, text=True, timeout=600)
+    """scripts/train.py at BASELINE configs[0]'s own sizes -- 10,000 notice x 10,000 company entities, 100,000 pairs, batch 256, E = 32,
+    towers [128, 64] -> 64 (the script's defaults) -- in the reference's loop (a few steps, then resume) and over a whole epoch
+    of the fast loop; artefacts as the reference driver leaves them: checkpoints with its dict keys (:506-511), the state-dict
+    keys / shapes of the real schema, and a results CSV with its columns in its order (:37-57; tests/golden/api_surface.json)."""
+    import csv
+    out, res_csv = tmp_path / "models", tmp_path / "train_results.csv"
+    base = [sys.executable, str(ROOT / "scripts" / "train.py"), "--results-csv", str(res_csv)]
+    r = subprocess.run(base + ["--steps", "12", "--output-dir", str(out)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert (out / "final_model.pt").exists() and (out / "model_weights.pt").exists() and (out / "best_model.pt").exists()
     ck = torch.load(out / "final_model.pt", map_location="cpu", weights_only=True)
@@ -99,20 +104,30 @@ def test_train_driver_smoke(tmp_path):
     man = json.loads((GOLD / "manifest.json").read_text())
     assert {k: list(v.shape) for k, v in ck["model_state_dict"].items()} == man["state_dict_keys_real"]
     # resume restores model and optimiser state
-    r2 = subprocess.run([sys.executable, str(ROOT / "scripts" / "train.py"), "--entities", "2000", "--pairs", "8192", "--batch-size",
-                         "256", "--steps", "3", "--output-dir", str(out), "--resume", str(out / "best_model.pt")],
-                        capture_output=True, text=True, timeout=600)
+    r2 = subprocess.run(base + ["--steps", "3", "--output-dir", str(out), "--resume", str(out / "best_model.pt")],
+                        capture_output=True, text=True, timeout=900)
     assert r2.returncode == 0, r2.stdout[-2000:] + r2.stderr[-2000:]
-    # the fast loop: captured step fed from the device stores (bf16, sparse gradients), ragged last batch eager, same artefacts
+    # the fast loop over the whole epoch: captured steps (full batches + the ragged one) fed from the device stores, same artefacts
     out3 = tmp_path / "models_fast"
-    r3 = subprocess.run([sys.executable, str(ROOT / "scripts" / "train.py"), "--entities", "2000", "--pairs", "8192", "--batch-size", "256",
-                         "--output-dir", str(out3), "--fast"], capture_output=True, text=True, timeout=600)
+    r3 = subprocess.run(base + ["--output-dir", str(out3), "--fast"], capture_output=True, text=True, timeout=900)
     assert r3.returncode == 0, r3.stdout[-2000:] + r3.stderr[-2000:]
     assert "fast: captured step fed from the device stores" in r3.stdout and "--- 추론 예제 ---" in r3.stdout
     ck3 = torch.load(out3 / "final_model.pt", map_location="cpu", weights_only=True)
     assert {k: list(v.shape) for k, v in ck3["model_state_dict"].items()} == man["state_dict_keys_real"]
     losses = [float(ln.split("loss")[1].split()[0]) for ln in r3.stdout.splitlines() if ln.startswith("step ")]
-    assert len(losses) >= 1 and all(np.isfinite(losses))
+    assert len(losses) >= 10 and all(np.isfinite(losses))                 # 313 steps, a line every 20
+    # results CSV: the reference's columns, one row per run, values where the reference's row has them
+    surface = json.loads((GOLD / "api_surface.json").read_text())["harness"]["scripts/train.py"]
+    cols = [c["column"] for c in surface["results_csv"]["columns"]]
+    with open(res_csv, newline="", encoding="utf-8") as f:
+        rows = list(csv.reader(f))
+    assert rows[0] == cols and len(rows) == 4
+    fast = dict(zip(rows[0], rows[3]))
+    assert fast["batch_size"] == "256" and fast["model_params"] == "2204832" and fast["hidden_dims"] == "[128, 64]" and fast["epochs"] == "1"
+    assert fast["train_batches"] == "313" and fast["test_batches"] == "79"            # sklearn's split: 80,000 / 20,000 pairs
+    for k in ("train_loss", "train_acc", "val_loss", "val_acc", "recall_at_5", "recall_at_10", "mrr", "similarity_gap"):
+        assert np.isfinite(float(fast[k])), (k, fast[k])
+    assert abs(float(fast["train_loss"]) - float(np.log(256))) < 1.0
 
 
 def test_reference_driver_sequence(tt, tmp_path, capsys):
@@ -248,7 +263,10 @@ def test_ingest_store_equals_gather_then_ingest(tt, dims, B, use_order):
 def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
     """An epoch driven through DevicePairLoader.step_batches (GraphedTrainStep.step_from_store: the batch gathered out of the device
     stores by the step's own hand-over launch; ragged last batch through the eager step) == the same epoch with the loader's
-    batch tensors handed to GraphedTrainStep.step / the eager step, bit for bit: per-step losses and the final state."""
+    batch tensors handed to GraphedTrainStep.step / the eager step, bit for bit: per-step losses and the final state.  Third leg
+    (ADVICE round 3): the same two epochs with EVERY batch through the eager step and no captured step at all -- the capture's
+    warm-up steps must leave no trace (preserve_state) and the replays' Adam step numbers must follow the optimiser's own count
+    across the eager ragged batches (FusedAdam.peek_step): also bit for bit (pairs % batch != 0, two epochs)."""
     from jodalrob_twotower_amd import synthetic
     from jodalrob_twotower_amd.data_loader import create_unified_bid_dataloaders
     from jodalrob_twotower_amd.graph import GraphedTrainStep
@@ -261,7 +279,7 @@ def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
     schema = tt.build_torchrec_schema_from_meta(notice_table="notice", company_table="company", pair_table="bid_two_tower",
                                                 pair_notice_id_cols=["bidntceno", "bidntceord"], pair_company_id_cols=["bizno"], metadata_path=str(meta))
     finals = {}
-    for mode in ("tensors", "store"):
+    for mode in ("tensors", "store", "eager"):
         torch.manual_seed(123)                                           # the preprocessor's frozen random projectors draw from it
         src = synthetic.SyntheticSource(900, 700, 1200, vn, vc)
         train_loader, _ = create_unified_bid_dataloaders(src, schema, batch_size=256, test_split=0.0, shuffle_seed=7, test_mode=True, pair_limit=1200, device=DEV)
@@ -278,7 +296,7 @@ def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
                 p.copy_(0.05 * torch.randn(p.shape, device=DEV))
         task.train()
         opt = FusedAdam.for_task(task, lr=1e-2, weight_decay=1e-5)
-        gs = GraphedTrainStep(task, opt, first, warmup=1)
+        gs = GraphedTrainStep(task, opt, first, warmup=1) if mode != "eager" else None
 
         def eager(b):
             opt.zero_grad()
@@ -293,14 +311,19 @@ def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
                     losses.append(r["loss"].item())
             else:
                 for b in train_loader:
-                    r = gs.step(b) if b["notice"]["dense"].shape[0] == 256 else eager(b)
+                    r = gs.step(b) if (gs is not None and b["notice"]["dense"].shape[0] == 256) else eager(b)
                     losses.append(r["loss"].item())
         torch.cuda.synchronize()
         assert len(losses) == 10
-        finals[mode] = (losses, {k: v.detach().cpu().clone() for k, v in task.state_dict().items()})
-        gs.close()
+        finals[mode] = (losses, {k: v.detach().cpu().clone() for k, v in task.state_dict().items()}, opt.current_step())
+        if gs is not None:
+            gs.close()
     assert finals["tensors"][0] == finals["store"][0] and len(set(finals["store"][0])) == 10
     for k, v in finals["tensors"][1].items():
+        assert torch.equal(v, finals["store"][1][k]), k
+    assert finals["eager"][2] == finals["store"][2] == 10                # ten optimiser steps, whoever ran them
+    assert finals["eager"][0] == finals["store"][0], (finals["eager"][0], finals["store"][0])
+    for k, v in finals["eager"][1].items():
         assert torch.equal(v, finals["store"][1][k]), k
 
 

@@ -183,3 +183,26 @@ def test_bench_self_launch_plumbing():
     # a failing rank fails the launch
     r3 = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--no-such-flag"], env=env, capture_output=True, text=True, timeout=60)
     assert r3.returncode != 0
+
+
+def test_train_test_split_is_sklearns():
+    """Membership and order of the train / test pair lists == sklearn.model_selection.train_test_split(random_state=seed), the
+    call the reference's test-mode loader makes (unified_bid_data_loader.py:1222-1226).  Fixture: oracle/gen_split_fixture.py
+    (scikit-learn itself, run in the build container).  Bit-exact: index work."""
+    from jodalrob_twotower_amd.data_loader import sklearn_split_indices
+    fx = json.loads((GOLD / "split_indices.json").read_text())
+    for c in fx["cases"]:
+        tr, te = sklearn_split_indices(c["n"], c["test_size"], c["seed"])
+        assert (len(tr), len(te)) == (c["n_train"], c["n_test"]), c
+        assert tr.dtype == np.int64 and te.dtype == np.int64
+        if "train" in c:
+            assert tr.tolist() == c["train"] and te.tolist() == c["test"], (c["n"], c["seed"])
+        else:
+            w = np.arange(1, c["n"] + 1, dtype=np.int64)
+            assert tr[:16].tolist() == c["train_head"] and tr[-16:].tolist() == c["train_tail"]
+            assert te[:16].tolist() == c["test_head"] and te[-16:].tolist() == c["test_tail"]
+            assert int((tr * w[:len(tr)]).sum() % (2 ** 61 - 1)) == c["train_checksum"]
+            assert int((te * w[:len(te)]).sum() % (2 ** 61 - 1)) == c["test_checksum"]
+        assert sorted(tr.tolist() + te.tolist()) == list(range(c["n"]))        # a partition
+    tr, te = sklearn_split_indices(17, 0.0, 42)                                 # test_split == 0: every pair trains, in order (:1227-1228)
+    assert tr.tolist() == list(range(17)) and len(te) == 0
