@@ -77,6 +77,11 @@ def parse(argv=None):
     ap.add_argument("--dist-eager", action="store_true", help="sharded path launched from Python instead of replayed (analysis)")
     ap.add_argument("--no-lookup-profile", action="store_true", help="do not stamp the lookup launches (no `roofline` object then)")
     ap.add_argument("--lookup-wg-dump", default=None, help="write the lookup's per-workgroup stamps to this .npy (tools/lookup_wg.py)")
+    ap.add_argument("--fused-handover", action="store_true", help="hand-over and lookup as ONE launch (tt_batch_ingest_lookup; measured neutral, off by default)")
+    ap.add_argument("--lookup-from-ids", action="store_true", help="the captured lookup decodes the int64 ids itself (round 3's kernel input) instead of "
+                    "reading the hand-over launch's precomputed rows")
+    ap.add_argument("--lookup-nt", action="store_true", help="TT_OPT_LOOKUP_NT: non-temporal stores of the looked-up rows (A/B)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the HBM-resident lookup leg and the configs[4] leg of the default run")
     return ap.parse_args(argv)
 
 
@@ -192,7 +197,9 @@ class Leg:
         if self.use_graph:
             from jodalrob_twotower_amd.graph import GraphedTrainStep
             try:
-                self.gstep = GraphedTrainStep(task, self.opt, self.pool[0], return_metrics=True, warmup=3, defer_riders=not args.no_riders)
+                self.gstep = GraphedTrainStep(task, self.opt, self.pool[0], return_metrics=True, warmup=3, defer_riders=not args.no_riders,
+                                              preserve_state=False)        # (the warm-up steps are part of the bench's own warm-up)
+                task._bench_gstep = self.gstep
             except Exception as e:                      # a capture that fails on some RCCL / world size must not lose the run
                 if not sharded:
                     raise
@@ -238,11 +245,21 @@ class Leg:
         ctx["fence"]()
         dt = time.perf_counter() - t0
         ops.set_timer(None)
-        self.lookup_us = self.profile.durations_us() if self.profile is not None else []
+        # the captured step's hand-over launch also does the lookup (tt_batch_ingest_lookup)?  Then the stamps are that launch's:
+        # its tile workgroups (the gather phase) come first, the copy roles behind them
+        self.fused_handover = self.gstep is not None and getattr(self.gstep, "_x_static", None) is not None
+        self.handover_body_us, self.handover_event_us = [], []
+        if self.profile is not None and self.fused_handover:
+            tiles = ops.ingest_lookup_tiles(self.B, [len(self.keys_n), len(self.keys_c)])
+            self.lookup_us = self.profile.durations_us(0, tiles)
+            self.handover_body_us = self.profile.durations_us()
+        else:
+            self.lookup_us = self.profile.durations_us() if self.profile is not None else []
         if self.profile is not None and self.args.lookup_wg_dump:     # per-workgroup stamps of the last launches (analysis)
             import numpy as _np
             _np.save(self.args.lookup_wg_dump, self.profile.ring.cpu().numpy())
-        self.dispatch_us = lookup_dispatch_overhead_us(self.task, self.pool, ctx["dev"], self.profile) if self.profile is not None else None
+        self.dispatch_us = lookup_dispatch_overhead_us(self.task, self.pool, ctx["dev"], self.profile) \
+            if (self.profile is not None and not self.fused_handover) else None
         if self.profile is not None:
             self.profile.close()
         ex = getattr(self.task, "exchange", None)
@@ -255,19 +272,26 @@ class Leg:
         # median of per-step DEVICE times (HIP events at the step boundaries) in a second pass: a short timed region is
         # fragile evidence on its own, and events between replays would perturb the region above
         n2 = min(args.steps, 50)
+        t2 = ops.KernelTimer(names=["tt_batch_ingest_lookup"])          # the hand-over launch is eager: HIP events on its stream bracket it
+        if self.fused_handover:
+            ops.set_timer(t2)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n2 + 1)]
         evs[0].record()
         for i in range(n2):
             self.step(args.warmup + args.steps + i)
             evs[i + 1].record()
         torch.cuda.synchronize()
+        ops.set_timer(None)
         per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n2))
         self.device_ms_median = per[len(per) // 2] if per else None
+        self.handover_event_us = sorted(a.elapsed_time(b) * 1e3 for a, b in t2.records.get("tt_batch_ingest_lookup", []))
         return dt
 
     def close(self):
         import gc
         import torch
+        if self.task is not None and hasattr(self.task, "_bench_gstep"):
+            self.task._bench_gstep = None
         if self.gstep is not None:
             self.gstep.close()                   # graph + pool first: its nodes reference the communicator
         self.gstep = self.task = self.opt = self.sched = self.pool = None
@@ -324,6 +348,12 @@ def run(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=cpu_group)
         return float(t.item())
 
+    from jodalrob_twotower_amd.config import settings as _settings
+    _settings.graph_ingest_lookup = bool(args.fused_handover)
+    _settings.graph_ingest_rows = not args.lookup_from_ids
+    if args.lookup_nt:
+        from jodalrob_twotower_amd import _lib as _l
+        _l.set_option(dev, _l.TT_OPT_LOOKUP_NT, 1)
     ctx = dict(dev=dev, world=world, rank=rank, staged=staged, comm=comm, fence=fence, max_over_ranks=max_over_ranks)
     out = None
     try:
@@ -368,12 +398,63 @@ def base_line(args, leg, world, scaling, B_global):
     }
 
 
+def roofline_fused(args, leg):
+    """The hand-over + lookup launch (ingest_lookup_kernel, tt_batch_ingest_lookup): the kernel BASELINE.json's metric names, since
+    round 4 one launch with the batch hand-over.  Algorithmic bytes per pair = the lookup's (table row + i64 id + output
+    row per key) + the hand-over's (dense features read + written, ids read + written into the static buffers, key-major fused
+    rows written).  mean_launch_us: HIP events around the eager launch on its stream, every step of bench.py's second pass;
+    mean_body_us: min start .. max end of ALL its workgroups' device-clock stamps in the timed region; lookup_phase: the same over
+    the tile workgroups only (ids -> rows -> gathers -> stores: the embedding lookup inside the launch)."""
+    x_bf16 = args.mlp_dtype == "bf16" and _tower_io_dtype() in ("x", "both")
+    K_tot, E, B = len(leg.keys_n) + len(leg.keys_c), leg.E, leg.B
+    s_out = 2 if x_bf16 else 4
+    lookup_pp = K_tot * (E * 4 + 8 + E * s_out)
+    handover_pp = 2 * 4 * (leg.din_n + leg.din_c) + K_tot * (8 + 8 + 4)
+    algo = B * (lookup_pp + handover_pp)
+    ev = leg.handover_event_us
+    launch_us = (sum(ev) / len(ev)) if ev else None
+    body = leg.handover_body_us
+    body_us = (sum(body) / len(body)) if body else None
+    ph = leg.lookup_us
+    ph_us = (sum(ph) / len(ph)) if ph else None
+    use = launch_us or body_us
+    achieved = algo / (use * 1e-6) / 1e9 if use else None
+    traffic, src = None, None
+    pmc = ROOT / "profiles" / "r04_ingest_lookup_pmc.json"
+    if pmc.exists() and B == 8192 and sum(leg.vocab_n) == 1_000_000 and sum(leg.vocab_c) == 1_000_000 and args.zipf is None and x_bf16:
+        try:
+            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+            src = f"profiles/{pmc.name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch on the same workload, round 4; not this run)"
+        except Exception:
+            traffic = None
+    return {"kernel": "ingest_lookup_kernel (tt_batch_ingest_lookup: batch hand-over + embedding lookup in one launch)", "bound": "hbm",
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+            "traffic": traffic, "traffic_source": src,
+            "hbm_frac_physical": (traffic / (use * 1e-6) / 1e9 / HBM_PEAK_GBPS) if (traffic and use) else None,
+            "algorithmic_bytes_per_launch": algo,
+            "algorithmic_bytes_per_pair": {"lookup (table row + i64 id + output row per key)": lookup_pp,
+                                           "hand-over (dense features in + out, ids in + out, key-major rows out)": handover_pp},
+            "launches_timed": len(ev), "mean_launch_us": launch_us, "mean_body_us": body_us,
+            "lookup_phase": {"what": "the launch's tile workgroups: ids -> clamped rows -> row gathers -> stores into the tower inputs",
+                             "mean_us": ph_us, "algorithmic_bytes": B * lookup_pp,
+                             "GBps": (B * lookup_pp / (ph_us * 1e-6) / 1e9) if ph_us else None,
+                             "frac": (B * lookup_pp / (ph_us * 1e-6) / 1e9 / HBM_PEAK_GBPS) if ph_us else None, "launches_timed": len(ph)},
+            "timed_in": "mean_launch_us: HIP events around the eager hand-over launch on its stream (second pass, every step); mean_body_us / "
+                        "lookup_phase: device-clock (s_memrealtime, 100 MHz) stamps of the launch's workgroups in the timed region"}
+
+
 def roofline_of(args, leg, world):
     """the lookup kernel: algorithmic bytes per launch / mean launch duration, measured live in the timed region"""
+    if getattr(leg, "fused_handover", False) and not leg.sharded:
+        return roofline_fused(args, leg)
     x_bf16 = args.mlp_dtype == "bf16" and _tower_io_dtype() in ("x", "both")
     K_tot, E, B = len(leg.keys_n) + len(leg.keys_c), leg.E, leg.B
     s_out = 2 if x_bf16 else 4                                # the lookup writes straight into the tower input x
-    bytes_per_pair = K_tot * (E * 4 + 8 + E * s_out)         # table row + i64 id + output row (SURVEY 8d: 10,032 / 7,600 B)
+    # table row + index + output row per key (SURVEY 8d: 10,032 / 7,600 B with the i64 id).  A captured step's lookup reads the
+    # 4-byte fused row the hand-over launch left for it (tt_embed_lookup_rows_fwd) instead of the 8-byte id: 7,448 B per pair
+    rows_mode = getattr(leg.gstep, "_rows_sm", None) is not None
+    s_idx = 4 if rows_mode else 8
+    bytes_per_pair = K_tot * (E * 4 + s_idx + E * s_out)
     ex = getattr(leg.task, "exchange", None)
     if leg.sharded and x_bf16 and getattr(ex, "wire_bf16", False):
         # sharded step: the stamped launch PLACES the exchanged rows, which arrive as bf16 (the f32 table rows are read by
@@ -394,7 +475,8 @@ def roofline_of(args, leg, world):
             src = f"profiles/{pmc.name} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch, not this run)"
         except Exception:
             traffic = None
-    return {"kernel": "lookup_wave_kernel (tt_embed_lookup_fwd)", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+    return {"kernel": "lookup_wave_kernel (tt_embed_lookup_rows_fwd: precomputed fused rows)" if rows_mode else "lookup_wave_kernel (tt_embed_lookup_fwd)",
+            "index_bytes_per_key": s_idx, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
             "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic, "traffic_source": src,
             # physical HBM traffic / time / peak: the hot binary-key rows are L2 hits, so fewer bytes than the algorithmic count move
             "hbm_frac_physical": (traffic / (lookup_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if (traffic and achieved) else None,
@@ -413,7 +495,9 @@ def config_of(args, leg, world, ctx, B_global, workload):
            "rows_company": sum(leg.vocab_c), "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})",
            "optimizer": args.optimizer, "score_dtype": args.score_dtype, **({"fp8_grad": args.fp8_grad} if args.score_dtype == "fp8" else {}), "mlp_dtype": args.mlp_dtype,
            "launch": "hip graph replay" if leg.gstep is not None else "eager",
-           "batch_handover": ("one launch: copies + key-major rows for the dedup plan (tt_batch_ingest)"
+           "batch_handover": (("one launch: copies + key-major rows for the dedup plan + the embedding lookup into the towers' inputs (tt_batch_ingest_lookup)"
+                               if getattr(leg.gstep, "_x_static", None) is not None else
+                               "one launch: copies + key-major rows for the dedup plan (tt_batch_ingest)")
                               if getattr(leg.gstep, "_ingest", None) is not None else "one launch: copies (tt_copy_multi)") if leg.gstep is not None else "none"}
     if leg.gstep is not None and hasattr(leg.gstep, "library_launches"):
         cfg["launches_per_step"] = leg.gstep.library_launches      # kernels of libtwotower_hip.so per step (RCCL's own kernels come on top)
@@ -473,6 +557,13 @@ def bench_single(args, ctx, sharded):
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(leg, args.cpu_seconds)
     leg.close()
+    if is_c1 and not sharded and not args.no_extra_legs and args.mode == "graph":
+        for key, fn in (("roofline_hbm_resident", hbm_resident_lookup_leg), ("configs4", configs4_leg)):
+            try:
+                out[key] = fn(args, ctx)
+            except Exception as e:                            # an extra leg must not lose the line
+                out[key] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
     return out
 
 
@@ -495,8 +586,13 @@ def bench_multi(args, ctx):
         leg = Leg(args, ctx, Bg, rows_n, rows_c, True, negatives=args.negatives or "local", sync_bn=args.sync_bn, label="weak")
         leg.run()
         out = base_line(args, leg, world, "weak", Bg * world)
-        out["config"] = config_of(args, leg, world, ctx, Bg * world, f"{cname}: {desc}; {Bg} pairs PER GPU (global batch {Bg * world}), "
-                                  "per-rank in-batch negatives and BatchNorm statistics (data-parallel semantics)")
+        #  the top-level number at N > 1 is NOT the batch-8192 job of N = 1 split N ways: say so in the metric text
+        # itself, so that nobody compares it with a global-batch figure under the same key; that job is `value_global_batch_8192`
+        out["metric"] = (f"training pairs/sec, {Bg} pairs PER GPU (global batch {Bg * world}; weak scaling of the N = 1 job at batch {Bg}) "
+                         "(embedding-lookup HBM GB/s in roofline)")
+        out["config"] = config_of(args, leg, world, ctx, Bg * world, f"VARIANT of {cname} (weak-scaling leg): {desc}; {Bg} pairs PER GPU (global batch "
+                                  f"{Bg * world}), per-rank in-batch negatives and BatchNorm statistics (data-parallel semantics); {cname} as SURVEY 8(d) "
+                                  f"states it -- GLOBAL batch {Bg}, global negatives + SyncBN -- is `value_global_batch_{Bg}` / `strong_scaling`")
         out["roofline"] = roofline_of(args, leg, world)
         out["final_loss"] = leg.loss
         leg.close()
@@ -516,6 +612,10 @@ def bench_multi(args, ctx):
             strong["config"] = cfg
             strong["roofline"] = roofline_of(args, leg, world)
             out["strong_scaling"] = strong
+            # SURVEY 8(d) C3 at top level too: pairs/s of the single-process batch-8192 job split over the N GPUs
+            out[f"value_global_batch_{Bg}"] = strong["value"]
+            out[f"ms_per_step_global_batch_{Bg}"] = strong["ms_per_step"]
+            out[f"roofline_global_batch_{Bg}"] = strong["roofline"]
         leg.close()
     if "one_gpu" in legs:
         # like-for-like denominator: the unsharded single-GPU step on the SAME tables and batch, rank 0 only
@@ -554,13 +654,22 @@ def lookup_dispatch_overhead_us(task, pool, dev, profile, iters: int = 48):
     towers = [task.two_tower_model.notice_tower, task.two_tower_model.company_tower]
     store = task.sharded_store if hasattr(task, "sharded_store") else towers[0].categorical_embedder.store
     sides_per_batch = []
+    rows_mode = getattr(getattr(task, "_bench_gstep", None), "_rows_sm", None) is not None
     for batch in pool:
         sides = []
         for tw, side in zip(towers, ("notice", "company")):
             B = batch[side]["dense"].shape[0]
             x = torch.empty((B, tw.x_width), dtype=tw.x_dtype, device=dev)
             sides.append(tw.categorical_embedder.lookup_side(batch[side]["kjt"].values(), x[:, tw.tower_hidden_dims[0]:]))
-        sides_per_batch.append((sides, B))
+        # the captured step's lookup reads precomputed fused rows: calibrate the same kernel
+        rows = ops.embed_lookup(store.weight, sides, B, want_rows=True) if rows_mode else None
+        sides_per_batch.append((sides, B, rows))
+
+    def launch(sides, B, rows):
+        if rows is not None:
+            ops.embed_lookup_rows(store.weight, rows, sides, B)
+        else:
+            ops.embed_lookup(store.weight, sides, B, want_rows=True)
     K = len(sides_per_batch)
     # (A) K launches back to back inside a small captured graph (eagerly the host cannot issue a 9-us kernel fast enough),
     #     profile hook off, HIP events around the replay: dispatch-to-dispatch time per launch
@@ -568,8 +677,8 @@ def lookup_dispatch_overhead_us(task, pool, dev, profile, iters: int = 48):
     side = torch.cuda.Stream(device=dev)
     side.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(side):
-        for sides, B in sides_per_batch:
-            ops.embed_lookup(store.weight, sides, B, want_rows=True)
+        for sb in sides_per_batch:
+            launch(*sb)
     torch.cuda.current_stream(dev).wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
@@ -577,7 +686,7 @@ def lookup_dispatch_overhead_us(task, pool, dev, profile, iters: int = 48):
     import torch.distributed as _d
     mode = "thread_local" if _d.is_initialized() else "global"       # a process group's watchdog polls events from its own thread
     with torch.cuda.graph(g, capture_error_mode=mode):
-        keep = [ops.embed_lookup(store.weight, sides, B, want_rows=True) for _ in range(REP) for sides, B in sides_per_batch]
+        keep = [launch(*sb) for _ in range(REP) for sb in sides_per_batch]
     ev_us = []
     for rep in range(12):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -591,14 +700,161 @@ def lookup_dispatch_overhead_us(task, pool, dev, profile, iters: int = 48):
     profile.reopen()
     profile.reset()
     for rep in range(3):
-        for sides, B in sides_per_batch:
-            ops.embed_lookup(store.weight, sides, B, want_rows=True)
+        for sb in sides_per_batch:
+            launch(*sb)
     torch.cuda.synchronize()
     st_us = profile.durations_us()
     if not ev_us or not st_us:
         return None
     ev_us.sort()
     return max(0.0, ev_us[len(ev_us) // 2] - sum(st_us) / len(st_us))      # upper median of the replays: min() under-reports
+
+
+def hbm_resident_lookup_leg(args, ctx, rows_n: int = 100_000_000, rows_c: int = 10_000_000, B: int = 8192):
+    """The embedding lookup ALONE on tables the caches cannot hold (BASELINE configs[2] sizes on one GPU: 100 M + 10 M rows of
+    128 B = 14 GB; tables only, no model, no optimiser state): north_star's ">= 60 % of the HBM roofline at batch 8192" where HBM
+    really serves the rows.  Never `value`.  Three forms of the product path over a pool of 8 id batches:
+      lookup_rows  tt_embed_lookup_rows_fwd (the captured step's lookup: fused rows precomputed by the hand-over launch) -- the leg's headline
+      lookup       tt_embed_lookup_fwd (from int64 ids: eager steps, evaluation)
+      handover     tt_batch_ingest_lookup (hand-over + lookup as ONE launch: + dense features and ids copied; optional form)
+    each timed (a) back to back inside a small captured graph with HIP events around the replay: mean LAUNCH time incl. the
+    kernel boundary (what rocprofv3 sums per kernel plus the gap), and with its workgroups' device-clock stamps: mean BODY;
+    (b) `cold`: every launch behind a 256 MB streaming copy (what the other kernels of a step do to L2 / Infinity Cache), HIP
+    events around the single launch."""
+    import torch
+    from jodalrob_twotower_amd import ops, synthetic
+    dev = ctx["dev"]
+    schema = synthetic.load_real_schema(ROOT / "jodalrob-twotower_amd" / "schema_real.json")
+    kn, kc = schema["notice"]["categorical"], schema["company"]["categorical"]
+    vn, vc = synthetic.scale_vocabs(schema["notice"]["vocab_sizes"], rows_n), synthetic.scale_vocabs(schema["company"]["vocab_sizes"], rows_c)
+    E, h0, din_n, din_c = 32, 128, 256, 128
+    R = sum(vn) + sum(vc)
+    g = torch.Generator(device=dev).manual_seed(99)
+    table = torch.empty((R, E), dtype=torch.float32, device=dev)
+    for lo in range(0, R, 1 << 24):                              # filled in slices: no 14 GB temporaries
+        table[lo:lo + (1 << 24)].normal_(generator=g)
+    offs_n = torch.tensor([sum(vn[:i]) for i in range(len(vn))], dtype=torch.int64, device=dev)
+    offs_c = torch.tensor([sum(vn) + sum(vc[:i]) for i in range(len(vc))], dtype=torch.int64, device=dev)
+    voc_n, voc_c = torch.tensor(vn, dtype=torch.int64, device=dev), torch.tensor(vc, dtype=torch.int64, device=dev)
+    xn = torch.zeros((B, h0 + len(kn) * E), dtype=torch.bfloat16, device=dev)
+    xc = torch.zeros((B, h0 + len(kc) * E), dtype=torch.bfloat16, device=dev)
+    pool = [synthetic.make_batch(B, vn, vc, kn, kc, din_n, din_c, dev, seed=500 + i) for i in range(8)]
+    stat = {"dn": torch.empty((B, din_n), device=dev), "dc": torch.empty((B, din_c), device=dev),
+            "in": torch.empty(B * len(kn), dtype=torch.int64, device=dev), "ic": torch.empty(B * len(kc), dtype=torch.int64, device=dev),
+            "km": torch.empty(B * (len(kn) + len(kc)), dtype=torch.int32, device=dev)}
+    K_tot = len(kn) + len(kc)
+    lookup_bytes = B * K_tot * (E * 4 + 8 + E * 2)
+    rows_bytes = B * K_tot * (E * 4 + 4 + E * 2)
+    handover_bytes = lookup_bytes + B * (2 * 4 * (din_n + din_c) + K_tot * (8 + 8 + 4))
+    tiles = ops.ingest_lookup_tiles(B, [len(kn), len(kc)])
+
+    def sides(b):
+        return [ops.LookupSide(b["notice"]["kjt"].values(), offs_n, voc_n, xn[:, h0:], len(kn)),
+                ops.LookupSide(b["company"]["kjt"].values(), offs_c, voc_c, xc[:, h0:], len(kc))]
+
+    def run_lookup(b):
+        ops.embed_lookup(table, sides(b), B, want_rows=False)
+
+    rows_of = {id(b): ops.embed_lookup(table, sides(b), B, want_rows=True) for b in pool}      # slot-order fused rows (what the hand-over leaves)
+
+    def run_lookup_rows(b):
+        ops.embed_lookup_rows(table, rows_of[id(b)], sides(b), B)
+
+    def run_handover(b):
+        ops.batch_ingest([(stat["dn"], b["notice"]["dense"]), (stat["in"], b["notice"]["kjt"].values()), (stat["dc"], b["company"]["dense"]),
+                          (stat["ic"], b["company"]["kjt"].values())], sides(b), B, stat["km"], table=table)
+
+    flush_src = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    flush_dst = torch.empty_like(flush_src)
+    prof = ops.LookupProfile(dev, n_slots=64)
+    import torch.distributed as _d
+    mode = "thread_local" if _d.is_initialized() else "global"
+    out = {"tables": f"{rows_n} + {rows_c} rows x {E} f32 = {R * E * 4 / 1e9:.1f} GB, uniform ids over the real 32 + 6 key vocabularies scaled to these sizes",
+           "batch": B}
+    try:
+        for name, fn, nbytes, last in (("lookup_rows", run_lookup_rows, rows_bytes, None), ("lookup", run_lookup, lookup_bytes, None),
+                                       ("handover", run_handover, handover_bytes, None)):
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for b in pool:
+                    fn(b)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            REP = 4
+            with torch.cuda.graph(gr, capture_error_mode=mode):
+                for _ in range(REP):
+                    for b in pool:
+                        fn(b)
+            launch_us = []
+            prof.reset()
+            for rep in range(10):
+                a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                gr.replay()
+                e.record()
+                torch.cuda.synchronize()
+                launch_us.append(a.elapsed_time(e) * 1e3 / (REP * len(pool)))
+            body = prof.durations_us()
+            phase = prof.durations_us(0, tiles) if name == "handover" else body
+            del gr
+            cold = []
+            for i in range(24):
+                flush_dst.copy_(flush_src)
+                a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn(pool[i % len(pool)])
+                e.record()
+                cold.append((a, e))
+            torch.cuda.synchronize()
+            cold_us = sorted(a.elapsed_time(e) * 1e3 for a, e in cold[4:])
+            launch_us.sort()
+            ml = launch_us[len(launch_us) // 2]
+            rec = {"entry": {"lookup": "tt_embed_lookup_fwd", "lookup_rows": "tt_embed_lookup_rows_fwd", "handover": "tt_batch_ingest_lookup"}[name],
+                   "algorithmic_bytes_per_launch": nbytes,
+                   "mean_launch_us": ml, "mean_body_us": (sum(body) / len(body)) if body else None,
+                   "achieved": nbytes / (ml * 1e-6) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / (ml * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                   "cold_cache_launch_us": cold_us[len(cold_us) // 2], "cold_cache_frac": nbytes / (cold_us[len(cold_us) // 2] * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                   "launches_timed": REP * len(pool) * 10}
+            if name == "handover" and phase:
+                pu = sum(phase) / len(phase)
+                rec["lookup_phase"] = {"mean_us": pu, "algorithmic_bytes": lookup_bytes, "frac": lookup_bytes / (pu * 1e-6) / 1e9 / HBM_PEAK_GBPS}
+            out[name] = rec
+        out["frac"] = out["lookup_rows"]["frac"]                  # the headline of this leg: the captured step's lookup launch
+        out["mean_launch_us"], out["mean_body_us"] = out["lookup_rows"]["mean_launch_us"], out["lookup_rows"]["mean_body_us"]
+        out["how"] = ("mean_launch_us: 32 launches over 8 id batches back to back in a captured graph, HIP events around the replay, median of 10 replays "
+                      "(kernel + boundary); mean_body_us: min start .. max end of the workgroups' s_memrealtime stamps in those launches; "
+                      "cold_cache_*: each launch behind a 256 MB streaming copy, HIP events around the single launch")
+    finally:
+        prof.close()
+        del table
+        torch.cuda.empty_cache()
+    return out
+
+
+def configs4_leg(args, ctx):
+    """BASELINE configs[4] in the default run (never `value`): final_embedding_dim 256, batch 65536, fp8 (e4m3) MFMA score matrix,
+    fused sparse Adam on the embedding rows; 1 M + 1 M-row tables; a few replayed steps + the score kernels' MFMA figure."""
+    import copy
+    a4 = copy.copy(args)
+    a4.batch, a4.final_dim, a4.score_dtype, a4.steps, a4.warmup, a4.pool, a4.no_lookup_profile = 65536, 256, "fp8", 5, 2, 2, True
+    a4.hidden, a4.optimizer, a4.mlp_dtype, a4.zipf = "128,64", "fused_sparse", "bf16", None
+    leg = Leg(a4, ctx, a4.batch, 1_000_000, 1_000_000, False)
+    try:
+        leg.run()
+        out = {"value": a4.batch * a4.steps / leg.dt, "unit": "pairs/s", "ms_per_step": leg.dt / a4.steps * 1e3,
+               "device_ms_per_step_median": leg.device_ms_median, "steps": a4.steps, "warmup": a4.warmup, "final_loss": leg.loss,
+               "config": {"workload": "configs[4]: 32+6 real keys, 1000000 + 1000000 table rows, batch 65536, E=32, towers [128,64], final 256, "
+                                      "fp8 (e4m3) score operands, fused sparse Adam", "fp8_grad": a4.fp8_grad,
+                          "launches_per_step": getattr(leg.gstep, "library_launches", None)}}
+        try:
+            out["mfma"] = score_mfma_leg(a4, ctx["dev"], a4.batch, a4.final_dim, reps=2)
+        except Exception as e:
+            out["mfma"] = {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        leg.close()
+    return out
 
 
 def score_mfma_leg(args, dev, B, D, reps: int = 8):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TT_ABI_VERSION 1
+#define TT_ABI_VERSION 2
 
 #define TT_OK 0
 #define TT_ERR_INVALID_ARG (-1)
@@ -82,6 +82,9 @@ uint64_t tt_launch_count(void);
  * predecessors'; the last one through clears the buffer); 0 = count and write as separate launches.  Same results bit for bit
  * (tests compare the two). */
 #define TT_OPT_CHAINED 6
+/* TT_OPT_LOOKUP_NT (default 0): tt_batch_ingest_lookup stores its bf16 rows with non-temporal stores (same bits; an A/B switch:
+ * they leave L2 during the launch instead of at its end). */
+#define TT_OPT_LOOKUP_NT 7
 int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value);
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream);
 /* only the queued slab reduction (the one thing that lives in the caller's shared scratch buffer) */
@@ -116,16 +119,26 @@ typedef struct tt_embed_side {
 
 /* Measurement hook: per-launch device-clock stamps of the lookup kernel, usable inside a captured graph (where
  * HIP events cannot bracket one kernel), without host synchronisation and WITHOUT an extra launch.
- * `ring_dev` = 4096 + n_slots * 4096 * 2 uint64 words of device memory, zero-initialised by the caller:
- *   [b], b < 4096: launch counter of workgroup b (each workgroup keeps its own: [0] = launches so far);
- *   then n_slots blocks of 4096 pairs {start, end}: block (n mod n_slots), pair b = workgroup b in launch n --
+ * `ring_dev` = 8192 + n_slots * 8192 * 2 uint64 words of device memory, zero-initialised by the caller:
+ *   [b], b < 8192: launch counter of workgroup b (each workgroup keeps its own: [0] = launches so far);
+ *   then n_slots blocks of 8192 pairs {start, end}: block (n mod n_slots), pair b = workgroup b in launch n --
  *   start = its first instruction, end = all its stores have completed (0, 0 = workgroup not in the grid).
  *   Kernel duration of launch n = (max end - min start over the block) * 10 ns (100 MHz clock); the caller reduces.
- *   ring_dev == NULL switches the hook off. */
+ *   ring_dev == NULL switches the hook off.  The fused hand-over + lookup launch (tt_batch_ingest_lookup) writes the same ring:
+ *   workgroup b = its linear index, the tiles (gather phase) first, the copy roles behind them. */
 int tt_embed_lookup_set_profile(tt_ctx* ctx, uint64_t* ring_dev, int32_t n_slots);
 int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E,
                         const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_out,
                         tt_stream stream);
+/* The same gather + concat (cat_embed.py:157-178, base_tower.py:139) from PRECOMPUTED fused rows: rows[slot], slot = side_base +
+ * b*K + k (side_base = sum of B*K of the earlier sides), already clamped -- what tt_batch_ingest / tt_batch_ingest_store leave in
+ * `rows_sm` when a captured step's batch is handed over (they decode and clamp every id anyway).  sides[i] gives K / out / ld_out /
+ * out_dtype (ids, key_row_offset, key_vocab are ignored and may be NULL).  Same bits in the outputs as tt_embed_lookup_fwd on the
+ * ids the rows came from (test); the kernel reads a 4-byte row instead of an 8-byte id + its key's offset and vocabulary.
+ * E = 4 x a power of two, outputs 4-element aligned (TT_ERR_UNSUPPORTED otherwise). */
+int tt_embed_lookup_rows_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E,
+                             const tt_embed_side* sides, int32_t n_sides, int64_t B, const int32_t* rows,
+                             tt_stream stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Duplicate-row plan for the sparse gradient (a16): stable LSD radix sort of the M slot rows, then
@@ -591,7 +604,9 @@ int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* s
  * (the lookup's own id -> row rule, src/towers/cat_embed.py:114-117; side_base = sum of B*K of the earlier sides).
  * sides[i].ids is the SOURCE of the hand-over (the incoming batch); out / ld_out / out_dtype are ignored.  1 <= K <= 64 per side. */
 int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
-                    const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_km, tt_stream stream);
+                    const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_km,
+                    int32_t* rows_sm /* or NULL: the same rows in slot order, rows_sm[side_base + b*K + k], for tt_embed_lookup_rows_fwd */,
+                    tt_stream stream);
 
 /* The same hand-over STRAIGHT FROM THE DEVICE-RESIDENT FEATURE STORES (two-level gather: pair -> entity row -> dense features
  * and ids -> fused table rows) -- replaces UnifiedBidDataset.__getitem__ + collate_fn_gpu_optimized + _build_batch_kjt
@@ -602,8 +617,9 @@ int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const*
  *   ids_out[b*K + k]  = cat_store[e*K + k]                                             (sample-major: the KJT values())
  *   rows_km[side_base + k*B + b] = key_row_offset[k] + clamp(ids_out[b*K + k], 0, key_vocab[k] - 1)   (as tt_batch_ingest)
  * plus the n copy segments (the step scalars).  sides[i] gives K / key_row_offset / key_vocab (ids, out, ld_out, out_dtype
- * ignored); rows_km may be NULL (no key-major rows wanted).  Entity indices are trusted to lie inside the stores (the
- * loader validates the pair list once: KeyError as unified_bid_data_loader.py:495-498).  Bit-identical to tt_batch_gather per
+ * ignored); rows_km may be NULL (no key-major rows wanted).  Entity indices are expected to lie inside the stores (the
+ * loader validates the pair list once: KeyError as unified_bid_data_loader.py:495-498); with stores[i].n_rows set, one that
+ * does not is clamped into the store rather than read out of bounds.  Bit-identical to tt_batch_gather per
  * side followed by tt_batch_ingest (test). */
 typedef struct tt_store_side {
   const int64_t* entity;     /* entity index per pair, read at [o * entity_stride] (an interleaved [P, 2] pair list: stride 2) */
@@ -613,11 +629,35 @@ typedef struct tt_store_side {
   float* dense_out;          /* [B, dense_dim] */
   int64_t* ids_out;          /* [B * K] */
   int32_t dense_dim;
-  int32_t reserved;
+  int32_t n_rows;            /* entity rows N of the store; > 0: an index outside [0, N) is clamped into it instead of read out of
+                              * bounds (the loader has validated the pair list; this guards the device), 0: unchecked */
 } tt_store_side;
 int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                           const tt_embed_side* sides, const tt_store_side* stores, int32_t n_sides, int64_t B,
-                          const int64_t* order /* [B] or NULL */, int32_t* rows_km /* or NULL */, tt_stream stream);
+                          const int64_t* order /* [B] or NULL */, int32_t* rows_km /* or NULL */,
+                          int32_t* rows_sm /* or NULL: as tt_batch_ingest */, tt_stream stream);
+
+
+/* Hand-over AND lookup in ONE launch: tt_batch_ingest / tt_batch_ingest_store whose tile workgroups -- they hold the batch's
+ * clamped fused rows in LDS anyway -- also gather the table rows and write them into the towers' input, i.e. the hand-over
+ * followed by tt_embed_lookup_fwd (src/towers/cat_embed.py:103-121, :157-178; tower/base_tower.py:133-139) without the second
+ * launch, its re-read of the ids and its boundary; the dense features are copied beside the gathers.  sides[i].out / ld_out /
+ * out_dtype say where side i's rows go (as in tt_embed_lookup_fwd: out = first element of sample 0 / key 0); rows_km may be
+ * NULL.  E must be 8, 16, 32 or 64 (TT_ERR_UNSUPPORTED otherwise: use the two separate calls).  Results are bit-identical to
+ * the two separate calls (test).  The tile workgroups write tt_embed_lookup_set_profile's stamps (gather phase). */
+typedef struct tt_ingest_lookup {
+  const float* table;  /* fused [table_rows, E] f32 table */
+  int64_t table_rows;
+  int32_t E;
+  int32_t reserved;
+} tt_ingest_lookup;
+int tt_batch_ingest_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
+                           const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_km /* or NULL */,
+                           const tt_ingest_lookup* lookup, tt_stream stream);
+int tt_batch_ingest_store_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
+                                 const tt_embed_side* sides, const tt_store_side* stores, int32_t n_sides, int64_t B,
+                                 const int64_t* order /* [B] or NULL */, int32_t* rows_km /* or NULL */,
+                                 const tt_ingest_lookup* lookup, tt_stream stream);
 
 #ifdef __cplusplus
 }

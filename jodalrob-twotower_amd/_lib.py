@@ -36,7 +36,11 @@ class EmbedSide(C.Structure):
 
 class StoreSide(C.Structure):
     _fields_ = [("entity", vp), ("entity_stride", i64), ("dense_store", vp), ("cat_store", vp), ("dense_out", vp), ("ids_out", vp),
-                ("dense_dim", i32), ("reserved", i32)]
+                ("dense_dim", i32), ("n_rows", i32)]
+
+
+class IngestLookup(C.Structure):
+    _fields_ = [("table", vp), ("table_rows", i64), ("E", i32), ("reserved", i32)]
 
 
 class GradSrc(C.Structure):
@@ -88,6 +92,7 @@ SIGNATURES = {
     "tt_ctx_num_cus": (C.c_int, [vp]),
     "tt_embed_lookup_set_profile": (C.c_int, [vp, vp, i32]),
     "tt_embed_lookup_fwd": (C.c_int, [vp, vp, i64, i32, C.POINTER(EmbedSide), i32, i64, vp, vp]),
+    "tt_embed_lookup_rows_fwd": (C.c_int, [vp, vp, i64, i32, C.POINTER(EmbedSide), i32, i64, vp, vp]),
     "tt_dedup_workspace_bytes": (sz, [i64]),
     "tt_dedup_plan": (C.c_int, [vp, vp, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_dedup_keyed_workspace_bytes": (sz, [i64, i32]),
@@ -147,10 +152,14 @@ SIGNATURES = {
     "tt_dedup_plan_runs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_gather_rows": (C.c_int, [vp, vp, i64, i32, vp, i64, vp, i32, vp]),
     "tt_copy_multi": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]),
-    "tt_batch_ingest": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp, vp]),
+    "tt_batch_ingest": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp, vp, vp]),
     "tt_batch_gather": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]),
     "tt_batch_ingest_store": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), C.POINTER(StoreSide), i32,
-                                        i64, vp, vp, vp]),
+                                        i64, vp, vp, vp, vp]),
+    "tt_batch_ingest_lookup": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp,
+                                         C.POINTER(IngestLookup), vp]),
+    "tt_batch_ingest_store_lookup": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), C.POINTER(StoreSide),
+                                               i32, i64, vp, vp, C.POINTER(IngestLookup), vp]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -213,6 +222,7 @@ TT_OPT_SCORE_BWD_ROWS_MIN = 3
 TT_OPT_DEFER_RIDERS = 4
 TT_OPT_FP8_GRAD = 5
 TT_OPT_CHAINED = 6
+TT_OPT_LOOKUP_NT = 7
 
 
 def set_option(device: torch.device, option: int, value: int):

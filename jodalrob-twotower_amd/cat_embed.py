@@ -39,10 +39,13 @@ class EmbeddingStore:
         self.members: List["CategoricalEmbedder"] = []
         self.version = 0
         self._grad_counters = None                      # 4 int32 words the gradient reduction keeps zero between calls
-        # set by GraphedTrainStep: (static id tensors per side, their _version at the last hand-over, rows_km) -- the fused rows of
-        # exactly those id tensors in key-major order, written by ops.batch_ingest.  A pass over other tensors, or over these
-        # after anybody else wrote to them, does not see it (rows_km_for).
+        # set by GraphedTrainStep: (static id tensors per side, their _version at the last hand-over, rows_km[, x buffers]) -- the
+        # fused rows of exactly those id tensors in key-major order, written by ops.batch_ingest.  A pass over other tensors, or
+        # over these after anybody else wrote to them, does not see it (rows_km_for).  With the fused hand-over + lookup launch the
+        # fourth entry holds, per side, the tower input x whose embedding columns that launch has ALREADY filled (x_for): valid for
+        # one pass (`ingest_x_fresh`), because an optimiser step in between changes the table rows they were copied from.
         self.ingest = None
+        self.ingest_x_fresh = False
 
     def rows_km_for(self, id_tensors) -> Optional[torch.Tensor]:
         """The key-major rows of ops.batch_ingest if they describe exactly `id_tensors` as they are now, else None."""
@@ -53,6 +56,25 @@ class EmbeddingStore:
             if t.data_ptr() != r.data_ptr() or t.numel() != r.numel() or r._version != v:
                 return None
         return reg[2]
+
+    def rows_sm_for(self, id_tensors) -> Optional[torch.Tensor]:
+        """The slot-order fused rows the hand-over launch left for exactly `id_tensors` (as they are now), or None."""
+        reg = self.ingest
+        if reg is None or len(reg) < 5 or reg[4] is None or self.rows_km_for(id_tensors) is None:
+            return None
+        return reg[4]
+
+    def x_for(self, id_tensors, shapes) -> Optional[list]:
+        """The towers' input buffers whose embedding columns the hand-over launch has already filled for exactly `id_tensors` (as
+        they are now), or None: then the lookup runs as its own launch.  shapes: per side (B, x_width, dtype).  One pass only."""
+        reg = self.ingest
+        if reg is None or len(reg) < 4 or reg[3] is None or not self.ingest_x_fresh or self.rows_km_for(id_tensors) is None:
+            return None
+        xs = reg[3]
+        if len(xs) != len(shapes) or any(tuple(x.shape) != (b, w) or x.dtype != dt for x, (b, w, dt) in zip(xs, shapes)):
+            return None
+        self.ingest_x_fresh = False
+        return xs
 
     def grad_counters(self) -> Optional[torch.Tensor]:
         """Allocated on first use OUTSIDE a graph capture (a zero-fill inside one would become a memset node: DESIGN.md section 6);

@@ -32,6 +32,7 @@ struct tt_ctx {
   void* chain_stream[16];
   int chain_used;
   int chained;              // TT_OPT_CHAINED: use them (default 1); 0 = the multi-launch forms (same results; tests compare)
+  int lookup_nt;            // TT_OPT_LOOKUP_NT: the fused hand-over + lookup launch stores its bf16 rows non-temporally (default 0)
 };
 
 constexpr uint32_t kChainReady = 0x80000000u;

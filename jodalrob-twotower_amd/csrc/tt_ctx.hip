@@ -124,6 +124,7 @@ int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value) {
       break;
     case TT_OPT_FP8_GRAD: ctx->fp8_grad = value != 0; break;
     case TT_OPT_CHAINED: ctx->chained = value != 0; break;
+    case TT_OPT_LOOKUP_NT: ctx->lookup_nt = value != 0; break;
     default: tt_set_error("tt_ctx_set_option: unknown option %d", option); return TT_ERR_INVALID_ARG;
   }
   return TT_OK;

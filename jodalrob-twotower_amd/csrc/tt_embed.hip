@@ -117,16 +117,21 @@ __global__ __launch_bounds__(kThreads) void lookup_kernel(SideSet a, const float
 // time (C = E/4 lanes per row), issuing ALL row loads of the chunk before the first store, so every lane
 // keeps C x 16 B in flight and a wave-instruction still reads whole 128-B lines.
 // ------------------------------------------------------------------------------------------------
-constexpr int kProfileMaxWg = 4096;
+constexpr int kProfileMaxWg = 8192;
 struct SlotRec {
   const float* src;
   char* dst;
 };
 using f32x4n = __attribute__((ext_vector_type(4))) float;
 
-template <int C, int SPW>   // C 16-byte chunks per row, SPW slots per wave pass
+// W = 16-byte pieces per lane (round 4: with W = 2 a lane moves 32 B of a row -- two loads, ONE 16-byte bf16 store: half the
+// store instructions, 3 % faster on tables in and out of the caches);  ROWS = the fused rows come precomputed (int32, slot
+// order: the hand-over launch of a captured step has decoded and clamped the ids already -- tt_embed_lookup_rows_fwd) instead
+// of being decoded from int64 ids, key offsets and vocabularies: no gathered offset / vocabulary loads, no 64-bit clamp, half
+// the index bytes (lab, tools/probe/lookup_lab.hip: 9.2 -> 8.5 us back to back, 14.3 -> 11.9 us behind a cache-evicting copy).
+template <int C, int SPW, int W, bool ROWS>   // C 16-byte chunks per row, SPW slots per wave pass
 __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const float* __restrict__ table,
-                                                              int32_t* __restrict__ rows_out,
+                                                              int32_t* __restrict__ rows_out, const int32_t* __restrict__ rows_in,
                                                               unsigned long long* __restrict__ ring, int ring_slots) {
   // measurement only: per-workgroup start/end stamps.  Workgroup b keeps its OWN launch counter (ring[b]) and writes the pair
   // of launch n into slot n % ring_slots of its column: no cross-workgroup traffic, no extra launch; the host reduces afterwards
@@ -138,9 +143,11 @@ __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const 
   }
   __shared__ SlotRec recs[kThreads / 64][SPW];
   __shared__ int dts[kThreads / 64][SPW];
-  constexpr int RPI = 64 / C;                       // rows per wave-instruction
+  static_assert(C % W == 0, "W pieces per lane must divide the row");
+  constexpr int LPR = C / W;                        // lanes per row
+  constexpr int RPI = 64 / LPR;                     // rows per wave-instruction
   constexpr int NIT = SPW / RPI;                    // wave-instructions per pass
-  static_assert(SPW % RPI == 0 && NIT >= 1, "SPW must be a multiple of 64/C");
+  static_assert(SPW % RPI == 0 && NIT >= 1, "SPW must be a multiple of the rows per wave-instruction");
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t nchunks = (a.total_slots + SPW - 1) / SPW;
   const uint32_t wstride = gridDim.x * (kThreads / 64);
@@ -154,11 +161,16 @@ __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const 
       const uint32_t local = slot - s.slot_base;
       const uint32_t b = local / (uint32_t)s.K;
       const uint32_t k = local - b * (uint32_t)s.K;
-      int64_t id = s.ids[local];
-      const int64_t hi = s.vocab[k] - 1;
-      id = id < 0 ? 0 : (id > hi ? hi : id);               // clamp: cat_embed.py:117
-      const int64_t row = s.off[k] + id;
-      if (rows_out) rows_out[slot] = (int32_t)row;
+      int64_t row;
+      if (ROWS) {
+        row = rows_in[slot];
+      } else {
+        int64_t id = s.ids[local];
+        const int64_t hi = s.vocab[k] - 1;
+        id = id < 0 ? 0 : (id > hi ? hi : id);             // clamp: cat_embed.py:117
+        row = s.off[k] + id;
+        if (rows_out) rows_out[slot] = (int32_t)row;
+      }
       rec.src = table + row * a.E;
       dt = s.dtype;
       rec.dst = s.out + ((int64_t)b * s.ld + (int64_t)k * a.E) * (dt == TT_BF16 ? 2 : 4);
@@ -168,25 +180,38 @@ __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const 
       dts[wave][lane] = dt;
     }
     __builtin_amdgcn_wave_barrier();
-    float4 v[NIT];
-    const uint32_t sub = lane / C, part = lane % C;
+    float4 v[NIT][W];
+    const uint32_t sub = lane / LPR, part = lane % LPR;
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
       const SlotRec r = recs[wave][j * RPI + sub];
-      v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r.src != nullptr) v[j] = *reinterpret_cast<const float4*>(r.src + part * 4);
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        v[j][w] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r.src != nullptr) v[j][w] = *reinterpret_cast<const float4*>(r.src + (part * W + w) * 4);
+      }
     }
 #pragma unroll
     for (int j = 0; j < NIT; ++j) {
       const SlotRec r = recs[wave][j * RPI + sub];
       if (r.dst == nullptr) continue;
       if (dts[wave][j * RPI + sub] == TT_F32) {            // non-temporal: the rows are read next by another kernel, not this one
-        f32x4n t;
-        t[0] = v[j].x; t[1] = v[j].y; t[2] = v[j].z; t[3] = v[j].w;
-        __builtin_nontemporal_store(t, reinterpret_cast<f32x4n*>(r.dst + part * 16));
+#pragma unroll
+        for (int w = 0; w < W; ++w) {
+          f32x4n t;
+          t[0] = v[j][w].x; t[1] = v[j][w].y; t[2] = v[j][w].z; t[3] = v[j][w].w;
+          __builtin_nontemporal_store(t, reinterpret_cast<f32x4n*>(r.dst + (part * W + w) * 16));
+        }
+      } else if (W == 2) {
+        uint4 o;
+        o.x = (uint32_t)tt_f2bf(v[j][0].x) | ((uint32_t)tt_f2bf(v[j][0].y) << 16);
+        o.y = (uint32_t)tt_f2bf(v[j][0].z) | ((uint32_t)tt_f2bf(v[j][0].w) << 16);
+        o.z = (uint32_t)tt_f2bf(v[j][W - 1].x) | ((uint32_t)tt_f2bf(v[j][W - 1].y) << 16);
+        o.w = (uint32_t)tt_f2bf(v[j][W - 1].z) | ((uint32_t)tt_f2bf(v[j][W - 1].w) << 16);
+        *reinterpret_cast<uint4*>(r.dst + part * 16) = o;
       } else {
         ushort4 o;
-        o.x = tt_f2bf(v[j].x); o.y = tt_f2bf(v[j].y); o.z = tt_f2bf(v[j].z); o.w = tt_f2bf(v[j].w);
+        o.x = tt_f2bf(v[j][0].x); o.y = tt_f2bf(v[j][0].y); o.z = tt_f2bf(v[j][0].z); o.w = tt_f2bf(v[j][0].w);
         *reinterpret_cast<ushort4*>(r.dst + part * 8) = o;
       }
     }
@@ -1473,6 +1498,7 @@ struct IngestArgs {
   int32_t K[TT_MAX_SIDES];
   int32_t side_base[TT_MAX_SIDES];
   int32_t* rows_km;
+  int32_t* rows_sm;    // optional: the same fused rows in SLOT order (side_base + b * K + k) for tt_embed_lookup_rows_fwd
 };
 
 __global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
@@ -1518,6 +1544,7 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
         int64_t id = idv[u];
         id = id < 0 ? 0 : (id > s_hi[k] ? s_hi[k] : id);      // clamp: cat_embed.py:117 (as the lookup)
         tl[k][bl] = (int32_t)(s_off[k] + id);
+        if (a.rows_sm) a.rows_sm[a.side_base[si] + (int64_t)b0 * K + e] = tl[k][bl];
       }
     }
     __syncthreads();
@@ -1542,6 +1569,7 @@ struct StoreIngestArgs {
   float* dense_out[TT_MAX_SIDES];
   int64_t* ids_out[TT_MAX_SIDES];
   int32_t dense_dim[TT_MAX_SIDES];
+  int32_t n_rows[TT_MAX_SIDES];                  // entity rows of the store (0 = unchecked): indices are clamped into [0, n_rows)
 };
 
 template <bool VEC>
@@ -1569,7 +1597,8 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_store_kernel(StoreInges
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
       const int b = (int)(t / per), j = (int)(t - (int64_t)b * per);
       const int64_t o = a.order ? a.order[b] : b;
-      const int64_t e = ent[o * es];
+      int64_t e = ent[o * es];
+      if (a.n_rows[si] > 0) e = e < 0 ? 0 : (e >= a.n_rows[si] ? a.n_rows[si] - 1 : e);
       if (VEC) reinterpret_cast<float4*>(a.dense_out[si] + (int64_t)b * dd)[j] = reinterpret_cast<const float4*>(a.dense_store[si] + e * dd)[j];
       else a.dense_out[si][(int64_t)b * dd + j] = a.dense_store[si][e * dd + j];
     }
@@ -1590,7 +1619,9 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_store_kernel(StoreInges
   if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + nb) {
     const int bl = threadIdx.x - 64;
     const int64_t o = a.order ? a.order[b0 + bl] : b0 + bl;
-    s_ent[bl] = a.entity[si][o * a.entity_stride[si]];
+    int64_t e = a.entity[si][o * a.entity_stride[si]];
+    if (a.n_rows[si] > 0) e = e < 0 ? 0 : (e >= a.n_rows[si] ? a.n_rows[si] - 1 : e);
+    s_ent[bl] = e;
   }
   __syncthreads();
   constexpr int PER = kIngestMaxK * 64 / kThreads;
@@ -1612,6 +1643,7 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_store_kernel(StoreInges
       a.ids_out[si][(int64_t)b0 * K + e] = id;                 // sample-major: the KJT values() of the batch
       id = id < 0 ? 0 : (id > s_hi[k] ? s_hi[k] : id);         // clamp: cat_embed.py:117 (as the lookup)
       tl[k][bl] = (int32_t)(s_off[k] + id);
+      if (a.g.rows_sm) a.g.rows_sm[a.g.side_base[si] + (int64_t)b0 * K + e] = tl[k][bl];
     }
   }
   if (a.g.rows_km == nullptr) return;
@@ -1619,6 +1651,206 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_store_kernel(StoreInges
   for (int e = threadIdx.x; e < K * 64; e += kThreads) {
     const int k = e >> 6, bl = e & 63;
     if (bl < nb) a.g.rows_km[a.g.side_base[si] + (int64_t)k * B + b0 + bl] = tl[k][bl];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hand-over AND lookup in one launch (tt_batch_ingest_lookup / tt_batch_ingest_store_lookup; round 4).  The hand-over's tile
+// workgroups already hold the batch's clamped fused rows in LDS; here they gather the table rows themselves and write them
+// into the towers' input x (cat_embed.py:157-178 + base_tower.py:139), so the separate lookup launch -- its boundary, its
+// re-read of the ids and its dispatch ramp -- is gone, and the copies of the dense features run beside the gathers.
+//   tile = TS samples of one side, TS = 2^ts_shift chosen so that TS * K <= 512 slots: a 256-thread workgroup decodes two
+//   slots per thread, a wave gathers up to two 64-slot chunks (every load issued before the first store: 16 x 16 B per lane
+//   in flight, the standalone kernel's 19 waves per CU x 8 become ~10 x 16);
+//   a lane moves 32 B of a row (LPR = E / 8 lanes per row): two 16-B loads, one 16-B bf16 store (two for f32 rows).
+// Grid row 0 = every side's tiles (dispatched first); then, from the stores, one row per side for the dense features; then
+// the copy segments.  Bit-identical to the hand-over followed by tt_embed_lookup_fwd (test).
+// ------------------------------------------------------------------------------------------------
+struct LookupPart {
+  const float* table;
+  char* out[TT_MAX_SIDES];
+  int64_t ld[TT_MAX_SIDES];          // elements
+  int32_t dtype[TT_MAX_SIDES];
+  int32_t ts_shift[TT_MAX_SIDES];
+  int32_t tile_base[TT_MAX_SIDES + 1];
+  int32_t E;
+  unsigned long long* ring;          // measurement: per-workgroup stamps of the tile role (tt_embed_lookup_set_profile)
+  int32_t ring_slots;
+  int32_t nt;                        // TT_OPT_LOOKUP_NT: bf16 rows leave by non-temporal stores
+};
+constexpr int kTileSlots = 512;
+
+template <int LPR, bool FROM_STORE, bool VEC>
+__device__ __forceinline__ void ingest_lookup_body(const StoreIngestArgs& a, const LookupPart& lp) {
+  const int B = a.g.B;
+  const int first_copy_row = 1 + (FROM_STORE ? a.g.n_sides : 0);
+  if ((int)blockIdx.y >= first_copy_row) {                     // copy segments
+    const int seg = blockIdx.y - first_copy_row;
+    const int64_t n16 = a.g.c.bytes[seg] / 16, tail0 = n16 * 16;
+    const float4* __restrict__ s = reinterpret_cast<const float4*>(a.g.c.src[seg]);
+    float4* __restrict__ d = reinterpret_cast<float4*>(a.g.c.dst[seg]);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) d[i] = s[i];
+    if (blockIdx.x == 0)
+      for (int64_t i = tail0 + threadIdx.x; i < a.g.c.bytes[seg]; i += blockDim.x) a.g.c.dst[seg][i] = a.g.c.src[seg][i];
+    return;
+  }
+  if (FROM_STORE && blockIdx.y >= 1) {                         // dense feature rows of one side
+    const int si = blockIdx.y - 1;
+    const int dd = a.dense_dim[si];
+    if (dd == 0) return;
+    const int64_t* __restrict__ ent = a.entity[si];
+    const int64_t es = a.entity_stride[si];
+    const int64_t nr = a.n_rows[si];
+    const int per = VEC ? dd / 4 : dd;
+    const int64_t total = (int64_t)B * per, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+      const int b = (int)(t / per), j = (int)(t - (int64_t)b * per);
+      const int64_t o = a.order ? a.order[b] : b;
+      int64_t e = ent[o * es];
+      if (nr > 0) e = e < 0 ? 0 : (e >= nr ? nr - 1 : e);
+      if (VEC) reinterpret_cast<float4*>(a.dense_out[si] + (int64_t)b * dd)[j] = reinterpret_cast<const float4*>(a.dense_store[si] + e * dd)[j];
+      else a.dense_out[si][(int64_t)b * dd + j] = a.dense_store[si][e * dd + j];
+    }
+    return;
+  }
+  // ---- row 0: tiles ----
+  int si = 0;
+#pragma unroll
+  for (int i = 1; i < TT_MAX_SIDES; ++i)
+    if (i < a.g.n_sides && (int)blockIdx.x >= lp.tile_base[i]) si = i;
+  if ((int)blockIdx.x >= lp.tile_base[a.g.n_sides]) return;
+  const int tile = (int)blockIdx.x - lp.tile_base[si];
+  const int K = a.g.K[si], KP = K | 1, sh = lp.ts_shift[si], TS = 1 << sh;
+  const int b0 = tile << sh;
+  const int nb = min(TS, B - b0), n = nb * K;                  // <= kTileSlots
+  // A wave works alone up to its gathers: it decodes its two 64-slot chunks (w and w + 4) itself -- id, key offset and vocabulary
+  // straight from memory, like the stand-alone lookup -- parks {row, destination} in wave-private LDS and issues every row load;
+  // only the key-major read-out of the tile's rows (tl) needs the other waves, and by then the rows are in flight.
+  __shared__ int32_t rows_w[kThreads / 64][2][64];             // fused row of the wave's slot (the gather's order)
+  __shared__ int64_t dst_w[kThreads / 64][2][64];              // byte offset of the slot's destination row in x (-1: no slot)
+  __shared__ int32_t tl[kTileSlots + 64];                      // the tile's rows at bl * KP + k (odd stride: the key-major read-out)
+  const int esz = lp.dtype[si] == TT_BF16 ? 2 : 4;
+  constexpr int RPI = 64 / LPR;                                  // rows per wave-instruction
+  constexpr int NIT = LPR;                                       // wave-instructions per chunk
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane / LPR, part = lane % LPR;
+  const int64_t* __restrict__ offp = a.g.off[si];
+  const int64_t* __restrict__ vocp = a.g.vocab[si];
+  float4 v[2][NIT][2];
+  int64_t dv[2][NIT];
+  // decode both chunks first (their id loads are independent and issued together), then every row load of both
+  int64_t idv[2], hiv[2], ofv[2];
+  int blv[2], kv[2];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int e = (wave + cc * (kThreads / 64)) * 64 + lane;
+    const int ec = e < n ? e : 0;
+    const int bl = ec / K, k = ec - bl * K;
+    blv[cc] = bl; kv[cc] = k;
+    if (FROM_STORE) {
+      const int64_t o = a.order ? a.order[b0 + bl] : b0 + bl;
+      int64_t en = a.entity[si][o * a.entity_stride[si]];
+      const int64_t nr = a.n_rows[si];
+      if (nr > 0) en = en < 0 ? 0 : (en >= nr ? nr - 1 : en);
+      idv[cc] = a.cat_store[si][en * K + k];
+    } else {
+      idv[cc] = a.g.ids[si][(int64_t)b0 * K + ec];
+    }
+    hiv[cc] = vocp[k] - 1;
+    ofv[cc] = offp[k];
+  }
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const int e = (wave + cc * (kThreads / 64)) * 64 + lane;
+    int32_t row = 0;
+    int64_t dst = -1;
+    if (e < n) {
+      int64_t id = idv[cc];
+      if (FROM_STORE) a.ids_out[si][(int64_t)b0 * K + e] = id;  // sample-major: the KJT values() of the batch
+      id = id < 0 ? 0 : (id > hiv[cc] ? hiv[cc] : id);           // clamp: cat_embed.py:117
+      row = (int32_t)(ofv[cc] + id);
+      dst = ((int64_t)(b0 + blv[cc]) * lp.ld[si] + (int64_t)kv[cc] * lp.E) * esz;
+      tl[blv[cc] * KP + kv[cc]] = row;
+    }
+    rows_w[wave][cc][lane] = row;
+    dst_w[wave][cc][lane] = dst;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int sl = j * RPI + sub;
+      dv[cc][j] = dst_w[wave][cc][sl];
+      v[cc][j][0] = v[cc][j][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (dv[cc][j] >= 0) {
+        const float* src = lp.table + (int64_t)rows_w[wave][cc][sl] * lp.E + part * 8;
+        v[cc][j][0] = *reinterpret_cast<const float4*>(src);
+        v[cc][j][1] = *reinterpret_cast<const float4*>(src + 4);
+      }
+    }
+  }
+  // while the rows fly: the key-major rows for the duplicate-row plan
+  if (a.g.rows_km != nullptr) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < (K << sh); e += kThreads) {
+      const int k = e >> sh, bl = e & (TS - 1);
+      if (bl < nb) a.g.rows_km[a.g.side_base[si] + (int64_t)k * B + b0 + bl] = tl[bl * KP + k];
+    }
+  }
+  char* __restrict__ out = lp.out[si];
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      if (dv[cc][j] < 0) continue;
+      if (esz == 4) {                                          // non-temporal: the rows are read next by another kernel
+        f32x4n t0, t1;
+        t0[0] = v[cc][j][0].x; t0[1] = v[cc][j][0].y; t0[2] = v[cc][j][0].z; t0[3] = v[cc][j][0].w;
+        t1[0] = v[cc][j][1].x; t1[1] = v[cc][j][1].y; t1[2] = v[cc][j][1].z; t1[3] = v[cc][j][1].w;
+        f32x4n* d = reinterpret_cast<f32x4n*>(out + dv[cc][j] + part * 32);
+        __builtin_nontemporal_store(t0, d);
+        __builtin_nontemporal_store(t1, d + 1);
+      } else {
+        uint4 o;
+        o.x = (uint32_t)tt_f2bf(v[cc][j][0].x) | ((uint32_t)tt_f2bf(v[cc][j][0].y) << 16);
+        o.y = (uint32_t)tt_f2bf(v[cc][j][0].z) | ((uint32_t)tt_f2bf(v[cc][j][0].w) << 16);
+        o.z = (uint32_t)tt_f2bf(v[cc][j][1].x) | ((uint32_t)tt_f2bf(v[cc][j][1].y) << 16);
+        o.w = (uint32_t)tt_f2bf(v[cc][j][1].z) | ((uint32_t)tt_f2bf(v[cc][j][1].w) << 16);
+        if (lp.nt) {
+          using u32x4n = __attribute__((ext_vector_type(4))) unsigned int;
+          u32x4n t; t[0] = o.x; t[1] = o.y; t[2] = o.z; t[3] = o.w;
+          __builtin_nontemporal_store(t, reinterpret_cast<u32x4n*>(out + dv[cc][j] + part * 16));
+        } else {
+          *reinterpret_cast<uint4*>(out + dv[cc][j] + part * 16) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int LPR, bool FROM_STORE, bool VEC>
+__global__ __launch_bounds__(kThreads) void ingest_lookup_kernel(StoreIngestArgs a, LookupPart lp) {
+  // measurement only (tt_embed_lookup_set_profile): start / end stamps of EVERY workgroup, column = its linear index -- the tiles
+  // (gather phase) come first, the copy roles after them; the host reduces either set
+  const uint32_t wg = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool stamp = lp.ring && wg < (uint32_t)kProfileMaxWg && threadIdx.x == 0;
+  unsigned long long t_start = 0, n_launch = 0;
+  if (stamp) {
+    t_start = __builtin_amdgcn_s_memrealtime();
+    n_launch = lp.ring[wg];
+  }
+  ingest_lookup_body<LPR, FROM_STORE, VEC>(a, lp);
+  if (lp.ring) {                                               // wait for this workgroup's stores
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (stamp) {
+      unsigned long long* pair = lp.ring + kProfileMaxWg + ((n_launch % (unsigned long long)lp.ring_slots) * kProfileMaxWg + wg) * 2;
+      pair[0] = t_start;
+      pair[1] = __builtin_amdgcn_s_memrealtime();
+      lp.ring[wg] = n_launch + 1;
+    }
   }
 }
 
@@ -1866,8 +2098,24 @@ int tt_embed_lookup_set_profile(tt_ctx* ctx, uint64_t* ring_dev, int32_t n_slots
   return TT_OK;
 }
 
+static int lookup_fwd_impl(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const tt_embed_side* sides, int32_t n_sides, int64_t B,
+                           int32_t* rows_out, const int32_t* rows_in, tt_stream stream);
+
 int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const tt_embed_side* sides,
                         int32_t n_sides, int64_t B, int32_t* rows_out, tt_stream stream) {
+  return lookup_fwd_impl(ctx, table, table_rows, E, sides, n_sides, B, rows_out, nullptr, stream);
+}
+
+int tt_embed_lookup_rows_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const tt_embed_side* sides,
+                             int32_t n_sides, int64_t B, const int32_t* rows, tt_stream stream) {
+  TT_CHECK_ARG(table && rows, "tt_embed_lookup_rows_fwd: NULL table / rows");
+  TT_CHECK_ARG(E % 4 == 0 && E / 4 <= 64 && ((E / 4) & (E / 4 - 1)) == 0 && tt_aligned(table, 16),
+               "tt_embed_lookup_rows_fwd: E=%d must be 4 x a power of two <= 256 and the table 16-byte aligned", E);
+  return lookup_fwd_impl(ctx, table, table_rows, E, sides, n_sides, B, nullptr, rows, stream);
+}
+
+static int lookup_fwd_impl(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E, const tt_embed_side* sides, int32_t n_sides, int64_t B,
+                           int32_t* rows_out, const int32_t* rows_in, tt_stream stream) {
   TT_CHECK_ARG(ctx && sides && (table || rows_out), "tt_embed_lookup_fwd: NULL argument");
   TT_CHECK_ARG(n_sides >= 1 && n_sides <= TT_MAX_SIDES, "tt_embed_lookup_fwd: n_sides=%d not in [1,%d]", n_sides, TT_MAX_SIDES);
   TT_CHECK_ARG(E >= 1 && B >= 0 && table_rows >= 1, "tt_embed_lookup_fwd: bad E=%d B=%lld rows=%lld", E, (long long)B, (long long)table_rows);
@@ -1879,7 +2127,7 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
   int64_t slots = 0;
   for (int i = 0; i < n_sides; ++i) {
     const tt_embed_side& s = sides[i];
-    TT_CHECK_ARG(s.K >= 0 && (s.K == 0 || (s.ids && s.key_row_offset && s.key_vocab && (s.out || !table))), "tt_embed_lookup_fwd: side %d has NULL pointers", i);
+    TT_CHECK_ARG(s.K >= 0 && (s.K == 0 || (((s.ids && s.key_row_offset && s.key_vocab) || rows_in) && (s.out || !table))), "tt_embed_lookup_fwd: side %d has NULL pointers", i);
     TT_CHECK_ARG(s.out_dtype == TT_F32 || s.out_dtype == TT_BF16, "tt_embed_lookup_fwd: side %d bad out_dtype %d", i, s.out_dtype);
     TT_CHECK_ARG(s.ld_out >= (int64_t)s.K * E, "tt_embed_lookup_fwd: side %d ld_out %lld < K*E", i, (long long)s.ld_out);
     a.s[i] = SideDev{s.ids, s.key_row_offset, s.key_vocab, reinterpret_cast<char*>(s.out), s.ld_out, (uint32_t)slots, s.K, s.out_dtype, 0u};
@@ -1900,9 +2148,17 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
     int64_t wg = tt_cdiv(tt_cdiv(slots, spw), kThreads / 64);
     const int64_t cap = (int64_t)ctx->num_cus * 16;
     const int grid = (int)(wg < cap ? wg : cap);
-#define TT_LK(CV) lookup_wave_kernel<CV, spw><<<grid, kThreads, 0, st>>>(a, table, rows_out, ctx->lookup_stamps, ctx->lookup_stamp_slots)
+    // two 16-byte pieces per lane when the rows and the outputs allow 32-byte lanes
+    bool wide = C >= 2;
+    for (int i = 0; i < n_sides; ++i) {
+      const size_t esz = sides[i].out_dtype == TT_BF16 ? 2 : 4;
+      wide = wide && (sides[i].ld_out % 8 == 0) && tt_aligned(sides[i].out, 8 * esz);
+    }
+#define TT_LK1(CV, WV) do { if (rows_in) lookup_wave_kernel<CV, spw, WV, true><<<grid, kThreads, 0, st>>>(a, table, rows_out, rows_in, ctx->lookup_stamps, ctx->lookup_stamp_slots); \
+                            else lookup_wave_kernel<CV, spw, WV, false><<<grid, kThreads, 0, st>>>(a, table, rows_out, rows_in, ctx->lookup_stamps, ctx->lookup_stamp_slots); } while (0)
+#define TT_LK(CV) do { if (wide) TT_LK1(CV, (CV >= 2 ? 2 : 1)); else TT_LK1(CV, 1); } while (0)
     switch (C) {
-      case 1: TT_LK(1); break;
+      case 1: TT_LK1(1, 1); break;
       case 2: TT_LK(2); break;
       case 4: TT_LK(4); break;
       case 8: TT_LK(8); break;
@@ -1911,8 +2167,13 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
       default: TT_LK(64); break;
     }
 #undef TT_LK
+#undef TT_LK1
     TT_LAUNCH_CHECK();
     return TT_OK;
+  }
+  if (rows_in) {
+    tt_set_error("tt_embed_lookup_rows_fwd: outputs must be 4-element aligned (ld_out and base) for the precomputed-row form");
+    return TT_ERR_UNSUPPORTED;
   }
   const int grid = grid_for(ctx, tt_cdiv(slots * C, U));
   if (vec4 && table) lookup_kernel<4, U><<<grid, kThreads, 0, st>>>(a, table, rows_out);
@@ -2466,7 +2727,7 @@ int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* s
 }
 
 int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
-                    int32_t n_sides, int64_t B, int32_t* rows_km, tt_stream stream) {
+                    int32_t n_sides, int64_t B, int32_t* rows_km, int32_t* rows_sm, tt_stream stream) {
   TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest: bad copy arguments");
   TT_CHECK_ARG(sides && rows_km && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest: bad side arguments");
   IngestArgs a{};
@@ -2483,6 +2744,7 @@ int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const*
   a.n_sides = n_sides;
   a.B = (int32_t)B;
   a.rows_km = rows_km;
+  a.rows_sm = rows_sm;
   for (int i = 0; i < n_sides; ++i) {
     const tt_embed_side& s = sides[i];
     TT_CHECK_ARG(s.K >= 1 && s.ids && s.key_row_offset && s.key_vocab, "tt_batch_ingest: side %d NULL / no keys", i);
@@ -2506,7 +2768,8 @@ int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const*
 }
 
 int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
-                          const tt_store_side* stores, int32_t n_sides, int64_t B, const int64_t* order, int32_t* rows_km, tt_stream stream) {
+                          const tt_store_side* stores, int32_t n_sides, int64_t B, const int64_t* order, int32_t* rows_km, int32_t* rows_sm,
+                          tt_stream stream) {
   TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest_store: bad copy arguments");
   TT_CHECK_ARG(sides && stores && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest_store: bad side arguments");
   StoreIngestArgs a{};
@@ -2524,6 +2787,7 @@ int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* 
   a.g.n_sides = n_sides;
   a.g.B = (int32_t)B;
   a.g.rows_km = rows_km;
+  a.g.rows_sm = rows_sm;
   a.order = order;
   for (int i = 0; i < n_sides; ++i) {
     const tt_embed_side& s = sides[i];
@@ -2540,6 +2804,7 @@ int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* 
     slots += B * s.K;
     a.entity[i] = t.entity; a.entity_stride[i] = t.entity_stride; a.dense_store[i] = t.dense_store; a.cat_store[i] = t.cat_store;
     a.dense_out[i] = t.dense_out; a.ids_out[i] = t.ids_out; a.dense_dim[i] = t.dense_dim;
+    a.n_rows[i] = t.n_rows > 0 ? t.n_rows : 0;
     vec = vec && t.dense_dim % 4 == 0 && tt_aligned(t.dense_store, 16) && tt_aligned(t.dense_out, 16);
     const int64_t p = B * (int64_t)t.dense_dim;
     dense_pieces = p > dense_pieces ? p : dense_pieces;
@@ -2555,6 +2820,166 @@ int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* 
   const dim3 grid((unsigned)gx, (unsigned)(1 + n_sides + n));
   if (vec) batch_ingest_store_kernel<true><<<grid, kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
   else batch_ingest_store_kernel<false><<<grid, kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+// shared by the two fused hand-over + lookup entries: checks the lookup half and fills LookupPart; returns the tile count or < 0
+static int64_t fill_lookup_part(tt_ctx* ctx, const char* who, const tt_embed_side* sides, int32_t n_sides, int64_t B, const tt_ingest_lookup* lk,
+                                LookupPart* lp) {
+  if (!(lk && lk->table && lk->table_rows >= 1 && lk->table_rows <= INT32_MAX)) {
+    tt_set_error("%s: lookup part NULL / bad table", who);
+    return TT_ERR_INVALID_ARG;
+  }
+  const int E = lk->E;
+  if (!(E == 8 || E == 16 || E == 32 || E == 64) || !tt_aligned(lk->table, 16)) {
+    tt_set_error("%s: E=%d not in {8, 16, 32, 64} or table not 16-byte aligned (use the separate hand-over and tt_embed_lookup_fwd)", who, E);
+    return TT_ERR_UNSUPPORTED;
+  }
+  lp->table = lk->table;
+  lp->E = E;
+  lp->ring = ctx->lookup_stamps;
+  lp->ring_slots = ctx->lookup_stamp_slots;
+  lp->nt = ctx->lookup_nt;
+  int64_t tiles = 0;
+  for (int i = 0; i < n_sides; ++i) {
+    const tt_embed_side& s = sides[i];
+    if (!(s.out && (s.out_dtype == TT_F32 || s.out_dtype == TT_BF16) && s.ld_out >= (int64_t)s.K * E)) {
+      tt_set_error("%s: side %d needs an output (out, ld_out >= K*E, out_dtype f32 | bf16)", who, i);
+      return TT_ERR_INVALID_ARG;
+    }
+    const size_t esz = s.out_dtype == TT_BF16 ? 2 : 4;
+    if (!tt_aligned(s.out, 8 * esz) || (s.ld_out * esz) % (8 * esz) != 0) {
+      tt_set_error("%s: side %d output not aligned to 8 elements", who, i);
+      return TT_ERR_UNSUPPORTED;
+    }
+    int sh = 6;                                              // TS = 64 samples, halved until TS * K <= 512 slots (K <= 64: TS >= 8)
+    while (sh > 3 && ((int64_t)s.K << sh) > kTileSlots) --sh;
+    lp->out[i] = reinterpret_cast<char*>(s.out);
+    lp->ld[i] = s.ld_out;
+    lp->dtype[i] = s.out_dtype;
+    lp->ts_shift[i] = sh;
+    lp->tile_base[i] = (int32_t)tiles;
+    tiles += tt_cdiv(B, (int64_t)1 << sh);
+  }
+  lp->tile_base[n_sides] = (int32_t)tiles;
+  for (int i = n_sides + 1; i <= TT_MAX_SIDES; ++i) lp->tile_base[i] = (int32_t)tiles;
+  if (tiles >= ((int64_t)1 << 30)) {
+    tt_set_error("%s: too many tiles", who);
+    return TT_ERR_INVALID_ARG;
+  }
+  return tiles;
+}
+
+#define TT_INGEST_LOOKUP_LAUNCH(FROM_STORE, VEC)                                                                         \
+  do {                                                                                                                    \
+    switch (lp.E) {                                                                                                       \
+      case 8: ingest_lookup_kernel<1, FROM_STORE, VEC><<<grid, kThreads, 0, st>>>(a, lp); break;                          \
+      case 16: ingest_lookup_kernel<2, FROM_STORE, VEC><<<grid, kThreads, 0, st>>>(a, lp); break;                         \
+      case 32: ingest_lookup_kernel<4, FROM_STORE, VEC><<<grid, kThreads, 0, st>>>(a, lp); break;                         \
+      default: ingest_lookup_kernel<8, FROM_STORE, VEC><<<grid, kThreads, 0, st>>>(a, lp); break;                         \
+    }                                                                                                                     \
+  } while (0)
+
+int tt_batch_ingest_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
+                           int32_t n_sides, int64_t B, int32_t* rows_km, const tt_ingest_lookup* lk, tt_stream stream) {
+  TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest_lookup: bad copy arguments");
+  TT_CHECK_ARG(sides && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest_lookup: bad side arguments");
+  StoreIngestArgs a{};
+  LookupPart lp{};
+  int64_t mx = 0, slots = 0;
+  for (int i = 0; i < n; ++i) {
+    TT_CHECK_ARG(bytes[i] >= 0 && (bytes[i] == 0 || (dst[i] && src[i])), "tt_batch_ingest_lookup: segment %d NULL", i);
+    TT_CHECK_ARG(tt_aligned(dst[i], 16) && tt_aligned(src[i], 16), "tt_batch_ingest_lookup: segment %d not 16-byte aligned", i);
+    a.g.c.dst[i] = reinterpret_cast<char*>(dst[i]);
+    a.g.c.src[i] = reinterpret_cast<const char*>(src[i]);
+    a.g.c.bytes[i] = bytes[i];
+    mx = bytes[i] > mx ? bytes[i] : mx;
+  }
+  a.g.n_copy = n;
+  a.g.n_sides = n_sides;
+  a.g.B = (int32_t)B;
+  a.g.rows_km = rows_km;
+  for (int i = 0; i < n_sides; ++i) {
+    const tt_embed_side& s = sides[i];
+    TT_CHECK_ARG(s.K >= 1 && s.ids && s.key_row_offset && s.key_vocab, "tt_batch_ingest_lookup: side %d NULL / no keys", i);
+    if (s.K > kIngestMaxK) {
+      tt_set_error("tt_batch_ingest_lookup: side %d has %d keys (max %d)", i, s.K, kIngestMaxK);
+      return TT_ERR_UNSUPPORTED;
+    }
+    a.g.ids[i] = s.ids; a.g.off[i] = s.key_row_offset; a.g.vocab[i] = s.key_vocab; a.g.K[i] = s.K;
+    a.g.side_base[i] = (int32_t)slots;
+    slots += B * s.K;
+  }
+  TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_batch_ingest_lookup: too many slots");
+  const int64_t tiles = fill_lookup_part(ctx, "tt_batch_ingest_lookup", sides, n_sides, B, lk, &lp);
+  if (tiles < 0) return (int)tiles;
+  int64_t gx = tt_cdiv(mx / 16 + 1, kThreads);
+  const int64_t cap = (int64_t)ctx->num_cus * 4;
+  if (gx > cap) gx = cap;
+  if (tiles > gx) gx = tiles;
+  const dim3 grid((unsigned)gx, (unsigned)(n + 1));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  TT_INGEST_LOOKUP_LAUNCH(false, true);
+  TT_LAUNCH_CHECK();
+  return TT_OK;
+}
+
+int tt_batch_ingest_store_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
+                                 const tt_embed_side* sides, const tt_store_side* stores, int32_t n_sides, int64_t B, const int64_t* order,
+                                 int32_t* rows_km, const tt_ingest_lookup* lk, tt_stream stream) {
+  TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest_store_lookup: bad copy arguments");
+  TT_CHECK_ARG(sides && stores && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest_store_lookup: bad side arguments");
+  StoreIngestArgs a{};
+  LookupPart lp{};
+  int64_t mx = 0, slots = 0, dense_pieces = 0;
+  bool vec = true;
+  for (int i = 0; i < n; ++i) {
+    TT_CHECK_ARG(bytes[i] >= 0 && (bytes[i] == 0 || (dst[i] && src[i])), "tt_batch_ingest_store_lookup: segment %d NULL", i);
+    TT_CHECK_ARG(tt_aligned(dst[i], 16) && tt_aligned(src[i], 16), "tt_batch_ingest_store_lookup: segment %d not 16-byte aligned", i);
+    a.g.c.dst[i] = reinterpret_cast<char*>(dst[i]);
+    a.g.c.src[i] = reinterpret_cast<const char*>(src[i]);
+    a.g.c.bytes[i] = bytes[i];
+    mx = bytes[i] > mx ? bytes[i] : mx;
+  }
+  a.g.n_copy = n;
+  a.g.n_sides = n_sides;
+  a.g.B = (int32_t)B;
+  a.g.rows_km = rows_km;
+  a.order = order;
+  for (int i = 0; i < n_sides; ++i) {
+    const tt_embed_side& s = sides[i];
+    const tt_store_side& t = stores[i];
+    TT_CHECK_ARG(s.K >= 1 && s.key_row_offset && s.key_vocab, "tt_batch_ingest_store_lookup: side %d NULL / no keys", i);
+    TT_CHECK_ARG(t.entity && t.entity_stride >= 1 && t.cat_store && t.ids_out && t.dense_dim >= 0 && t.n_rows >= 0 &&
+                 (t.dense_dim == 0 || (t.dense_store && t.dense_out)), "tt_batch_ingest_store_lookup: store %d NULL / bad shape", i);
+    if (s.K > kIngestMaxK) {
+      tt_set_error("tt_batch_ingest_store_lookup: side %d has %d keys (max %d)", i, s.K, kIngestMaxK);
+      return TT_ERR_UNSUPPORTED;
+    }
+    a.g.off[i] = s.key_row_offset; a.g.vocab[i] = s.key_vocab; a.g.K[i] = s.K;
+    a.g.side_base[i] = (int32_t)slots;
+    slots += B * s.K;
+    a.entity[i] = t.entity; a.entity_stride[i] = t.entity_stride; a.dense_store[i] = t.dense_store; a.cat_store[i] = t.cat_store;
+    a.dense_out[i] = t.dense_out; a.ids_out[i] = t.ids_out; a.dense_dim[i] = t.dense_dim;
+    a.n_rows[i] = t.n_rows > 0 ? t.n_rows : 0;
+    vec = vec && t.dense_dim % 4 == 0 && tt_aligned(t.dense_store, 16) && tt_aligned(t.dense_out, 16);
+    const int64_t p = B * (int64_t)t.dense_dim;
+    dense_pieces = p > dense_pieces ? p : dense_pieces;
+  }
+  TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_batch_ingest_store_lookup: too many slots");
+  const int64_t tiles = fill_lookup_part(ctx, "tt_batch_ingest_store_lookup", sides, n_sides, B, lk, &lp);
+  if (tiles < 0) return (int)tiles;
+  int64_t gx = tt_cdiv(mx / 16 + 1, kThreads);
+  const int64_t rows_wg = tt_cdiv(vec ? dense_pieces / 4 : dense_pieces, kThreads);
+  if (rows_wg > gx) gx = rows_wg;
+  const int64_t cap = (int64_t)ctx->num_cus * 8;
+  if (gx > cap) gx = cap;
+  if (tiles > gx) gx = tiles;
+  const dim3 grid((unsigned)gx, (unsigned)(1 + n_sides + n));
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (vec) TT_INGEST_LOOKUP_LAUNCH(true, true);
+  else TT_INGEST_LOOKUP_LAUNCH(true, false);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }

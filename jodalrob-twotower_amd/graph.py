@@ -80,6 +80,8 @@ class GraphedTrainStep:
             self._restore_state(snap)
         if self.metric_sums is not None:
             self.metric_sums.zero_()
+        if self._ingest is not None:
+            self._run_ingest([], None)
         self._push_scalars()
         for t in self._towers:
             t._seed_dev = self._seed_dev
@@ -106,6 +108,7 @@ class GraphedTrainStep:
         """Key-major row hand-over (ops.batch_ingest) when the step looks the static ids up in ONE local fused table with the
         per-key plan: returns (store, embedders, rows_km, static id tensors, B) or None (then the batch is handed over by plain
         copies and the plan gathers its rows out of the lookup's slot-major array)."""
+        self._x_static, self._rows_sm = None, None
         if not settings.graph_ingest:
             return None
         model = getattr(self.task, "two_tower_model", None)
@@ -134,15 +137,41 @@ class GraphedTrainStep:
                for e, v in zip(embs, ids)):
             return None
         rows_km = torch.empty(sum(v.numel() for v in ids), dtype=torch.int32, device=ids[0].device)
+        # persistent tower inputs x = [projection | embedding rows]: the hand-over launch looks the batch's rows up straight into
+        # their embedding columns (tt_batch_ingest_lookup), the captured forward finds them filled and has no lookup launch
+        if settings.graph_ingest_lookup:
+            xs = [torch.zeros((B, t.x_width), dtype=t.x_dtype, device=ids[0].device) for t in towers]
+            outs = [ops.LookupSide(v, e._key_row_offset, e._key_vocab, x[:, t.tower_hidden_dims[0]:], len(e.keys))
+                    for e, v, x, t in zip(embs, ids, xs, towers)]
+            if ops.ingest_lookup_supported(store.weight, outs):
+                self._x_static = xs
+        # the same rows in slot order: the captured lookup reads them instead of decoding the ids again (tt_embed_lookup_rows_fwd)
+        if self._x_static is None and settings.graph_ingest_rows and store.weight.shape[1] % 4 == 0:
+            self._rows_sm = torch.empty_like(rows_km)
         return store, embs, rows_km, ids, B
 
+    def _lookup_outs(self):
+        towers = [self.task.two_tower_model.notice_tower, self.task.two_tower_model.company_tower]
+        return [x[:, t.tower_hidden_dims[0]:] for x, t in zip(self._x_static, towers)]
+
+    def _register(self, store, ids, rows_km):
+        xs = getattr(self, "_x_static", None)
+        store.ingest = (ids, [v._version for v in ids], rows_km, xs, getattr(self, "_rows_sm", None))
+        store.ingest_x_fresh = xs is not None
+
     def _run_ingest(self, pairs, src_ids):
-        """One launch: the copy segments + the key-major rows of `src_ids` (default: the static id buffers themselves)."""
+        """One launch: the copy segments + the key-major rows of `src_ids` (default: the static id buffers themselves) (+ the
+        lookup of those rows into the persistent tower inputs)."""
         store, embs, rows_km, ids, B = self._ingest
         src = ids if src_ids is None else src_ids
-        sides = [ops.LookupSide(v, e._key_row_offset, e._key_vocab, None, len(e.keys)) for e, v in zip(embs, src)]
-        ops.batch_ingest(pairs, sides, B, rows_km)
-        store.ingest = (ids, [v._version for v in ids], rows_km)
+        xs = getattr(self, "_x_static", None)
+        if xs is not None:
+            sides = [ops.LookupSide(v, e._key_row_offset, e._key_vocab, o, len(e.keys)) for e, v, o in zip(embs, src, self._lookup_outs())]
+            ops.batch_ingest(pairs, sides, B, rows_km, table=store.weight)
+        else:
+            sides = [ops.LookupSide(v, e._key_row_offset, e._key_vocab, None, len(e.keys)) for e, v in zip(embs, src)]
+            ops.batch_ingest(pairs, sides, B, rows_km, rows_sm=getattr(self, "_rows_sm", None))
+        self._register(store, ids, rows_km)
 
     def _body(self):
         self.opt.zero_grad(set_to_none=True)
@@ -189,6 +218,8 @@ class GraphedTrainStep:
         return res
 
     def _eager_once(self):
+        if self._ingest is not None:
+            self._run_ingest([], None)          # (an optimiser step has changed the rows since the last hand-over filled x)
         self._body()
 
     # ---- warm-up without side effects ---------------------------------------------------------------------------------
@@ -342,16 +373,20 @@ class GraphedTrainStep:
         model = self.task.two_tower_model
         embs = [model.notice_tower.categorical_embedder, model.company_tower.categorical_embedder]
         sides, stores = [], []
+        xs = getattr(self, "_x_static", None) if self._ingest is not None else None
+        outs = self._lookup_outs() if xs is not None else [None, None]
         for i, (side, fs, e) in enumerate(zip(("notice", "company"), (notice_store, company_store), embs)):
             sd, sv = self.static[side]["dense"], self.static[side]["kjt"].values()
-            sides.append(ops.LookupSide(None, e._key_row_offset, e._key_vocab, None, len(e.keys)))
+            sides.append(ops.LookupSide(None, e._key_row_offset, e._key_vocab, outs[i], len(e.keys)))
             stores.append(ops.StoreSide(flat[base + i:], 2, fs.dense, fs.categorical, sd, sv))
         rows_km = self._ingest[2] if self._ingest is not None else None
-        ops.batch_ingest_store([self._fill_slot()], sides, stores, B, order, rows_km, offset if order is not None else 0)
+        ops.batch_ingest_store([self._fill_slot()], sides, stores, B, order, rows_km, offset if order is not None else 0,
+                               table=self._ingest[0].weight if xs is not None else None,
+                               rows_sm=getattr(self, "_rows_sm", None) if (self._ingest is not None and xs is None) else None)
         self._mark_slot()
         if self._ingest is not None:
             store, _, _, ids, _ = self._ingest
-            store.ingest = (ids, [v._version for v in ids], rows_km)
+            self._register(store, ids, rows_km)
         return self._replay()
 
     def close(self):

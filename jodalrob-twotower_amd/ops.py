@@ -109,11 +109,27 @@ def embed_lookup(table: Optional[torch.Tensor], sides: Sequence[LookupSide], B: 
     return rows
 
 
+def embed_lookup_rows(table: torch.Tensor, rows: torch.Tensor, sides: Sequence[LookupSide], B: int):
+    """tt_embed_lookup_rows_fwd: the lookup from precomputed fused rows (int32, slot order: the hand-over launch's `rows_sm`)."""
+    dev, E = table.device, table.shape[1]
+    arr = (L.EmbedSide * len(sides))()
+    M = 0
+    for i, s in enumerate(sides):
+        assert s.out is not None and s.out.stride(1) == 1
+        arr[i] = L.EmbedSide(None, None, None, L.ptr(s.out), s.out.stride(0), s.K, _dt(s.out))
+        M += B * s.K
+    if rows.dtype != torch.int32 or rows.numel() != M or not rows.is_contiguous() or rows.device != dev:
+        raise ValueError("embed_lookup_rows: rows must be a contiguous int32 tensor of sum(B*K) elements on the table's device")
+    with _timed("tt_embed_lookup_fwd"):
+        L.check(L.load().tt_embed_lookup_rows_fwd(L.ctx(dev), L.ptr(table), table.shape[0], E, arr, len(sides), B, L.ptr(rows), L.stream(dev)),
+                "tt_embed_lookup_rows_fwd")
+
+
 class LookupProfile:
     """Device-clock stamps of the lookup kernel, one block of per-workgroup pairs per launch (works inside captured graphs,
     needs no host synchronisation and no extra launch while measuring; reduced on the host afterwards)."""
 
-    MAX_WG = 4096
+    MAX_WG = 8192
 
     def __init__(self, device, n_slots: int = 256):
         self.device, self.n = torch.device(device), n_slots
@@ -123,13 +139,19 @@ class LookupProfile:
     def reset(self):
         self.ring.zero_()
 
-    def durations_us(self):
-        """Kernel durations (us) of the (last n_slots) launches since the last reset(), oldest first; synchronises."""
+    def durations_us(self, first_wg: int = 0, last_wg: Optional[int] = None):
+        """Kernel durations (us) of the (last n_slots) launches since the last reset(), oldest first; synchronises.
+        first_wg / last_wg: only the workgroups [first_wg, last_wg) (the fused hand-over + lookup launch: its tiles -- the gather
+        phase -- are the first workgroups, the copy roles follow)."""
         torch.cuda.synchronize(self.device)
         r = self.ring.cpu()
         launches = int(r[0])
         pairs = r[self.MAX_WG:].view(self.n, self.MAX_WG, 2)
         same = r[:self.MAX_WG] == launches          # workgroups that took part in every launch (grids of one size)
+        if first_wg or last_wg is not None:
+            sel = torch.zeros_like(same)
+            sel[first_wg:last_wg] = True
+            same = same & sel
         out = []
         for n in range(max(0, launches - self.n), launches):
             blk = pairs[n % self.n]
@@ -654,9 +676,74 @@ def copy_multi(pairs):
         L.check(L.load().tt_copy_multi(L.ctx(dev), n, dst, src, nb, L.stream(dev)), "tt_copy_multi")
 
 
-def batch_ingest(pairs, sides: Sequence[LookupSide], B: int, rows_km: torch.Tensor):
+def ingest_lookup_supported(table: Optional[torch.Tensor], sides: Sequence[LookupSide]) -> bool:
+    """Shapes the fused hand-over + lookup launch takes (tt_batch_ingest_lookup): E in {8, 16, 32, 64}, 8-element aligned outputs."""
+    if table is None or table.dtype != torch.float32 or table.dim() != 2 or table.shape[1] not in (8, 16, 32, 64) or table.data_ptr() % 16:
+        return False
+    for s_ in sides:
+        o = s_.out
+        if o is None or o.dtype not in (torch.float32, torch.bfloat16) or o.stride(1) != 1 or o.stride(0) % 8 or \
+                o.data_ptr() % (8 * o.element_size()) or not (1 <= s_.K <= 64):
+            return False
+    return True
+
+
+def ingest_lookup_tiles(B: int, side_K: Sequence[int]) -> int:
+    """Tile workgroups of the fused hand-over + lookup launch (csrc/tt_embed.hip fill_lookup_part: TS = 64 samples, halved until
+    TS * K <= 512 slots, not below 8)."""
+    n = 0
+    for K in side_K:
+        sh = 6
+        while sh > 3 and (K << sh) > 512:
+            sh -= 1
+        n += (B + (1 << sh) - 1) >> sh
+    return n
+
+
+def _lookup_part(table: torch.Tensor):
+    return L.IngestLookup(L.ptr(table), table.shape[0], table.shape[1], 0)
+
+
+def _embed_sides(sides, B, dev, who, with_ids: bool, with_out: bool):
+    arr = (L.EmbedSide * len(sides))()
+    M = 0
+    for i, s in enumerate(sides):
+        if with_ids and (s.ids.dtype != torch.int64 or not s.ids.is_contiguous() or s.ids.device != dev or s.ids.numel() != B * s.K):
+            raise ValueError(f"{who}: side {i} needs {B}*{s.K} contiguous int64 ids on {dev}")
+        if with_out:
+            if s.out.shape[0] != B or s.out.shape[1] < s.K or s.out.device != dev:
+                raise ValueError(f"{who}: side {i}: output view must be [B, K*E] on {dev}")
+            arr[i] = L.EmbedSide(L.ptr(s.ids) if with_ids else None, L.ptr(s.key_row_offset), L.ptr(s.key_vocab), L.ptr(s.out), s.out.stride(0),
+                                 s.K, _dt(s.out))
+        else:
+            arr[i] = L.EmbedSide(L.ptr(s.ids) if with_ids else None, L.ptr(s.key_row_offset), L.ptr(s.key_vocab), None, 0, s.K, TT_F32)
+        M += B * s.K
+    return arr, M
+
+
+def batch_ingest(pairs, sides: Sequence[LookupSide], B: int, rows_km: Optional[torch.Tensor], table: Optional[torch.Tensor] = None,
+                 rows_sm: Optional[torch.Tensor] = None):
     """copy_multi's segments plus, per side, the fused rows of the side's ids in key-major order (tt_batch_ingest): the batch
-    hand-over of a graph-replayed step in one launch.  sides[i].ids is the id source (the incoming batch or the static buffer)."""
+    hand-over of a graph-replayed step in one launch.  sides[i].ids is the id source (the incoming batch or the static buffer).
+    table given (and sides[i].out set): the same launch also looks the rows up and writes them into sides[i].out -- the towers'
+    input (tt_batch_ingest_lookup); rows_km may then be None.  rows_sm (without `table`): the same fused rows also in slot order,
+    the input of embed_lookup_rows."""
+    if table is not None:
+        dev, n = table.device, len(pairs)
+        dst = (L.vp * max(n, 1))(*[d.data_ptr() for d, _ in pairs])
+        src = (L.vp * max(n, 1))(*[s.data_ptr() for _, s in pairs])
+        nb = (L.i64 * max(n, 1))(*[d.numel() * d.element_size() for d, _ in pairs])
+        for d, s_ in pairs:
+            if d.numel() * d.element_size() != s_.numel() * s_.element_size() or not d.is_contiguous() or not s_.is_contiguous():
+                raise ValueError("batch_ingest: segments must be contiguous and equally sized")
+        arr, M = _embed_sides(sides, B, dev, "batch_ingest", True, True)
+        if rows_km is not None and (rows_km.dtype != torch.int32 or rows_km.numel() != M or not rows_km.is_contiguous()):
+            raise ValueError("batch_ingest: rows_km must be a contiguous int32 tensor of sum(B*K) elements")
+        lk = _lookup_part(table)
+        with _timed("tt_batch_ingest_lookup"):
+            L.check(L.load().tt_batch_ingest_lookup(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), C.byref(lk), L.stream(dev)),
+                    "tt_batch_ingest_lookup")
+        return
     dev, n = rows_km.device, len(pairs)
     dst = (L.vp * max(n, 1))(*[d.data_ptr() for d, _ in pairs])
     src = (L.vp * max(n, 1))(*[s.data_ptr() for _, s in pairs])
@@ -673,8 +760,11 @@ def batch_ingest(pairs, sides: Sequence[LookupSide], B: int, rows_km: torch.Tens
         M += B * s.K
     if rows_km.dtype != torch.int32 or rows_km.numel() != M or not rows_km.is_contiguous():
         raise ValueError("batch_ingest: rows_km must be a contiguous int32 tensor of sum(B*K) elements")
+    if rows_sm is not None and (rows_sm.dtype != torch.int32 or rows_sm.numel() != M or not rows_sm.is_contiguous()):
+        raise ValueError("batch_ingest: rows_sm must be a contiguous int32 tensor of sum(B*K) elements")
     with _timed("tt_batch_ingest"):
-        L.check(L.load().tt_batch_ingest(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), L.stream(dev)), "tt_batch_ingest")
+        L.check(L.load().tt_batch_ingest(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), L.ptr(rows_sm), L.stream(dev)),
+                "tt_batch_ingest")
 
 
 @dataclass
@@ -689,10 +779,21 @@ class StoreSide:
 
 
 def batch_ingest_store(pairs, sides: Sequence[LookupSide], stores: Sequence[StoreSide], B: int, order: Optional[torch.Tensor],
-                       rows_km: Optional[torch.Tensor], order_offset: int = 0):
+                       rows_km: Optional[torch.Tensor], order_offset: int = 0, table: Optional[torch.Tensor] = None,
+                       rows_sm: Optional[torch.Tensor] = None):
     """tt_batch_ingest_store: the batch `order[order_offset : order_offset + B]` of the pair list gathered out of the device
-    stores straight into the step's static buffers (+ key-major fused rows, + the copy segments `pairs`), one launch."""
+    stores straight into the step's static buffers (+ key-major fused rows, + the copy segments `pairs`), one launch.
+    table given (and sides[i].out set): the launch also looks the batch's rows up into sides[i].out (tt_batch_ingest_store_lookup).
+    Without `order` the entity view must hold the batch (B entries at its stride); a pair list or offset that does not is a
+    ValueError here, not an out-of-bounds read on the device (the reference raises IndexError / KeyError:
+    unified_bid_data_loader.py:495-498); entity indices are clamped into the store by the kernel (tt_store_side.n_rows)."""
     dev, n = stores[0].dense_out.device, len(pairs)
+    for i, t in enumerate(stores):
+        if t.entity.dtype != torch.int64 or t.entity.dim() != 1 or t.entity_stride < 1 or t.entity.device != dev:
+            raise ValueError(f"batch_ingest_store: store {i}: entity must be a 1-D int64 view on {dev}")
+        need = (B - 1) * t.entity_stride + 1 if order is None else 1
+        if t.entity.numel() < need:
+            raise ValueError(f"batch_ingest_store: store {i}: the batch runs past the pair list ({t.entity.numel()} entries, {need} needed)")
     dst = (L.vp * max(n, 1))(*[d.data_ptr() for d, _ in pairs])
     src = (L.vp * max(n, 1))(*[s.data_ptr() for _, s in pairs])
     nb = (L.i64 * max(n, 1))(*[d.numel() * d.element_size() for d, _ in pairs])
@@ -707,8 +808,14 @@ def batch_ingest_store(pairs, sides: Sequence[LookupSide], stores: Sequence[Stor
         if t.dense_out.shape != (B, dd) or not t.dense_out.is_contiguous() or t.dense_out.dtype != torch.float32 or \
                 t.ids_out.numel() != B * s.K or t.ids_out.dtype != torch.int64 or not t.ids_out.is_contiguous():
             raise ValueError(f"batch_ingest_store: side {i}: static buffers must be contiguous f32 [{B}, {dd}] and int64 [{B * s.K}]")
-        arr[i] = L.EmbedSide(None, L.ptr(s.key_row_offset), L.ptr(s.key_vocab), None, 0, s.K, TT_F32)
-        st[i] = L.StoreSide(L.ptr(t.entity), t.entity_stride, L.ptr(t.dense_store), L.ptr(t.cat_store), L.ptr(t.dense_out), L.ptr(t.ids_out), dd, 0)
+        if table is not None:
+            if s.out.shape[0] != B or s.out.device != dev:
+                raise ValueError(f"batch_ingest_store: side {i}: output view must be [B, K*E] on {dev}")
+            arr[i] = L.EmbedSide(None, L.ptr(s.key_row_offset), L.ptr(s.key_vocab), L.ptr(s.out), s.out.stride(0), s.K, _dt(s.out))
+        else:
+            arr[i] = L.EmbedSide(None, L.ptr(s.key_row_offset), L.ptr(s.key_vocab), None, 0, s.K, TT_F32)
+        st[i] = L.StoreSide(L.ptr(t.entity), t.entity_stride, L.ptr(t.dense_store), L.ptr(t.cat_store), L.ptr(t.dense_out), L.ptr(t.ids_out), dd,
+                            min(int(t.dense_store.shape[0]), 2 ** 31 - 1))
         M += B * s.K
     if rows_km is not None and (rows_km.dtype != torch.int32 or rows_km.numel() != M or not rows_km.is_contiguous()):
         raise ValueError("batch_ingest_store: rows_km must be a contiguous int32 tensor of sum(B*K) elements")
@@ -718,9 +825,17 @@ def batch_ingest_store(pairs, sides: Sequence[LookupSide], stores: Sequence[Stor
         order_ptr = L.vp(order.data_ptr() + 8 * order_offset)
     else:
         order_ptr = L.vp(0)
+    if table is not None:
+        lk = _lookup_part(table)
+        with _timed("tt_batch_ingest_lookup"):
+            L.check(L.load().tt_batch_ingest_store_lookup(L.ctx(dev), n, dst, src, nb, arr, st, len(sides), B, order_ptr, L.ptr(rows_km),
+                                                          C.byref(lk), L.stream(dev)), "tt_batch_ingest_store_lookup")
+        return
+    if rows_sm is not None and (rows_sm.dtype != torch.int32 or rows_sm.numel() != M or not rows_sm.is_contiguous()):
+        raise ValueError("batch_ingest_store: rows_sm must be a contiguous int32 tensor of sum(B*K) elements")
     with _timed("tt_batch_ingest_store"):
-        L.check(L.load().tt_batch_ingest_store(L.ctx(dev), n, dst, src, nb, arr, st, len(sides), B, order_ptr, L.ptr(rows_km), L.stream(dev)),
-                "tt_batch_ingest_store")
+        L.check(L.load().tt_batch_ingest_store(L.ctx(dev), n, dst, src, nb, arr, st, len(sides), B, order_ptr, L.ptr(rows_km), L.ptr(rows_sm),
+                                               L.stream(dev)), "tt_batch_ingest_store")
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU routing

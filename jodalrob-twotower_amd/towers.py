@@ -202,7 +202,7 @@ def run_towers(towers: Sequence[BaseTower], inputs: Sequence[Dict]) -> List[torc
 
 
 class _Side:
-    __slots__ = ("tower", "B", "acts", "acts_struct", "buf", "x", "emb", "train", "seed", "p_drop", "sync_keep", "packed")
+    __slots__ = ("tower", "B", "acts", "acts_struct", "buf", "x", "emb", "train", "seed", "p_drop", "sync_keep", "packed", "values")
 
 
 class _TowersFn(torch.autograd.Function):
@@ -232,17 +232,41 @@ class _TowersFn(torch.autograd.Function):
             s.p_drop = tw.dropout_rate if tw.training else 0.0
             s.seed = 0 if s.p_drop <= 0 else (tw._seed_override if tw._seed_override is not None else
                                               int(torch.empty((), dtype=torch.int64).random_().item()))
+            s.values = values
+            s.acts = (dense,)
+            sides.append(s)
+        # a graph-replayed step's hand-over launch may ALREADY have looked the rows up into persistent input buffers
+        # (ops.batch_ingest(table=...): tt_batch_ingest_lookup): then x is that buffer and no lookup launch follows
+        pre = {}
+        if towers[0].exchange is None and grad_on:
+            by_store: Dict[int, list] = {}
+            for s in sides:
+                emb = s.tower.categorical_embedder
+                if s.B and len(emb.keys):
+                    by_store.setdefault(id(emb.store), []).append(s)
+            for group in by_store.values():
+                st = group[0].tower.categorical_embedder.store
+                xs = st.x_for([g.values for g in group], [(g.B, g.tower.x_width, g.tower.x_dtype) for g in group])
+                if xs is not None:
+                    for g, x in zip(group, xs):
+                        pre[id(g)] = x
+        for s in sides:
+            tw, B, dense, values = s.tower, s.B, s.acts[0], s.values
+            emb = tw.categorical_embedder
+            K, E = len(emb.keys), emb.embedding_dim
+            dev = emb.store.device
             # one flat activation buffer: x | (pre_i, act_i)* | (mean_i, rstd_i)* | y
             hid = tw.tower_hidden_dims[1:]
-            x_f32 = tw.x_dtype == torch.float32
+            px = pre.get(id(s))
+            x_f32 = tw.x_dtype == torch.float32 and px is None
             sizes = [_al(B * tw.x_width) if x_f32 else 0] + [_al(B * h) for h in hid for _ in (0, 1)] + \
                     [_al(h) for h in hid for _ in (0, 1)] + [_al(B * tw.final_embedding_dim)]
             s.buf = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
             offs = [0]
             for z in sizes:
                 offs.append(offs[-1] + z)
-            s.x = s.buf[:B * tw.x_width].view(B, tw.x_width) if x_f32 else \
-                torch.empty((B, tw.x_width), dtype=tw.x_dtype, device=dev)
+            s.x = px if px is not None else (s.buf[:B * tw.x_width].view(B, tw.x_width) if x_f32 else
+                                             torch.empty((B, tw.x_width), dtype=tw.x_dtype, device=dev))
             s.emb = torch.empty((B, tw.final_embedding_dim), dtype=torch.float32, device=dev)
             a = L.TowerActs()
             base, esz = s.buf.data_ptr(), 4
@@ -259,10 +283,9 @@ class _TowersFn(torch.autograd.Function):
                 # the score kernels' bf16 operand images of the unit rows, written by the tower pass itself (tt_tower_acts.emb_packed)
                 s.packed = torch.empty(L.load().tt_score_pack_bytes(B, tw.final_embedding_dim), dtype=torch.uint8, device=dev)
                 a.emb_packed, a.emb_pack_scale = s.packed.data_ptr(), float(tw.pack_scale)
-            s.acts, s.acts_struct = (dense,), a
-            sides.append(s)
+            s.acts_struct = a
             if K and B:
-                lookups.setdefault(id(emb.store), []).append((s, emb.lookup_side(values, s.x[:, tw.tower_hidden_dims[0]:])))
+                lookups.setdefault(id(emb.store), []).append((s, emb.lookup_side(values, s.x[:, tw.tower_hidden_dims[0]:]), px is not None))
         # fused lookup (+ duplicate-row plan when a backward will follow) per store
         plans = []
         exch = towers[0].exchange
@@ -285,7 +308,14 @@ class _TowersFn(torch.autograd.Function):
             # a graph-replayed step hands the batch over with ops.batch_ingest, which leaves the fused rows of exactly these id
             # tensors in key-major order: the plan sorts those, the lookup need not write its slot-major copy
             km = store.rows_km_for([g[1].ids for g in group]) if (grad_on and 0 < B <= ops.KEYED_MAX_B) else None
-            rows = ops.embed_lookup(store.weight, [g[1] for g in group], B, want_rows=grad_on and km is None)
+            sm = store.rows_sm_for([g[1].ids for g in group]) if km is not None else None
+            if all(g[2] for g in group) and km is not None:
+                rows = None                             # the hand-over launch has filled x already (tt_batch_ingest_lookup)
+            elif sm is not None and store.weight.shape[1] % 4 == 0 and all(g[1].out.stride(0) % 4 == 0 for g in group):
+                rows = None                             # ... or left the clamped fused rows in slot order: no id decoding here
+                ops.embed_lookup_rows(store.weight, sm, [g[1] for g in group], B)
+            else:
+                rows = ops.embed_lookup(store.weight, [g[1] for g in group], B, want_rows=grad_on and km is None)
             plans.append([store, [g[0] for g in group], None, rows if km is None else km, grad_on, km is not None])
         # duplicate-row plans: depend on ids only, first needed in the backward.  In line on the launch stream (a side stream
         # overlapped the sort with the score kernels, but a captured graph with two streams is replayed node by node with

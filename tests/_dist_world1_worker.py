@@ -63,7 +63,7 @@ def main():
             losses = []
             gs = None
             if mode == "padded-graph":
-                gs = GraphedTrainStep(t, o, batches[0], warmup=1)       # the eager warm-up step calibrates the bucket capacity
+                gs = GraphedTrainStep(t, o, batches[0], warmup=1, preserve_state=False)   # the eager warm-up step (a real step here, as in the eager leg) calibrates the bucket capacity
                 for bt in batches:
                     losses.append(gs.step(bt)["loss"].item())
                     probe = torch.full((1024,), 3.0, device=DEV)
@@ -139,7 +139,7 @@ def deferred_slabs_before_all_reduce():
         gs = None
         if mode == "graph":
             seen["pending"].clear(); seen["defer_on"].clear()
-            gs = GraphedTrainStep(t, o, batches[0], warmup=1)
+            gs = GraphedTrainStep(t, o, batches[0], warmup=1, preserve_state=False)
             assert any(seen["defer_on"]), "the slab deferral was never on while the dense all-reduce was issued: nothing tested"
             assert not any(seen["pending"]), "a slab reduction was still queued when the dense gradients were all-reduced"
             for bt in batches:

@@ -260,6 +260,101 @@ def test_ingest_store_equals_gather_then_ingest(tt, dims, B, use_order):
     assert all(torch.equal(sd_c[i], sd_b[i]) and torch.equal(sv_c[i], sv_b[i]) for i in range(2))
 
 
+@pytest.mark.parametrize("E,Ks,vocab,B,out_dtype,use_order", [
+    (32, [32, 6], None, 8192, "bf16", True),            # the bench shape (real 32 + 6 keys scaled to 1 M rows per tower)
+    (32, [32, 6], None, 1000, "f32", False),            # ragged tiles, f32 rows (parity mode)
+    (8, [5, 2], [[40, 9, 3000, 12, 7], [50, 6]], 300, "bf16", True),
+    (16, [64, 1], None, 70, "f32", True),               # K = 64: 8-sample tiles; a one-key side
+    (64, [3, 33], None, 129, "bf16", False),            # K = 33: 8-sample tiles with a partial last chunk
+])
+def test_ingest_lookup_equals_separate_launches(tt, schema_real, E, Ks, vocab, B, out_dtype, use_order):
+    """Hand-over AND lookup in one launch (tt_batch_ingest_lookup / tt_batch_ingest_store_lookup) == the hand-over followed by
+    tt_embed_lookup_fwd, bit for bit: the embedding columns of the towers' inputs (f32 copies / RNE bf16), the untouched projection
+    columns, rows_km, the static ids and dense buffers, the copied scalars -- from batch tensors and from the device stores, with
+    out-of-range ids (clamp: cat_embed.py:114-117), ragged tiles, every supported row width."""
+    from jodalrob_twotower_amd import ops, synthetic
+    rng = np.random.default_rng(B + E)
+    dev = torch.device(DEV)
+    if vocab is None:
+        if Ks == [32, 6]:
+            vocab = [synthetic.scale_vocabs(schema_real["notice"]["vocab_sizes"], 1_000_000), synthetic.scale_vocabs(schema_real["company"]["vocab_sizes"], 1_000_000)]
+        else:
+            vocab = [[int(v) for v in rng.integers(2, 5000, k)] for k in Ks]
+    dims, h0 = (24, 8), 64
+    N, M, P = 1500, 700, 3 * B + 17
+    R = sum(sum(v) for v in vocab)
+    table = torch.from_numpy(rng.standard_normal((R, E)).astype(np.float32)).to(dev)
+    dense = [torch.from_numpy(rng.standard_normal((n, d)).astype(np.float32)).to(dev) for n, d in zip((N, M), dims)]
+    cat = [torch.from_numpy(np.stack([rng.integers(-3, v + 3, n) for v in vs], axis=1).astype(np.int64)).to(dev) for n, vs in zip((N, M), vocab)]
+    pairs = torch.from_numpy(np.stack([rng.integers(0, N, P), rng.integers(0, M, P)], axis=1).astype(np.int64)).to(dev)
+    order = torch.from_numpy(rng.permutation(P).astype(np.int64)).to(dev) if use_order else None
+    lo = B + 3
+    offs, base = [], 0
+    for vs in vocab:
+        offs.append(torch.tensor(base + np.concatenate([[0], np.cumsum(vs)[:-1]]), dtype=torch.int64, device=dev))
+        base += sum(vs)
+    vocs = [torch.tensor(vs, dtype=torch.int64, device=dev) for vs in vocab]
+    scal_src = torch.arange(12, dtype=torch.float32, device=dev)
+    odt = torch.bfloat16 if out_dtype == "bf16" else torch.float32
+
+    def fresh():
+        return ([torch.full((B, d), -7.0, device=dev) for d in dims], [torch.full((B * k,), -9, dtype=torch.int64, device=dev) for k in Ks],
+                torch.full((B * sum(Ks),), -1, dtype=torch.int32, device=dev), torch.zeros(12, device=dev),
+                [torch.full((B, h0 + k * E), 3.0, dtype=odt, device=dev) for k in Ks])
+
+    sel = pairs[lo:lo + B] if order is None else pairs[order[lo:lo + B]]
+    got = [ops.batch_gather(sel[:, i].contiguous(), dense[i], cat[i]) for i in range(2)]      # the batch as tensors
+    # A: hand-over, then the lookup launch
+    sd_a, sv_a, km_a, sc_a, x_a = fresh()
+    copies = lambda sd, sv, sc: [(sd[0], got[0][0]), (sv[0], got[0][1]), (sd[1], got[1][0]), (sv[1], got[1][1]), (sc, scal_src)]
+    ops.batch_ingest(copies(sd_a, sv_a, sc_a), [ops.LookupSide(got[i][1], offs[i], vocs[i], None, Ks[i]) for i in range(2)], B, km_a)
+    rows_a = ops.embed_lookup(table, [ops.LookupSide(sv_a[i], offs[i], vocs[i], x_a[i][:, h0:], Ks[i]) for i in range(2)], B, want_rows=True)
+    # B: one launch from the batch tensors
+    sd_b, sv_b, km_b, sc_b, x_b = fresh()
+    sides_b = [ops.LookupSide(got[i][1], offs[i], vocs[i], x_b[i][:, h0:], Ks[i]) for i in range(2)]
+    assert ops.ingest_lookup_supported(table, sides_b)
+    ops.batch_ingest(copies(sd_b, sv_b, sc_b), sides_b, B, km_b, table=table)
+    # C: one launch from the device stores
+    sd_c, sv_c, km_c, sc_c, x_c = fresh()
+    flat = pairs.view(-1)
+    base_el = 0 if order is not None else 2 * lo
+    sides_c = [ops.LookupSide(None, offs[i], vocs[i], x_c[i][:, h0:], Ks[i]) for i in range(2)]
+    stores_c = [ops.StoreSide(flat[base_el + i:], 2, dense[i], cat[i], sd_c[i], sv_c[i]) for i in range(2)]
+    ops.batch_ingest_store([(sc_c, scal_src)], sides_c, stores_c, B, order, km_c, lo if order is not None else 0, table=table)
+    # D / E: the hand-over (from batch tensors / from the stores) also leaves the rows in slot order, the lookup reads those
+    # (tt_embed_lookup_rows_fwd: what a captured step does) -- the same bits in x, and rows_sm == the id lookup's own rows
+    sd_d, sv_d, km_d, sc_d, x_d = fresh()
+    sm_d = torch.full_like(km_d, -1)
+    ops.batch_ingest(copies(sd_d, sv_d, sc_d), [ops.LookupSide(got[i][1], offs[i], vocs[i], None, Ks[i]) for i in range(2)], B, km_d, rows_sm=sm_d)
+    ops.embed_lookup_rows(table, sm_d, [ops.LookupSide(None, None, None, x_d[i][:, h0:], Ks[i]) for i in range(2)], B)
+    sd_e, sv_e, km_e, sc_e, x_e = fresh()
+    sm_e = torch.full_like(km_e, -1)
+    stores_e = [ops.StoreSide(flat[base_el + i:], 2, dense[i], cat[i], sd_e[i], sv_e[i]) for i in range(2)]
+    ops.batch_ingest_store([(sc_e, scal_src)], [ops.LookupSide(None, offs[i], vocs[i], None, Ks[i]) for i in range(2)], stores_e, B, order, km_e,
+                           lo if order is not None else 0, rows_sm=sm_e)
+    ops.embed_lookup_rows(table, sm_e, [ops.LookupSide(None, None, None, x_e[i][:, h0:], Ks[i]) for i in range(2)], B)
+    torch.cuda.synchronize()
+    assert torch.equal(sm_d, rows_a) and torch.equal(sm_e, rows_a)
+    for name, (sd, sv, km, sc, x) in (("batch", (sd_b, sv_b, km_b, sc_b, x_b)), ("store", (sd_c, sv_c, km_c, sc_c, x_c)),
+                                      ("batch + rows lookup", (sd_d, sv_d, km_d, sc_d, x_d)), ("store + rows lookup", (sd_e, sv_e, km_e, sc_e, x_e))):
+        for i in range(2):
+            assert torch.equal(x[i].view(torch.int16 if odt == torch.bfloat16 else torch.int32), x_a[i].view(torch.int16 if odt == torch.bfloat16 else torch.int32)), (name, i)
+            assert torch.equal(sd[i], sd_a[i]) and torch.equal(sv[i], sv_a[i]), (name, i)
+        assert torch.equal(km, km_a) and torch.equal(sc, sc_a), name
+    assert bool((x_b[0][:, :h0] == 3.0).all()) and int(km_b.min()) >= 0              # projection columns untouched
+    # the rows really are the table's (first and last sample, every key), not merely equal on both paths
+    r = rows_a.cpu().numpy()
+    t = table.cpu()
+    for b in (0, B - 1):
+        for k in range(Ks[0]):
+            want = t[r[b * Ks[0] + k]].to(odt)
+            assert torch.equal(x_b[0][b, h0 + k * E: h0 + (k + 1) * E].cpu(), want), (b, k)
+    # a pair list the batch runs past is an error here, not a device fault (reference: IndexError / KeyError)
+    with pytest.raises(ValueError):
+        bad = [ops.StoreSide(flat[2 * (P - B + 5) + i:], 2, dense[i], cat[i], sd_c[i], sv_c[i]) for i in range(2)]
+        ops.batch_ingest_store([], sides_c, bad, B, None, km_c, 0, table=table)
+
+
 def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
     """An epoch driven through DevicePairLoader.step_batches (GraphedTrainStep.step_from_store: the batch gathered out of the device
     stores by the step's own hand-over launch; ragged last batch through the eager step) == the same epoch with the loader's

@@ -586,13 +586,13 @@ def test_graphed_step_equals_eager(tt, manifest, mlp_dtype):
         shapes = {k: tuple(v.shape) for k, v in task.state_dict().items()}
         load_state(task, init_state_numpy(shapes, 55))
         task.train()
+        task._pair_check_done = True                # (the first call's alignment check takes the two-direction forward kernel, whose
+        #                                             reciprocals differ from the steady state's in the last bit; the capture's warm-up has it behind it)
         opt = FusedAdam.for_task(task, lr=1e-2, weight_decay=1e-5)
         sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: (s + 1) / 4 if s < 3 else 1.0)
         tb = [to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]) for b in batches]
         losses = []
-        if mode == "eager":
-            for i in range(3):                      # same 3 warm-up steps the graph wrapper runs eagerly
-                opt.zero_grad(); task(tb[0], return_metrics=True)["loss"].backward(); opt.step()
+        if mode == "eager":                         # (the graph wrapper's three eager warm-up steps leave no trace: preserve_state)
             for b in tb:
                 opt.zero_grad()
                 r = task(b, return_metrics=True)
@@ -605,7 +605,7 @@ def test_graphed_step_equals_eager(tt, manifest, mlp_dtype):
                 r = gs.step(b)
                 sched.step()
                 losses.append(r["loss"].item())
-            assert opt.current_step() == 3 + len(tb)
+            assert opt.current_step() == len(tb)
         finals[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in task.state_dict().items()})
     assert finals["eager"][0] == finals["graph"][0]
     for k, v in finals["eager"][1].items():
@@ -617,7 +617,9 @@ def test_graph_ingest_key_major_plan(tt, manifest, monkeypatch):
     which the duplicate-row plan then sorts instead of gathering every key's rows out of the sample-major array) == the same
     replayed steps with plain copies and the strided gather (TT_GRAPH_INGEST=0), bit for bit: ragged last 64-sample tile,
     out-of-range ids (the ingest clamps like the lookup), a batch that arrives in host memory, and static id buffers that
-    somebody overwrote with a torch op between replays (the stale key-major rows must not be used)."""
+    somebody overwrote with a torch op between replays (the stale key-major rows must not be used).  Round 4: the same steps
+    with the captured lookup reading the hand-over launch's slot-order rows (tt_embed_lookup_rows_fwd, the default) or decoding the
+    ids itself, and with hand-over and lookup as ONE launch (tt_batch_ingest_lookup) -- all bit for bit."""
     from jodalrob_twotower_amd.graph import GraphedTrainStep
     from jodalrob_twotower_amd.optim import FusedAdam
     from jodalrob_twotower_amd import ops as _ops
@@ -625,8 +627,10 @@ def test_graph_ingest_key_major_plan(tt, manifest, monkeypatch):
     cfg["B"] = 300
     batches = [synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 930 + i, oob=True) for i in range(5)]
     finals = {}
-    for ingest in ("0", "1"):
+    for ingest, rows_sm, fused in (("0", False, False), ("1", False, False), ("1", True, False), ("1", False, True)):
         monkeypatch.setattr(_cfg.settings, "graph_ingest", ingest == "1")
+        monkeypatch.setattr(_cfg.settings, "graph_ingest_rows", rows_sm)
+        monkeypatch.setattr(_cfg.settings, "graph_ingest_lookup", fused)
         task = make_task(tt, cfg, embedding_grad="sparse", score_dtype="bf16", mlp_dtype="bf16", dropout_rate=0.0)
         load_state(task, init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 56))
         task.train()
@@ -639,6 +643,7 @@ def test_graph_ingest_key_major_plan(tt, manifest, monkeypatch):
         store = task.two_tower_model.embedding_store
         store = store() if callable(store) else store
         assert (gs._ingest is not None) == (ingest == "1") and (store.ingest is not None) == (ingest == "1")
+        assert (gs._rows_sm is not None) == rows_sm and (gs._x_static is not None) == fused
         assert len(seen) == 3 and all(k == (ingest == "1") for k in seen)      # warm-up and capture sort the key-major rows
         losses = [gs.step(b)["loss"].item() for b in tb[:3]]
         host = {s: {"dense": tb[3][s]["dense"].cpu(), "kjt": type(tb[3][s]["kjt"])(tb[3][s]["kjt"].keys(), tb[3][s]["kjt"].values().cpu())}
@@ -651,11 +656,15 @@ def test_graph_ingest_key_major_plan(tt, manifest, monkeypatch):
         with torch.no_grad():                                             # a write no version counter sees
             gs.static["notice"]["kjt"].values().data.copy_(tb[2]["notice"]["kjt"].values())
         losses.append(gs.step(None)["loss"].item())
-        finals[ingest] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in task.state_dict().items()})
+        finals[(ingest, rows_sm, fused)] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in task.state_dict().items()}, gs.library_launches)
         gs.close()
-    assert finals["0"][0] == finals["1"][0] and len(set(finals["0"][0])) > 1
-    for k, v in finals["0"][1].items():
-        assert np.array_equal(v, finals["1"][1][k]), k
+    base = finals[("0", False, False)]
+    assert len(set(base[0])) > 1
+    for key, (losses, state, _) in finals.items():
+        assert losses == base[0], key
+        for k, v in base[1].items():
+            assert np.array_equal(v, state[k]), (key, k)
+    assert finals[("1", False, True)][2] == finals[("1", True, False)][2] - 1        # the fused hand-over has no lookup launch in the graph
 
 
 @pytest.mark.parametrize("B,grad", [(2048, "sparse"), (777, "sparse"), (8192, "dense")])
@@ -1809,6 +1818,32 @@ BF16_STEP_BOUNDS = {
 FP8_STEP_BOUNDS = dict(BF16_STEP_BOUNDS, loss_rtol=2e-5, metric_atol=6e-6, dense_grad_vector_norm=6e-3)
 FP8S_STEP_BOUNDS = dict(BF16_STEP_BOUNDS, loss_rtol=2e-5, metric_atol=6e-6)
 
+# The same quantities against the REFERENCE'S OWN ARITHMETIC -- oracle_np.task_step(rounding=None): every Linear, the score
+# matrix and its gradients in unrounded f64, i.e. the reference's f32 forward / backward (two_tower_train_task.py:99-134,
+# base_tower.py:83-99) without any operand rounding -- at the benchmarked shape.  This is the stated tolerance of the measured
+# mode (north_star: "stated fp tolerance on embeddings / loss"); DESIGN.md section 4 quotes the measured column.
+# Measured (round 4, B = 8192, 1 M + 1 M rows): loss 3.0e-7; embeddings 3.5e-3 / 3.7e-3 norm-wise (= bf16's 2^-9 per operand
+# element through three Linears), 2.8e-3 max-abs; metrics <= 1.3e-5; accuracy 1 / 8192; Linear weights 5.2e-3 ... 5.7e-3 behind
+# the BatchNorm (mlp.2, mlp.4) and 3.9e-2 ... 4.2e-2 in front of it (dense_projection, mlp.0); table-gradient rows 4.1e-2; bias /
+# BN vectors 1.1e-2 ... 1.0e-1.  Why the first block's gradients and the vectors sit an order above the operands' 2^-9: at a
+# random initialisation the loss is ln B and every gradient is a sum over the batch whose terms cancel -- the BatchNorm backward
+# removes the batch mean and the batch-variance direction, the softmax's dS sums to zero along rows and columns -- so the
+# independent 2^-9 roundings of the 8192 terms (sqrt(B) growth) stand against a sum that cancelled to about a tenth of its
+# random-walk size; column sums (the bias / BN gradients) cancel hardest.  Against the oracle with the SAME operand rounding these
+# tensors sit at <= 9.7e-4 (BF16_STEP_BOUNDS): the kernels compute the rounded arithmetic they claim, and the distance from the
+# reference is bf16 operand rounding itself, not accumulation or kernel error.  The vector bound (1.2e-1) is below round 3's
+# 1.5e-1 at B = 512; it cannot go lower without wider operands (the reference's own TF32 matmuls -- scripts/train.py:147-148 --
+# round to 2^-11: a quarter of these figures).
+BF16_VS_REFERENCE_BOUNDS = {"loss_rtol": 2e-6, "emb_norm": 6e-3, "emb_maxabs": 5e-3, "metric_atol": 5e-5, "dense_grad_matrix_norm": 6e-2,
+                            "dense_grad_vector_norm": 1.2e-1, "row_grad_norm": 6e-2}
+# configs[4]'s arithmetic (fp8 score operands + block-scaled e4m3 gradient products) at B = 2048, D = 256.  Measured: loss 3.1e-6;
+# embeddings 3.5e-3 / 3.8e-3 (they do not depend on the score kernels); metrics <= 4.6e-5; Linear weights 5.9e-3 ... 8.4e-3 behind
+# the BatchNorm, 3.8e-2 ... 4.5e-2 in front of it; rows 4.4e-2; vectors 6.8e-2 ... 1.2e-1 in the first block and 1.8e-1 ... 3.8e-1
+# for the BatchNorm shift and the last layer's bias: those two are column sums of d(embedding) over the batch, which cancel to
+# ~1/400 of their terms' norm (FP8_STEP_BOUNDS above), so the e4m3 weights' 2^-4 roundings show there and nowhere else
+# (TT_OPT_FP8_GRAD 0 -- bf16 gradient products -- puts them back at the bf16 figures).
+FP8_VS_REFERENCE_BOUNDS = dict(BF16_VS_REFERENCE_BOUNDS, loss_rtol=1e-5, metric_atol=1e-4, dense_grad_vector_norm=5e-1)
+
 
 @pytest.mark.parametrize("rows_per_tower,B,T,hidden,D,score_dtype", [(1_000_000, 8192, 1.0, [128, 64], 64, "bf16"), (None, 1000, 0.5, [128, 64], 64, "bf16"),
                                                                      (None, 2240, 1.0, [512, 256], 128, "bf16"), (None, 4096, 0.7, [256, 128], 96, "bf16"),
@@ -1888,11 +1923,42 @@ def test_bf16_step_vs_rounded_oracle(tt, schema_real, tmp_path, ctx_option, rows
     rows_equal = np.array_equal(got_rows, np.concatenate([rn, rc]))
     report["row_grads"] = _rel(got_grad, np.concatenate([gn, gc])) if rows_equal else float("inf")
     print(f"\n[{score_rounding or score_dtype} step vs rounded oracle]", json.dumps({k: (v if not isinstance(v, tuple) else list(v)) for k, v in report.items()}))
+    # ---- the same step against the reference's arithmetic (no operand rounding anywhere): the benchmarked shape and configs[4]'s
+    # score arithmetic at the largest batch the f64 oracle holds
+    ref_metric = {k: float(ref[k]) for k in ("positive_similarity_mean", "negative_similarity_mean", "similarity_gap")}
+    if (rows_per_tower and B == 8192) or (score_rounding == "fp8" and B == 2048):
+        del ref, rn, gn, rc, gc
+        refu = O.task_step(state, b, kn, kc, vn, vc, T, True, dtype=np.float64, rounding=None, table_grads="none", keep_sim=False)
+        bu = FP8_VS_REFERENCE_BOUNDS if score_rounding else BF16_VS_REFERENCE_BOUNDS
+        ru = {"loss": abs(res["loss"].item() - refu["loss"]) / refu["loss"]}
+        for name, got, want in (("notice_emb", ne, refu["notice_emb"]), ("company_emb", ce, refu["company_emb"])):
+            got = got.cpu().numpy()
+            ru[name] = (_rel(got, want), float(np.abs(got - want).max()))
+        for k in ("positive_similarity_mean", "negative_similarity_mean", "similarity_gap", "accuracy"):
+            ru[k] = abs(res[k].item() - float(refu[k]))
+        for n_, p in task.named_parameters():
+            if "categorical_embedder" not in n_:
+                ru[n_] = _rel(p.grad.cpu().numpy(), refu["grads"][n_])
+        rnu, gnu = O.embed_grad_sparse(refu["d_concat_notice"], refu["ids_notice"], offs_n, 32)
+        rcu, gcu = O.embed_grad_sparse(refu["d_concat_company"], refu["ids_company"], offs_c, 32)
+        ru["row_grads"] = _rel(got_grad, np.concatenate([gnu, gcu])) if np.array_equal(got_rows, np.concatenate([rnu, rcu])) else float("inf")
+        print(f"[{score_rounding or score_dtype} step vs REFERENCE arithmetic (unrounded f64 oracle)]",
+              json.dumps({k: (v if not isinstance(v, tuple) else list(v)) for k, v in ru.items()}))
+        assert ru["loss"] <= bu["loss_rtol"], ru
+        for name in ("notice_emb", "company_emb"):
+            assert ru[name][0] <= bu["emb_norm"] and ru[name][1] <= bu["emb_maxabs"], (name, ru[name])
+        for k in ("positive_similarity_mean", "negative_similarity_mean", "similarity_gap"):
+            assert ru[k] <= bu["metric_atol"], (k, ru[k])
+        assert ru["accuracy"] <= 4.0 / B, ru["accuracy"]
+        for n_, p in task.named_parameters():
+            if "categorical_embedder" not in n_:
+                assert ru[n_] <= (bu["dense_grad_matrix_norm"] if p.ndim > 1 else bu["dense_grad_vector_norm"]), (n_, ru[n_])
+        assert ru["row_grads"] <= bu["row_grad_norm"], ru["row_grads"]
     assert report["loss"] <= bd["loss_rtol"], report
     for name in ("notice_emb", "company_emb"):
         assert report[name][0] <= bd["emb_norm"] and report[name][1] <= bd["emb_maxabs"], (name, report[name])
     for k in ("positive_similarity_mean", "negative_similarity_mean", "similarity_gap"):
-        assert report[k] <= bd["metric_atol"] + 1e-4 * abs(float(ref[k])), (k, report[k])
+        assert report[k] <= bd["metric_atol"] + 1e-4 * abs(ref_metric[k]), (k, report[k])
     assert report["accuracy"] <= 2.0 / B
     for n_, p in task.named_parameters():
         if "categorical_embedder" not in n_:
@@ -2165,7 +2231,7 @@ def test_configs4_whole_step_full_size(tt, schema_real, tmp_path):
     del opt, runs, r
     task.load_state_dict(state0)
     opt = FusedAdam.for_task(task, lr=1e-3, weight_decay=1e-5)
-    gs = GraphedTrainStep(task, opt, batches[0], warmup=1)                  # its one eager warm-up step IS step 1
+    gs = GraphedTrainStep(task, opt, batches[0], warmup=1, preserve_state=False)     # its one eager warm-up step IS step 1
     losses_g = [None] + [gs.step(b)["loss"].item() for b in batches[1:]]
     torch.cuda.synchronize()
     assert losses_g[1:] == losses_e[1:], (losses_g, losses_e)

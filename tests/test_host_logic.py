@@ -108,20 +108,20 @@ def test_c_abi_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/twotower.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.tt_abi_version() == 1
+    assert lib.tt_abi_version() == 2
     assert lib.tt_dedup_workspace_bytes(1000) > 0 and lib.tt_score_pack_bytes(100, 64) == 4 * 128 * 64
 
 
 def test_ctypes_structs_match_c_layout(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include "twotower.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include "twotower.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(tt_embed_side),sizeof(tt_grad_src),sizeof(tt_adam_tensor),sizeof(tt_tower_params),sizeof(tt_tower_acts),'
-                   'sizeof(tt_tower_grads),sizeof(tt_score_fwd_dir),sizeof(tt_score_bwd_dir),sizeof(tt_store_side));return 0;}\n')
+                   'sizeof(tt_tower_grads),sizeof(tt_score_fwd_dir),sizeof(tt_score_bwd_dir),sizeof(tt_store_side),sizeof(tt_ingest_lookup));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
     sizes = list(map(int, subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()))
     mine = [ctypes.sizeof(c) for c in (_lib.EmbedSide, _lib.GradSrc, _lib.AdamTensor, _lib.TowerParams, _lib.TowerActs,
-                                       _lib.TowerGrads, _lib.ScoreFwdDir, _lib.ScoreBwdDir, _lib.StoreSide)]
+                                       _lib.TowerGrads, _lib.ScoreFwdDir, _lib.ScoreBwdDir, _lib.StoreSide, _lib.IngestLookup)]
     assert sizes == mine
 
 

@@ -102,19 +102,19 @@ __device__ __forceinline__ Rec decode(const Args& a, uint32_t slot) {
 }
 
 // ---- the shipping form and its variants: a wave owns CPW chunks of 64 consecutive slots ----
-template <int ST, int CPW, int PAIR, int SRC>
-__global__ __launch_bounds__(kThreads) void lab_kernel(Args a) {
+template <int ST, int CPW, int PAIR, int SRC, int TPB = kThreads>
+__global__ __launch_bounds__(TPB) void lab_kernel(Args a) {
   const bool stamp = a.stamps && blockIdx.x < kMaxWg && threadIdx.x == 0;
   unsigned long long t0 = 0;
   if (stamp) t0 = __builtin_amdgcn_s_memrealtime();
   constexpr int LPR = PAIR ? 4 : 8;          // lanes per row
   constexpr int RPI = 64 / LPR;              // rows per wave-instruction
   constexpr int NIT = 64 / RPI;              // wave-instructions per chunk
-  __shared__ Rec recs[kThreads / 64][2][64];
+  __shared__ Rec recs[TPB / 64][2][64];
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t nchunks = (a.total_slots + 63) / 64;
-  const uint32_t nwaves = gridDim.x * (kThreads / 64);
-  const uint32_t w = blockIdx.x * (kThreads / 64) + wave;
+  const uint32_t nwaves = gridDim.x * (TPB / 64);
+  const uint32_t w = blockIdx.x * (TPB / 64) + wave;
   const uint32_t sub = lane / LPR, part = lane % LPR;
   float4 v[2][NIT][PAIR ? 2 : 1];
   // chunk c of this wave = w + c * nwaves (grid-stride); software pipeline: loads of chunk c+1 are issued before chunk c is stored
@@ -272,9 +272,16 @@ int main(int argc, char** argv) {
   for (int p = 0; p < POOL; ++p) rows_of<<<1024, 256>>>(args(p, xn, xc, false), d_rows[p]);
   CK(hipDeviceSynchronize());
   const uint32_t nchunks = (uint32_t)((B * 38 + 63) / 64);
-  struct V { const char* name; void (*k)(Args); int cpw; };
+  struct V { const char* name; void (*k)(Args); int cpw; int tpb = kThreads; };
   const V vs[] = {
       {"ST0 plain stores          (shipping)", lab_kernel<0, 1, 0, 0>, 1},
+      {"ST0 PAIR SRC1", lab_kernel<0, 1, 1, 1>, 1},
+      {"ST1 PAIR SRC1", lab_kernel<1, 1, 1, 1>, 1},
+      {"ST2 PAIR SRC1", lab_kernel<2, 1, 1, 1>, 1},
+      {"ST1 PAIR", lab_kernel<1, 1, 1, 0>, 1},
+      {"ST0 PAIR 128 threads", lab_kernel<0, 1, 1, 0, 128>, 1, 128},
+      {"ST0 PAIR 512 threads", lab_kernel<0, 1, 1, 0, 512>, 1, 512},
+      {"ST0 PAIR 1024 threads", lab_kernel<0, 1, 1, 0, 1024>, 1, 1024},
       {"ST1 nontemporal stores", lab_kernel<1, 1, 0, 0>, 1},
       {"ST2 sc0 sc1 stores", lab_kernel<2, 1, 0, 0>, 1},
       {"ST0 PAIR (32 B per lane)", lab_kernel<0, 1, 1, 0>, 1},
@@ -283,25 +290,21 @@ int main(int argc, char** argv) {
       {"ST2 rows precomputed (SRC1)", lab_kernel<2, 1, 0, 1>, 1},
       {"ST0 CPW2 pipelined", lab_kernel<0, 2, 0, 0>, 2},
       {"ST2 CPW2 pipelined", lab_kernel<2, 2, 0, 0>, 2},
-      {"ST0 CPW4 pipelined", lab_kernel<0, 4, 0, 0>, 4},
-      {"ST2 CPW4 pipelined", lab_kernel<2, 4, 0, 0>, 4},
-      {"ST2 CPW4 PAIR SRC1", lab_kernel<2, 4, 1, 1>, 4},
       {"ST1 CPW2 pipelined", lab_kernel<1, 2, 0, 0>, 2},
-      {"ST0 two passes per wave, not pipelined", lab_kernel<0, 1, 0, 0>, 2},
-      {"ST2 two passes per wave, not pipelined", lab_kernel<2, 1, 0, 0>, 2},
   };
   printf("tables %lld + %lld rows (%.2f GB), B = %d, %u chunks, %d launches per timing, small_giants %d\n", (long long)rows_n, (long long)rows_c,
          (double)R * 128 / 1e9, B, nchunks, launches, small_giants);
-  printf("%-40s %8s %8s %8s %8s | %s\n", "variant", "launch", "body", "gap", "frac", "workgroup anatomy (us): start p90, duration mean / p90, end p50");
+  printf("%-40s %8s %8s %8s %8s | %s\n", "variant", "launch", "coldbody", "instep", "frac", "workgroup anatomy (us): start p90, duration mean / p90, end p50");
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double algo = (double)B * 38 * (128 + 8 + 64);
   for (size_t vi = 0; vi < sizeof(vs) / sizeof(vs[0]); ++vi) {
     const V& v = vs[vi];
-    const int grid = (int)((nchunks + 4 * v.cpw - 1) / (4 * v.cpw));
+    const int wpb = v.tpb / 64;
+    const int grid = (int)((nchunks + wpb * v.cpw - 1) / (wpb * v.cpw));
     // correctness against variant 0 on pool batch 3
     CK(hipMemset(xn, 0, (size_t)B * ldn * 2)); CK(hipMemset(xc, 0, (size_t)B * ldc * 2));
-    v.k<<<grid, kThreads>>>(args(3, vi == 0 ? xn0 : xn, vi == 0 ? xc0 : xc, false));
+    v.k<<<grid, v.tpb>>>(args(3, vi == 0 ? xn0 : xn, vi == 0 ? xc0 : xc, false));
     CK(hipGetLastError());
     unsigned long long bad = 0;
     if (vi) {
@@ -312,12 +315,12 @@ int main(int argc, char** argv) {
       // the first 128 columns are never written: both hold their fill (xn0 is unwritten memory there) -- compare written columns only
     }
     // back-to-back launches
-    for (int i = 0; i < 8; ++i) v.k<<<grid, kThreads>>>(args(i % POOL, xn, xc, false));
+    for (int i = 0; i < 8; ++i) v.k<<<grid, v.tpb>>>(args(i % POOL, xn, xc, false));
     stream_copy<<<2048, 256>>>(fl_s, fl_d, FL / 16);
     double best = 1e9, sum = 0;
     for (int rep = 0; rep < 5; ++rep) {
       CK(hipEventRecord(e0));
-      for (int i = 0; i < launches; ++i) v.k<<<grid, kThreads>>>(args(i % POOL, xn, xc, false));
+      for (int i = 0; i < launches; ++i) v.k<<<grid, v.tpb>>>(args(i % POOL, xn, xc, false));
       CK(hipEventRecord(e1));
       CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -325,6 +328,23 @@ int main(int argc, char** argv) {
       best = std::min(best, us); sum += us;
     }
     const double launch_us = sum / 5;
+    // in-step-like: every lookup behind a 2 x 192 MB streaming copy (what the other kernels of a step do to the caches); the
+    // copy alone is timed the same way and subtracted
+    double pair_us = 0;
+    {
+      const size_t cp = ((size_t)192 << 20) / 16;
+      const int NP = 24;
+      float ms_c = 0, ms_p = 0;
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < NP; ++i) stream_copy<<<2048, 256>>>(fl_s, fl_d, cp);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_c, e0, e1));
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < NP; ++i) { stream_copy<<<2048, 256>>>(fl_s, fl_d, cp); v.k<<<grid, v.tpb>>>(args(i % POOL, xn, xc, false)); }
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms_p, e0, e1));
+      }
+      pair_us = (ms_p - ms_c) * 1e3 / NP;
+    }
     // body: stamped launches (each behind a cache-evicting stream copy, as inside a training step)
     double body = 0; int nb = 0;
     std::vector<unsigned long long> h(2 * kMaxWg);
@@ -332,7 +352,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < 6; ++i) {
       stream_copy<<<2048, 256>>>(fl_s, fl_d, FL / 16);
       CK(hipMemset(stamps, 0, 2 * kMaxWg * 8));
-      v.k<<<grid, kThreads>>>(args(i % POOL, xn, xc, true));
+      v.k<<<grid, v.tpb>>>(args(i % POOL, xn, xc, true));
       CK(hipMemcpy(h.data(), stamps, 2 * kMaxWg * 8, hipMemcpyDeviceToHost));
       const int n = std::min(grid, kMaxWg);
       unsigned long long lo = ~0ull, hi = 0;
@@ -345,7 +365,7 @@ int main(int argc, char** argv) {
       if (i) { body += (hi - lo) * 0.01; ++nb; a_start90 += stv[(size_t)(0.9 * n)]; a_dur += dm; a_dur90 += dur[(size_t)(0.9 * n)]; a_end50 += en[n / 2]; }
     }
     body /= nb;
-    printf("%-40s %8.2f %8.2f %8.2f %8.3f | %.2f, %.2f / %.2f, %.2f   grid %d  min-of-5 %.2f  %s\n", v.name, launch_us, body, launch_us - body,
+    printf("%-40s %8.2f %8.2f %8.2f %8.3f | %.2f, %.2f / %.2f, %.2f   grid %d  min-of-5 %.2f  %s\n", v.name, launch_us, body, pair_us,
            algo / (launch_us * 1e-6) / 8e12, a_start90 / nb, a_dur / nb, a_dur90 / nb, a_end50 / nb, grid, best, bad ? "MISMATCH" : "ok");
     fflush(stdout);
   }
