@@ -75,6 +75,8 @@ def parse(argv=None):
                     "(default), 0 bf16 gradient products")
     ap.add_argument("--no-riders", action="store_true", help="plan compaction / loss reduction as launches of their own (A/B of TT_OPT_DEFER_RIDERS)")
     ap.add_argument("--dist-eager", action="store_true", help="sharded path launched from Python instead of replayed (analysis)")
+    ap.add_argument("--dist-segmented", action="store_true", help="sharded path: the compute between two collectives as graphs of its own, the "
+                    "collectives eager (the fallback when a capture with RCCL nodes fails; this flag forces it)")
     ap.add_argument("--no-lookup-profile", action="store_true", help="do not stamp the lookup launches (no `roofline` object then)")
     ap.add_argument("--lookup-wg-dump", default=None, help="write the lookup's per-workgroup stamps to this .npy (tools/lookup_wg.py)")
     ap.add_argument("--fused-handover", action="store_true", help="hand-over and lookup as ONE launch (tt_batch_ingest_lookup; measured neutral, off by default)")
@@ -196,19 +198,33 @@ class Leg:
             torch.cuda.synchronize()
         if self.use_graph:
             from jodalrob_twotower_amd.graph import GraphedTrainStep
+            kw = dict(return_metrics=True, warmup=3, defer_riders=not args.no_riders, preserve_state=False)   # (warm-up steps: part of the bench's own)
+            self.launch_form = "hip graph replay"
             try:
-                self.gstep = GraphedTrainStep(task, self.opt, self.pool[0], return_metrics=True, warmup=3, defer_riders=not args.no_riders,
-                                              preserve_state=False)        # (the warm-up steps are part of the bench's own warm-up)
+                if sharded and args.dist_segmented:
+                    raise RuntimeError("--dist-segmented")
+                self.gstep = GraphedTrainStep(task, self.opt, self.pool[0], **kw)
                 task._bench_gstep = self.gstep
             except Exception as e:                      # a capture that fails on some RCCL / world size must not lose the run
                 if not sharded:
                     raise
-                print(f"[bench] rank {rank}: graph capture of the sharded step failed ({type(e).__name__}: {e}); running eagerly",
+                # first fallback: the compute between two collectives as graphs of its own, the 3-5 collectives eager between the
+                # replays (segmented.SegmentedTrainStep); last resort: ~75 launches per step from Python
+                print(f"[bench] rank {rank}: one-graph capture of the sharded step not used ({type(e).__name__}: {e}); capturing it in segments",
                       file=sys.stderr, flush=True)
-                if self.profile is not None:
-                    self.profile.close()
-                self.gstep, self.profile = None, None
                 torch.cuda.synchronize()
+                try:
+                    from jodalrob_twotower_amd.segmented import SegmentedTrainStep
+                    self.gstep = SegmentedTrainStep(task, self.opt, self.pool[0], **kw)
+                    task._bench_gstep = self.gstep
+                    self.launch_form = f"segmented graph replay ({self.gstep.collectives_per_step()} eager collectives between the segments)"
+                except Exception as e2:
+                    print(f"[bench] rank {rank}: segmented capture failed too ({type(e2).__name__}: {e2}); running eagerly", file=sys.stderr, flush=True)
+                    if self.profile is not None:
+                        self.profile.close()
+                    self.gstep, self.profile = None, None
+                    self.launch_form = "eager"
+                    torch.cuda.synchronize()
 
     def step(self, i, batch=None, eager=False):
         b = batch if batch is not None else self.pool[i % len(self.pool)]
@@ -494,7 +510,7 @@ def config_of(args, leg, world, ctx, B_global, workload):
     cfg = {"workload": workload, "batch_per_gpu": leg.B, "global_batch": B_global, "rows_notice": sum(leg.vocab_n),
            "rows_company": sum(leg.vocab_c), "ids": "uniform" if args.zipf is None else f"zipf({args.zipf})",
            "optimizer": args.optimizer, "score_dtype": args.score_dtype, **({"fp8_grad": args.fp8_grad} if args.score_dtype == "fp8" else {}), "mlp_dtype": args.mlp_dtype,
-           "launch": "hip graph replay" if leg.gstep is not None else "eager",
+           "launch": getattr(leg, "launch_form", "hip graph replay") if leg.gstep is not None else "eager",
            "batch_handover": (("one launch: copies + key-major rows for the dedup plan + the embedding lookup into the towers' inputs (tt_batch_ingest_lookup)"
                                if getattr(leg.gstep, "_x_static", None) is not None else
                                "one launch: copies + key-major rows for the dedup plan (tt_batch_ingest)")

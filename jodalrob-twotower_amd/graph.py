@@ -86,7 +86,7 @@ class GraphedTrainStep:
         for t in self._towers:
             t._seed_dev = self._seed_dev
         optimizer._hp_dev = self._hp_dev
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = None
         # With a process group alive, its watchdog thread polls events while we capture; under the default "global" capture
         # mode that poll is an error ("operation not permitted when stream is capturing") that aborts the process --
         # now and then, depending on timing.  "thread_local" restricts the check to the capturing thread.
@@ -94,8 +94,7 @@ class GraphedTrainStep:
         mode = "thread_local" if (_dist.is_available() and _dist.is_initialized()) else "global"
         n0 = L.load().tt_launch_count()
         try:
-            with torch.cuda.graph(self.graph, capture_error_mode=mode):
-                self.result = self._body()
+            self._capture(mode)
         finally:
             self.library_launches = int(L.load().tt_launch_count() - n0) + 1       # (+ the hand-over launch in front of every replay)
             optimizer._hp_dev = None
@@ -103,6 +102,15 @@ class GraphedTrainStep:
                 t._seed_dev = None
         # the capture itself ran the host-side bookkeeping of one optimiser step without executing it
         optimizer.advance_steps(-1)
+
+    def _capture(self, mode: str):
+        """Captures self._body() into self.graph (ONE graph; segmented.SegmentedTrainStep cuts it at the collectives instead)."""
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
+            self.result = self._body()
+
+    def _replay_graph(self):
+        self.graph.replay()
 
     def _setup_ingest(self):
         """Key-major row hand-over (ops.batch_ingest) when the step looks the static ids up in ONE local fused table with the
@@ -349,7 +357,7 @@ class GraphedTrainStep:
         return self._replay()
 
     def _replay(self):
-        self.graph.replay()
+        self._replay_graph()
         self.opt.advance_steps(1)
         ex = getattr(self.task, "exchange", None)
         if ex is not None and hasattr(ex, "poll_overflow"):

@@ -23,6 +23,7 @@ for p in (ROOT, ROOT / "tests", ROOT / "oracle"):
 import jodalrob_twotower_amd as tt  # noqa: E402
 from jodalrob_twotower_amd.distributed import create_distributed_train_task  # noqa: E402
 from jodalrob_twotower_amd.graph import GraphedTrainStep  # noqa: E402
+from jodalrob_twotower_amd.segmented import SegmentedTrainStep  # noqa: E402
 from jodalrob_twotower_amd.optim import FusedAdam  # noqa: E402
 from params_init import init_state_numpy, synth_batch_numpy  # noqa: E402
 
@@ -48,7 +49,7 @@ def main():
                for i in range(4)]
     for mlp in ("fp32", "bf16"):
         finals, state = {}, None
-        for mode in ("exact", "padded", "padded-graph"):
+        for mode in ("exact", "padded", "padded-graph", "padded-segmented"):
             t = create_distributed_train_task(
                 cfg["keys_n"], cfg["keys_c"], metadata_path=str(GOLD / "synthetic_metadata.csv"), categorical_embedding_dim=cfg["E"],
                 notice_dense_input_dim=cfg["din_n"], company_dense_input_dim=cfg["din_c"], tower_hidden_dims=list(cfg["hidden"]),
@@ -62,8 +63,15 @@ def main():
             o = FusedAdam.for_task(t, lr=1e-2, weight_decay=1e-5)
             losses = []
             gs = None
-            if mode == "padded-graph":
-                gs = GraphedTrainStep(t, o, batches[0], warmup=1, preserve_state=False)   # the eager warm-up step (a real step here, as in the eager leg) calibrates the bucket capacity
+            if mode in ("padded-graph", "padded-segmented"):
+                # padded-segmented: the fallback for a step whose collectives cannot be captured -- the compute between two collectives
+                # as graphs of its own, the collectives eager between the replays (segmented.SegmentedTrainStep)
+                Step = GraphedTrainStep if mode == "padded-graph" else SegmentedTrainStep
+                gs = Step(t, o, batches[0], warmup=1, preserve_state=False)   # the eager warm-up step (a real step here, as in the eager leg) calibrates the bucket capacity
+                if mode == "padded-segmented":
+                    print(f"[segmented] {mlp}: {gs.collectives_per_step()} collectives, {sum(g is not None for g in gs._segments)} graph segments "
+                          f"of {len(gs._segments)}", flush=True)
+                    assert gs.collectives_per_step() == 4, gs.collectives_per_step()      # ids, rows, row gradients (all-to-all), dense gradients (all-reduce)
                 for bt in batches:
                     losses.append(gs.step(bt)["loss"].item())
                     probe = torch.full((1024,), 3.0, device=DEV)
@@ -83,17 +91,60 @@ def main():
             if gs is not None:
                 gs.close()                                              # graph + pool go before the communicator does
             del gs, o, t
-        for mode in ("padded", "padded-graph"):
+        for mode in ("padded", "padded-graph", "padded-segmented"):
             assert finals[mode][0] == finals["exact"][0], (mlp, mode, finals[mode][0], finals["exact"][0])
             for k, v in finals["exact"][1].items():
                 np.testing.assert_allclose(finals[mode][1][k], v, rtol=1e-6, atol=1e-7, err_msg=f"{mlp}:{mode}:{k}")
     resume_check(cfg, batches)
     deferred_slabs_before_all_reduce()
+    segmented_global_negatives(cfg, batches)
     import gc
     gc.collect()
     torch.cuda.synchronize()
     dist.destroy_process_group()
     print("DIST_WORLD1_OK", flush=True)
+
+
+def segmented_global_negatives(cfg, batches):
+    """The segmented fallback on the SURVEY-C3 semantics (global in-batch negatives + SyncBN: all-gathers back to back leave empty
+    segments, the SyncBN tail runs in two phases with a collective between them) == the same steps eager, bit for bit."""
+    finals, state = {}, None
+    for mode in ("eager", "segmented"):
+        t = create_distributed_train_task(
+            cfg["keys_n"], cfg["keys_c"], metadata_path=str(GOLD / "synthetic_metadata.csv"), categorical_embedding_dim=cfg["E"],
+            notice_dense_input_dim=cfg["din_n"], company_dense_input_dim=cfg["din_c"], tower_hidden_dims=list(cfg["hidden"]),
+            final_embedding_dim=cfg["D"], dropout_rate=0.0, temperature=cfg["T"], device=DEV, embedding_grad="sparse",
+            mlp_dtype="bf16", score_dtype="bf16", exchange="padded", negatives="global", sync_bn=True)
+        if state is None:
+            shapes = {k: tuple(v.shape) for k, v in t.full_state_dict().items()}
+            state = {k: torch.from_numpy(np.asarray(v)) for k, v in init_state_numpy(shapes, 555).items()}
+        t.load_full_state_dict(state)
+        t.train()
+        t._pair_check_done = True
+        o = FusedAdam.for_task(t, lr=1e-2, weight_decay=1e-5)
+        losses, gs = [], None
+        if mode == "segmented":
+            gs = SegmentedTrainStep(t, o, batches[0], warmup=1, preserve_state=False)
+            for bt in batches:
+                losses.append(gs.step(bt)["loss"].item())
+        else:
+            o.zero_grad(); t(batches[0], return_metrics=True)["loss"].backward(); o.step()     # the capture's warm-up step
+            for bt in batches:
+                o.zero_grad()
+                r = t(bt, return_metrics=True)
+                r["loss"].backward()
+                o.step()
+                losses.append(r["loss"].item())
+        torch.cuda.synchronize()
+        finals[mode] = (losses, {k: v.detach().cpu().clone() for k, v in t.full_state_dict().items()}, None if gs is None else gs.collectives_per_step())
+        if gs is not None:
+            gs.close()
+        del gs, o, t
+    assert finals["segmented"][0] == finals["eager"][0], (finals["segmented"][0], finals["eager"][0])
+    for k, v in finals["eager"][1].items():
+        assert torch.equal(v, finals["segmented"][1][k]), k
+    print(f"[segmented, global negatives + SyncBN] {finals['segmented'][2]} collectives per step", flush=True)
+    assert finals["segmented"][2] >= 8, finals["segmented"][2]       # 3 all-to-alls + all-reduce + SyncBN (2) + tower outputs / softmax sums (>= 4 all-gathers)
 
 
 def deferred_slabs_before_all_reduce():
