@@ -484,11 +484,13 @@ def roofline_of(args, leg, world):
         n_launch, lookup_ms = len(leg.lookup_us), (body_us + (leg.dispatch_us or 0.0)) * 1e-3
     achieved = algo_bytes / (lookup_ms * 1e-3) / 1e9 if lookup_ms == lookup_ms and lookup_ms > 0 else None
     traffic, src = None, None
-    pmc = ROOT / "profiles" / ("lookup_pmc_bf16out.json" if x_bf16 else "lookup_pmc.json")
+    pmc = ROOT / "profiles" / (("r04_lookup_pmc.json" if rows_mode else "lookup_pmc_bf16out.json") if x_bf16 else "lookup_pmc.json")
     if pmc.exists() and not leg.sharded and B == 8192 and sum(leg.vocab_n) == 1_000_000 and sum(leg.vocab_c) == 1_000_000 and args.zipf is None:
         try:                                                 # the PMC passes were taken on this exact launch (configs[1]), not in this run
             traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
-            src = f"profiles/{pmc.name} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch, not this run)"
+            src = (f"profiles/{pmc.name} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch inside the replayed step, "
+                   "collected in round 4 with tools/r04_profiles.sh; not this run)" if rows_mode else
+                   f"profiles/{pmc.name} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same launch, not this run)")
         except Exception:
             traffic = None
     return {"kernel": "lookup_wave_kernel (tt_embed_lookup_rows_fwd: precomputed fused rows)" if rows_mode else "lookup_wave_kernel (tt_embed_lookup_fwd)",

@@ -2157,6 +2157,63 @@ def test_score_fp8_vs_rounded_oracle(tt, ctx_option, B, D, T, fp8_grad):
 
 
 # ------------------------------------------------------------------ BASELINE configs[2] / [3] / [4] at their own sizes
+FP8_GRAD_TRAJECTORY_BOUNDS = {"loss_rel": 0.05, "accuracy_abs": 0.05, "recall_abs": 0.05}
+
+
+@pytest.mark.parametrize("T", [1.0, 0.05])
+def test_fp8_grad_default_trains_like_bf16_gradient_products(tt, schema_real, tmp_path, ctx_option, T):
+    """TT_OPT_FP8_GRAD defaults to 1 -- e4m3 softmax weights and e4m3 operands in the backward's gradient
+    products -- and the single-step bounds (FP8_STEP_BOUNDS) say nothing about whether that default still TRAINS like the bf16
+    gradient products (TT_OPT_FP8_GRAD 0).  200 captured steps of configs[4]'s arithmetic (final_embedding_dim 256, fp8 score
+    operands, row-sparse FusedAdam) on a fixed pool of 8 batches (B = 1024: the model memorises them -- loss falls, in-batch
+    accuracy and recall@10 rise), from the same seed, with fp8_grad 1 and 0, at T = 1 and T = 0.05 (1/T = 20 in the exponent: the
+    regime where the e4m3 rounding of S's operands costs most): the two trajectories must end at the same loss, accuracy and
+    recall@10 within the stated bounds, and both must have learned.  (The reference holds no fp8 fixture: fp8 parity is pinned by
+    the rounded oracle per step and by this A/B per trajectory, not by reference outputs.)"""
+    from jodalrob_twotower_amd import synthetic
+    from jodalrob_twotower_amd.graph import GraphedTrainStep
+    from jodalrob_twotower_amd.optim import FusedAdam
+    kn, kc = schema_real["notice"]["categorical"][:6], schema_real["company"]["categorical"][:3]
+    vn, vc = [3000, 500, 12, 12, 40, 7], [2000, 30, 9]
+    meta = synthetic.write_metadata(tmp_path / "m.csv", {"notice": dict(zip(kn, vn)), "company": dict(zip(kc, vc))})
+    B, steps = 1024, 200
+    pool = [synthetic.make_batch(B, vn, vc, kn, kc, 64, 32, torch.device(DEV), seed=4000 + i) for i in range(8)]
+    ends = {}
+    for fp8_grad in (1, 0):
+        ctx_option(_L.TT_OPT_FP8_GRAD, fp8_grad, 1)
+        torch.manual_seed(99)
+        task = tt.create_two_tower_train_task(kn, kc, metadata_path=str(meta), categorical_embedding_dim=32, notice_dense_input_dim=64,
+                                              company_dense_input_dim=32, tower_hidden_dims=[128, 64], final_embedding_dim=256, dropout_rate=0.0,
+                                              temperature=T, device=DEV, embedding_grad="sparse", score_dtype="fp8", mlp_dtype="bf16")
+        task.train()
+        task._pair_check_done = True
+        opt = FusedAdam.for_task(task, lr=3e-3, weight_decay=1e-5)
+        gs = GraphedTrainStep(task, opt, pool[0], warmup=1, accumulate_metrics=True)
+        first = None
+        for i in range(steps):
+            r = gs.step(pool[i % len(pool)])
+            if i == 0:
+                first = float(r["loss"].item())
+            if i == steps - 2 * len(pool):
+                gs.metric_sums.zero_()                       # means over the last two passes through the pool
+        sums = gs.metric_sums.cpu()
+        gs.close()
+        task.eval()
+        rec = float(np.mean([float((task.diagonal_ranks(b) < 10).float().mean().item()) for b in pool]))
+        ends[fp8_grad] = {"first_loss": first, "loss": float(sums[0]) / (2 * len(pool)), "accuracy": float(sums[1]) / (2 * len(pool)), "recall@10": rec}
+        del task, opt, gs
+        torch.cuda.empty_cache()
+    print(f"\n[fp8_grad trajectory A/B, T = {T}]", json.dumps(ends))
+    a, b = ends[1], ends[0]
+    bd = FP8_GRAD_TRAJECTORY_BOUNDS
+    assert a["first_loss"] == pytest.approx(b["first_loss"], rel=1e-6)                     # same start
+    for e in (a, b):
+        assert e["loss"] < 0.8 * e["first_loss"] and e["recall@10"] > 10.0 / B * 5, e      # both learned
+    assert abs(a["loss"] - b["loss"]) <= bd["loss_rel"] * abs(b["loss"]), (a, b)
+    assert abs(a["accuracy"] - b["accuracy"]) <= bd["accuracy_abs"], (a, b)
+    assert abs(a["recall@10"] - b["recall@10"]) <= bd["recall_abs"], (a, b)
+
+
 def test_configs4_whole_step_full_size(tt, schema_real, tmp_path):
     """BASELINE configs[4] as ONE WHOLE STEP at its own size -- batch 65536, final_embedding_dim 256, score_dtype "fp8", row-sparse
     table gradients, FusedAdam (fused sparse Adam on the looked-up rows), 1 M + 1 M-row tables -- eagerly and replayed from the
