@@ -318,6 +318,12 @@ typedef struct tt_tower_params {
   int32_t sync_ranks;
   int64_t rng_row_offset; /* first global row of this rank's batch: dropout masks are drawn per GLOBAL (row, column), so a
                              split batch drops the same elements as the whole one */
+  /* Optional bf16 SHADOWS of w_proj / w[i] (same shapes, RNE of the f32 values; NULL = none): the one-launch front reads them
+   * instead of the f32 weights -- every 64-row workgroup re-reads its tower's weights, and the f32 copies are two thirds of the bytes
+   * it moves.  The caller keeps them equal to bf16(w) (a captured step: refreshed by the hand-over launch, tt_cvt_list); results
+   * are bit-identical to the f32 path, which rounds the same values on the way into LDS. */
+  const void* w_proj_bf16;
+  const void* w_bf16[TT_MAX_HIDDEN];
 } tt_tower_params;
 /* run the tail of a training pass (BN of the last block, output Linear, L2 normalise) as the separate kernels even when
    the fused form applies (last hidden width and d_out <= 64, compute_dtype TT_BF16): for A/B comparison */
@@ -595,6 +601,18 @@ int tt_gather_rows(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t 
  * buffers (dense features and ids of both towers); sizes in bytes, all pointers 16-byte aligned.
  * ---------------------------------------------------------------------------------------------- */
 #define TT_MAX_COPIES 8
+/* f32 -> bf16 (round to nearest even) conversions that ride in a hand-over launch: dst[i][0 .. count[i]) = bf16(src[i][...]).  A captured
+ * step refreshes the towers' bf16 weight shadows (tt_tower_params.w_proj_bf16 / w_bf16) this way at every hand-over, so whoever changed
+ * the weights since the last step -- the captured Adam, an eager step, a checkpoint load -- the shadows are current when the replay
+ * reads them.  Sources 16-byte, destinations 8-byte aligned; NULL list or n = 0: none. */
+#define TT_MAX_CVT 8
+typedef struct tt_cvt_list {
+  int32_t n;
+  int32_t reserved;
+  const float* src[TT_MAX_CVT];
+  void* dst[TT_MAX_CVT];
+  int64_t count[TT_MAX_CVT];
+} tt_cvt_list;
 int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                   tt_stream stream);
 
@@ -606,7 +624,7 @@ int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* s
 int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                     const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_km,
                     int32_t* rows_sm /* or NULL: the same rows in slot order, rows_sm[side_base + b*K + k], for tt_embed_lookup_rows_fwd */,
-                    tt_stream stream);
+                    const tt_cvt_list* cvt /* or NULL */, tt_stream stream);
 
 /* The same hand-over STRAIGHT FROM THE DEVICE-RESIDENT FEATURE STORES (two-level gather: pair -> entity row -> dense features
  * and ids -> fused table rows) -- replaces UnifiedBidDataset.__getitem__ + collate_fn_gpu_optimized + _build_batch_kjt
@@ -635,7 +653,7 @@ typedef struct tt_store_side {
 int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                           const tt_embed_side* sides, const tt_store_side* stores, int32_t n_sides, int64_t B,
                           const int64_t* order /* [B] or NULL */, int32_t* rows_km /* or NULL */,
-                          int32_t* rows_sm /* or NULL: as tt_batch_ingest */, tt_stream stream);
+                          int32_t* rows_sm /* or NULL: as tt_batch_ingest */, const tt_cvt_list* cvt /* or NULL */, tt_stream stream);
 
 
 /* Hand-over AND lookup in ONE launch: tt_batch_ingest / tt_batch_ingest_store whose tile workgroups -- they hold the batch's
@@ -653,11 +671,11 @@ typedef struct tt_ingest_lookup {
 } tt_ingest_lookup;
 int tt_batch_ingest_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                            const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_km /* or NULL */,
-                           const tt_ingest_lookup* lookup, tt_stream stream);
+                           const tt_ingest_lookup* lookup, const tt_cvt_list* cvt /* or NULL */, tt_stream stream);
 int tt_batch_ingest_store_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                                  const tt_embed_side* sides, const tt_store_side* stores, int32_t n_sides, int64_t B,
                                  const int64_t* order /* [B] or NULL */, int32_t* rows_km /* or NULL */,
-                                 const tt_ingest_lookup* lookup, tt_stream stream);
+                                 const tt_ingest_lookup* lookup, const tt_cvt_list* cvt /* or NULL */, tt_stream stream);
 
 #ifdef __cplusplus
 }

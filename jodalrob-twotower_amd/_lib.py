@@ -39,6 +39,13 @@ class StoreSide(C.Structure):
                 ("dense_dim", i32), ("n_rows", i32)]
 
 
+TT_MAX_CVT = 8
+
+
+class CvtList(C.Structure):
+    _fields_ = [("n", i32), ("reserved", i32), ("src", vp * TT_MAX_CVT), ("dst", vp * TT_MAX_CVT), ("count", i64 * TT_MAX_CVT)]
+
+
 class IngestLookup(C.Structure):
     _fields_ = [("table", vp), ("table_rows", i64), ("E", i32), ("reserved", i32)]
 
@@ -70,7 +77,8 @@ class TowerParams(C.Structure):
                 ("w_proj", vp), ("b_proj", vp), ("w", _H), ("b", _H), ("bn_w", _H), ("bn_b", _H),
                 ("bn_rm", _H), ("bn_rv", _H), ("bn_nbt", _H), ("w_out", vp), ("b_out", vp), ("compute_dtype", i32),
                 ("x_dtype", i32), ("dx_dtype", i32), ("flags", i32),
-                ("sync_phase", i32), ("sync_ranks", i32), ("rng_row_offset", i64)]
+                ("sync_phase", i32), ("sync_ranks", i32), ("rng_row_offset", i64),
+                ("w_proj_bf16", vp), ("w_bf16", _H)]
 
 
 class TowerActs(C.Structure):
@@ -152,14 +160,14 @@ SIGNATURES = {
     "tt_dedup_plan_runs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_gather_rows": (C.c_int, [vp, vp, i64, i32, vp, i64, vp, i32, vp]),
     "tt_copy_multi": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]),
-    "tt_batch_ingest": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp, vp, vp]),
+    "tt_batch_ingest": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp, vp, C.POINTER(CvtList), vp]),
     "tt_batch_gather": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]),
     "tt_batch_ingest_store": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), C.POINTER(StoreSide), i32,
-                                        i64, vp, vp, vp, vp]),
+                                        i64, vp, vp, vp, C.POINTER(CvtList), vp]),
     "tt_batch_ingest_lookup": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp,
-                                         C.POINTER(IngestLookup), vp]),
+                                         C.POINTER(IngestLookup), C.POINTER(CvtList), vp]),
     "tt_batch_ingest_store_lookup": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), C.POINTER(StoreSide),
-                                               i32, i64, vp, vp, C.POINTER(IngestLookup), vp]),
+                                               i32, i64, vp, vp, C.POINTER(IngestLookup), C.POINTER(CvtList), vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -34,6 +34,7 @@ class Settings:
     tower_unfused_back: bool = False     # first-block / projection gradient GEMMs as separate launches
     tower_pack: bool = True              # the towers' fused tail emits the score kernels' operand images
     graph_ingest: bool = True            # GraphedTrainStep hands the batch over with tt_batch_ingest (key-major rows)
+    graph_weight_shadows: bool = True    # ... and refreshes bf16 shadows of the towers' projection / block weights, which the one-launch front reads
     graph_ingest_rows: bool = True       # ... which also leaves the rows in slot order: the captured lookup reads those (tt_embed_lookup_rows_fwd)
     graph_ingest_lookup: bool = False    # the hand-over launch ALSO does the lookup (tt_batch_ingest_lookup): one launch fewer, measured neutral
     #                                      (both halves are bandwidth-bound: 0.2332 vs 0.2339 ms per step, profiles/NOTES.md round 4) -- off

@@ -1489,8 +1489,31 @@ __global__ __launch_bounds__(kThreads) void copy_multi_kernel(CopyArgs a) {
 // tile in LDS and writes 256-byte runs per key.  Grid row 0: every side's 64-sample tiles, side by side (dispatched first: the
 // few transposing workgroups must not queue behind the thousands of copy workgroups); row y >= 1: copy segment y - 1.
 constexpr int kIngestMaxK = 64;
+// f32 -> bf16 (RNE) copies riding in the hand-over launch (tt_cvt_list): the towers' bf16 weight shadows, refreshed every step
+struct CvtDev {
+  const float* src[TT_MAX_CVT];
+  uint16_t* dst[TT_MAX_CVT];
+  int64_t count[TT_MAX_CVT];
+  int32_t n;
+};
+__device__ __forceinline__ void cvt_role(const CvtDev& v) {
+  for (int seg = 0; seg < v.n; ++seg) {
+    const int64_t n4 = v.count[seg] / 4, stride = (int64_t)gridDim.x * blockDim.x;
+    const float4* __restrict__ s = reinterpret_cast<const float4*>(v.src[seg]);
+    ushort4* __restrict__ d = reinterpret_cast<ushort4*>(v.dst[seg]);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+      const float4 x = s[i];
+      ushort4 o;
+      o.x = tt_f2bf(x.x); o.y = tt_f2bf(x.y); o.z = tt_f2bf(x.z); o.w = tt_f2bf(x.w);
+      d[i] = o;
+    }
+    if (blockIdx.x == 0)
+      for (int64_t i = 4 * n4 + threadIdx.x; i < v.count[seg]; i += blockDim.x) v.dst[seg][i] = tt_f2bf(v.src[seg][i]);
+  }
+}
 struct IngestArgs {
   CopyArgs c;
+  CvtDev v;
   int32_t n_copy, n_sides, B;
   const int64_t* ids[TT_MAX_SIDES];
   const int64_t* off[TT_MAX_SIDES];
@@ -1502,6 +1525,7 @@ struct IngestArgs {
 };
 
 __global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
+  if ((int)blockIdx.y == a.n_copy + 1) { cvt_role(a.v); return; }        // (last grid row, present when a.v.n > 0)
   if (blockIdx.y >= 1) {
     const int seg = blockIdx.y - 1;
     const int64_t n16 = a.c.bytes[seg] / 16, tail0 = n16 * 16;
@@ -1575,6 +1599,7 @@ struct StoreIngestArgs {
 template <bool VEC>
 __global__ __launch_bounds__(kThreads) void batch_ingest_store_kernel(StoreIngestArgs a) {
   const int B = a.g.B;
+  if ((int)blockIdx.y == 1 + a.g.n_sides + a.g.n_copy) { cvt_role(a.g.v); return; }
   if ((int)blockIdx.y > a.g.n_sides) {
     const int seg = blockIdx.y - 1 - a.g.n_sides;
     const int64_t n16 = a.g.c.bytes[seg] / 16, tail0 = n16 * 16;
@@ -1684,6 +1709,7 @@ template <int LPR, bool FROM_STORE, bool VEC>
 __device__ __forceinline__ void ingest_lookup_body(const StoreIngestArgs& a, const LookupPart& lp) {
   const int B = a.g.B;
   const int first_copy_row = 1 + (FROM_STORE ? a.g.n_sides : 0);
+  if ((int)blockIdx.y == first_copy_row + a.g.n_copy) { cvt_role(a.g.v); return; }
   if ((int)blockIdx.y >= first_copy_row) {                     // copy segments
     const int seg = blockIdx.y - first_copy_row;
     const int64_t n16 = a.g.c.bytes[seg] / 16, tail0 = n16 * 16;
@@ -2084,6 +2110,28 @@ AdamK make_adam(int64_t step, float lr, float b1, float b2, float eps, float wd,
   k.b1 = b1; k.b2 = b2; k.eps = eps; k.wd = wd;
   k.dev = dev;
   return k;
+}
+
+// checks a tt_cvt_list and fills the device form; returns the number of extra grid rows (0 or 1) or < 0
+static int fill_cvt(const char* who, const tt_cvt_list* cvt, CvtDev* v, int64_t* widest) {
+  v->n = 0;
+  if (!cvt || cvt->n == 0) return 0;
+  if (cvt->n < 0 || cvt->n > TT_MAX_CVT) {
+    tt_set_error("%s: cvt->n = %d not in [0, %d]", who, cvt->n, TT_MAX_CVT);
+    return TT_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < cvt->n; ++i) {
+    if (!(cvt->count[i] >= 0 && (cvt->count[i] == 0 || (cvt->src[i] && cvt->dst[i]))) || !tt_aligned(cvt->src[i], 16) || !tt_aligned(cvt->dst[i], 8)) {
+      tt_set_error("%s: conversion %d NULL / misaligned (f32 source 16-byte, bf16 destination 8-byte aligned)", who, i);
+      return TT_ERR_INVALID_ARG;
+    }
+    v->src[i] = cvt->src[i];
+    v->dst[i] = reinterpret_cast<uint16_t*>(cvt->dst[i]);
+    v->count[i] = cvt->count[i];
+    if (cvt->count[i] * 4 > *widest) *widest = cvt->count[i] * 4;       // (bytes of f32 read: sizes the grid like a copy segment)
+  }
+  v->n = cvt->n;
+  return 1;
 }
 
 }  // namespace
@@ -2727,7 +2775,7 @@ int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* s
 }
 
 int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
-                    int32_t n_sides, int64_t B, int32_t* rows_km, int32_t* rows_sm, tt_stream stream) {
+                    int32_t n_sides, int64_t B, int32_t* rows_km, int32_t* rows_sm, const tt_cvt_list* cvt, tt_stream stream) {
   TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest: bad copy arguments");
   TT_CHECK_ARG(sides && rows_km && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest: bad side arguments");
   IngestArgs a{};
@@ -2757,19 +2805,21 @@ int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const*
     slots += B * s.K;
   }
   TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_batch_ingest: too many slots");
+  const int cvt_rows = fill_cvt("tt_batch_ingest", cvt, &a.v, &mx);
+  if (cvt_rows < 0) return cvt_rows;
   int64_t gx = tt_cdiv(mx / 16 + 1, kThreads);
   const int64_t cap = (int64_t)ctx->num_cus * 4;
   if (gx > cap) gx = cap;
   const int64_t tiles = tt_cdiv(B, 64) * n_sides;        // row 0 holds every tile (the copy rows stride over their segments)
   if (tiles > gx) gx = tiles;
-  batch_ingest_kernel<<<dim3((unsigned)gx, (unsigned)(n + 1)), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
+  batch_ingest_kernel<<<dim3((unsigned)gx, (unsigned)(n + 1 + cvt_rows)), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
   TT_LAUNCH_CHECK();
   return TT_OK;
 }
 
 int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
                           const tt_store_side* stores, int32_t n_sides, int64_t B, const int64_t* order, int32_t* rows_km, int32_t* rows_sm,
-                          tt_stream stream) {
+                          const tt_cvt_list* cvt, tt_stream stream) {
   TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest_store: bad copy arguments");
   TT_CHECK_ARG(sides && stores && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest_store: bad side arguments");
   StoreIngestArgs a{};
@@ -2810,6 +2860,8 @@ int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* 
     dense_pieces = p > dense_pieces ? p : dense_pieces;
   }
   TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_batch_ingest_store: too many slots");
+  const int cvt_rows = fill_cvt("tt_batch_ingest_store", cvt, &a.g.v, &mx);
+  if (cvt_rows < 0) return cvt_rows;
   int64_t gx = tt_cdiv(mx / 16 + 1, kThreads);
   const int64_t rows_wg = tt_cdiv(vec ? dense_pieces / 4 : dense_pieces, kThreads);
   if (rows_wg > gx) gx = rows_wg;
@@ -2817,7 +2869,7 @@ int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* 
   if (gx > cap) gx = cap;
   const int64_t tiles = tt_cdiv(B, 64) * n_sides;        // row 0 holds every tile (the other rows stride over their work)
   if (tiles > gx) gx = tiles;
-  const dim3 grid((unsigned)gx, (unsigned)(1 + n_sides + n));
+  const dim3 grid((unsigned)gx, (unsigned)(1 + n_sides + n + cvt_rows));
   if (vec) batch_ingest_store_kernel<true><<<grid, kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
   else batch_ingest_store_kernel<false><<<grid, kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
   TT_LAUNCH_CHECK();
@@ -2882,7 +2934,7 @@ static int64_t fill_lookup_part(tt_ctx* ctx, const char* who, const tt_embed_sid
   } while (0)
 
 int tt_batch_ingest_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
-                           int32_t n_sides, int64_t B, int32_t* rows_km, const tt_ingest_lookup* lk, tt_stream stream) {
+                           int32_t n_sides, int64_t B, int32_t* rows_km, const tt_ingest_lookup* lk, const tt_cvt_list* cvt, tt_stream stream) {
   TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest_lookup: bad copy arguments");
   TT_CHECK_ARG(sides && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest_lookup: bad side arguments");
   StoreIngestArgs a{};
@@ -2914,11 +2966,13 @@ int tt_batch_ingest_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void*
   TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_batch_ingest_lookup: too many slots");
   const int64_t tiles = fill_lookup_part(ctx, "tt_batch_ingest_lookup", sides, n_sides, B, lk, &lp);
   if (tiles < 0) return (int)tiles;
+  const int cvt_rows = fill_cvt("tt_batch_ingest_lookup", cvt, &a.g.v, &mx);
+  if (cvt_rows < 0) return cvt_rows;
   int64_t gx = tt_cdiv(mx / 16 + 1, kThreads);
   const int64_t cap = (int64_t)ctx->num_cus * 4;
   if (gx > cap) gx = cap;
   if (tiles > gx) gx = tiles;
-  const dim3 grid((unsigned)gx, (unsigned)(n + 1));
+  const dim3 grid((unsigned)gx, (unsigned)(n + 1 + cvt_rows));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   TT_INGEST_LOOKUP_LAUNCH(false, true);
   TT_LAUNCH_CHECK();
@@ -2927,7 +2981,7 @@ int tt_batch_ingest_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void*
 
 int tt_batch_ingest_store_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                                  const tt_embed_side* sides, const tt_store_side* stores, int32_t n_sides, int64_t B, const int64_t* order,
-                                 int32_t* rows_km, const tt_ingest_lookup* lk, tt_stream stream) {
+                                 int32_t* rows_km, const tt_ingest_lookup* lk, const tt_cvt_list* cvt, tt_stream stream) {
   TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest_store_lookup: bad copy arguments");
   TT_CHECK_ARG(sides && stores && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest_store_lookup: bad side arguments");
   StoreIngestArgs a{};
@@ -2970,13 +3024,15 @@ int tt_batch_ingest_store_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const
   TT_CHECK_ARG(slots < ((int64_t)1 << 31), "tt_batch_ingest_store_lookup: too many slots");
   const int64_t tiles = fill_lookup_part(ctx, "tt_batch_ingest_store_lookup", sides, n_sides, B, lk, &lp);
   if (tiles < 0) return (int)tiles;
+  const int cvt_rows = fill_cvt("tt_batch_ingest_store_lookup", cvt, &a.g.v, &mx);
+  if (cvt_rows < 0) return cvt_rows;
   int64_t gx = tt_cdiv(mx / 16 + 1, kThreads);
   const int64_t rows_wg = tt_cdiv(vec ? dense_pieces / 4 : dense_pieces, kThreads);
   if (rows_wg > gx) gx = rows_wg;
   const int64_t cap = (int64_t)ctx->num_cus * 8;
   if (gx > cap) gx = cap;
   if (tiles > gx) gx = tiles;
-  const dim3 grid((unsigned)gx, (unsigned)(1 + n_sides + n));
+  const dim3 grid((unsigned)gx, (unsigned)(1 + n_sides + n + cvt_rows));
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (vec) TT_INGEST_LOOKUP_LAUNCH(true, true);
   else TT_INGEST_LOOKUP_LAUNCH(true, false);

@@ -480,6 +480,7 @@ struct FrontArgs {
   uint16_t* x; int64_t ldx; int kx;
   const float* w; const float* bias; float* pre;
   BnStatArgs s;
+  const uint16_t* w_proj16; const uint16_t* w16;   // W16: bf16 shadows of w_proj / w (tt_tower_params.w_proj_bf16 / w_bf16)
 };
 constexpr int kFS = 136;                                         // bf16 elements per LDS row of a 128-wide k stage
 constexpr int kFrontThreads = 512;                               // 8 waves at up to 256 registers: three stages of loads in flight
@@ -500,6 +501,10 @@ __device__ __forceinline__ T front_ld(const void* base, uint32_t off) {
   return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + off);
 }
 
+// W16 (round 4): the weights come as bf16 shadows -- pieces of 8 elements laid out like the x pieces (row (t >> 4) + 32 pass,
+// k = 8 (t & 15)), copied into LDS as they are: 213 of the 637 KB a notice workgroup moved were the f32 halves of values it rounded
+// to bf16 anyway, and the 112 registers of weight pieces in flight become 56 (no scratch).  Same bits in LDS, same results.
+template <bool W16>
 __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontArgs> batch) {
   const FrontArgs& f = batch.a[blockIdx.y];
   const BnStatArgs& a = f.s;
@@ -522,41 +527,47 @@ __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontA
   // behind the end of the buffer (harmless for the result: those columns are zeroed on the way into LDS; a fault when the
   // buffer ends a mapping)
   const int fkp = din >= 128 ? fk : (fk & 63), fkb = kx >= 128 ? fk : (fk & 63), xkb = kx >= 128 ? xk : (xk & 63);
+  const int xkp = din >= 128 ? xk : (xk & 63);
   const int ns2 = 3 * ((kx + 383) / 384);                       // block stages, padded to the unroll of 3 (pad stages are zeros)
   const int pn = (wave >> 1) * 32 + li;                         // this lane's projection column
   const float bp = pn < h0 ? f.b_proj[pn] : 0.f;
   float x0 = 0.f, s = 0.f, q = 0.f, cnt = 0.f;
   for (int b0 = r0; b0 < r1; b0 += 64) {
     // ---- everything that can be requested now: the projection's two stages, the block GEMM's first three ----
-    float4 pa[2][4], pb[2][8];
-    uint32_t oa[4], ob[8];                                  // byte offsets of this thread's rows (k = fk)
+    constexpr int NPB = W16 ? 4 : 8, NQB = W16 ? 2 : 4;     // weight pieces per thread and stage: projection / block
+    float4 pa[2][4], pb[2][NPB];                            // (W16: the float4 holds 8 bf16 -- moved, never computed on)
+    uint32_t oa[4], ob[NPB];                                // byte offsets of this thread's rows (k = fk)
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) oa[ps] = (uint32_t)(min(b0 + frow + 16 * ps, B - 1) * (int)f.ld_dense + fkp) * 4u;
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) ob[ps] = (uint32_t)(min(frow + 16 * ps, h0 - 1) * din + fkp) * 4u;
+    for (int ps = 0; ps < NPB; ++ps)
+      ob[ps] = W16 ? (uint32_t)(min(xrow + 32 * ps, h0 - 1) * din + xkp) * 2u : (uint32_t)(min(frow + 16 * ps, h0 - 1) * din + fkp) * 4u;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       // a piece past the end re-reads this thread's own first piece (discarded): never ONE address for the whole grid
       const uint32_t ko = 128 * st + fk < din ? 512u * st : 0u;
+      const uint32_t ko16 = 128 * st + xk < din ? 256u * st : 0u;
 #pragma unroll
       for (int ps = 0; ps < 4; ++ps) pa[st][ps] = front_ld<float4>(f.dense, oa[ps] + ko);
 #pragma unroll
-      for (int ps = 0; ps < 8; ++ps) pb[st][ps] = front_ld<float4>(f.w_proj, ob[ps] + ko);
+      for (int ps = 0; ps < NPB; ++ps) pb[st][ps] = W16 ? front_ld<float4>(f.w_proj16, ob[ps] + ko16) : front_ld<float4>(f.w_proj, ob[ps] + ko);
     }
     uint4 qa[3][2];
-    float4 qb[3][4];
-    uint32_t ox[2], ow[4];
+    float4 qb[3][NQB];
+    uint32_t ox[2], ow[NQB];
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) ox[ps] = (uint32_t)(min(b0 + xrow + 32 * ps, B - 1) * (int)f.ldx + xkb) * 2u;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) ow[ps] = (uint32_t)(min(frow + 16 * ps, H - 1) * kx + fkb) * 4u;
+    for (int ps = 0; ps < NQB; ++ps)
+      ow[ps] = W16 ? (uint32_t)(min(xrow + 32 * ps, H - 1) * kx + xkb) * 2u : (uint32_t)(min(frow + 16 * ps, H - 1) * kx + fkb) * 4u;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int ka = 128 * u + xk, kb = 128 * u + fk;
 #pragma unroll
       for (int ps = 0; ps < 2; ++ps) qa[u][ps] = front_ld<uint4>(f.x, ox[ps] + (ka < kx ? 256u * u : 0u));
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) qb[u][ps] = front_ld<float4>(f.w, ow[ps] + (kb < kx ? 512u * u : 0u));
+      for (int ps = 0; ps < NQB; ++ps)
+        qb[u][ps] = W16 ? front_ld<float4>(f.w16, ow[ps] + (ka < kx ? 256u * u : 0u)) : front_ld<float4>(f.w, ow[ps] + (kb < kx ? 512u * u : 0u));
     }
     __builtin_amdgcn_sched_barrier(0);                      // 36 loads in flight before the first one is waited for
     // ---- projection: wave = tile (rt, ct) of the 64 x h0 block, whole K ----
@@ -567,18 +578,22 @@ __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontA
       for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        const bool live = 128 * st + fk < din;
+        const bool live = 128 * st + fk < din, live16 = 128 * st + xk < din;
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) front_put4(bufA + st * 64 * kFS + (frow + 16 * ps) * kFS + fk, pa[st][ps], live);
 #pragma unroll
-        for (int ps = 0; ps < 8; ++ps) front_put4(bufB + st * 128 * kFS + (frow + 16 * ps) * kFS + fk, pb[st][ps], live);
+        for (int ps = 0; ps < NPB; ++ps) {
+          if (W16) *reinterpret_cast<float4*>(bufB + st * 128 * kFS + (xrow + 32 * ps) * kFS + xk) = live16 ? pb[st][ps] : float4{0.f, 0.f, 0.f, 0.f};
+          else front_put4(bufB + st * 128 * kFS + (frow + 16 * ps) * kFS + fk, pb[st][ps], live);
+        }
       }
       {                                                     // third block stage, into the registers the projection just freed
         const int ka = 256 + xk, kb = 256 + fk;
 #pragma unroll
         for (int ps = 0; ps < 2; ++ps) qa[2][ps] = front_ld<uint4>(f.x, ox[ps] + (ka < kx ? 512u : 0u));
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) qb[2][ps] = front_ld<float4>(f.w, ow[ps] + (kb < kx ? 1024u : 0u));
+        for (int ps = 0; ps < NQB; ++ps)
+          qb[2][ps] = W16 ? front_ld<float4>(f.w16, ow[ps] + (ka < kx ? 512u : 0u)) : front_ld<float4>(f.w, ow[ps] + (kb < kx ? 1024u : 0u));
       }
       __syncthreads();
 #pragma unroll
@@ -623,14 +638,19 @@ __global__ __launch_bounds__(kFrontThreads) void tower_front_kernel(Batch<FrontA
           for (int ps = 0; ps < 2; ++ps)
             *reinterpret_cast<uint4*>(A + (xrow + 32 * ps) * kFS + xk) = (128 * st + xk < kx) ? qa[u][ps] : uint4{0u, 0u, 0u, 0u};
 #pragma unroll
-          for (int ps = 0; ps < 4; ++ps) front_put4(Bm + (frow + 16 * ps) * kFS + fk, qb[u][ps], 128 * st + fk < kx);
+          for (int ps = 0; ps < NQB; ++ps) {
+            if (W16) *reinterpret_cast<float4*>(Bm + (xrow + 32 * ps) * kFS + xk) = (128 * st + xk < kx) ? qb[u][ps] : float4{0.f, 0.f, 0.f, 0.f};
+            else front_put4(Bm + (frow + 16 * ps) * kFS + fk, qb[u][ps], 128 * st + fk < kx);
+          }
           __syncthreads();
           {                                                 // three stages ahead, into the registers just stored
             const int ka = 128 * (st + 3) + xk, kb = 128 * (st + 3) + fk;
 #pragma unroll
             for (int ps = 0; ps < 2; ++ps) qa[u][ps] = front_ld<uint4>(f.x, ox[ps] + (ka < kx ? 256u * (uint32_t)(st + 3) : 0u));
 #pragma unroll
-            for (int ps = 0; ps < 4; ++ps) qb[u][ps] = front_ld<float4>(f.w, ow[ps] + (kb < kx ? 512u * (uint32_t)(st + 3) : 0u));
+            for (int ps = 0; ps < NQB; ++ps)
+              qb[u][ps] = W16 ? front_ld<float4>(f.w16, ow[ps] + (ka < kx ? 256u * (uint32_t)(st + 3) : 0u))
+                              : front_ld<float4>(f.w, ow[ps] + (kb < kx ? 512u * (uint32_t)(st + 3) : 0u));
           }
 #pragma unroll
           for (int s2 = 0; s2 < 4; ++s2) {
@@ -1797,12 +1817,21 @@ int tt_towers_mlp_fwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
       // slabs (+ bias) -> pre with the chunk statistics in the same pass, then everything up to the unit rows in one kernel
       if (phase != 2) {
         if (front) {
-          TT_LDS_ONCE(kFrontLds, tower_front_kernel);
           Batch<FrontArgs> fb{};
-          for (int t = 0; t < n; ++t)
+          bool w16 = true;                                // every tower brings bf16 shadows of both weights (16-byte aligned)
+          for (int t = 0; t < n; ++t) {
             fb.a[t] = FrontArgs{A[t]->dense, P[t]->din, P[t]->din, P[t]->w_proj, P[t]->b_proj, P[t]->h0,
-                                reinterpret_cast<uint16_t*>(A[t]->x), in_w[t], in_w[t], P[t]->w[i], P[t]->b[i], A[t]->pre[i], bs.a[t]};
-          tower_front_kernel<<<dim3((unsigned)cmax, (unsigned)n), kFrontThreads, kFrontLds, st>>>(fb);
+                                reinterpret_cast<uint16_t*>(A[t]->x), in_w[t], in_w[t], P[t]->w[i], P[t]->b[i], A[t]->pre[i], bs.a[t],
+                                reinterpret_cast<const uint16_t*>(P[t]->w_proj_bf16), reinterpret_cast<const uint16_t*>(P[t]->w_bf16[i])};
+            w16 = w16 && P[t]->w_proj_bf16 && P[t]->w_bf16[i] && tt_aligned(P[t]->w_proj_bf16, 16) && tt_aligned(P[t]->w_bf16[i], 16);
+          }
+          if (w16) {
+            TT_LDS_ONCE(kFrontLds, tower_front_kernel<true>);
+            tower_front_kernel<true><<<dim3((unsigned)cmax, (unsigned)n), kFrontThreads, kFrontLds, st>>>(fb);
+          } else {
+            TT_LDS_ONCE(kFrontLds, tower_front_kernel<false>);
+            tower_front_kernel<false><<<dim3((unsigned)cmax, (unsigned)n), kFrontThreads, kFrontLds, st>>>(fb);
+          }
         } else if (nd[0].splits > 0) {
           Batch<HeadArgs> hb{};
           for (int t = 0; t < n; ++t) hb.a[t] = HeadArgs{nd[t].slabs, nd[t].slab_stride, nd[t].splits, P[t]->b[i], A[t]->pre[i], bs.a[t]};

@@ -65,6 +65,7 @@ class GraphedTrainStep:
         self._towers = [m for m in task.modules() if hasattr(m, "_seed_dev") and hasattr(m, "dense_parameters")]
         self.metric_sums = torch.zeros(8, dtype=torch.float32, device=dev) if (accumulate_metrics and return_metrics) else None
         self._ingest = self._setup_ingest()
+        self._shadows = self._setup_shadows()
         if self._ingest is not None:
             self._run_ingest([], None)                           # rows_km of the example batch: warm-up and capture see it
         # eager warm-up on a side stream (allocator + first-call paths), then capture
@@ -158,6 +159,29 @@ class GraphedTrainStep:
             self._rows_sm = torch.empty_like(rows_km)
         return store, embs, rows_km, ids, B
 
+    def _setup_shadows(self):
+        """bf16 shadows of the towers' projection and block weights (bf16 towers): [(tower, w_proj16, [w16 per block])].  The hand-over
+        launch converts the f32 weights into them at EVERY step (ops.batch_ingest(cvt=...)), so whoever updated the weights since
+        the last hand-over -- the replayed Adam, an eager step, load_state_dict -- the replay reads current values; the towers see the
+        shadows only while this object's step runs (_body)."""
+        if not settings.graph_weight_shadows or self._ingest is None:
+            return []
+        out = []
+        for t in self._towers:
+            if getattr(t, "mlp_dtype", None) != "bf16" or t.n_hidden < 1:
+                continue
+            lins = [t.mlp[4 * i] for i in range(t.n_hidden)]
+            ws = [t.dense_projection.weight] + [l.weight for l in lins]
+            if any(w.dtype != torch.float32 or not w.is_contiguous() or w.numel() % 8 for w in ws):
+                continue
+            sh = [torch.empty(w.shape, dtype=torch.bfloat16, device=w.device) for w in ws]
+            out.append((t, ws, sh))
+        n = sum(len(ws) for _, ws, _ in out)
+        return out if 0 < n <= L.TT_MAX_CVT else []
+
+    def _cvt(self):
+        return [(s_, w) for _, ws, sh in self._shadows for w, s_ in zip(ws, sh)]
+
     def _lookup_outs(self):
         towers = [self.task.two_tower_model.notice_tower, self.task.two_tower_model.company_tower]
         return [x[:, t.tower_hidden_dims[0]:] for x, t in zip(self._x_static, towers)]
@@ -175,10 +199,10 @@ class GraphedTrainStep:
         xs = getattr(self, "_x_static", None)
         if xs is not None:
             sides = [ops.LookupSide(v, e._key_row_offset, e._key_vocab, o, len(e.keys)) for e, v, o in zip(embs, src, self._lookup_outs())]
-            ops.batch_ingest(pairs, sides, B, rows_km, table=store.weight)
+            ops.batch_ingest(pairs, sides, B, rows_km, table=store.weight, cvt=self._cvt())
         else:
             sides = [ops.LookupSide(v, e._key_row_offset, e._key_vocab, None, len(e.keys)) for e, v in zip(embs, src)]
-            ops.batch_ingest(pairs, sides, B, rows_km, rows_sm=getattr(self, "_rows_sm", None))
+            ops.batch_ingest(pairs, sides, B, rows_km, rows_sm=getattr(self, "_rows_sm", None), cvt=self._cvt())
         self._register(store, ids, rows_km)
 
     def _body(self):
@@ -200,6 +224,8 @@ class GraphedTrainStep:
         # in the chain).  A sharded task's exchange reads the plan at once: only the loss reduction rides there (and not under SyncBN,
         # whose tail kernels run in two phases with a collective between them)
         riders = self._defer_riders and self._ingest is not None and (ex is None or not getattr(self.task, "sync_bn", False))
+        for t, _, sh in self._shadows:                 # the hand-over launch in front of this step has refreshed them
+            t._w16 = (sh[0], sh[1:])
         try:
             if riders:
                 L.set_defer_riders(dev, True, loss_only=ex is not None)
@@ -219,6 +245,8 @@ class GraphedTrainStep:
             if self.metric_sums is not None:           # (behind the backward: a riding loss reduction has written out8 by now)
                 self.metric_sums.add_(res.out8)
         finally:
+            for t, _, _ in self._shadows:
+                t._w16 = None
             if riders:
                 L.set_defer_riders(dev, False)         # (launches what nobody hosted: e.g. the loss reduction of a forward-only pass)
             for st in stores:
@@ -390,7 +418,8 @@ class GraphedTrainStep:
         rows_km = self._ingest[2] if self._ingest is not None else None
         ops.batch_ingest_store([self._fill_slot()], sides, stores, B, order, rows_km, offset if order is not None else 0,
                                table=self._ingest[0].weight if xs is not None else None,
-                               rows_sm=getattr(self, "_rows_sm", None) if (self._ingest is not None and xs is None) else None)
+                               rows_sm=getattr(self, "_rows_sm", None) if (self._ingest is not None and xs is None) else None,
+                               cvt=self._cvt())
         self._mark_slot()
         if self._ingest is not None:
             store, _, _, ids, _ = self._ingest

@@ -349,7 +349,7 @@ def _fill(arr, tensors):
 
 
 def tower_params_struct(din, h0, kcat_e, hidden, d_out, w_proj, b_proj, ws, bs, bn_w, bn_b, bn_rm, bn_rv, w_out, b_out,
-                        bn_nbt=(), compute_dtype=TT_F32, x_dtype=TT_F32, dx_dtype=TT_F32, flags=0):
+                        bn_nbt=(), compute_dtype=TT_F32, x_dtype=TT_F32, dx_dtype=TT_F32, flags=0, w_proj_bf16=None, w_bf16=()):
     if len(hidden) > L.TT_MAX_HIDDEN:
         raise ValueError(f"at most {L.TT_MAX_HIDDEN} hidden blocks per tower are supported")
     p = L.TowerParams()
@@ -360,6 +360,8 @@ def tower_params_struct(din, h0, kcat_e, hidden, d_out, w_proj, b_proj, ws, bs, 
     _fill(p.w, ws); _fill(p.b, bs); _fill(p.bn_w, bn_w); _fill(p.bn_b, bn_b); _fill(p.bn_rm, bn_rm); _fill(p.bn_rv, bn_rv)
     _fill(p.bn_nbt, bn_nbt)
     p.compute_dtype, p.x_dtype, p.dx_dtype, p.flags = compute_dtype, x_dtype, dx_dtype, flags
+    p.w_proj_bf16 = w_proj_bf16.data_ptr() if w_proj_bf16 is not None else 0      # bf16 shadows (tt_tower_params.w_proj_bf16 / w_bf16)
+    _fill(p.w_bf16, w_bf16)
     return p
 
 
@@ -700,6 +702,22 @@ def ingest_lookup_tiles(B: int, side_K: Sequence[int]) -> int:
     return n
 
 
+def _cvt_list(cvt):
+    """[(dst bf16, src f32)] -> ctypes tt_cvt_list pointer (or None): conversions that ride in the hand-over launch."""
+    if not cvt:
+        return None
+    if len(cvt) > L.TT_MAX_CVT:
+        raise ValueError(f"at most {L.TT_MAX_CVT} conversions per hand-over launch")
+    c = L.CvtList()
+    c.n = len(cvt)
+    for i, (d, s_) in enumerate(cvt):
+        if d.dtype != torch.bfloat16 or s_.dtype != torch.float32 or d.numel() != s_.numel() or not d.is_contiguous() or not s_.is_contiguous() \
+                or d.device != s_.device:
+            raise ValueError("cvt: (bf16 destination, f32 source) pairs of contiguous tensors of one size on one device")
+        c.src[i], c.dst[i], c.count[i] = s_.data_ptr(), d.data_ptr(), s_.numel()
+    return C.byref(c)
+
+
 def _lookup_part(table: torch.Tensor):
     return L.IngestLookup(L.ptr(table), table.shape[0], table.shape[1], 0)
 
@@ -722,7 +740,7 @@ def _embed_sides(sides, B, dev, who, with_ids: bool, with_out: bool):
 
 
 def batch_ingest(pairs, sides: Sequence[LookupSide], B: int, rows_km: Optional[torch.Tensor], table: Optional[torch.Tensor] = None,
-                 rows_sm: Optional[torch.Tensor] = None):
+                 rows_sm: Optional[torch.Tensor] = None, cvt=None):
     """copy_multi's segments plus, per side, the fused rows of the side's ids in key-major order (tt_batch_ingest): the batch
     hand-over of a graph-replayed step in one launch.  sides[i].ids is the id source (the incoming batch or the static buffer).
     table given (and sides[i].out set): the same launch also looks the rows up and writes them into sides[i].out -- the towers'
@@ -741,8 +759,8 @@ def batch_ingest(pairs, sides: Sequence[LookupSide], B: int, rows_km: Optional[t
             raise ValueError("batch_ingest: rows_km must be a contiguous int32 tensor of sum(B*K) elements")
         lk = _lookup_part(table)
         with _timed("tt_batch_ingest_lookup"):
-            L.check(L.load().tt_batch_ingest_lookup(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), C.byref(lk), L.stream(dev)),
-                    "tt_batch_ingest_lookup")
+            L.check(L.load().tt_batch_ingest_lookup(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), C.byref(lk), _cvt_list(cvt),
+                                                    L.stream(dev)), "tt_batch_ingest_lookup")
         return
     dev, n = rows_km.device, len(pairs)
     dst = (L.vp * max(n, 1))(*[d.data_ptr() for d, _ in pairs])
@@ -763,8 +781,8 @@ def batch_ingest(pairs, sides: Sequence[LookupSide], B: int, rows_km: Optional[t
     if rows_sm is not None and (rows_sm.dtype != torch.int32 or rows_sm.numel() != M or not rows_sm.is_contiguous()):
         raise ValueError("batch_ingest: rows_sm must be a contiguous int32 tensor of sum(B*K) elements")
     with _timed("tt_batch_ingest"):
-        L.check(L.load().tt_batch_ingest(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), L.ptr(rows_sm), L.stream(dev)),
-                "tt_batch_ingest")
+        L.check(L.load().tt_batch_ingest(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), L.ptr(rows_sm), _cvt_list(cvt),
+                                         L.stream(dev)), "tt_batch_ingest")
 
 
 @dataclass
@@ -780,7 +798,7 @@ class StoreSide:
 
 def batch_ingest_store(pairs, sides: Sequence[LookupSide], stores: Sequence[StoreSide], B: int, order: Optional[torch.Tensor],
                        rows_km: Optional[torch.Tensor], order_offset: int = 0, table: Optional[torch.Tensor] = None,
-                       rows_sm: Optional[torch.Tensor] = None):
+                       rows_sm: Optional[torch.Tensor] = None, cvt=None):
     """tt_batch_ingest_store: the batch `order[order_offset : order_offset + B]` of the pair list gathered out of the device
     stores straight into the step's static buffers (+ key-major fused rows, + the copy segments `pairs`), one launch.
     table given (and sides[i].out set): the launch also looks the batch's rows up into sides[i].out (tt_batch_ingest_store_lookup).
@@ -829,13 +847,13 @@ def batch_ingest_store(pairs, sides: Sequence[LookupSide], stores: Sequence[Stor
         lk = _lookup_part(table)
         with _timed("tt_batch_ingest_lookup"):
             L.check(L.load().tt_batch_ingest_store_lookup(L.ctx(dev), n, dst, src, nb, arr, st, len(sides), B, order_ptr, L.ptr(rows_km),
-                                                          C.byref(lk), L.stream(dev)), "tt_batch_ingest_store_lookup")
+                                                          C.byref(lk), _cvt_list(cvt), L.stream(dev)), "tt_batch_ingest_store_lookup")
         return
     if rows_sm is not None and (rows_sm.dtype != torch.int32 or rows_sm.numel() != M or not rows_sm.is_contiguous()):
         raise ValueError("batch_ingest_store: rows_sm must be a contiguous int32 tensor of sum(B*K) elements")
     with _timed("tt_batch_ingest_store"):
         L.check(L.load().tt_batch_ingest_store(L.ctx(dev), n, dst, src, nb, arr, st, len(sides), B, order_ptr, L.ptr(rows_km), L.ptr(rows_sm),
-                                               L.stream(dev)), "tt_batch_ingest_store")
+                                               _cvt_list(cvt), L.stream(dev)), "tt_batch_ingest_store")
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU routing

@@ -79,6 +79,7 @@ class BaseTower(nn.Module):
         self._last_packed = None
         self.pack_scale = 1.0           # the images hold bf16(pack_scale * emb)
         self._seed_dev = None           # set by GraphedTrainStep: device word added to the dropout seed
+        self._w16 = None                # set by GraphedTrainStep while its step runs: (bf16 shadow of w_proj, [bf16 shadows of the blocks' weights])
         self._seed_override = None      # tests: a fixed dropout seed instead of one drawn from torch's CPU generator
         self.device = device
         self.tower_hidden_dims = list(tower_hidden_dims)
@@ -127,7 +128,9 @@ class BaseTower(nn.Module):
         tensors = [self.dense_projection.weight, self.dense_projection.bias, out.weight, out.bias]
         for lin, bn in zip(lins, bns):
             tensors += [lin.weight, lin.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var]
-        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype, self.x_dtype, self.dx_dtype, self.unfused_tail, self.unfused_front, self.unfused_back)
+        w16 = self._w16
+        key = tuple(t.data_ptr() for t in tensors) + tuple(b.num_batches_tracked.data_ptr() for b in bns) + (self.mlp_dtype, self.x_dtype, self.dx_dtype, self.unfused_tail, self.unfused_front, self.unfused_back) + \
+            ((w16[0].data_ptr(),) + tuple(w.data_ptr() for w in w16[1]) if w16 is not None else ())
         if key != self._struct_key:
             for t in tensors:
                 if t.dtype != torch.float32 or not t.is_contiguous():
@@ -142,7 +145,8 @@ class BaseTower(nn.Module):
                 compute_dtype=ops.TT_BF16 if self.mlp_dtype == "bf16" else ops.TT_F32,
                 x_dtype=ops.TT_BF16 if self.x_dtype == torch.bfloat16 else ops.TT_F32,
                 dx_dtype=ops.TT_BF16 if self.dx_dtype == torch.bfloat16 else ops.TT_F32,
-                flags=(ops.L.TT_TOWER_UNFUSED_TAIL if self.unfused_tail else 0) | (ops.L.TT_TOWER_UNFUSED_FRONT if self.unfused_front else 0) | (ops.L.TT_TOWER_UNFUSED_BACK if self.unfused_back else 0))
+                flags=(ops.L.TT_TOWER_UNFUSED_TAIL if self.unfused_tail else 0) | (ops.L.TT_TOWER_UNFUSED_FRONT if self.unfused_front else 0) | (ops.L.TT_TOWER_UNFUSED_BACK if self.unfused_back else 0),
+                w_proj_bf16=None if w16 is None else w16[0], w_bf16=() if w16 is None else w16[1])
             self._struct_key = key
         return self._params_struct
 

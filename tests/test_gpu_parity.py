@@ -1476,7 +1476,11 @@ def test_full_size_properties(tt, schema_real):
 
 
 def test_full_size_step_is_reproducible(tt, schema_real, tmp_path):
+    """configs[1]'s own shapes (B = 8192, 1 M + 1 M rows): two eager steps twice -- the same bits; and the same two steps REPLAYED
+    from a captured graph (round 4: the hand-over launch leaves the lookup its precomputed rows and refreshes the bf16 shadows of the
+    tower weights that the one-launch front reads instead of the f32 weights) -- the same bits again, losses and every parameter."""
     from jodalrob_twotower_amd import synthetic
+    from jodalrob_twotower_amd.graph import GraphedTrainStep
     from jodalrob_twotower_amd.optim import FusedAdam
     B = 8192
     kn, kc = schema_real["notice"]["categorical"], schema_real["company"]["categorical"]
@@ -1485,7 +1489,7 @@ def test_full_size_step_is_reproducible(tt, schema_real, tmp_path):
     meta = synthetic.write_metadata(tmp_path / "m.csv", {"notice": dict(zip(kn, vn)), "company": dict(zip(kc, vc))})
     batches = [synthetic.make_batch(B, vn, vc, kn, kc, 256, 128, torch.device(DEV), seed=7 + i) for i in range(2)]
     finals = []
-    for _ in range(2):
+    for mode in ("eager", "eager", "graph"):
         torch.manual_seed(11)
         task = tt.create_two_tower_train_task(kn, kc, metadata_path=str(meta), categorical_embedding_dim=32, notice_dense_input_dim=256,
                                               company_dense_input_dim=128, tower_hidden_dims=[128, 64], final_embedding_dim=64,
@@ -1494,16 +1498,27 @@ def test_full_size_step_is_reproducible(tt, schema_real, tmp_path):
         task.train(); task._pair_check_done = True
         opt = FusedAdam.for_task(task, lr=1e-3, weight_decay=1e-5)
         losses = []
-        for b in batches:
-            opt.zero_grad()
-            r = task(b, return_metrics=True)
-            r["loss"].backward()
-            opt.step()
-            losses.append(r["loss"].item())
+        if mode == "graph":
+            gs = GraphedTrainStep(task, opt, batches[0], warmup=1)          # (its warm-up step leaves no trace: preserve_state)
+            assert gs._rows_sm is not None and len(gs._shadows) == 2 and all(len(sh) == 2 for _, _, sh in gs._shadows)
+            for b in batches:
+                losses.append(gs.step(b)["loss"].item())
+            for t_, ws, sh in gs._shadows:                                   # the shadows hold bf16(weights as of the last hand-over)
+                assert t_._w16 is None
+            gs.close()
+        else:
+            for b in batches:
+                opt.zero_grad()
+                r = task(b, return_metrics=True)
+                r["loss"].backward()
+                opt.step()
+                losses.append(r["loss"].item())
         finals.append((losses, [p.detach().clone() for p in task.parameters()]))
+        del task, opt
     assert finals[0][0] == finals[1][0] and finals[0][0][0] > 8.5           # ln(8192) = 9.01 at random init
-    for a, b in zip(finals[0][1], finals[1][1]):
-        assert torch.equal(a, b)
+    assert finals[2][0] == finals[0][0], (finals[2][0], finals[0][0])
+    for a, b, c in zip(finals[0][1], finals[1][1], finals[2][1]):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 @pytest.mark.parametrize("G,M,U,C", [(1, 5000, 4000, 4096), (2, 70000, 65000, 40000), (3, 10000, 9999, 3000), (8, 311296, 65731, 12288),
