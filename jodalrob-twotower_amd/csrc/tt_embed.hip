@@ -255,13 +255,16 @@ __global__ __launch_bounds__(kThreads) void sort_hist_kernel(const uint32_t* __r
 }
 
 // per digit: exclusive scan over the tiles (hist[tile][digit], in place) and the digit total.
-// grid = R/64 workgroups; thread = (digit, one of 4 tile segments)
+// grid = R/64 workgroups; thread = (digit, one of kScanSeg tile segments).  Round 4: 16 segments (1024 threads) instead of 4 -- at
+// configs[4] (608 tiles) a thread walked 152 tiles twice and the launch took 42 us on 32 CUs; now 38 tiles: the same sums in the same
+// order per segment, segment totals added in segment order (integers: any order gives the same bits)
+constexpr int kScanSeg = 16;
 template <int BITS>
-__global__ __launch_bounds__(kThreads) void sort_colscan_kernel(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ total) {
+__global__ __launch_bounds__(64 * kScanSeg) void sort_colscan_kernel(uint32_t* __restrict__ hist, uint32_t nblk, uint32_t* __restrict__ total) {
   constexpr uint32_t R = 1u << BITS;
-  __shared__ uint32_t sh[4][64];
+  __shared__ uint32_t sh[kScanSeg][64];
   const uint32_t d = blockIdx.x * 64 + (threadIdx.x & 63), seg = threadIdx.x >> 6;
-  const uint32_t per = (nblk + 3) / 4;
+  const uint32_t per = (nblk + kScanSeg - 1) / kScanSeg;
   const uint32_t lo = seg * per < nblk ? seg * per : nblk;
   const uint32_t hi = lo + per < nblk ? lo + per : nblk;
   uint32_t s = 0;
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(kThreads) void sort_colscan_kernel(uint32_t* __rest
     hist[b * R + d] = run;
     run += t;
   }
-  if (seg == 3) total[d] = run;
+  if (seg == kScanSeg - 1) total[d] = run;
 }
 
 template <int BITS>
@@ -2094,7 +2097,7 @@ int sort_pass(hipStream_t st, const uint32_t* kin, const uint32_t* vin, uint32_t
               uint32_t* hist, uint32_t* total, uint32_t nblk) {
   sort_hist_kernel<BITS><<<nblk, kThreads, 0, st>>>(kin, M, shift, hist, nblk);
   TT_LAUNCH_CHECK();
-  sort_colscan_kernel<BITS><<<(1u << BITS) / 64, kThreads, 0, st>>>(hist, nblk, total);
+  sort_colscan_kernel<BITS><<<(1u << BITS) / 64, 64 * kScanSeg, 0, st>>>(hist, nblk, total);
   TT_LAUNCH_CHECK();
   sort_scatter_kernel<BITS><<<nblk, kThreads, 0, st>>>(kin, vin, kout, vout, M, shift, hist, total);
   TT_LAUNCH_CHECK();
