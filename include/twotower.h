@@ -33,6 +33,7 @@ extern "C" {
 #define TT_ERR_HIP (-2)
 #define TT_ERR_WORKSPACE (-3)
 #define TT_ERR_UNSUPPORTED (-4)
+#define TT_ERR_DEVICE (-5) /* tt_ctx_check_device_errors: a kernel raised the context's sticky device error word */
 
 #define TT_F32 0
 #define TT_BF16 1
@@ -85,7 +86,18 @@ uint64_t tt_launch_count(void);
 /* TT_OPT_LOOKUP_NT (default 0): tt_batch_ingest_lookup stores its bf16 rows with non-temporal stores (same bits; an A/B switch:
  * they leave L2 during the launch instead of at its end). */
 #define TT_OPT_LOOKUP_NT 7
+/* TT_OPT_CHAIN_SPIN (default 2^22): polls after which a tile of a chained launch stops waiting for a predecessor (it then raises
+ * the device error word instead of hanging the GPU); tests lower it to provoke the error path. */
+#define TT_OPT_CHAIN_SPIN 8
 int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value);
+/* Device-side errors.  A kernel that cannot complete its contract without hanging the GPU (today: a tile of a chained
+ * segment-head launch whose bounded wait for a predecessor expired) raises a STICKY word in device memory owned by the context
+ * (TT_DEVERR_* bits) and finishes; nothing reaches the host by itself.  tt_ctx_check_device_errors reads the word (synchronises
+ * `stream`), and if it is set: clears it, zeroes the context's chain buffers, sets the error string and returns TT_ERR_DEVICE --
+ * every plan built since the previous check must then be considered corrupt.  Call it where the host synchronises anyway (end of an
+ * epoch, before a checkpoint, when a captured step is closed). */
+#define TT_DEVERR_CHAIN_TIMEOUT 1u
+int tt_ctx_check_device_errors(tt_ctx* ctx, tt_stream stream);
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream);
 /* only the queued slab reduction (the one thing that lives in the caller's shared scratch buffer) */
 int tt_flush_deferred_slabs(tt_ctx* ctx, tt_stream stream);

@@ -120,6 +120,7 @@ SIGNATURES = {
     "tt_embed_grad_finish": (C.c_int, [vp, i32, vp, i64, vp, vp, sz, vp]),
     "tt_ctx_set_option": (C.c_int, [vp, i32, i32]),
     "tt_flush_deferred": (C.c_int, [vp, vp]),
+    "tt_ctx_check_device_errors": (C.c_int, [vp, vp]),
     "tt_deferred_pending": (C.c_int, [vp]),
     "tt_launch_count": (C.c_uint64, []),
     "tt_flush_deferred_slabs": (C.c_int, [vp, vp]),
@@ -231,6 +232,7 @@ TT_OPT_DEFER_RIDERS = 4
 TT_OPT_FP8_GRAD = 5
 TT_OPT_CHAINED = 6
 TT_OPT_LOOKUP_NT = 7
+TT_OPT_CHAIN_SPIN = 8
 
 
 def set_option(device: torch.device, option: int, value: int):
@@ -266,6 +268,16 @@ def riders_deferred(device: torch.device, which: int = 3) -> bool:
     """which: 1 the plan compaction, 2 the loss reduction"""
     idx = torch.device(device).index
     return bool(_riders_on.get(idx if idx is not None else torch.cuda.current_device(), 0) & which)
+
+
+def check_device_errors(device: torch.device):
+    """tt_ctx_check_device_errors: raises TwoTowerHipError if a kernel has raised the context's sticky device error word since the
+    last check (synchronises the current stream; the word and the chain buffers are reset).  No-op on a device without a context."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else (torch.cuda.current_device() if device.type == "cuda" else None)
+    if device.type != "cuda" or idx not in _ctxs:
+        return
+    check(load().tt_ctx_check_device_errors(_ctxs[idx], stream(device)), "tt_ctx_check_device_errors")
 
 
 def flush_deferred(device: torch.device):

@@ -32,6 +32,8 @@ struct tt_ctx {
   void* chain_stream[16];
   int chain_used;
   int chained;              // TT_OPT_CHAINED: use them (default 1); 0 = the multi-launch forms (same results; tests compare)
+  uint32_t* dev_err;        // sticky device-side error word (TT_DEVERR_*): behind the chain pool; tt_ctx_check_device_errors
+  int chain_spin;           // TT_OPT_CHAIN_SPIN: polls before a chained tile gives up (default 2^22)
   int lookup_nt;            // TT_OPT_LOOKUP_NT: the fused hand-over + lookup launch stores its bf16 rows non-temporally (default 0)
 };
 

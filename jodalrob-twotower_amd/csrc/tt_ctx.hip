@@ -79,12 +79,15 @@ int tt_ctx_create(int device, tt_ctx** out) {
   c->chain_words = 0;
   c->chain_used = 0;
   c->chained = 1;
+  c->chain_spin = 1 << 22;
+  c->dev_err = nullptr;
   {
     int prev = 0;
     TT_HIP(hipGetDevice(&prev));
     TT_HIP(hipSetDevice(device));
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->chain), sizeof(uint32_t) * kChainWords * kChainSlices);
-    if (e == hipSuccess) e = hipMemset(c->chain, 0, sizeof(uint32_t) * kChainWords * kChainSlices);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->chain), sizeof(uint32_t) * (kChainWords * kChainSlices + 64));
+    if (e == hipSuccess) e = hipMemset(c->chain, 0, sizeof(uint32_t) * (kChainWords * kChainSlices + 64));
+    if (e == hipSuccess) c->dev_err = c->chain + (size_t)kChainWords * kChainSlices;       // (its own 256-byte line behind the pool)
     (void)hipSetDevice(prev);
     if (e != hipSuccess) {
       tt_set_error("tt_ctx_create: %s", hipGetErrorString(e));
@@ -125,9 +128,30 @@ int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value) {
     case TT_OPT_FP8_GRAD: ctx->fp8_grad = value != 0; break;
     case TT_OPT_CHAINED: ctx->chained = value != 0; break;
     case TT_OPT_LOOKUP_NT: ctx->lookup_nt = value != 0; break;
+    case TT_OPT_CHAIN_SPIN:
+      TT_CHECK_ARG(value >= 1, "tt_ctx_set_option: TT_OPT_CHAIN_SPIN needs a value >= 1");
+      ctx->chain_spin = value;
+      break;
     default: tt_set_error("tt_ctx_set_option: unknown option %d", option); return TT_ERR_INVALID_ARG;
   }
   return TT_OK;
+}
+
+int tt_ctx_check_device_errors(tt_ctx* ctx, tt_stream stream) {
+  TT_CHECK_ARG(ctx != nullptr, "tt_ctx_check_device_errors: NULL context");
+  if (!ctx->dev_err) return TT_OK;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  uint32_t word = 0;
+  TT_HIP(hipMemcpyAsync(&word, ctx->dev_err, sizeof(word), hipMemcpyDeviceToHost, st));
+  TT_HIP(hipStreamSynchronize(st));
+  if (word == 0) return TT_OK;
+  // clear the word and every chain slice: a launch that gave up half way leaves ready bits and a ticket behind, which the next
+  // chained launch on that stream would read as prefix sums
+  TT_HIP(hipMemsetAsync(ctx->chain, 0, sizeof(uint32_t) * ((size_t)kChainWords * kChainSlices + 64), st));
+  TT_HIP(hipStreamSynchronize(st));
+  tt_set_error("device error word 0x%x:%s the plans built since the last check are invalid (their steps must be rejected)", word,
+               (word & TT_DEVERR_CHAIN_TIMEOUT) ? " a chained segment-head launch gave up waiting for a predecessor tile (tt_dedup_plan / tt_dedup_plan_runs);" : "");
+  return TT_ERR_DEVICE;
 }
 
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream) {

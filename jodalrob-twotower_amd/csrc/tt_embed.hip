@@ -472,8 +472,8 @@ __global__ __launch_bounds__(kThreads) void head_write_kernel(const uint32_t* __
 __device__ __forceinline__ void chain_publish(uint32_t* slot, uint32_t v) {
   __hip_atomic_store(slot, v | kChainReady, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ uint32_t chain_wait(const uint32_t* slot, bool& stuck) {
-  for (int spin = 0; spin < (1 << 22); ++spin) {
+__device__ __forceinline__ uint32_t chain_wait(const uint32_t* slot, bool& stuck, int max_spin) {
+  for (int spin = 0; spin < max_spin; ++spin) {
     const uint32_t v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (v & kChainReady) return v & ~kChainReady;
     __builtin_amdgcn_s_sleep(1);
@@ -486,7 +486,8 @@ __device__ __forceinline__ uint32_t chain_wait(const uint32_t* slot, bool& stuck
 // it; the last tile also writes the totals.  chain[0] counts the tiles that are through with their reads: the last one clears.
 __global__ __launch_bounds__(kThreads) void head_chained_kernel(const uint32_t* __restrict__ keys, uint32_t M, uint32_t* __restrict__ chain,
                                                                int32_t* __restrict__ n_unique, int32_t* __restrict__ unique_rows,
-                                                               int32_t* __restrict__ seg_offsets, uint32_t drop_from) {
+                                                               int32_t* __restrict__ seg_offsets, uint32_t drop_from, uint32_t* __restrict__ dev_err,
+                                                               int max_spin) {
   __shared__ uint32_t wsum[4], wbefore[4];
   __shared__ uint32_t s_stuck, s_last;
   constexpr uint32_t PER = kSortTile / kThreads;
@@ -511,11 +512,17 @@ __global__ __launch_bounds__(kThreads) void head_chained_kernel(const uint32_t* 
   if (tid == 0) chain_publish(chain + 1 + blockIdx.x, total);
   uint32_t before = 0;
   bool stuck = false;
-  for (uint32_t b = tid; b < blockIdx.x; b += kThreads) before += chain_wait(chain + 1 + b, stuck);
+  for (uint32_t b = tid; b < blockIdx.x; b += kThreads) before += chain_wait(chain + 1 + b, stuck, max_spin);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
   if (lane == 0) wbefore[wave] = before;
-  if (stuck) s_stuck = 1;
+  if (stuck) {
+    s_stuck = 1;
+    // ANY tile whose wait expired raises the context's sticky device error word: the last tile only knows about
+    // itself, and a plan with a middle tile's prefix missing is corrupt, not empty.  tt_ctx_check_device_errors reports it, clears
+    // it and zeroes the chain buffers (a half-run launch leaves ready bits behind)
+    atomicOr(dev_err, TT_DEVERR_CHAIN_TIMEOUT);
+  }
   __syncthreads();
   before = wbefore[0] + wbefore[1] + wbefore[2] + wbefore[3];
   uint32_t u = before + x - c;
@@ -2059,7 +2066,8 @@ static int launch_heads(tt_ctx* ctx, hipStream_t st, const DedupWs& w, int64_t M
                         int32_t* seg_offsets, uint32_t drop_from) {
   uint32_t* chain = (int64_t)nblk + 1 <= ctx->chain_words && nblk <= 2048 ? tt_chain_for(ctx, st) : nullptr;
   if (chain) {
-    head_chained_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, chain, n_unique, unique_rows, seg_offsets, drop_from);
+    head_chained_kernel<<<nblk, kThreads, 0, st>>>(w.keysA, (uint32_t)M, chain, n_unique, unique_rows, seg_offsets, drop_from, ctx->dev_err,
+                                                   ctx->chain_spin);
     TT_LAUNCH_CHECK();
     return TT_OK;
   }

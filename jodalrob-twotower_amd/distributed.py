@@ -176,10 +176,12 @@ class HipBackend:
         order); the pad value `local_rows` groups into one (last) row that is left out of the plan's row count"""
         return ops.dedup_plan_runs(recv_ids, G, recv_ids.numel() // G, local_rows)
 
-    def reduce_into_buckets(self, plan, pos_u: torch.Tensor, srcs, B: int, E: int, n_rows: int, counters=None) -> torch.Tensor:
-        """[n_rows, E] f32: row pos_u[u] = summed gradient of plan row u; the other rows are not written"""
+    def reduce_into_buckets(self, plan, pos_u: torch.Tensor, srcs, B: int, E: int, n_rows: int, counters=None, out=None) -> torch.Tensor:
+        """[n_rows, E] f32: row pos_u[u] = summed gradient of plan row u; the other rows are not written (`out`: a caller-owned
+        buffer whose unwritten rows therefore keep what they held)"""
         import dataclasses
-        out = torch.empty((n_rows, E), dtype=torch.float32, device=pos_u.device)
+        if out is None:
+            out = torch.empty((n_rows, E), dtype=torch.float32, device=pos_u.device)
         ops.embed_grad(dataclasses.replace(plan, unique_rows=pos_u), srcs, B, E, ops.TT_GRAD_DENSE_SET, out, counters=counters)
         return out
 
@@ -327,6 +329,8 @@ class PaddedRowExchange(RowExchange):
         self.C, self.slack = capacity, slack
         self._overflow = None
         self._place_buf = None           # [G * C + 1, E] rows as received; the LAST row stays zero (target of rows that did not fit)
+        self._send_buf = None            # [G * C + 1, E] f32 row gradients in bucket order: allocated ZEROED once, so an unused bucket entry
+        #                                  never puts uninitialised memory on the wire: it carries zeros or an older step's sum
         self._flag_host, self._flag_event, self._flag_pending = None, None, False
         self.poll_lag = 2                # steps a raised overflow may lag behind the step that caused it
         self.wire_bf16 = True            # looked-up rows travel as bf16 (the towers round them to bf16 anyway: bit-identical)
@@ -446,7 +450,15 @@ class PaddedRowExchange(RowExchange):
             # with the bucket positions as its row indices): no [M, E] intermediate, no gather launch.  Unused bucket entries keep
             # whatever the buffer held: their ids are pads, which the owner's plan leaves out of its row count -- never read.
             # Rows that did not fit all land on the spare row behind the buckets (the step is rejected anyway).
-            send = be.reduce_into_buckets(state["plan"], state["pos_u"], srcs, B, self.E, self.world * self.C + 1, self.store.grad_counters())
+            n = self.world * self.C + 1
+            sb = self._send_buf
+            if sb is None or sb.shape[0] != n or sb.device != state["pos_u"].device:
+                if state["pos_u"].device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+                    sb = None                            # (a capture without an eager step before it: a fresh buffer, as before)
+                else:
+                    sb = self._send_buf = torch.zeros((n, self.E), dtype=torch.float32, device=state["pos_u"].device)
+            send = be.reduce_into_buckets(state["plan"], state["pos_u"], srcs, B, self.E, n, self.store.grad_counters(), out=sb) \
+                if isinstance(be, HipBackend) else be.reduce_into_buckets(state["plan"], state["pos_u"], srcs, B, self.E, n, self.store.grad_counters())
             d_rows = self._a2a_equal(send[:self.world * self.C])
         else:
             grad_u = be.reduce_local(state["plan"], srcs, B, self.E, self.store.grad_counters())  # one row per distinct row (+ a zero row)

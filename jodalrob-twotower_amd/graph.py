@@ -434,6 +434,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         ex = getattr(self.task, "exchange", None)
         try:
+            L.check_device_errors(dev)                          # (a chained plan launch that gave up: the steps since the last check are invalid)
             if ex is not None and hasattr(ex, "check_overflow"):
                 ex.check_overflow()
         finally:

@@ -261,6 +261,34 @@ def test_dedup_plan_bit_exact(tt, ctx_option, M, table_rows, dist, chained):
     assert np.array_equal(plan.seg_offsets[:U + 1].cpu().numpy(), np.concatenate([start, [M]]).astype(np.int32))
 
 
+def test_chained_plan_timeout_raises_device_error(tt, ctx_option):
+    """a tile of the chained segment-head launch whose bounded wait expires must not leave a silently empty (or corrupt)
+    plan behind.  With the wait cut to ONE poll (TT_OPT_CHAIN_SPIN) some tile of a 600-tile plan gives up: the context's sticky device
+    error word is raised, tt_ctx_check_device_errors reports it (TwoTowerHipError), clears it and zeroes the chain buffers; the next plan,
+    with the default wait, is the oracle's again (no stale ready bits) and the check is clean."""
+    from jodalrob_twotower_amd import ops
+    rng = np.random.default_rng(5)
+    M, R = 2_400_000, 3_000_000
+    rows = torch.from_numpy(rng.integers(0, R, M).astype(np.int32)).to(DEV)
+    _L.check_device_errors(torch.device(DEV))                               # start clean
+    ctx_option(_L.TT_OPT_CHAIN_SPIN, 1, 1 << 22)
+    raised = 0
+    for _ in range(4):                                                       # (whether a tile has to wait is a race: four tries, one error suffices)
+        ops.dedup_plan(rows, R)
+        try:
+            _L.check_device_errors(torch.device(DEV))
+        except _L.TwoTowerHipError as e:
+            assert "chained segment-head launch" in str(e)
+            raised += 1
+    assert raised >= 1
+    _L.set_option(torch.device(DEV), _L.TT_OPT_CHAIN_SPIN, 1 << 22)
+    plan = ops.dedup_plan(rows, R)
+    _L.check_device_errors(torch.device(DEV))                               # clean, and the plan is whole
+    U = int(plan.n_unique.item())
+    want = np.unique(rows.cpu().numpy())
+    assert U == len(want) and np.array_equal(plan.unique_rows[:U].cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("E,B,vocabs,src_dtype", [(32, 2048, [[2, 2, 12, 5000], [3, 100000]], "f32"), (8, 300, [[5, 9], [4]], "f32"),
                                                    (6, 64, [[3, 1000]], "f32"), (64, 512, [[2, 300], [7]], "f32"),
                                                    (16, 700, [[2, 50]], "f32"), (32, 1500, [[3, 40, 9000], [2]], "bf16"),
@@ -2172,7 +2200,9 @@ def test_score_fp8_vs_rounded_oracle(tt, ctx_option, B, D, T, fp8_grad):
 
 
 # ------------------------------------------------------------------ BASELINE configs[2] / [3] / [4] at their own sizes
-FP8_GRAD_TRAJECTORY_BOUNDS = {"loss_rel": 0.05, "accuracy_abs": 0.05, "recall_abs": 0.05}
+# measured (round 4): T = 1: loss 5.818 vs 5.813, accuracy 0.093 vs 0.107, recall@10 0.525 vs 0.547; T = 0.05: loss 2.729 vs 2.748, accuracy
+# 0.401 vs 0.391, recall@10 0.797 vs 0.797 (fp8_grad 1 vs 0; both from loss ln(1024) + ... = 6.93 / 7.66 at step 0)
+FP8_GRAD_TRAJECTORY_BOUNDS = {"loss_rel": 0.02, "accuracy_abs": 0.03, "recall_abs": 0.04}
 
 
 @pytest.mark.parametrize("T", [1.0, 0.05])
@@ -2223,7 +2253,7 @@ def test_fp8_grad_default_trains_like_bf16_gradient_products(tt, schema_real, tm
     bd = FP8_GRAD_TRAJECTORY_BOUNDS
     assert a["first_loss"] == pytest.approx(b["first_loss"], rel=1e-6)                     # same start
     for e in (a, b):
-        assert e["loss"] < 0.8 * e["first_loss"] and e["recall@10"] > 10.0 / B * 5, e      # both learned
+        assert e["loss"] < e["first_loss"] - 0.5 and e["recall@10"] > 10.0 / B * 5, e      # both learned (recall@10 of a random model: 0.01)
     assert abs(a["loss"] - b["loss"]) <= bd["loss_rel"] * abs(b["loss"]), (a, b)
     assert abs(a["accuracy"] - b["accuracy"]) <= bd["accuracy_abs"], (a, b)
     assert abs(a["recall@10"] - b["recall@10"]) <= bd["recall_abs"], (a, b)
