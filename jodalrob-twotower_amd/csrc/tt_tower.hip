@@ -31,6 +31,25 @@ __device__ __forceinline__ Wf wf_combine(Wf a, Wf b) {
   return o;
 }
 
+// Canonical merge order of the chunk statistics (round 4; every finish -- bn_stats_finish_kernel, the fused tails, the SyncBN hand-over
+// -- uses it, so their results stay bit-identical to each other).  Chunk lane jl owns chunks jl, jl + 4, jl + 8, ... in four SUB-CHAINS of
+// kMaxChunks / 16 chunks each:   lane(jl) = ((C0 + C1) + C2) + C3,  C_s = ((v[8 s] + v[8 s + 1]) + ...) + v[8 s + 7];
+// the four lanes then merge as (lane0 + lane1) + (lane2 + lane3).  Sub-chains exist so that the fused forward tail can give each one to
+// its own thread (16 per column: 8 triples in flight per thread instead of 32 -- 52 registers, two workgroups per CU) without changing
+// the association; before, a lane was one chain of 32.
+constexpr int kSubChain = kMaxChunks / 16;
+__device__ __forceinline__ Wf wf_lane_merge(const Wf* v /* [kMaxChunks / 4] */) {
+  Wf o{0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    Wf cs{0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < kSubChain; ++i) cs = wf_combine(cs, v[kSubChain * s + i]);
+    o = wf_combine(o, cs);
+  }
+  return o;
+}
+
 template <typename A>
 struct Batch {
   A a[TT_MAX_SIDES];
@@ -96,8 +115,7 @@ __global__ __launch_bounds__(kThreads) void bn_stats_finish_kernel(Batch<BnStatA
       const float* p = a.partial + (int64_t)k * (a.pstride ? a.pstride : 3 * H);
       v[i] = k < a.nchunks ? Wf{p[c], p[H + c], p[2 * H + c]} : Wf{0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int i = 0; i < kMaxChunks / 4; ++i) o = wf_combine(o, v[i]);
+    o = wf_lane_merge(v);
   }
   sh[jl][threadIdx.x & 63] = o;
   __syncthreads();
@@ -729,8 +747,13 @@ struct TailFwdArgs {
 static_assert(kTailThreads == kRiderThreads, "the riders run in the tail kernels' workgroups");
 // (cr_wg > 0: the FIRST grid row -- dispatched first: not every workgroup of the launch is resident at once -- is the keyed plan's
 // compaction riding in this launch: tt_riders.h)
-__global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed0,
-                                                               const uint64_t* __restrict__ seed_dev, CompactRider cr, int cr_wg) {
+// Round 4: at most 64 registers, so that TWO of these 1024-thread workgroups share a CU: the launch is 256 tail workgroups plus the
+// riding compaction's grid row, and at 116 registers (one workgroup per CU) the riders' row -- dispatched first -- made half the
+// tail workgroups wait for a CU (18.6 us for a 10-us chain).  The 96 registers were the chunk statistics' partials, all in flight at
+// once: every thread now fetches and merges ONE sub-chain of eight chunks (wf_lane_merge's order), all 1024 threads taking part.
+__global__ __launch_bounds__(kTailThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed0,
+                     const uint64_t* __restrict__ seed_dev, CompactRider cr, int cr_wg) {
   if (cr_wg > 0 && blockIdx.y == 0) {
     if ((int)blockIdx.x < cr_wg) compact_body(cr, blockIdx.x);
     return;
@@ -740,7 +763,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArg
   const int H = a.H, D = f.D, B = a.B;
   const int m0 = blockIdx.x * 64;
   if (m0 >= B) return;
-  __shared__ Wf sh[4][64];
+  __shared__ Wf sh[16][64];
   __shared__ float s_mean[64], s_rstd[64];
   __shared__ __attribute__((aligned(16))) __bf16 As[64 * kTailLd];
   __shared__ __attribute__((aligned(16))) __bf16 Bs[64 * kTailLd];
@@ -754,21 +777,23 @@ __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArg
     const float v = a.pre[(int64_t)min(r, B - 1) * H + min(c, H - 1)];     // (clamped address, no branch around the load)
     pre[j] = (c < H && r < B) ? v : 0.f;
   }
-  if (t < 256) {
-    Wf o{0.f, 0.f, 0.f};
+  {                                                      // thread (c, rq): sub-chain rq >> 2 of chunk lane rq & 3 (wf_lane_merge's order)
+    Wf cs{0.f, 0.f, 0.f};
     if (c < H) {
-      Wf v[kMaxChunks / 4];
+      const int jl = rq & 3, sc = rq >> 2;
+      Wf v[kSubChain];
       const int64_t ps = a.pstride ? a.pstride : 3 * H;
 #pragma unroll
-      for (int i = 0; i < kMaxChunks / 4; ++i) {
-        const int k = rq + 4 * i;
-        const float* q = a.partial + (int64_t)k * ps;
-        v[i] = k < a.nchunks ? Wf{q[c], q[H + c], q[2 * H + c]} : Wf{0.f, 0.f, 0.f};
+      for (int i = 0; i < kSubChain; ++i) {
+        const int k = jl + 4 * (kSubChain * sc + i);
+        const float* q = a.partial + (int64_t)min(k, a.nchunks - 1) * ps;      // (clamped address, no branch around the loads)
+        const float x0 = q[c], x1 = q[H + c], x2 = q[2 * H + c];
+        v[i] = k < a.nchunks ? Wf{x0, x1, x2} : Wf{0.f, 0.f, 0.f};
       }
 #pragma unroll
-      for (int i = 0; i < kMaxChunks / 4; ++i) o = wf_combine(o, v[i]);
+      for (int i = 0; i < kSubChain; ++i) cs = wf_combine(cs, v[i]);
     }
-    sh[rq][c] = o;
+    sh[rq][c] = cs;
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {                          // W_out [D, H] -> Bs[n][k]
@@ -778,7 +803,15 @@ __global__ __launch_bounds__(kTailThreads) void tail_fwd_kernel(Batch<TailFwdArg
   }
   __syncthreads();
   if (t < 64 && c < H) {
-    const Wf o = wf_combine(wf_combine(sh[0][c], sh[1][c]), wf_combine(sh[2][c], sh[3][c]));
+    Wf ln[4];
+#pragma unroll
+    for (int jl = 0; jl < 4; ++jl) {                       // lane(jl) = ((C0 + C1) + C2) + C3, starting from the empty statistic
+      Wf o{0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sc = 0; sc < 4; ++sc) o = wf_combine(o, sh[4 * sc + jl][c]);
+      ln[jl] = o;
+    }
+    const Wf o = wf_combine(wf_combine(ln[0], ln[1]), wf_combine(ln[2], ln[3]));
     const float var = o.n > 0.f ? o.m2 / o.n : 0.f;
     const float rstd = 1.f / sqrtf(var + kBnEps);
     s_mean[c] = o.mean;
@@ -921,8 +954,7 @@ __global__ __launch_bounds__(kTailThreads) void tail_fwd_wide_kernel(Batch<TailF
         const float* q = a.partial + (int64_t)k * ps;
         v[i] = k < a.nchunks ? Wf{q[col], q[H + col], q[2 * H + col]} : Wf{0.f, 0.f, 0.f};
       }
-#pragma unroll
-      for (int i = 0; i < kMaxChunks / 4; ++i) o = wf_combine(o, v[i]);
+      o = wf_lane_merge(v);
     }
     sh[cb][jl][c] = o;
   }
@@ -1559,8 +1591,7 @@ __global__ __launch_bounds__(kThreads) void tail_local_stats_kernel(Batch<LocalA
       const float* q = a.partial + (int64_t)k * 3 * H;
       v[i] = k < a.nchunks ? Wf{q[c], q[H + c], q[2 * H + c]} : Wf{0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int i = 0; i < kMaxChunks / 4; ++i) o = wf_combine(o, v[i]);
+    o = wf_lane_merge(v);
   }
   sh[jl][cl] = o;
   __syncthreads();
