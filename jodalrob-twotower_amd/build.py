@@ -16,7 +16,7 @@ INCLUDE = PKG.parent / "include"
 OUT = PKG / "libtwotower_hip.so"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         f"-I{INCLUDE}", f"-I{CSRC}"]
+         f"-I{INCLUDE}", f"-I{CSRC}"] + os.environ.get("TT_EXTRA_HIPCC_FLAGS", "").split()      # (measurement builds: -DTT_TAIL_STAMPS)
 
 
 def _stale(target: Path, deps) -> bool:

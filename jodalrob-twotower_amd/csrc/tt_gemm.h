@@ -136,6 +136,7 @@ struct GemmBack {
   void* ws_dw; size_t ws_dw_bytes;                // >= tt_gemm_tn_workspace_bytes(H, kx, B)
   void* ws_g; size_t ws_g_bytes;                  // >= tt_gemm_back_g_workspace_bytes(H, h0, din, B)
   int64_t B;
+  const void* w16 = nullptr;                      // optional bf16 shadow of w (same shape): read by the row-gradient product
 };
 bool tt_gemm_back_supported(const GemmBack* items, int n);
 size_t tt_gemm_back_g_workspace_bytes(int64_t H, int64_t h0, int64_t din, int64_t B);

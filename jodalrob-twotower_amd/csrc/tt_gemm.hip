@@ -547,13 +547,15 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_bf16_fast_kernel(GemmBatch ba
 // role 2 of gemm_back_kernel with K = 64: C[64 rows, nb x 64 columns] = A[64, 64] . W[64, columns].  The row tile of A (d_pre)
 // is staged in LDS ONCE for up to kNnCols column tiles -- as one 64 x 64 tile per workgroup every tile re-read its 16 KB of A
 // next to 16 KB of W for 16 KB of output (78 MB of L2 reads for the 40 MB of d_x at B = 8192).
+// WB16 (round 4): W arrives as its bf16 shadow (tt_tower_params.w_bf16): half the bytes of the operand every workgroup re-reads.
 constexpr int kNnCols = 4;
+template <bool WB16>
 __device__ __forceinline__ void gemm_nn_k64_tiles(const GemmArgs& g, int bx, int by0, int nb, FastSmem& sm) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
   const int m0 = bx * BM;
   FastLoader16<0, false> la[2];
-  FastLoader16<1, false> lb[2];
+  FastLoader16<1, WB16> lb[2];
   la[0].load(g.A, g.lda, m0, 0, t);
   la[1].load(g.A, g.lda, m0, BK16, t);
   lb[0].load(g.B, g.ldb, by0 * BN, 0, t);
@@ -610,7 +612,8 @@ __global__ __launch_bounds__(THREADS, 4) void gemm_back_kernel(BackBatch b) {
   else if (b.role[p] == 1) gemm_fast_tile<1, 1, false, false, false, true>(g, split, bx, by, sm);
   else if (g.K == 64) {                                    // by = group of kNnCols column tiles
     const int nt_cols = g.N / BN;
-    gemm_nn_k64_tiles(g, bx, by * kNnCols, min(kNnCols, nt_cols - by * kNnCols), sm);
+    if (g.b_bf16) gemm_nn_k64_tiles<true>(g, bx, by * kNnCols, min(kNnCols, nt_cols - by * kNnCols), sm);
+    else gemm_nn_k64_tiles<false>(g, bx, by * kNnCols, min(kNnCols, nt_cols - by * kNnCols), sm);
   } else gemm_fast_tile<0, 1, false, false, false>(g, split, bx, by, sm);
 }
 
@@ -926,8 +929,11 @@ int tt_gemm_back_batched(hipStream_t st, const GemmBack* it, int n, TnPending* p
         maxtotal = (int64_t)g.h0 * g.din > maxtotal ? (int64_t)g.h0 * g.din : maxtotal;
       } else {
         float* c = g.dx_bf16 ? reinterpret_cast<float*>(reinterpret_cast<uint16_t*>(g.dx) + g.h0) : g.dx + g.h0;
-        b.g[p] = GemmArgs{g.dpre, g.H, g.w + g.h0, g.kx, c, g.ld_dx, 0, (int)g.B, g.kx - g.h0, g.H, (int)(tt_cdiv(g.H, BK16) * BK16), 1,
-                          nullptr, 0, 1.f, nullptr, 0, 0, g.dx_bf16 ? 1 : 0};
+        // (the K = 64 form can read W's bf16 shadow: the same values it would round on the way into LDS)
+        const bool w16 = g.w16 != nullptr && g.H == 64 && tt_aligned(g.w16, 16);
+        const float* wsrc = w16 ? reinterpret_cast<const float*>(reinterpret_cast<const uint16_t*>(g.w16) + g.h0) : g.w + g.h0;
+        b.g[p] = GemmArgs{g.dpre, g.H, wsrc, g.kx, c, g.ld_dx, 0, (int)g.B, g.kx - g.h0, g.H, (int)(tt_cdiv(g.H, BK16) * BK16), 1,
+                          nullptr, 0, 1.f, nullptr, 0, w16 ? 1 : 0, g.dx_bf16 ? 1 : 0};
         tm = (int)(g.B / BM); tn_ = (g.kx - g.h0) / BN;
         if (g.H == 64) tn_ = (int)tt_cdiv(tn_, kNnCols);    // K = 64: a workgroup takes kNnCols column tiles (gemm_nn_k64_tiles)
       }

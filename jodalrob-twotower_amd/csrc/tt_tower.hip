@@ -751,6 +751,14 @@ static_assert(kTailThreads == kRiderThreads, "the riders run in the tail kernels
 // riding compaction's grid row, and at 116 registers (one workgroup per CU) the riders' row -- dispatched first -- made half the
 // tail workgroups wait for a CU (18.6 us for a 10-us chain).  The 96 registers were the chunk statistics' partials, all in flight at
 // once: every thread now fetches and merges ONE sub-chain of eight chunks (wf_lane_merge's order), all 1024 threads taking part.
+// measurement aid, compiled in with -DTT_TAIL_STAMPS only (tools/r04_tail_stamps.py): phase stamps of the tail kernels' workgroups
+#ifdef TT_TAIL_STAMPS
+__device__ unsigned long long g_tail_stamps[2][512 * 8];
+#define TT_TAIL_STAMP(k, i) do { if (threadIdx.x == 0) g_tail_stamps[k][((blockIdx.y * gridDim.x + blockIdx.x) & 511) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define TT_TAIL_STAMP(k, i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(kTailThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
 void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed0,
                      const uint64_t* __restrict__ seed_dev, CompactRider cr, int cr_wg) {
@@ -763,6 +771,7 @@ void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed
   const int H = a.H, D = f.D, B = a.B;
   const int m0 = blockIdx.x * 64;
   if (m0 >= B) return;
+  TT_TAIL_STAMP(0, 0);
   __shared__ Wf sh[16][64];
   __shared__ float s_mean[64], s_rstd[64];
   __shared__ __attribute__((aligned(16))) __bf16 As[64 * kTailLd];
@@ -802,6 +811,7 @@ void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed
     Bs[n * kTailLd + c] = (__bf16)((n < D && c < H) ? w : 0.f);
   }
   __syncthreads();
+  TT_TAIL_STAMP(0, 1);
   if (t < 64 && c < H) {
     Wf ln[4];
 #pragma unroll
@@ -827,6 +837,7 @@ void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed
     }
   }
   __syncthreads();
+  TT_TAIL_STAMP(0, 2);
   {
     const uint64_t seed = drop ? seed_of(seed0, seed_dev) : 0;
     const float mean = c < H ? s_mean[c] : 0.f, rstd = c < H ? s_rstd[c] : 0.f;
@@ -846,6 +857,7 @@ void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed
     }
   }
   __syncthreads();
+  TT_TAIL_STAMP(0, 3);
   const int lane = t & 63, wave = t >> 6;
   if (wave < 4) {
     const int wr = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
@@ -867,6 +879,7 @@ void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed
     }
   }
   __syncthreads();
+  TT_TAIL_STAMP(0, 4);
   // one wave per row as l2norm_fwd_kernel, four independent rows per wave in flight.  mul_rn: a plain v * v is
   // contracted into the first butterfly add (fma(v, v, partner's square)), which leaves the two partners -- and so the
   // lanes of one row -- with differently rounded sums
@@ -913,6 +926,11 @@ void tail_fwd_kernel(Batch<TailFwdArgs> batch, bool drop, float p, uint64_t seed
     for (int j = 0; j < 4; ++j) o[j] = (__bf16)(e[j] * f.pk_scale);
     *reinterpret_cast<bf16x4*>(f.pk_frag + fi * 8 + (q >> 3) * 4) = o;
   }
+#ifdef TT_TAIL_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  TT_TAIL_STAMP(0, 5);
+#endif
 }
 
 // (B') the same kernel for wider towers: last hidden width H <= 256, output D <= 128 (scripts/train.py's own [512, 256] -> 128).
@@ -2177,6 +2195,7 @@ int tt_towers_mlp_bwd(tt_ctx* ctx, int32_t n, const tt_tower_params* const* P, c
         gb[t] = GemmBack{tn[t].A, P[t]->hidden[0], A[t]->x, wx, wx, P[t]->x_dtype == TT_BF16, A[t]->dense, P[t]->din, P[t]->din,
                          P[t]->w[0], P[t]->h0, reinterpret_cast<float*>(g->d_x), wx, P[t]->dx_dtype == TT_BF16, g->w[0], g->b[0],
                          g->w_proj, g->b_proj, ws[t].tn[1], ws[t].tn_bytes[1], ws[t].tn[0], ws[t].tn_bytes[0], B};
+        gb[t].w16 = P[t]->w_bf16[0];
       }
       if (ok && tt_gemm_back_supported(gb, n)) {
         if (int rc = tt_gemm_back_batched(st, gb, n, pend.p)) return rc;
@@ -2222,3 +2241,10 @@ int tt_linear_fwd(tt_ctx* ctx, const float* X, int64_t ldx, const float* W, cons
 }
 
 }  // extern "C"
+
+#ifdef TT_TAIL_STAMPS
+extern "C" int tt_debug_tail_stamps(int which, unsigned long long* host_out /* [512 * 8] */) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_tail_stamps), sizeof(unsigned long long) * 512 * 8,
+                             sizeof(unsigned long long) * 512 * 8 * (size_t)which, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
