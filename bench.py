@@ -7,7 +7,7 @@ Self-contained for every N: with --gpus N > 1 and no WORLD_SIZE in the environme
 per GPU, before anything touches a GPU) and rank 0 prints the JSON line; under `python -m torch.distributed.run` it uses the
 ranks it is given.  When the box has fewer GPUs than ranks (a one-GPU rehearsal) the ranks share a device and their
 collectives are staged through gloo (RCCL refuses two ranks on one device): every kernel is still the product path, the line
-is labelled "rehearsal" and runs eagerly.
+is labelled "rehearsal" and runs eagerly (with --dist-segmented: as replayed graph segments with the staged collectives between them).
 
 Step = TwoTowerTrainTask forward (return_metrics=True) + loss.backward() + optimiser step + LR schedule on one synthetic
 batch whose ids and dense features are already resident in HBM.
@@ -179,7 +179,8 @@ class Leg:
         # global-batch legs: rank r holds rows [r*B_local, (r+1)*B_local) of the global batch -- its own seeded slice
         self.pool = [synthetic.make_batch(B, self.vocab_n, self.vocab_c, self.keys_n, self.keys_c, self.din_n, self.din_c, dev,
                                           seed=1234 + 7919 * (rank * args.pool + i), zipf_alpha=args.zipf) for i in range(args.pool)]
-        eager_only = ctx["staged"] or args.dist_eager
+        # (a rehearsal's host-staged collectives cannot be captured; with --dist-segmented they run between the replayed segments)
+        eager_only = (ctx["staged"] and not args.dist_segmented) or args.dist_eager
         self.use_graph = (args.mode == "graph" and args.optimizer == "fused_sparse" and not eager_only) if sharded else \
             (args.mode == "graph" and args.optimizer != "torch_adam")
         self.gstep = None
@@ -524,9 +525,10 @@ def config_of(args, leg, world, ctx, B_global, workload):
                     "exchange_bytes_per_rank_fwd": world * ex.C * leg.E * (2 if (x_bf16 and ex.wire_bf16) else 4),
                     "exchange_bytes_per_rank_bwd": world * ex.C * leg.E * (2 if ex.grad_wire_bf16 else 4)})
     cfg["parallelism"] = "single GPU" if not leg.sharded else (
-        f"row-wise sharded tables x{world} (dedup-first fixed-capacity all-to-all" + (", RCCL inside the graph" if leg.gstep is not None else "") +
+        f"row-wise sharded tables x{world} (dedup-first fixed-capacity all-to-all" + (", RCCL inside the graph" if (leg.gstep is not None and not getattr(leg.gstep, "segmented", False)) else
+                                                                                 ", collectives eager between replayed segments" if leg.gstep is not None else "") +
         ") + data parallel towers, " + f"{leg.negatives} in-batch negatives" + (", SyncBN" if leg.sync_bn else "") +
-        (" -- REHEARSAL: the ranks share one GPU, collectives staged through gloo (host), eager launches" if ctx["staged"] else ""))
+        (" -- REHEARSAL: the ranks share one GPU, collectives staged through gloo (host)" if ctx["staged"] else ""))
     return cfg
 
 

@@ -32,6 +32,12 @@ def main():
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = dict(json.load(open(GOLD / "manifest.json"))["cases"]["wide_b40"])        # towers [32, 24] -> 16, E = 16
+    if os.environ.get("TT_W2_SEGMENTED") == "1":
+        segmented_equals_eager(rank, world, cfg)
+        dist.barrier()
+        dist.destroy_process_group()
+        print("DIST_WORLD2_SEGMENTED_OK", flush=True)
+        return
     if os.environ.get("TT_W2_WIDE") == "1":                  # wider than the fused tail takes: the separate kernels' SyncBN cut
         cfg["hidden"], cfg["D"] = [48, 80], 72
     Bl, drop = 96, 0.1
@@ -100,6 +106,67 @@ def main():
     dist.barrier()
     dist.destroy_process_group()                             # ordinary teardown and interpreter exit, as the world-1 worker
     print("DIST_WORLD2_OK", flush=True)
+
+
+def segmented_equals_eager(rank, world, cfg):
+    """SegmentedTrainStep with REAL peers: each rank trains on its own batches, rows and row gradients cross ranks in every step, the
+    collectives run eagerly (host-staged gloo) between the replayed segments.  Claim: on every rank the losses of 4 steps and the
+    whole state afterwards (this rank's table shard, towers, BN statistics) == the same steps issued launch by launch, bit for bit --
+    on the default semantics (per-rank negatives and BN statistics) and on global negatives + SyncBN."""
+    from jodalrob_twotower_amd.segmented import SegmentedTrainStep
+    Bl = 128
+
+    def to_batch(b):
+        return {"notice": {"dense": torch.from_numpy(b["notice_dense"]).to(DEV),
+                           "kjt": tt.build_batch_kjt(torch.from_numpy(b["notice_ids"]), cfg["keys_n"]).to(DEV)},
+                "company": {"dense": torch.from_numpy(b["company_dense"]).to(DEV),
+                            "kjt": tt.build_batch_kjt(torch.from_numpy(b["company_ids"]), cfg["keys_c"]).to(DEV)}}
+
+    batches = [to_batch(synth_batch_numpy(Bl, cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 3000 + 17 * rank + i, oob=True))
+               for i in range(4)]
+    for negatives, sync_bn in (("local", False), ("global", True)):
+        finals, state = {}, None
+        for mode in ("eager", "segmented"):
+            t = create_distributed_train_task(
+                cfg["keys_n"], cfg["keys_c"], metadata_path=str(GOLD / "synthetic_metadata.csv"), categorical_embedding_dim=cfg["E"],
+                notice_dense_input_dim=cfg["din_n"], company_dense_input_dim=cfg["din_c"], tower_hidden_dims=list(cfg["hidden"]),
+                final_embedding_dim=cfg["D"], dropout_rate=0.0, temperature=cfg["T"], device=DEV, embedding_grad="sparse",
+                mlp_dtype="bf16", score_dtype="bf16", exchange="padded", negatives=negatives, sync_bn=sync_bn, comm=HostStagedComm())
+            if state is None:
+                shapes = {k: tuple(v.shape) for k, v in t.full_state_dict().items()}
+                state = {k: torch.from_numpy(np.asarray(v)) for k, v in init_state_numpy(shapes, 556).items()}
+            t.load_full_state_dict(state)
+            t.train()
+            t._pair_check_done = True
+            o = FusedAdam.for_task(t, lr=1e-2, weight_decay=1e-5)
+            losses, gs = [], None
+            if mode == "segmented":
+                gs = SegmentedTrainStep(t, o, batches[0], warmup=1, preserve_state=False)
+                for bt in batches:
+                    losses.append(gs.step(bt)["loss"].item())
+            else:
+                o.zero_grad(); t(batches[0], return_metrics=True)["loss"].backward(); o.step()     # the capture's warm-up step
+                for bt in batches:
+                    o.zero_grad()
+                    r = t(bt, return_metrics=True)
+                    r["loss"].backward()
+                    o.step()
+                    losses.append(r["loss"].item())
+            torch.cuda.synchronize()
+            assert not t.exchange.overflowed()
+            local = {k: v.detach().cpu().clone() for k, v in t.state_dict().items()}          # (this rank's shard + replicated parts)
+            finals[mode] = (losses, local, None if gs is None else (gs.collectives_per_step(), sum(g is not None for g in gs._segments)))
+            if gs is not None:
+                gs.close()
+            del gs, o, t
+        assert finals["segmented"][0] == finals["eager"][0], (negatives, finals["segmented"][0], finals["eager"][0])
+        assert len(set(finals["eager"][0])) > 1
+        for k, v in finals["eager"][1].items():
+            assert torch.equal(v, finals["segmented"][1][k]), (negatives, k)
+        n_coll, n_seg = finals["segmented"][2]
+        print(f"[rank {rank}] segmented, {negatives} negatives, sync_bn={sync_bn}: {n_coll} eager collectives between {n_seg} replayed segments; "
+              f"losses {finals['segmented'][0]}", flush=True)
+        assert n_coll >= (4 if negatives == "local" else 6), n_coll
 
 
 if __name__ == "__main__":

@@ -1781,6 +1781,34 @@ def test_two_processes_equal_single_process(tt):
     assert ok, "\n".join(o[1][-1500:] for o in outs)
 
 
+def test_segmented_capture_with_real_peers_equals_eager(tt):
+    """The segmented fallback (segmented.SegmentedTrainStep) with TWO ranks exchanging rows in every step (two processes on the one
+    GPU, collectives staged through gloo between the replayed segments): on each rank 4 steps == the same steps launch by launch,
+    bit for bit -- losses and the rank's whole state -- on per-rank negatives and on global negatives + SyncBN
+    (tests/_dist_world2_worker.py: segmented_equals_eager)."""
+    import os, socket, subprocess, sys
+    from pathlib import Path
+    worker = Path(__file__).resolve().parent / "_dist_world2_worker.py"
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    env = dict(os.environ, TT_W2_SEGMENTED="1")
+    procs = [subprocess.Popen([sys.executable, str(worker), str(r), "2", str(port)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+             for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=300) + (p.returncode,))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    ok = len(outs) == 2 and all("DIST_WORLD2_SEGMENTED_OK" in o[0] and o[2] == 0 for o in outs)
+    if not ok:
+        log = Path(__file__).resolve().parents[1] / "gpurun_out"
+        log.mkdir(exist_ok=True)
+        (log / "dist_world2_segmented.log").write_text("\n".join(f"==== rank {i} stdout ====\n{o[0]}\n==== stderr ====\n{o[1]}" for i, o in enumerate(outs)))
+    assert ok, "\n".join(o[0][-800:] + o[1][-1500:] for o in outs)
+
+
 @pytest.mark.parametrize("G,B,D", [(2, 300, 64), (3, 129, 32), (4, 256, 64)])
 def test_global_negatives_equal_single_process(tt, G, B, D):
     """Global in-batch negatives on G virtual ranks == the single-process loss over the concatenated batch of G*B pairs
