@@ -672,21 +672,34 @@ def lookup_dispatch_overhead_us(task, pool, dev, profile, iters: int = 48):
     import torch
     from jodalrob_twotower_amd import ops
     towers = [task.two_tower_model.notice_tower, task.two_tower_model.company_tower]
-    store = task.sharded_store if hasattr(task, "sharded_store") else towers[0].categorical_embedder.store
+    ex = getattr(task, "exchange", None)
+    store = None if ex is not None else towers[0].categorical_embedder.store
+    place_buf = getattr(ex, "_place_buf", None) if ex is not None else None
+    if ex is not None and place_buf is None:
+        return None
     sides_per_batch = []
     rows_mode = getattr(getattr(task, "_bench_gstep", None), "_rows_sm", None) is not None
-    for batch in pool:
+    for i, batch in enumerate(pool):
         sides = []
         for tw, side in zip(towers, ("notice", "company")):
             B = batch[side]["dense"].shape[0]
             x = torch.empty((B, tw.x_width), dtype=tw.x_dtype, device=dev)
             sides.append(tw.categorical_embedder.lookup_side(batch[side]["kjt"].values(), x[:, tw.tower_hidden_dims[0]:]))
-        # the captured step's lookup reads precomputed fused rows: calibrate the same kernel
-        rows = ops.embed_lookup(store.weight, sides, B, want_rows=True) if rows_mode else None
+        if ex is not None:
+            # row-wise sharded tables: the launch that fills the tower inputs gathers out of the exchange's RECEIVE buffer by bucket
+            # position (tt_embed_lookup_fwd[place]) -- this rank's shard holds 1/G of the rows and is never indexed by global rows
+            M = sum(B * s.K for s in sides)
+            g = torch.Generator(device=dev).manual_seed(4321 + i)
+            rows = torch.randint(0, place_buf.shape[0] - 1, (M,), dtype=torch.int64, device=dev, generator=g)
+        else:
+            # the captured step's lookup reads precomputed fused rows: calibrate the same kernel
+            rows = ops.embed_lookup(store.weight, sides, B, want_rows=True) if rows_mode else None
         sides_per_batch.append((sides, B, rows))
 
     def launch(sides, B, rows):
-        if rows is not None:
+        if ex is not None:
+            ex.backend.place_rows(place_buf, rows, sides, B)
+        elif rows is not None:
             ops.embed_lookup_rows(store.weight, rows, sides, B)
         else:
             ops.embed_lookup(store.weight, sides, B, want_rows=True)

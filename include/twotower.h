@@ -90,13 +90,15 @@ uint64_t tt_launch_count(void);
  * the device error word instead of hanging the GPU); tests lower it to provoke the error path. */
 #define TT_OPT_CHAIN_SPIN 8
 int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value);
-/* Device-side errors.  A kernel that cannot complete its contract without hanging the GPU (today: a tile of a chained
- * segment-head launch whose bounded wait for a predecessor expired) raises a STICKY word in device memory owned by the context
+/* Device-side errors.  A kernel that cannot complete its contract without hanging or faulting the GPU (a tile of a chained
+ * segment-head launch whose bounded wait for a predecessor expired; a lookup whose decoded row lies outside the table it was given
+ * -- key offsets / vocabularies of another table: the launch reads the table's last row instead) raises a STICKY word in device memory owned by the context
  * (TT_DEVERR_* bits) and finishes; nothing reaches the host by itself.  tt_ctx_check_device_errors reads the word (synchronises
  * `stream`), and if it is set: clears it, zeroes the context's chain buffers, sets the error string and returns TT_ERR_DEVICE --
  * every plan built since the previous check must then be considered corrupt.  Call it where the host synchronises anyway (end of an
  * epoch, before a checkpoint, when a captured step is closed). */
 #define TT_DEVERR_CHAIN_TIMEOUT 1u
+#define TT_DEVERR_ROW_RANGE 2u
 int tt_ctx_check_device_errors(tt_ctx* ctx, tt_stream stream);
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream);
 /* only the queued slab reduction (the one thing that lives in the caller's shared scratch buffer) */

@@ -149,8 +149,10 @@ int tt_ctx_check_device_errors(tt_ctx* ctx, tt_stream stream) {
   // chained launch on that stream would read as prefix sums
   TT_HIP(hipMemsetAsync(ctx->chain, 0, sizeof(uint32_t) * ((size_t)kChainWords * kChainSlices + 64), st));
   TT_HIP(hipStreamSynchronize(st));
-  tt_set_error("device error word 0x%x:%s the plans built since the last check are invalid (their steps must be rejected)", word,
-               (word & TT_DEVERR_CHAIN_TIMEOUT) ? " a chained segment-head launch gave up waiting for a predecessor tile (tt_dedup_plan / tt_dedup_plan_runs);" : "");
+  tt_set_error("device error word 0x%x:%s%s the steps since the last check are invalid (they must be rejected)", word,
+               (word & TT_DEVERR_CHAIN_TIMEOUT) ? " a chained segment-head launch gave up waiting for a predecessor tile (tt_dedup_plan / tt_dedup_plan_runs);" : "",
+               (word & TT_DEVERR_ROW_RANGE) ? " a lookup decoded rows outside its table (key offsets / vocabularies that belong to another table; tt_embed_lookup_fwd / "
+                                              "tt_embed_lookup_rows_fwd / tt_batch_ingest_lookup) and read the last row instead;" : "");
   return TT_ERR_DEVICE;
 }
 

@@ -33,7 +33,20 @@ struct SideSet {
   int32_t E;
   uint32_t C;          // VEC-wide chunks per row
   uint32_t total_slots;
+  int32_t table_rows;  // lookup kernels: rows of the table the decoded row indexes (0: unchecked)
+  uint32_t* dev_err;   // ... and the context's sticky error word (TT_DEVERR_ROW_RANGE)
 };
+
+// A decoded row that does not lie in the table: key offsets / vocabularies (device arrays the host cannot check without a
+// synchronisation) that belong to another table, or precomputed rows from elsewhere.  Reading it would be a GPU memory fault;
+// the launch reads the last row instead and raises the sticky error word (tt_ctx_check_device_errors -> TT_ERR_DEVICE).
+__device__ __forceinline__ int64_t row_in_table(int64_t row, int32_t table_rows, uint32_t* dev_err) {
+  if (table_rows > 0 && (uint64_t)row >= (uint64_t)table_rows) {
+    if (dev_err) atomicOr(dev_err, TT_DEVERR_ROW_RANGE);
+    row = table_rows - 1;
+  }
+  return row;
+}
 
 __device__ __forceinline__ int side_of(const SideSet& a, uint32_t slot) {
   int si = 0;
@@ -73,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void lookup_kernel(SideSet a, const float
         int64_t id = s.ids[local];
         const int64_t hi = s.vocab[k] - 1;
         id = id < 0 ? 0 : (id > hi ? hi : id);                 // clamp: cat_embed.py:117
-        const int64_t row = s.off[k] + id;
+        const int64_t row = row_in_table(s.off[k] + id, a.table_rows, a.dev_err);
         if (chunk == 0 && rows_out) rows_out[slot] = (int32_t)row;
         if (table == nullptr) { ok[u] = false; continue; }      // rows-only mode (wave-uniform)
         const float* src = table + row * a.E + chunk * VEC;
@@ -163,12 +176,12 @@ __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const 
       const uint32_t k = local - b * (uint32_t)s.K;
       int64_t row;
       if (ROWS) {
-        row = rows_in[slot];
+        row = row_in_table(rows_in[slot], a.table_rows, a.dev_err);
       } else {
         int64_t id = s.ids[local];
         const int64_t hi = s.vocab[k] - 1;
         id = id < 0 ? 0 : (id > hi ? hi : id);             // clamp: cat_embed.py:117
-        row = s.off[k] + id;
+        row = row_in_table(s.off[k] + id, a.table_rows, a.dev_err);
         if (rows_out) rows_out[slot] = (int32_t)row;
       }
       rec.src = table + row * a.E;
@@ -1712,6 +1725,8 @@ struct LookupPart {
   unsigned long long* ring;          // measurement: per-workgroup stamps of the tile role (tt_embed_lookup_set_profile)
   int32_t ring_slots;
   int32_t nt;                        // TT_OPT_LOOKUP_NT: bf16 rows leave by non-temporal stores
+  int32_t table_rows;                // row_in_table
+  uint32_t* dev_err;
 };
 constexpr int kTileSlots = 512;
 
@@ -1805,7 +1820,7 @@ __device__ __forceinline__ void ingest_lookup_body(const StoreIngestArgs& a, con
       int64_t id = idv[cc];
       if (FROM_STORE) a.ids_out[si][(int64_t)b0 * K + e] = id;  // sample-major: the KJT values() of the batch
       id = id < 0 ? 0 : (id > hiv[cc] ? hiv[cc] : id);           // clamp: cat_embed.py:117
-      row = (int32_t)(ofv[cc] + id);
+      row = (int32_t)row_in_table(ofv[cc] + id, lp.table_rows, lp.dev_err);
       dst = ((int64_t)(b0 + blv[cc]) * lp.ld[si] + (int64_t)kv[cc] * lp.E) * esz;
       tl[blv[cc] * KP + kv[cc]] = row;
     }
@@ -2199,6 +2214,8 @@ static int lookup_fwd_impl(tt_ctx* ctx, const float* table, int64_t table_rows, 
   if (slots == 0) return TT_OK;
   a.C = (uint32_t)C;
   a.total_slots = (uint32_t)slots;
+  a.table_rows = (int32_t)table_rows;
+  a.dev_err = ctx->dev_err;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   constexpr int U = 4;
   const bool pow2c = vec4 && table && C <= 64 && (C & (C - 1)) == 0;
@@ -2904,6 +2921,8 @@ static int64_t fill_lookup_part(tt_ctx* ctx, const char* who, const tt_embed_sid
   lp->ring = ctx->lookup_stamps;
   lp->ring_slots = ctx->lookup_stamp_slots;
   lp->nt = ctx->lookup_nt;
+  lp->table_rows = (int32_t)lk->table_rows;
+  lp->dev_err = ctx->dev_err;
   int64_t tiles = 0;
   for (int i = 0; i < n_sides; ++i) {
     const tt_embed_side& s = sides[i];

@@ -52,7 +52,7 @@ class _timed:
         return self
 
     def __exit__(self, *exc):
-        if _SYNC_DEBUG:                              # TT_SYNC_DEBUG=1: name every C-ABI call and wait for it (fault hunting)
+        if _SYNC_DEBUG and not torch.cuda.is_current_stream_capturing():     # TT_SYNC_DEBUG=1: name every C-ABI call and wait for it (fault hunting)
             import sys
             print(f"[tt] {self.name} ...", end="", file=sys.stderr, flush=True)
             torch.cuda.synchronize()

@@ -24,6 +24,7 @@ from typing import Dict, List
 
 import torch
 
+from .config import settings
 from .distributed import DistComm
 from .graph import GraphedTrainStep
 
@@ -95,6 +96,7 @@ class SegmentedTrainStep(GraphedTrainStep):
         if ex is None:
             raise ValueError("SegmentedTrainStep is for the row-wise sharded task (a step without collectives is ONE graph: GraphedTrainStep)")
         self._segments: List[torch.cuda.CUDAGraph] = []
+        self._all_graphs: List[torch.cuda.CUDAGraph] = []
         self._between = []
         self._pool = torch.cuda.graph_pool_handle()
         self._cap_stream = torch.cuda.Stream(device=self._dev.device)
@@ -129,6 +131,8 @@ class SegmentedTrainStep(GraphedTrainStep):
         ctx = torch.cuda.graph(g, pool=self._pool, stream=self._cap_stream, capture_error_mode=self._cap_mode)
         ctx.__enter__()
         self._cap_ctx, self._cap_graph = ctx, g
+        self._all_graphs.append(g)               # (every graph object lives until close(): destroying one -- an EMPTY segment's -- while a later
+        #                                          segment is being captured is "operation not permitted when stream is capturing", from a destructor)
 
     def _end_segment(self):
         import warnings
@@ -142,22 +146,38 @@ class SegmentedTrainStep(GraphedTrainStep):
 
     def _replay_graph(self):
         between = self._between
+        if settings.sync_debug:                      # TT_SYNC_DEBUG=1: name every replay and every collective and wait for it (fault hunting)
+            return self._replay_graph_traced()
         for i, g in enumerate(self._segments):
             if g is not None:
                 g.replay()
             if i < len(between):
                 between[i]()
 
+    def _replay_graph_traced(self):
+        import sys
+        dev = self._dev.device
+        for i, g in enumerate(self._segments):
+            if g is not None:
+                print(f"[tt] segment {i} replay ...", end="", file=sys.stderr, flush=True)
+                g.replay()
+                torch.cuda.synchronize(dev)
+                print(" done", file=sys.stderr, flush=True)
+            if i < len(self._between):
+                print(f"[tt] collective {i} ...", end="", file=sys.stderr, flush=True)
+                self._between[i]()
+                torch.cuda.synchronize(dev)
+                print(" done", file=sys.stderr, flush=True)
+
     def collectives_per_step(self) -> int:
         return len(self._between)
 
     def close(self):
-        segs = getattr(self, "_segments", [])
+        segs = getattr(self, "_all_graphs", [])
         super().close()
         for g in segs:
             try:
-                if g is not None:
-                    g.reset()
+                g.reset()
             except Exception:
                 pass
-        self._segments, self._between = [], []
+        self._segments, self._all_graphs, self._between = [], [], []

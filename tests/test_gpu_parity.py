@@ -289,6 +289,46 @@ def test_chained_plan_timeout_raises_device_error(tt, ctx_option):
     assert U == len(want) and np.array_equal(plan.unique_rows[:U].cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("E,form", [(32, "ids"), (32, "rows"), (6, "ids"), (32, "fused")])
+def test_lookup_rows_outside_the_table_raise_device_error(tt, E, form):
+    """Key offsets / vocabularies are device arrays: the host cannot check them against the table without a synchronisation.  A lookup
+    whose decoded rows lie past the table it was handed (here: offsets of a 3000-row space against a 1000-row table -- a rank's shard
+    indexed by global rows, the bench bug of round 4 that ended in a GPU memory fault) must not read there: it reads the table's last
+    row, raises the sticky device error word, and tt_ctx_check_device_errors reports it.  Forms: from int64 ids (wave kernel, generic
+    kernel at E = 6), from precomputed rows, and the fused hand-over + lookup launch.  In-range slots still get their own rows."""
+    from jodalrob_twotower_amd import ops
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(77)
+    R, B, K = 1000, 256, 3
+    table = torch.from_numpy(rng.standard_normal((R, E)).astype(np.float32)).to(dev)
+    off = torch.tensor([0, 500, 2000], dtype=torch.int64, device=dev)            # key 2 starts past the table
+    voc = torch.tensor([500, 500, 1000], dtype=torch.int64, device=dev)
+    ids = torch.from_numpy(rng.integers(0, 500, (B, K)).astype(np.int64)).to(dev).reshape(-1)
+    out = torch.zeros((B, K * E), dtype=torch.float32, device=dev)
+    _L.check_device_errors(dev)                                                  # start clean
+    side = ops.LookupSide(ids, off, voc, out, K)
+    if form == "ids":
+        ops.embed_lookup(table, [side], B, want_rows=False)
+    elif form == "rows":
+        rows = (ids.view(B, K) + off).to(torch.int32).reshape(-1).contiguous()
+        ops.embed_lookup_rows(table, rows, [side], B)
+    else:
+        if not ops.ingest_lookup_supported(table, [side]):
+            pytest.skip("fused hand-over + lookup does not take this shape")
+        rows_km = torch.empty(B * K, dtype=torch.int32, device=dev)
+        ops.batch_ingest([], [side], B, rows_km, table=table)
+    with pytest.raises(_L.TwoTowerHipError, match="outside its table"):
+        _L.check_device_errors(dev)
+    got = out.view(B, K, E).cpu().numpy()
+    idn = ids.view(B, K).cpu().numpy()
+    tab = table.cpu().numpy()
+    assert np.array_equal(got[:, 0], tab[idn[:, 0]]) and np.array_equal(got[:, 1], tab[500 + idn[:, 1]])
+    assert np.array_equal(got[:, 2], np.broadcast_to(tab[R - 1], (B, E)))        # the out-of-table key: the last row, not a fault
+    _L.check_device_errors(dev)                                                  # the word was cleared
+    ops.embed_lookup(table, [ops.LookupSide(ids, torch.tensor([0, 500, 0], dtype=torch.int64, device=dev), voc, out, K)], B, want_rows=False)
+    _L.check_device_errors(dev)                                                  # a consistent lookup leaves it clean
+
+
 @pytest.mark.parametrize("E,B,vocabs,src_dtype", [(32, 2048, [[2, 2, 12, 5000], [3, 100000]], "f32"), (8, 300, [[5, 9], [4]], "f32"),
                                                    (6, 64, [[3, 1000]], "f32"), (64, 512, [[2, 300], [7]], "f32"),
                                                    (16, 700, [[2, 50]], "f32"), (32, 1500, [[3, 40, 9000], [2]], "bf16"),
