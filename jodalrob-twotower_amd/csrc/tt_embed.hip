@@ -41,6 +41,9 @@ struct SideSet {
 // synchronisation) that belong to another table, or precomputed rows from elsewhere.  Reading it would be a GPU memory fault;
 // the launch reads the last row instead and raises the sticky error word (tt_ctx_check_device_errors -> TT_ERR_DEVICE).
 __device__ __forceinline__ int64_t row_in_table(int64_t row, int32_t table_rows, uint32_t* dev_err) {
+#ifdef TT_NO_ROW_CHECK                                      // measurement builds only (tools/r04_b13.sh: what the check costs)
+  return row;
+#endif
   if (table_rows > 0 && (uint64_t)row >= (uint64_t)table_rows) {
     if (dev_err) atomicOr(dev_err, TT_DEVERR_ROW_RANGE);
     row = table_rows - 1;
