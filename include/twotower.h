@@ -149,6 +149,8 @@ int tt_embed_lookup_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int
  * `rows_sm` when a captured step's batch is handed over (they decode and clamp every id anyway).  sides[i] gives K / out / ld_out /
  * out_dtype (ids, key_row_offset, key_vocab are ignored and may be NULL).  Same bits in the outputs as tt_embed_lookup_fwd on the
  * ids the rows came from (test); the kernel reads a 4-byte row instead of an 8-byte id + its key's offset and vocabulary.
+ * The rows are trusted to lie in [0, table_rows): the hand-over that formed them has checked them (its table_rows argument);
+ * tt_embed_lookup_fwd checks the rows it decodes itself (TT_DEVERR_ROW_RANGE).
  * E = 4 x a power of two, outputs 4-element aligned (TT_ERR_UNSUPPORTED otherwise). */
 int tt_embed_lookup_rows_fwd(tt_ctx* ctx, const float* table, int64_t table_rows, int32_t E,
                              const tt_embed_side* sides, int32_t n_sides, int64_t B, const int32_t* rows,
@@ -638,6 +640,9 @@ int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* s
 int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                     const tt_embed_side* sides, int32_t n_sides, int64_t B, int32_t* rows_km,
                     int32_t* rows_sm /* or NULL: the same rows in slot order, rows_sm[side_base + b*K + k], for tt_embed_lookup_rows_fwd */,
+                    int64_t table_rows /* rows of the table the fused rows index: a row outside [0, table_rows) -- key offsets /
+                                        * vocabularies of another table -- is stored as table_rows - 1 and raises TT_DEVERR_ROW_RANGE,
+                                        * so no consumer of rows_km / rows_sm reads or writes out of bounds; 0: unchecked */,
                     const tt_cvt_list* cvt /* or NULL */, tt_stream stream);
 
 /* The same hand-over STRAIGHT FROM THE DEVICE-RESIDENT FEATURE STORES (two-level gather: pair -> entity row -> dense features
@@ -667,7 +672,8 @@ typedef struct tt_store_side {
 int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
                           const tt_embed_side* sides, const tt_store_side* stores, int32_t n_sides, int64_t B,
                           const int64_t* order /* [B] or NULL */, int32_t* rows_km /* or NULL */,
-                          int32_t* rows_sm /* or NULL: as tt_batch_ingest */, const tt_cvt_list* cvt /* or NULL */, tt_stream stream);
+                          int32_t* rows_sm /* or NULL: as tt_batch_ingest */, int64_t table_rows /* as tt_batch_ingest */,
+                          const tt_cvt_list* cvt /* or NULL */, tt_stream stream);
 
 
 /* Hand-over AND lookup in ONE launch: tt_batch_ingest / tt_batch_ingest_store whose tile workgroups -- they hold the batch's

@@ -161,10 +161,10 @@ SIGNATURES = {
     "tt_dedup_plan_runs": (C.c_int, [vp, vp, i32, i64, i64, vp, vp, vp, vp, vp, sz, vp]),
     "tt_gather_rows": (C.c_int, [vp, vp, i64, i32, vp, i64, vp, i32, vp]),
     "tt_copy_multi": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), vp]),
-    "tt_batch_ingest": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp, vp, C.POINTER(CvtList), vp]),
+    "tt_batch_ingest": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp, vp, i64, C.POINTER(CvtList), vp]),
     "tt_batch_gather": (C.c_int, [vp, vp, i64, vp, i32, vp, i32, vp, vp, vp]),
     "tt_batch_ingest_store": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), C.POINTER(StoreSide), i32,
-                                        i64, vp, vp, vp, C.POINTER(CvtList), vp]),
+                                        i64, vp, vp, vp, i64, C.POINTER(CvtList), vp]),
     "tt_batch_ingest_lookup": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), i32, i64, vp,
                                          C.POINTER(IngestLookup), C.POINTER(CvtList), vp]),
     "tt_batch_ingest_store_lookup": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), C.POINTER(EmbedSide), C.POINTER(StoreSide),

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void lookup_wave_kernel(SideSet a, const 
       const uint32_t k = local - b * (uint32_t)s.K;
       int64_t row;
       if (ROWS) {
-        row = row_in_table(rows_in[slot], a.table_rows, a.dev_err);
+        row = rows_in[slot];                               // checked where they were formed (tt_batch_ingest*: table_rows), not here
       } else {
         int64_t id = s.ids[local];
         const int64_t hi = s.vocab[k] - 1;
@@ -1548,6 +1548,8 @@ struct IngestArgs {
   int32_t side_base[TT_MAX_SIDES];
   int32_t* rows_km;
   int32_t* rows_sm;    // optional: the same fused rows in SLOT order (side_base + b * K + k) for tt_embed_lookup_rows_fwd
+  int32_t table_rows;  // > 0: the rows are checked against this table size where they are formed (row_in_table)
+  uint32_t* dev_err;
 };
 
 __global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
@@ -1593,7 +1595,7 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_kernel(IngestArgs a) {
         const int bl = e / K, k = e - bl * K;
         int64_t id = idv[u];
         id = id < 0 ? 0 : (id > s_hi[k] ? s_hi[k] : id);      // clamp: cat_embed.py:117 (as the lookup)
-        tl[k][bl] = (int32_t)(s_off[k] + id);
+        tl[k][bl] = (int32_t)row_in_table(s_off[k] + id, a.table_rows, a.dev_err);
         if (a.rows_sm) a.rows_sm[a.side_base[si] + (int64_t)b0 * K + e] = tl[k][bl];
       }
     }
@@ -1693,7 +1695,7 @@ __global__ __launch_bounds__(kThreads) void batch_ingest_store_kernel(StoreInges
       int64_t id = idv[u];
       a.ids_out[si][(int64_t)b0 * K + e] = id;                 // sample-major: the KJT values() of the batch
       id = id < 0 ? 0 : (id > s_hi[k] ? s_hi[k] : id);         // clamp: cat_embed.py:117 (as the lookup)
-      tl[k][bl] = (int32_t)(s_off[k] + id);
+      tl[k][bl] = (int32_t)row_in_table(s_off[k] + id, a.g.table_rows, a.g.dev_err);
       if (a.g.rows_sm) a.g.rows_sm[a.g.side_base[si] + (int64_t)b0 * K + e] = tl[k][bl];
     }
   }
@@ -2806,9 +2808,10 @@ int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* s
 }
 
 int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
-                    int32_t n_sides, int64_t B, int32_t* rows_km, int32_t* rows_sm, const tt_cvt_list* cvt, tt_stream stream) {
+                    int32_t n_sides, int64_t B, int32_t* rows_km, int32_t* rows_sm, int64_t table_rows, const tt_cvt_list* cvt, tt_stream stream) {
   TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest: bad copy arguments");
   TT_CHECK_ARG(sides && rows_km && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest: bad side arguments");
+  TT_CHECK_ARG(table_rows >= 0 && table_rows <= INT32_MAX, "tt_batch_ingest: table_rows %lld out of range", (long long)table_rows);
   IngestArgs a{};
   int64_t mx = 0, slots = 0;
   for (int i = 0; i < n; ++i) {
@@ -2824,6 +2827,8 @@ int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const*
   a.B = (int32_t)B;
   a.rows_km = rows_km;
   a.rows_sm = rows_sm;
+  a.table_rows = (int32_t)table_rows;
+  a.dev_err = ctx->dev_err;
   for (int i = 0; i < n_sides; ++i) {
     const tt_embed_side& s = sides[i];
     TT_CHECK_ARG(s.K >= 1 && s.ids && s.key_row_offset && s.key_vocab, "tt_batch_ingest: side %d NULL / no keys", i);
@@ -2850,8 +2855,9 @@ int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const*
 
 int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
                           const tt_store_side* stores, int32_t n_sides, int64_t B, const int64_t* order, int32_t* rows_km, int32_t* rows_sm,
-                          const tt_cvt_list* cvt, tt_stream stream) {
+                          int64_t table_rows, const tt_cvt_list* cvt, tt_stream stream) {
   TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest_store: bad copy arguments");
+  TT_CHECK_ARG(table_rows >= 0 && table_rows <= INT32_MAX, "tt_batch_ingest_store: table_rows %lld out of range", (long long)table_rows);
   TT_CHECK_ARG(sides && stores && n_sides >= 1 && n_sides <= TT_MAX_SIDES && B >= 1, "tt_batch_ingest_store: bad side arguments");
   StoreIngestArgs a{};
   int64_t mx = 0, slots = 0, dense_pieces = 0;
@@ -2869,6 +2875,8 @@ int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* 
   a.g.B = (int32_t)B;
   a.g.rows_km = rows_km;
   a.g.rows_sm = rows_sm;
+  a.g.table_rows = (int32_t)table_rows;
+  a.g.dev_err = ctx->dev_err;
   a.order = order;
   for (int i = 0; i < n_sides; ++i) {
     const tt_embed_side& s = sides[i];

@@ -191,6 +191,12 @@ class GraphedTrainStep:
         store.ingest = (ids, [v._version for v in ids], rows_km, xs, getattr(self, "_rows_sm", None))
         store.ingest_x_fresh = xs is not None
 
+    @staticmethod
+    def _table_rows(store) -> int:
+        """Size of the row space the hand-over's fused rows index: the fused table, or the GLOBAL row space of row-wise sharded tables."""
+        g = getattr(store, "global_rows", None)
+        return int(g) if g is not None else int(store.weight.shape[0])
+
     def _run_ingest(self, pairs, src_ids):
         """One launch: the copy segments + the key-major rows of `src_ids` (default: the static id buffers themselves) (+ the
         lookup of those rows into the persistent tower inputs)."""
@@ -202,7 +208,7 @@ class GraphedTrainStep:
             ops.batch_ingest(pairs, sides, B, rows_km, table=store.weight, cvt=self._cvt())
         else:
             sides = [ops.LookupSide(v, e._key_row_offset, e._key_vocab, None, len(e.keys)) for e, v in zip(embs, src)]
-            ops.batch_ingest(pairs, sides, B, rows_km, rows_sm=getattr(self, "_rows_sm", None), cvt=self._cvt())
+            ops.batch_ingest(pairs, sides, B, rows_km, rows_sm=getattr(self, "_rows_sm", None), cvt=self._cvt(), table_rows=self._table_rows(store))
         self._register(store, ids, rows_km)
 
     def _body(self):
@@ -419,7 +425,7 @@ class GraphedTrainStep:
         ops.batch_ingest_store([self._fill_slot()], sides, stores, B, order, rows_km, offset if order is not None else 0,
                                table=self._ingest[0].weight if xs is not None else None,
                                rows_sm=getattr(self, "_rows_sm", None) if (self._ingest is not None and xs is None) else None,
-                               cvt=self._cvt())
+                               cvt=self._cvt(), table_rows=self._table_rows(self._ingest[0]) if self._ingest is not None else 0)
         self._mark_slot()
         if self._ingest is not None:
             store, _, _, ids, _ = self._ingest

@@ -740,12 +740,14 @@ def _embed_sides(sides, B, dev, who, with_ids: bool, with_out: bool):
 
 
 def batch_ingest(pairs, sides: Sequence[LookupSide], B: int, rows_km: Optional[torch.Tensor], table: Optional[torch.Tensor] = None,
-                 rows_sm: Optional[torch.Tensor] = None, cvt=None):
+                 rows_sm: Optional[torch.Tensor] = None, cvt=None, table_rows: int = 0):
     """copy_multi's segments plus, per side, the fused rows of the side's ids in key-major order (tt_batch_ingest): the batch
     hand-over of a graph-replayed step in one launch.  sides[i].ids is the id source (the incoming batch or the static buffer).
     table given (and sides[i].out set): the same launch also looks the rows up and writes them into sides[i].out -- the towers'
     input (tt_batch_ingest_lookup); rows_km may then be None.  rows_sm (without `table`): the same fused rows also in slot order,
-    the input of embed_lookup_rows."""
+    the input of embed_lookup_rows.  table_rows (without `table`): the size of the row space the fused rows index -- a row outside
+    it is stored as the last row and raises the device error word (_lib.check_device_errors), so neither embed_lookup_rows nor the
+    plan's consumers touch memory outside the table; 0 = unchecked."""
     if table is not None:
         dev, n = table.device, len(pairs)
         dst = (L.vp * max(n, 1))(*[d.data_ptr() for d, _ in pairs])
@@ -781,8 +783,8 @@ def batch_ingest(pairs, sides: Sequence[LookupSide], B: int, rows_km: Optional[t
     if rows_sm is not None and (rows_sm.dtype != torch.int32 or rows_sm.numel() != M or not rows_sm.is_contiguous()):
         raise ValueError("batch_ingest: rows_sm must be a contiguous int32 tensor of sum(B*K) elements")
     with _timed("tt_batch_ingest"):
-        L.check(L.load().tt_batch_ingest(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), L.ptr(rows_sm), _cvt_list(cvt),
-                                         L.stream(dev)), "tt_batch_ingest")
+        L.check(L.load().tt_batch_ingest(L.ctx(dev), n, dst, src, nb, arr, len(sides), B, L.ptr(rows_km), L.ptr(rows_sm), int(table_rows),
+                                         _cvt_list(cvt), L.stream(dev)), "tt_batch_ingest")
 
 
 @dataclass
@@ -798,7 +800,7 @@ class StoreSide:
 
 def batch_ingest_store(pairs, sides: Sequence[LookupSide], stores: Sequence[StoreSide], B: int, order: Optional[torch.Tensor],
                        rows_km: Optional[torch.Tensor], order_offset: int = 0, table: Optional[torch.Tensor] = None,
-                       rows_sm: Optional[torch.Tensor] = None, cvt=None):
+                       rows_sm: Optional[torch.Tensor] = None, cvt=None, table_rows: int = 0):
     """tt_batch_ingest_store: the batch `order[order_offset : order_offset + B]` of the pair list gathered out of the device
     stores straight into the step's static buffers (+ key-major fused rows, + the copy segments `pairs`), one launch.
     table given (and sides[i].out set): the launch also looks the batch's rows up into sides[i].out (tt_batch_ingest_store_lookup).
@@ -853,7 +855,7 @@ def batch_ingest_store(pairs, sides: Sequence[LookupSide], stores: Sequence[Stor
         raise ValueError("batch_ingest_store: rows_sm must be a contiguous int32 tensor of sum(B*K) elements")
     with _timed("tt_batch_ingest_store"):
         L.check(L.load().tt_batch_ingest_store(L.ctx(dev), n, dst, src, nb, arr, st, len(sides), B, order_ptr, L.ptr(rows_km), L.ptr(rows_sm),
-                                               _cvt_list(cvt), L.stream(dev)), "tt_batch_ingest_store")
+                                               int(table_rows), _cvt_list(cvt), L.stream(dev)), "tt_batch_ingest_store")
 
 
 # ---------------------------------------------------------------------------------------------- multi-GPU routing

@@ -295,7 +295,8 @@ def test_lookup_rows_outside_the_table_raise_device_error(tt, E, form):
     whose decoded rows lie past the table it was handed (here: offsets of a 3000-row space against a 1000-row table -- a rank's shard
     indexed by global rows, the bench bug of round 4 that ended in a GPU memory fault) must not read there: it reads the table's last
     row, raises the sticky device error word, and tt_ctx_check_device_errors reports it.  Forms: from int64 ids (wave kernel, generic
-    kernel at E = 6), from precomputed rows, and the fused hand-over + lookup launch.  In-range slots still get their own rows."""
+    kernel at E = 6), the hand-over launch that precomputes the rows for tt_embed_lookup_rows_fwd (the check sits where the rows
+    are formed), and the fused hand-over + lookup launch.  In-range slots still get their own rows."""
     from jodalrob_twotower_amd import ops
     dev = torch.device(DEV)
     rng = np.random.default_rng(77)
@@ -310,8 +311,13 @@ def test_lookup_rows_outside_the_table_raise_device_error(tt, E, form):
     if form == "ids":
         ops.embed_lookup(table, [side], B, want_rows=False)
     elif form == "rows":
-        rows = (ids.view(B, K) + off).to(torch.int32).reshape(-1).contiguous()
-        ops.embed_lookup_rows(table, rows, [side], B)
+        # the captured step's pair: the hand-over forms the fused rows (and checks them against the row space it is told), the lookup
+        # from precomputed rows trusts them
+        rows_km = torch.empty(B * K, dtype=torch.int32, device=dev)
+        rows_sm = torch.empty(B * K, dtype=torch.int32, device=dev)
+        ops.batch_ingest([], [ops.LookupSide(ids, off, voc, None, K)], B, rows_km, rows_sm=rows_sm, table_rows=R)
+        assert int(rows_sm.max()) == R - 1 and int(rows_km.max()) == R - 1
+        ops.embed_lookup_rows(table, rows_sm, [side], B)
     else:
         if not ops.ingest_lookup_supported(table, [side]):
             pytest.skip("fused hand-over + lookup does not take this shape")
