@@ -84,6 +84,8 @@ def parse(argv=None):
                     "reading the hand-over launch's precomputed rows")
     ap.add_argument("--lookup-nt", action="store_true", help="TT_OPT_LOOKUP_NT: non-temporal stores of the looked-up rows (A/B)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the HBM-resident lookup leg and the configs[4] leg of the default run")
+    ap.add_argument("--unroll", type=int, default=1, help="training steps per graph launch (unrolled.UnrolledTrainStep: the hand-over launches become "
+                                                          "graph nodes re-pointed per launch; one graph launch costs ~8 us on this runtime); unsharded step only")
     return ap.parse_args(argv)
 
 
@@ -183,7 +185,7 @@ class Leg:
         eager_only = (ctx["staged"] and not args.dist_segmented) or args.dist_eager
         self.use_graph = (args.mode == "graph" and args.optimizer == "fused_sparse" and not eager_only) if sharded else \
             (args.mode == "graph" and args.optimizer != "torch_adam")
-        self.gstep = None
+        self.gstep, self.unroll = None, 1
         self.profile = ops.LookupProfile(dev) if (self.use_graph and not args.no_lookup_profile) else None
         ex = getattr(task, "exchange", None)
         if sharded and ex is not None and hasattr(ex, "reset_capacity"):
@@ -204,7 +206,15 @@ class Leg:
             try:
                 if sharded and args.dist_segmented:
                     raise RuntimeError("--dist-segmented")
-                self.gstep = GraphedTrainStep(task, self.opt, self.pool[0], **kw)
+                if args.unroll > 1 and not sharded and not args.fused_handover:
+                    from jodalrob_twotower_amd.unrolled import UnrolledTrainStep
+                    self.gstep = UnrolledTrainStep(task, self.opt, self.pool[0], unroll=args.unroll, **kw)
+                    self.unroll = args.unroll
+                    self.launch_form = f"hip graph replay, {args.unroll} steps (hand-overs included) per graph launch"
+                    if args.steps % args.unroll or args.warmup % args.unroll:
+                        self.gstep._single()                # remainder steps: the single-step sibling, captured here and not in the timed region
+                else:
+                    self.gstep = GraphedTrainStep(task, self.opt, self.pool[0], **kw)
                 task._bench_gstep = self.gstep
             except Exception as e:                      # a capture that fails on some RCCL / world size must not lose the run
                 if not sharded:
@@ -240,13 +250,24 @@ class Leg:
         self.sched.step()
         return res
 
+    def steps(self, start: int, count: int):
+        """issues steps start .. start + count - 1 (an unrolled captured step: `unroll` of them per graph launch, a remainder one by one)"""
+        res, i, U = None, 0, self.unroll
+        while i < count:
+            if U > 1 and count - i >= U:
+                res = self.gstep.step_many([self.pool[(start + i + j) % len(self.pool)] for j in range(U)], after_each=self.sched.step)[-1]
+                i += U
+            else:
+                res = self.step(start + i)
+                i += 1
+        return res
+
     def run(self):
         """W warm-up steps, then EXACTLY K steps between barrier + synchronize on both sides; MAX over ranks."""
         import torch
         from jodalrob_twotower_amd import ops
         args, ctx = self.args, self.ctx
-        for i in range(args.warmup):
-            res = self.step(i)
+        res = self.steps(0, args.warmup)
         ctx["fence"]()
         lookup_name = "tt_embed_lookup_fwd" if not self.sharded else "tt_embed_lookup_fwd[place]"   # sharded: the launch that fills the tower inputs
         timer = ops.KernelTimer(names=[lookup_name])
@@ -256,8 +277,7 @@ class Leg:
             self.profile.reset()
             torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            res = self.step(args.warmup + i)
+        res = self.steps(args.warmup, args.steps)
         t_enqueue = time.perf_counter() - t0                     # host time to issue the K steps (no sync inside)
         ctx["fence"]()
         dt = time.perf_counter() - t0
@@ -288,18 +308,19 @@ class Leg:
         self.dt, self.t_enqueue, self.loss = dt, t_enqueue, float(res["loss"].detach())
         # median of per-step DEVICE times (HIP events at the step boundaries) in a second pass: a short timed region is
         # fragile evidence on its own, and events between replays would perturb the region above
-        n2 = min(args.steps, 50)
+        U = self.unroll                                                 # (an unrolled step: events between graph launches, time / U)
+        n2 = max(min(args.steps, 50) // U, 1)
         t2 = ops.KernelTimer(names=["tt_batch_ingest_lookup"])          # the hand-over launch is eager: HIP events on its stream bracket it
         if self.fused_handover:
             ops.set_timer(t2)
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n2 + 1)]
         evs[0].record()
         for i in range(n2):
-            self.step(args.warmup + args.steps + i)
+            self.steps(args.warmup + args.steps + i * U, U)
             evs[i + 1].record()
         torch.cuda.synchronize()
         ops.set_timer(None)
-        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n2))
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) / U for i in range(n2))
         self.device_ms_median = per[len(per) // 2] if per else None
         self.handover_event_us = sorted(a.elapsed_time(b) * 1e3 for a, b in t2.records.get("tt_batch_ingest_lookup", []))
         return dt
@@ -1022,12 +1043,24 @@ def device_store_leg(args, leg, ctx, entities: int = 262_144, key: str = "value_
         res = leg.gstep.step_from_store(ns, cs, pairs, order, (j % 64) * B)
         leg.sched.step()
         return res
-    for j in range(min(10, K)):
-        one(j)
+    U = int(getattr(leg.gstep, "unroll", 1))
+
+    def many(j0, count):                                          # (an unrolled captured step: U batches per graph launch)
+        res, i = None, 0
+        while i < count:
+            if U > 1 and count - i >= U:
+                res = leg.gstep.steps_from_store(ns, cs, pairs, order, [((j0 + i + u) % 64) * B for u in range(U)], after_each=leg.sched.step)[-1]
+                i += U
+            else:
+                res = one(j0 + i)
+                i += 1
+        return res
+    many(0, min(10, K))
+    if U > 1 and K % U:
+        leg.gstep._single()
     ctx["fence"]()
     t0 = time.perf_counter()
-    for j in range(K):
-        res = one(10 + j)
+    res = many(10, K)
     ctx["fence"]()
     dt = ctx["max_over_ranks"](time.perf_counter() - t0)
     loss = float(res["loss"].detach())

@@ -100,6 +100,16 @@ int tt_ctx_set_option(tt_ctx* ctx, int32_t option, int32_t value);
 #define TT_DEVERR_CHAIN_TIMEOUT 1u
 #define TT_DEVERR_ROW_RANGE 2u
 int tt_ctx_check_device_errors(tt_ctx* ctx, tt_stream stream);
+/* The hand-over launch as a node of a captured graph.  A tt_batch_ingest* call on a stream that is being captured becomes a kernel
+ * node; tt_handover_captured_node hands that node out (NULL if the last call was not captured) and forgets it.  Later, between
+ * tt_handover_retarget(ctx, graph_exec, node) and tt_handover_retarget(ctx, NULL, NULL), every tt_batch_ingest* call launches
+ * NOTHING: it re-points `node` of the executable graph `graph_exec` (hipGraphExec_t) at the call's own kernel, grid and arguments
+ * (hipGraphExecKernelNodeSetParams), so that the next launch of the graph hands over THAT batch -- launches already enqueued keep
+ * theirs.  What it is for: a graph that holds SEVERAL training steps, hand-overs included (graph.GraphedTrainStep(unroll=U)): one graph
+ * launch costs ~8 us on top of its nodes on this runtime (tools/probe/graph_setparams.hip), U steps per launch pay it once.
+ * Reference counterpart: none (torch.compile(mode="reduce-overhead") replays one step per launch, scripts/train.py:223-225). */
+int tt_handover_retarget(tt_ctx* ctx, void* graph_exec, void* node);
+int tt_handover_captured_node(tt_ctx* ctx, void** node);
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream);
 /* only the queued slab reduction (the one thing that lives in the caller's shared scratch buffer) */
 int tt_flush_deferred_slabs(tt_ctx* ctx, tt_stream stream);

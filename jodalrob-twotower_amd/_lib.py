@@ -121,6 +121,8 @@ SIGNATURES = {
     "tt_ctx_set_option": (C.c_int, [vp, i32, i32]),
     "tt_flush_deferred": (C.c_int, [vp, vp]),
     "tt_ctx_check_device_errors": (C.c_int, [vp, vp]),
+    "tt_handover_retarget": (C.c_int, [vp, vp, vp]),
+    "tt_handover_captured_node": (C.c_int, [vp, C.POINTER(vp)]),
     "tt_deferred_pending": (C.c_int, [vp]),
     "tt_launch_count": (C.c_uint64, []),
     "tt_flush_deferred_slabs": (C.c_int, [vp, vp]),
@@ -278,6 +280,29 @@ def check_device_errors(device: torch.device):
     if device.type != "cuda" or idx not in _ctxs:
         return
     check(load().tt_ctx_check_device_errors(_ctxs[idx], stream(device)), "tt_ctx_check_device_errors")
+
+
+def handover_captured_node(device: torch.device) -> Optional[int]:
+    """tt_handover_captured_node: the graph node the last tt_batch_ingest* call became (its stream was being captured), or None."""
+    h = vp()
+    check(load().tt_handover_captured_node(ctx(device), C.byref(h)), "tt_handover_captured_node")
+    return h.value
+
+
+class handover_retarget:
+    """with handover_retarget(device, graph_exec, node): every tt_batch_ingest* call inside re-points that node of the executable
+    graph at its own kernel and arguments instead of launching (tt_handover_retarget)."""
+
+    def __init__(self, device: torch.device, graph_exec: int, node: int):
+        self.device, self.exec, self.node = device, graph_exec, node
+
+    def __enter__(self):
+        check(load().tt_handover_retarget(ctx(self.device), vp(self.exec), vp(self.node)), "tt_handover_retarget")
+        return self
+
+    def __exit__(self, *exc):
+        check(load().tt_handover_retarget(ctx(self.device), vp(0), vp(0)), "tt_handover_retarget")
+        return False
 
 
 def flush_deferred(device: torch.device):

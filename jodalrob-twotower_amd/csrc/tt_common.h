@@ -35,6 +35,12 @@ struct tt_ctx {
   uint32_t* dev_err;        // sticky device-side error word (TT_DEVERR_*): behind the chain pool; tt_ctx_check_device_errors
   int chain_spin;           // TT_OPT_CHAIN_SPIN: polls before a chained tile gives up (default 2^22)
   int lookup_nt;            // TT_OPT_LOOKUP_NT: the fused hand-over + lookup launch stores its bf16 rows non-temporally (default 0)
+  // hand-over launches as nodes of a captured graph (tt_handover_retarget): while ho_exec is set, tt_batch_ingest* re-point node
+  // ho_node of that executable graph at their arguments instead of launching; ho_last = the node the last tt_batch_ingest* call left
+  // in the capture its stream was in
+  void* ho_exec;
+  void* ho_node;
+  void* ho_last;
 };
 
 constexpr uint32_t kChainReady = 0x80000000u;

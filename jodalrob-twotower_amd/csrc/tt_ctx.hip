@@ -81,6 +81,7 @@ int tt_ctx_create(int device, tt_ctx** out) {
   c->chained = 1;
   c->chain_spin = 1 << 22;
   c->dev_err = nullptr;
+  c->ho_exec = c->ho_node = c->ho_last = nullptr;
   {
     int prev = 0;
     TT_HIP(hipGetDevice(&prev));
@@ -154,6 +155,20 @@ int tt_ctx_check_device_errors(tt_ctx* ctx, tt_stream stream) {
                (word & TT_DEVERR_ROW_RANGE) ? " a lookup decoded rows outside its table (key offsets / vocabularies that belong to another table; tt_embed_lookup_fwd / "
                                               "tt_embed_lookup_rows_fwd / tt_batch_ingest_lookup) and read the last row instead;" : "");
   return TT_ERR_DEVICE;
+}
+
+int tt_handover_retarget(tt_ctx* ctx, void* graph_exec, void* node) {
+  TT_CHECK_ARG(ctx != nullptr && ((graph_exec == nullptr) == (node == nullptr)), "tt_handover_retarget: NULL context / one of (graph_exec, node) NULL");
+  ctx->ho_exec = graph_exec;
+  ctx->ho_node = node;
+  return TT_OK;
+}
+
+int tt_handover_captured_node(tt_ctx* ctx, void** node) {
+  TT_CHECK_ARG(ctx != nullptr && node != nullptr, "tt_handover_captured_node: NULL argument");
+  *node = ctx->ho_last;
+  ctx->ho_last = nullptr;
+  return TT_OK;
 }
 
 int tt_flush_deferred(tt_ctx* ctx, tt_stream stream) {

@@ -2807,6 +2807,32 @@ int tt_copy_multi(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* s
   return TT_OK;
 }
 
+// The hand-over kernels leave by this door: an ordinary launch -- remembering, when the stream is being captured, the graph node the
+// launch became -- or, while the context is retargeting (tt_handover_retarget), no launch at all: the node of the executable graph
+// is re-pointed at this call's function, grid and arguments (hipGraphExecKernelNodeSetParams; launches of the graph already in flight
+// keep the arguments they were enqueued with: tools/probe/graph_setparams.hip).
+static int handover_launch(tt_ctx* ctx, const void* fn, dim3 grid, void** args, hipStream_t st) {
+  if (ctx->ho_exec) {
+    hipKernelNodeParams p{};
+    p.func = const_cast<void*>(fn);
+    p.gridDim = grid;
+    p.blockDim = dim3(kThreads);
+    p.kernelParams = args;
+    TT_HIP(hipGraphExecKernelNodeSetParams(reinterpret_cast<hipGraphExec_t>(ctx->ho_exec), reinterpret_cast<hipGraphNode_t>(ctx->ho_node), &p));
+    return TT_OK;
+  }
+  TT_HIP(hipLaunchKernel(fn, grid, dim3(kThreads), args, 0, st));
+  TT_LAUNCH_CHECK();
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const hipGraphNode_t* deps = nullptr;
+  size_t n_deps = 0;
+  if (hipStreamGetCaptureInfo_v2(st, &cs, nullptr, nullptr, &deps, &n_deps) == hipSuccess && cs == hipStreamCaptureStatusActive && n_deps == 1)
+    ctx->ho_last = const_cast<void*>(reinterpret_cast<const void*>(deps[0]));
+  else
+    (void)hipGetLastError();
+  return TT_OK;
+}
+
 int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
                     int32_t n_sides, int64_t B, int32_t* rows_km, int32_t* rows_sm, int64_t table_rows, const tt_cvt_list* cvt, tt_stream stream) {
   TT_CHECK_ARG(ctx && n >= 0 && n <= TT_MAX_COPIES && (n == 0 || (dst && src && bytes)), "tt_batch_ingest: bad copy arguments");
@@ -2848,9 +2874,9 @@ int tt_batch_ingest(tt_ctx* ctx, int32_t n, void* const* dst, const void* const*
   if (gx > cap) gx = cap;
   const int64_t tiles = tt_cdiv(B, 64) * n_sides;        // row 0 holds every tile (the copy rows stride over their segments)
   if (tiles > gx) gx = tiles;
-  batch_ingest_kernel<<<dim3((unsigned)gx, (unsigned)(n + 1 + cvt_rows)), kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
-  TT_LAUNCH_CHECK();
-  return TT_OK;
+  void* args[] = {&a};
+  return handover_launch(ctx, reinterpret_cast<const void*>(batch_ingest_kernel), dim3((unsigned)gx, (unsigned)(n + 1 + cvt_rows)), args,
+                         reinterpret_cast<hipStream_t>(stream));
 }
 
 int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
@@ -2909,10 +2935,9 @@ int tt_batch_ingest_store(tt_ctx* ctx, int32_t n, void* const* dst, const void* 
   const int64_t tiles = tt_cdiv(B, 64) * n_sides;        // row 0 holds every tile (the other rows stride over their work)
   if (tiles > gx) gx = tiles;
   const dim3 grid((unsigned)gx, (unsigned)(1 + n_sides + n + cvt_rows));
-  if (vec) batch_ingest_store_kernel<true><<<grid, kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
-  else batch_ingest_store_kernel<false><<<grid, kThreads, 0, reinterpret_cast<hipStream_t>(stream)>>>(a);
-  TT_LAUNCH_CHECK();
-  return TT_OK;
+  void* args[] = {&a};
+  return handover_launch(ctx, vec ? reinterpret_cast<const void*>(batch_ingest_store_kernel<true>) : reinterpret_cast<const void*>(batch_ingest_store_kernel<false>),
+                         grid, args, reinterpret_cast<hipStream_t>(stream));
 }
 
 // shared by the two fused hand-over + lookup entries: checks the lookup half and fills LookupPart; returns the tile count or < 0
@@ -2964,15 +2989,11 @@ static int64_t fill_lookup_part(tt_ctx* ctx, const char* who, const tt_embed_sid
   return tiles;
 }
 
-#define TT_INGEST_LOOKUP_LAUNCH(FROM_STORE, VEC)                                                                         \
-  do {                                                                                                                    \
-    switch (lp.E) {                                                                                                       \
-      case 8: ingest_lookup_kernel<1, FROM_STORE, VEC><<<grid, kThreads, 0, st>>>(a, lp); break;                          \
-      case 16: ingest_lookup_kernel<2, FROM_STORE, VEC><<<grid, kThreads, 0, st>>>(a, lp); break;                         \
-      case 32: ingest_lookup_kernel<4, FROM_STORE, VEC><<<grid, kThreads, 0, st>>>(a, lp); break;                         \
-      default: ingest_lookup_kernel<8, FROM_STORE, VEC><<<grid, kThreads, 0, st>>>(a, lp); break;                         \
-    }                                                                                                                     \
-  } while (0)
+#define TT_INGEST_LOOKUP_FN(FROM_STORE, VEC)                                                                              \
+  (lp.E == 8 ? reinterpret_cast<const void*>(ingest_lookup_kernel<1, FROM_STORE, VEC>)                                    \
+   : lp.E == 16 ? reinterpret_cast<const void*>(ingest_lookup_kernel<2, FROM_STORE, VEC>)                                 \
+   : lp.E == 32 ? reinterpret_cast<const void*>(ingest_lookup_kernel<4, FROM_STORE, VEC>)                                 \
+                : reinterpret_cast<const void*>(ingest_lookup_kernel<8, FROM_STORE, VEC>))
 
 int tt_batch_ingest_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes, const tt_embed_side* sides,
                            int32_t n_sides, int64_t B, int32_t* rows_km, const tt_ingest_lookup* lk, const tt_cvt_list* cvt, tt_stream stream) {
@@ -3014,10 +3035,8 @@ int tt_batch_ingest_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void*
   if (gx > cap) gx = cap;
   if (tiles > gx) gx = tiles;
   const dim3 grid((unsigned)gx, (unsigned)(n + 1 + cvt_rows));
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  TT_INGEST_LOOKUP_LAUNCH(false, true);
-  TT_LAUNCH_CHECK();
-  return TT_OK;
+  void* args[] = {&a, &lp};
+  return handover_launch(ctx, TT_INGEST_LOOKUP_FN(false, true), grid, args, reinterpret_cast<hipStream_t>(stream));
 }
 
 int tt_batch_ingest_store_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const void* const* src, const int64_t* bytes,
@@ -3074,11 +3093,8 @@ int tt_batch_ingest_store_lookup(tt_ctx* ctx, int32_t n, void* const* dst, const
   if (gx > cap) gx = cap;
   if (tiles > gx) gx = tiles;
   const dim3 grid((unsigned)gx, (unsigned)(1 + n_sides + n + cvt_rows));
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (vec) TT_INGEST_LOOKUP_LAUNCH(true, true);
-  else TT_INGEST_LOOKUP_LAUNCH(true, false);
-  TT_LAUNCH_CHECK();
-  return TT_OK;
+  void* args[] = {&a, &lp};
+  return handover_launch(ctx, vec ? TT_INGEST_LOOKUP_FN(true, true) : TT_INGEST_LOOKUP_FN(true, false), grid, args, reinterpret_cast<hipStream_t>(stream));
 }
 
 int tt_batch_gather(tt_ctx* ctx, const int64_t* entity, int64_t B, const float* dense_store, int32_t dense_dim,

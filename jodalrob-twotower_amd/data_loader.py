@@ -99,10 +99,17 @@ class DevicePairLoader:
         """One epoch on the fast path: every full batch is gathered out of the stores by the captured step's own hand-over launch
         (GraphedTrainStep.step_from_store) and replayed; the ragged last batch -- a captured step has one batch size -- goes
         through `ragged_step` (a second GraphedTrainStep captured at the remainder's size, sharing task and optimiser) or, without
-        one, through `eager_step(batch)` (skipped when None).  Yields the step's result dict per batch."""
+        one, through `eager_step(batch)` (skipped when None).  Yields the step's result dict per batch (an unrolled step's U results
+        arrive together, after its one launch: read them before the next launch overwrites them)."""
         order = self.epoch_order()
         n, B = self.pairs.shape[0], self.batch_size
-        for lo in range(0, n, B):
+        U = int(getattr(graphed_step, "unroll", 1))
+        lo = 0
+        while U > 1 and lo + U * B <= n:                      # unrolled.UnrolledTrainStep: U full batches per graph launch
+            for r in graphed_step.steps_from_store(self.notice, self.company, self.pairs, order, [lo + j * B for j in range(U)]):
+                yield r
+            lo += U * B
+        for lo in range(lo, n, B):
             if lo + B <= n:
                 yield graphed_step.step_from_store(self.notice, self.company, self.pairs, order, lo)
             elif ragged_step is not None and ragged_step.static["notice"]["dense"].shape[0] == n - lo:

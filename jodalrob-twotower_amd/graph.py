@@ -28,9 +28,11 @@ from .optim import FusedAdam
 
 
 class GraphedTrainStep:
+    _steps_per_replay = 1          # (unrolled.UnrolledTrainStep: several steps, hand-overs included, per graph launch)
+
     def __init__(self, task, optimizer: FusedAdam, example_batch: Dict, return_metrics: bool = True, warmup: int = 3,
                  defer_long: bool = True, defer_slabs: bool = True, defer_riders: bool = True, preserve_state: bool = True,
-                 accumulate_metrics: bool = False):
+                 accumulate_metrics: bool = False, metric_sums: Optional[torch.Tensor] = None):
         """defer_long / defer_slabs: the long rows' finish rides in the optimiser's launch and the towers' slab reduction in the
         embedding gradient's (both bit-identical to the separate launches; the arguments exist for that comparison).
         preserve_state: the eager warm-up steps (allocator + first-call paths) are REAL steps on the example batch; with this flag
@@ -39,7 +41,8 @@ class GraphedTrainStep:
         rows move and only those are saved; dense-gradient tables are saved whole).
         accumulate_metrics: `metric_sums` (device, 8 floats: loss, accuracy, positive mean, negative mean, gap, ...: twotower.h
         tt_score_loss_finish) += the step's figures inside the replay -- an epoch's mean loss / accuracy (the reference driver's
-        avg_train_loss: scripts/train.py:357-358) without a host sync per step."""
+        avg_train_loss: scripts/train.py:357-358) without a host sync per step.  metric_sums: add into THIS tensor (another captured
+        step's sums: the two then share one epoch total; what it holds survives this object's warm-up)."""
         if not isinstance(optimizer, FusedAdam):
             raise TypeError("GraphedTrainStep needs jodalrob_twotower_amd.optim.FusedAdam (device-side hyper-parameters)")
         self.task, self.opt, self.return_metrics = task, optimizer, return_metrics
@@ -57,6 +60,7 @@ class GraphedTrainStep:
         self._host_ring = torch.zeros(self._ring, self._slot_len, dtype=torch.float32).pin_memory()
         self._slot_events = [None] * self._ring
         self._slot = 0
+        self._unmarked = []                                            # ring slots filled since the last _mark_slot
         self._host = self._host_ring[0, :self._n_scalar]
         self._dev = torch.zeros(ng * 8 + 2, dtype=torch.float32, device=dev)
         self._hp_dev = self._dev[:ng * 8].view(ng, 8)
@@ -64,6 +68,9 @@ class GraphedTrainStep:
         self._ones = torch.ones((), dtype=torch.float32, device=dev)
         self._towers = [m for m in task.modules() if hasattr(m, "_seed_dev") and hasattr(m, "dense_parameters")]
         self.metric_sums = torch.zeros(8, dtype=torch.float32, device=dev) if (accumulate_metrics and return_metrics) else None
+        sums_before = None
+        if metric_sums is not None and self.metric_sums is not None:
+            self.metric_sums, sums_before = metric_sums, metric_sums.clone()
         self._ingest = self._setup_ingest()
         self._shadows = self._setup_shadows()
         if self._ingest is not None:
@@ -80,7 +87,7 @@ class GraphedTrainStep:
         if snap is not None:
             self._restore_state(snap)
         if self.metric_sums is not None:
-            self.metric_sums.zero_()
+            self.metric_sums.zero_() if sums_before is None else self.metric_sums.copy_(sums_before)
         if self._ingest is not None:
             self._run_ingest([], None)
         self._push_scalars()
@@ -101,8 +108,8 @@ class GraphedTrainStep:
             optimizer._hp_dev = None
             for t in self._towers:
                 t._seed_dev = None
-        # the capture itself ran the host-side bookkeeping of one optimiser step without executing it
-        optimizer.advance_steps(-1)
+        # the capture itself ran the host-side bookkeeping of one optimiser step (per captured body) without executing it
+        optimizer.advance_steps(-self._steps_per_replay)
 
     def _capture(self, mode: str):
         """Captures self._body() into self.graph (ONE graph; segmented.SegmentedTrainStep cuts it at the collectives instead)."""
@@ -335,9 +342,10 @@ class GraphedTrainStep:
         opt._step_cache = None
         opt.zero_grad(set_to_none=True)
 
-    def _fill_slot(self):
-        """Writes this step's scalars into the next ring slot; returns the (dst, src) copy pair."""
+    def _fill_slot(self, ahead: int = 0):
+        """Writes the scalars of the step `ahead` steps after the next one into the next ring slot; returns the (dst, src) copy pair."""
         self._slot = (self._slot + 1) % self._ring
+        self._unmarked.append(self._slot)
         ev = self._slot_events[self._slot]
         if ev is not None:
             ev.synchronize()                                        # the copy that last read this slot has run
@@ -345,7 +353,7 @@ class GraphedTrainStep:
         ng = len(self.opt.param_groups)
         # the optimiser's own count: eager steps taken between replays (a ragged last batch, another captured step sharing
         # the optimiser) advance the bias corrections exactly as they do in an all-eager loop
-        step = self.opt.peek_step() + 1
+        step = self.opt.peek_step() + 1 + ahead
         for gi, g in enumerate(self.opt.param_groups):
             hp = ops.adam_hparams(step, float(g["lr"]), g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"])
             host[gi * 8: gi * 8 + 6] = torch.tensor(hp)
@@ -353,37 +361,46 @@ class GraphedTrainStep:
         return (self._dev, host)
 
     def _mark_slot(self):
-        ev = self._slot_events[self._slot]
-        if ev is None:
-            ev = self._slot_events[self._slot] = torch.cuda.Event()
+        """One event behind the launch(es) that read the slots filled since the last mark: a slot is refilled only after it."""
+        slots, self._unmarked = self._unmarked, []
+        if not slots:
+            return
+        ev = self._slot_events[slots[0]]
+        if ev is None or len(slots) > 1:
+            ev = torch.cuda.Event()
         ev.record()
+        for sl in slots:
+            self._slot_events[sl] = ev
 
     def _push_scalars(self):
         ops.copy_multi([self._fill_slot()])
         self._mark_slot()
 
+    def _handover_pairs(self, batch: Optional[Dict]):
+        """(copy segments, per-side id sources) that hand `batch` over into the static buffers (None: nothing to copy)."""
+        pairs, src_ids = [], []                                 # src_ids per side: where this step's ids are read from
+        if batch is None:
+            return pairs, None
+        for side in ("notice", "company"):
+            d, v = batch[side]["dense"], batch[side]["kjt"].values()
+            sd, sv = self.static[side]["dense"], self.static[side]["kjt"].values()
+            if d.device == sd.device and d.dtype == sd.dtype and v.dtype == sv.dtype and d.is_contiguous() and v.is_contiguous():
+                pairs += [(sd, d), (sv, v)]
+                src_ids.append(v)
+            else:                                               # host batch / other dtype: ordinary copies
+                sd.copy_(d, non_blocking=True)
+                sv.copy_(v, non_blocking=True)
+                src_ids.append(sv)
+        return pairs, src_ids
+
     def step(self, batch: Optional[Dict] = None):
         """Train on `batch` (or on whatever the static buffers hold); returns the static result."""
-        src_ids = []                                            # per side: where this step's ids are read from
-        if batch is not None:
-            pairs = []
-            for side in ("notice", "company"):
-                d, v = batch[side]["dense"], batch[side]["kjt"].values()
-                sd, sv = self.static[side]["dense"], self.static[side]["kjt"].values()
-                if d.device == sd.device and d.dtype == sd.dtype and v.dtype == sv.dtype and d.is_contiguous() and v.is_contiguous():
-                    pairs += [(sd, d), (sv, v)]
-                    src_ids.append(v)
-                else:                                           # host batch / other dtype: ordinary copies
-                    sd.copy_(d, non_blocking=True)
-                    sv.copy_(v, non_blocking=True)
-                    src_ids.append(sv)
-        else:
-            pairs = []
+        pairs, src_ids = self._handover_pairs(batch)
         if self._ingest is not None:
             # ONE launch: the four batch buffers + the scalars + the key-major rows of this step's ids -- also when nobody handed a
             # batch over: the static id buffers may have been written to by means no version counter sees (`.data`), and the
             # replayed plan sorts whatever rows_km holds
-            self._run_ingest(pairs + [self._fill_slot()], src_ids if batch is not None else None)
+            self._run_ingest(pairs + [self._fill_slot()], src_ids)
             self._mark_slot()
         else:
             ops.copy_multi(pairs + [self._fill_slot()])         # ONE launch: the four batch buffers + the scalars
@@ -392,7 +409,7 @@ class GraphedTrainStep:
 
     def _replay(self):
         self._replay_graph()
-        self.opt.advance_steps(1)
+        self.opt.advance_steps(self._steps_per_replay)
         ex = getattr(self.task, "exchange", None)
         if ex is not None and hasattr(ex, "poll_overflow"):
             ex.poll_overflow()                                  # sharded tables: a bucket overflow rejects the step (non-blocking)
@@ -405,6 +422,12 @@ class GraphedTrainStep:
         (the reference assembles the batch on the host and copies it over: unified_bid_data_loader.py:461-504, :630-684;
         scripts/train.py:261-273).  `pairs`: int64 [P, 2] on the device, (notice row, company row) per pair; the stores are
         data_loader.DeviceFeatureStore objects (`.dense` f32 [N, D], `.categorical` int64 [N, K])."""
+        self._ingest_from_store(notice_store, company_store, pairs, order, offset)
+        self._mark_slot()
+        return self._replay()
+
+    def _ingest_from_store(self, notice_store, company_store, pairs: torch.Tensor, order: Optional[torch.Tensor], offset: int, ahead: int = 0):
+        """The hand-over launch of step_from_store (tt_batch_ingest_store) into the static buffers; `ahead`: _fill_slot."""
         B = self.static["notice"]["dense"].shape[0]
         if pairs.dtype != torch.int64 or pairs.dim() != 2 or pairs.shape[1] != 2 or not pairs.is_contiguous():
             raise ValueError("step_from_store: pairs must be a contiguous int64 [P, 2] tensor")
@@ -422,15 +445,13 @@ class GraphedTrainStep:
             sides.append(ops.LookupSide(None, e._key_row_offset, e._key_vocab, outs[i], len(e.keys)))
             stores.append(ops.StoreSide(flat[base + i:], 2, fs.dense, fs.categorical, sd, sv))
         rows_km = self._ingest[2] if self._ingest is not None else None
-        ops.batch_ingest_store([self._fill_slot()], sides, stores, B, order, rows_km, offset if order is not None else 0,
+        ops.batch_ingest_store([self._fill_slot(ahead)], sides, stores, B, order, rows_km, offset if order is not None else 0,
                                table=self._ingest[0].weight if xs is not None else None,
                                rows_sm=getattr(self, "_rows_sm", None) if (self._ingest is not None and xs is None) else None,
                                cvt=self._cvt(), table_rows=self._table_rows(self._ingest[0]) if self._ingest is not None else 0)
-        self._mark_slot()
         if self._ingest is not None:
             store, _, _, ids, _ = self._ingest
             self._register(store, ids, rows_km)
-        return self._replay()
 
     def close(self):
         """Final (synchronous) overflow check, then drop the captured graph and its private pool.  With a process group

@@ -361,7 +361,8 @@ def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
     batch tensors handed to GraphedTrainStep.step / the eager step, bit for bit: per-step losses and the final state.  Third leg
     (ADVICE round 3): the same two epochs with EVERY batch through the eager step and no captured step at all -- the capture's
     warm-up steps must leave no trace (preserve_state) and the replays' Adam step numbers must follow the optimiser's own count
-    across the eager ragged batches (FusedAdam.peek_step): also bit for bit (pairs % batch != 0, two epochs)."""
+    across the eager ragged batches (FusedAdam.peek_step): also bit for bit (pairs % batch != 0, two epochs).  Fourth leg (round 4):
+    the store-fed epochs with TWO batches per graph launch (unrolled.UnrolledTrainStep.steps_from_store) -- bit for bit again."""
     from jodalrob_twotower_amd import synthetic
     from jodalrob_twotower_amd.data_loader import create_unified_bid_dataloaders
     from jodalrob_twotower_amd.graph import GraphedTrainStep
@@ -374,7 +375,7 @@ def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
     schema = tt.build_torchrec_schema_from_meta(notice_table="notice", company_table="company", pair_table="bid_two_tower",
                                                 pair_notice_id_cols=["bidntceno", "bidntceord"], pair_company_id_cols=["bizno"], metadata_path=str(meta))
     finals = {}
-    for mode in ("tensors", "store", "eager"):
+    for mode in ("tensors", "store", "eager", "store_unrolled"):
         torch.manual_seed(123)                                           # the preprocessor's frozen random projectors draw from it
         src = synthetic.SyntheticSource(900, 700, 1200, vn, vc)
         train_loader, _ = create_unified_bid_dataloaders(src, schema, batch_size=256, test_split=0.0, shuffle_seed=7, test_mode=True, pair_limit=1200, device=DEV)
@@ -391,7 +392,11 @@ def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
                 p.copy_(0.05 * torch.randn(p.shape, device=DEV))
         task.train()
         opt = FusedAdam.for_task(task, lr=1e-2, weight_decay=1e-5)
-        gs = GraphedTrainStep(task, opt, first, warmup=1) if mode != "eager" else None
+        if mode == "store_unrolled":                                     # two full batches per graph launch (steps_from_store), the ragged one eager
+            from jodalrob_twotower_amd.unrolled import UnrolledTrainStep
+            gs = UnrolledTrainStep(task, opt, first, unroll=2, warmup=1)
+        else:
+            gs = GraphedTrainStep(task, opt, first, warmup=1) if mode != "eager" else None
 
         def eager(b):
             opt.zero_grad()
@@ -401,7 +406,7 @@ def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
             return r
         losses = []
         for ep in range(2):
-            if mode == "store":
+            if mode in ("store", "store_unrolled"):
                 for r in train_loader.step_batches(gs, eager):
                     losses.append(r["loss"].item())
             else:
@@ -420,6 +425,9 @@ def test_step_from_store_equals_step_on_loader_batches(tt, tmp_path):
     assert finals["eager"][0] == finals["store"][0], (finals["eager"][0], finals["store"][0])
     for k, v in finals["eager"][1].items():
         assert torch.equal(v, finals["store"][1][k]), k
+    assert finals["store_unrolled"][2] == 10 and finals["store_unrolled"][0] == finals["store"][0], (finals["store_unrolled"][0], finals["store"][0])
+    for k, v in finals["store"][1].items():
+        assert torch.equal(v, finals["store_unrolled"][1][k]), k
 
 
 def test_fast_evaluation_equals_batch_loop(tt, tmp_path):

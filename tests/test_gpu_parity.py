@@ -686,6 +686,79 @@ def test_graphed_step_equals_eager(tt, manifest, mlp_dtype):
         assert np.array_equal(v, finals["graph"][1][k]), k
 
 
+@pytest.mark.parametrize("U", [2, 3])
+def test_unrolled_step_equals_single_steps(tt, manifest, U):
+    """unrolled.UnrolledTrainStep: U whole steps -- their hand-over launches included, as graph nodes whose arguments the host
+    replaces before every launch (tt_handover_retarget) -- per graph launch == the same steps as U single-step replays, bit for
+    bit: per-step losses, final state, optimiser step count.  Covers a learning rate that changes between the steps of ONE launch
+    (after_each = the scheduler's step), dropout (a fresh seed per step through the ring; the test re-seeds torch's CPU generator,
+    which the ring draws from, before every step), out-of-range ids, a batch that arrives in host memory in lane 1; 7 steps = two
+    (U = 3) or three (U = 2) launches + a remainder through step() (the single-step sibling, created while training is under way:
+    its warm-up must leave no trace), and metric sums shared by both captured steps."""
+    from jodalrob_twotower_amd.graph import GraphedTrainStep
+    from jodalrob_twotower_amd.unrolled import UnrolledTrainStep
+    from jodalrob_twotower_amd.optim import FusedAdam
+    cfg = dict(manifest["cases"]["wide_b40"])
+    cfg["B"] = 256
+    n_steps = 7
+    batches = [synth_batch_numpy(cfg["B"], cfg["vocab_n"], cfg["vocab_c"], cfg["din_n"], cfg["din_c"], 1900 + i, oob=True) for i in range(n_steps)]
+    finals = {}
+    for mode in ("single", "unrolled"):
+        task = make_task(tt, cfg, embedding_grad="sparse", score_dtype="bf16", mlp_dtype="bf16", dropout_rate=0.1)
+        load_state(task, init_state_numpy({k: tuple(v.shape) for k, v in task.state_dict().items()}, 57))
+        task.train()
+        task._pair_check_done = True
+        for tw in (task.two_tower_model.notice_tower, task.two_tower_model.company_tower):
+            tw._seed_override = 4242               # a capture bakes a host seed (drawn at capture time) to which the ring's per-step word is added: the same one for both objects
+        opt = FusedAdam.for_task(task, lr=1e-2, weight_decay=1e-5)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lambda s: (s + 1) / 4 if s < 3 else 1.0)
+        tb = [to_batch(tt, b, cfg["keys_n"], cfg["keys_c"]) for b in batches]
+        tb[1] = {s_: {"dense": tb[1][s_]["dense"].cpu(), "kjt": type(tb[1][s_]["kjt"])(tb[1][s_]["kjt"].keys(), tb[1][s_]["kjt"].values().cpu())}
+                 for s_ in ("notice", "company")}                                     # a host batch (lane 1)
+        losses = []
+        if mode == "single":
+            gs = GraphedTrainStep(task, opt, tb[0], warmup=2, accumulate_metrics=True)
+            for i, b in enumerate(tb):
+                torch.manual_seed(1000 + i)                                         # the ring draws the step's dropout seed from torch's CPU generator
+                r = gs.step(b)
+                sched.step()
+                losses.append(r["loss"].item())
+        else:
+            gs = UnrolledTrainStep(task, opt, tb[0], unroll=U, warmup=2, accumulate_metrics=True)
+            assert gs.unroll == U and len(gs._nodes) == U
+            i, nxt = 0, [0]
+
+            def after_each():
+                sched.step()
+                nxt[0] += 1
+                torch.manual_seed(1000 + nxt[0])
+            while i + U <= n_steps:
+                torch.manual_seed(1000 + i)
+                nxt[0] = i
+                res = gs.step_many(tb[i:i + U], after_each=after_each)
+                losses += [r["loss"].item() for r in res]
+                i += U
+            while i < n_steps:                                                      # remainder: the single-step sibling
+                gs._single()
+                torch.manual_seed(1000 + i)
+                r = gs.step(tb[i])
+                sched.step()
+                losses.append(r["loss"].item())
+                i += 1
+            assert gs.single is not None or n_steps % U == 0
+        torch.cuda.synchronize()
+        assert opt.current_step() == n_steps
+        finals[mode] = (losses, {k: v.detach().cpu().numpy().copy() for k, v in task.state_dict().items()}, gs.metric_sums.cpu().numpy().copy(),
+                        gs.library_launches)
+        gs.close()
+    assert finals["single"][3] == finals["unrolled"][3]                              # launches per STEP: the hand-over counted once either way
+    assert len(set(finals["single"][0])) == n_steps
+    assert finals["single"][0] == finals["unrolled"][0], (finals["single"][0], finals["unrolled"][0])
+    for k, v in finals["single"][1].items():
+        assert np.array_equal(v, finals["unrolled"][1][k]), k
+    assert np.array_equal(finals["single"][2], finals["unrolled"][2])                # one epoch total, whoever ran the step
+
+
 def test_graph_ingest_key_major_plan(tt, manifest, monkeypatch):
     """GraphedTrainStep hands a batch over with ops.batch_ingest (copies + the fused rows of the batch's ids in key-major order,
     which the duplicate-row plan then sorts instead of gathering every key's rows out of the sample-major array) == the same

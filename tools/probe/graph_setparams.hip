@@ -8,6 +8,7 @@
 //   2. the same with the node's FUNCTION and grid replaced (mark -> mark_other).
 //   3. timing: [eager short kernel + graph of 13 dependent short kernels] against [graph of 14, first node's arguments replaced
 //      per launch], 2000 iterations each; the host cost of the update call.
+//   4. what one graph LAUNCH costs on top of its nodes: K-node graphs back to back, K = 7 .. 56, linear fit.
 //
 // Build: hipcc --offload-arch=gfx950 -O2 -o tools/probe/graph_setparams tools/probe/graph_setparams.hip
 #include <hip/hip_runtime.h>
@@ -201,6 +202,45 @@ int main(int argc, char** argv) {
     }
     CK(hipMemcpy(host.data(), out, sizeof(int) * (N + 8), hipMemcpyDeviceToHost));
     printf("   last values written: eager %d, replaced %d (both must be %d)\n", host[N + 1], host[N + 2], IT - 1);
+
+    // ---- 4: what ONE graph launch costs on top of its nodes: graphs of K dependent kernels, K = 7 .. 56, back to back ----
+    printf("4. per iteration of a K-node graph launched back to back (us), and per node:\n");
+    double t7 = 0, t56 = 0;
+    for (int KK : {7, 14, 28, 56}) {
+      hipGraph_t g;
+      hipGraphExec_t e;
+      CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+      for (int k = 0; k < KK; ++k) step_kernel<<<n / 256, 256, 0, st>>>(p, n);
+      CK(hipStreamEndCapture(st, &g));
+      CK(hipGraphInstantiate(&e, g, nullptr, nullptr, 0));
+      const int it = 2000 * 14 / KK;
+      for (int i = 0; i < 50; ++i) CK(hipGraphLaunch(e, st));
+      float ms;
+      CK(hipEventRecord(ev0, st));
+      for (int i = 0; i < it; ++i) CK(hipGraphLaunch(e, st));
+      CK(hipEventRecord(ev1, st));
+      CK(hipEventSynchronize(ev1));
+      CK(hipEventElapsedTime(&ms, ev0, ev1));
+      const double us = ms * 1000 / it;
+      printf("   K = %2d: %7.2f us per launch, %.3f us per node\n", KK, us, us / KK);
+      if (KK == 7) t7 = us;
+      if (KK == 56) t56 = us;
+      CK(hipGraphExecDestroy(e));
+      CK(hipGraphDestroy(g));
+    }
+    const double per_node = (t56 - t7) / 49.0;
+    printf("   linear fit over K = 7 .. 56: %.3f us per node + %.2f us per graph launch\n", per_node, t7 - 7 * per_node);
+    // the same K kernels launched eagerly (the host must keep up: 2000 x 14 launches)
+    {
+      float ms;
+      for (int i = 0; i < 200; ++i) step_kernel<<<n / 256, 256, 0, st>>>(p, n);
+      CK(hipEventRecord(ev0, st));
+      for (int i = 0; i < 2000 * 14; ++i) step_kernel<<<n / 256, 256, 0, st>>>(p, n);
+      CK(hipEventRecord(ev1, st));
+      CK(hipEventSynchronize(ev1));
+      CK(hipEventElapsedTime(&ms, ev0, ev1));
+      printf("   eager, back to back: %.3f us per kernel\n", ms * 1000 / (2000 * 14));
+    }
   }
   return 0;
 }
