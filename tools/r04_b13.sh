@@ -1,5 +1,7 @@
 #!/bin/bash
 # what the lookup's row check costs (same box, alternating libraries); whole GPU suite on the new library; kernel stats of the sharded world-1 step
+# (tools/probe/libtwotower_nocheck.so = the library linked with tt_embed.hip compiled -DTT_NO_ROW_CHECK: a measurement build made for this
+#  batch and not kept in the tree; rebuild it as jodalrob-twotower_amd/build.py does, one object replaced)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r04_b13; mkdir -p $out
 A="--no-extra-legs --no-cpu-baseline --no-h2d"

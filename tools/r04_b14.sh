@@ -1,5 +1,6 @@
 #!/bin/bash
 # row check moved to the hand-over launch: A/B against the unchecked build on one box; whole GPU suite
+# (tools/probe/libtwotower_nocheck.so: see tools/r04_b13.sh)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r04_b14; mkdir -p $out
 A="--no-extra-legs --no-cpu-baseline --no-h2d"

@@ -1,5 +1,7 @@
 #!/bin/bash
 # gemm_back: order of the three roles in the flat grid (012 = shipping), rocprof kernel time + step time on one box
+# (tools/probe/libtwotower_orderXYZ.so = the library with tt_gemm_back_batched's role loop reordered to X, Y, Z: measurement builds made for
+#  this batch from a three-line patch that was not kept -- profiles/NOTES.md, 'gemm_back: the order of its roles')
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/r04_b18; mkdir -p $out
 A="--no-extra-legs --no-cpu-baseline --no-h2d"
