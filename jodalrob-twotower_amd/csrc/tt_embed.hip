@@ -1215,22 +1215,76 @@ __global__ __launch_bounds__(kThreads) void seg_reduce_chunk_kernel(SideSet a, c
   else seg_chunk_body<VEC, DT, LGT>(a, sorted_src, ws, LG, blockIdx.x - g1, gridDim.x - g1);
 }
 
+// measurement aid, compiled in with -DTT_SEG_STAMPS only (tools/r04_seg_stamps.py): start / end stamps and role of every workgroup
+#ifdef TT_SEG_STAMPS
+__device__ unsigned long long g_seg_stamps[4096 * 4];
+#define TT_SEG_STAMP(i, role) do { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4096) { \
+  g_seg_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); g_seg_stamps[blockIdx.x * 4 + 2] = (role) + 1; } } while (0)
+#else
+#define TT_SEG_STAMP(i, role) do { } while (0)
+#endif
+
 // ... and, in front of both, the workgroups of a slab reduction tt_towers_mlp_bwd left queued in the context
 // (TT_OPT_DEFER_SLAB_REDUCE): the weight gradients' split-K slabs and this reduction do not depend on each other
+// Order of the roles in the flat grid (round 4, from per-workgroup stamps: tools/r04_seg_stamps.py).  The machine holds ~1800 of these
+// workgroups at a time and the dispatcher hands them out in index order, so what comes first starts at once and what comes last starts
+// when slots free up.  Longest first:
+//   [the first kChunkFirst chunk workgroups: the long rows' chunks, four dependent trips of gathers (9 us); they used to start last, 10 us in]
+//   [the first half of the row workgroups: the plan sorts a side's small-vocabulary keys first, whose 33-64-slot rows take 11 us]
+//   [the slab items: 2-4 us each; ONE workgroup per projection-bias item]
+//   [the second half of the rows: 3.5 us each]
+//   [the remaining chunk workgroups: idle unless the batch is skewed]
+constexpr uint32_t kChunkFirst = 8;
+#ifndef TT_SEG_THREADS
+#define TT_SEG_THREADS 256
+#endif
+constexpr int kSegThreads = TT_SEG_THREADS;          // (measurement builds: 512 / 1024 -- is the dispatch rate per workgroup or per wave?)
 template <int VEC, int DT, int LGT>
-__global__ __launch_bounds__(kThreads) void seg_reduce_chunk_slab_kernel(SideSet a, const int32_t* __restrict__ sorted_src,
+__global__ __launch_bounds__(kSegThreads) void seg_reduce_chunk_slab_kernel(SideSet a, const int32_t* __restrict__ sorted_src,
                                                                         const int32_t* __restrict__ seg, const int32_t* __restrict__ unique_rows,
                                                                         const int32_t* __restrict__ n_unique, int32_t mode,
                                                                         float* __restrict__ out, GradWs ws, uint32_t LG, uint32_t g1,
-                                                                        SlabBatch sb, uint32_t nsx, uint32_t nsy) {
-  const uint32_t ns = nsx * nsy;
-  if (blockIdx.x < ns) {
-    slab_reduce_block(sb, (int)(blockIdx.x % nsx), (int)nsx, (int)(blockIdx.x / nsx));
+                                                                        SlabBatch sb, uint32_t nsx, uint32_t n_items, uint32_t ns) {
+  const uint32_t g2 = gridDim.x - g1 - ns;
+  const uint32_t gc = g2 < kChunkFirst ? g2 : kChunkFirst;
+#ifndef TT_SEG_LAYOUT
+#define TT_SEG_LAYOUT 2
+#endif
+  // rows in front of the slab items: half of them (layout 2), all (3), none (4: measurement builds)
+  const uint32_t r1 = TT_SEG_LAYOUT == 2 ? (g1 + 1) / 2 : (TT_SEG_LAYOUT == 3 ? g1 : 0u);
+  uint32_t b = blockIdx.x;
+  if (b < gc) {
+    TT_SEG_STAMP(0, 2);
+    seg_chunk_body<VEC, DT, LGT>(a, sorted_src, ws, LG, b, g2);
+    TT_SEG_STAMP(1, 2);
     return;
   }
-  const uint32_t bid = blockIdx.x - ns, nb = gridDim.x - ns;
-  if (bid < g1) seg_reduce_body<VEC, DT, LGT>(a, sorted_src, seg, unique_rows, n_unique, mode, out, ws, LG, false, true, bid, g1);
-  else seg_chunk_body<VEC, DT, LGT>(a, sorted_src, ws, LG, bid - g1, nb - g1);
+  b -= gc;
+  if (b < r1) {
+    TT_SEG_STAMP(0, 1);
+    seg_reduce_body<VEC, DT, LGT>(a, sorted_src, seg, unique_rows, n_unique, mode, out, ws, LG, false, true, b, g1);
+    TT_SEG_STAMP(1, 1);
+    return;
+  }
+  b -= r1;
+  if (b < ns) {
+    TT_SEG_STAMP(0, 0);
+    int item, bx;
+    if (slab_role_locate(sb, (int)n_items, (int)nsx, (int)b, item, bx)) slab_reduce_block(sb, bx, (int)nsx, item);
+    TT_SEG_STAMP(1, 0);
+    return;
+  }
+  b -= ns;
+  if (b < g1 - r1) {
+    TT_SEG_STAMP(0, 1);
+    seg_reduce_body<VEC, DT, LGT>(a, sorted_src, seg, unique_rows, n_unique, mode, out, ws, LG, false, true, r1 + b, g1);
+    TT_SEG_STAMP(1, 1);
+    return;
+  }
+  b -= g1 - r1;
+  TT_SEG_STAMP(0, 2);
+  seg_chunk_body<VEC, DT, LGT>(a, sorted_src, ws, LG, gc + b, g2);
+  TT_SEG_STAMP(1, 2);
 }
 
 // one WORKGROUP per long row: its lane groups sum contiguous ranges of the row's chunk partials (8 loads in flight,
@@ -2169,6 +2223,16 @@ static int fill_cvt(const char* who, const tt_cvt_list* cvt, CvtDev* v, int64_t*
 
 extern "C" {
 
+#ifdef TT_SEG_STAMPS
+int tt_debug_seg_stamps(int clear, unsigned long long* host_out) {
+  if (clear) {
+    static unsigned long long zeros[4096 * 4];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_seg_stamps), zeros, sizeof(zeros)) == hipSuccess ? 0 : 1;
+  }
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_seg_stamps), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int tt_embed_lookup_set_profile(tt_ctx* ctx, uint64_t* ring_dev, int32_t n_slots) {
   TT_CHECK_ARG(ctx, "tt_embed_lookup_set_profile: ctx NULL");
   TT_CHECK_ARG(ring_dev == nullptr || n_slots >= 1, "tt_embed_lookup_set_profile: n_slots must be >= 1");
@@ -2487,7 +2551,7 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
     if (int rc = tt_gemm_deferred_flush(ctx, st)) return rc;
     slabs = nullptr;
   }
-  const int nsx = slabs ? tt_slab_blocks_x(slabs) : 0;
+  const int nsx = slabs ? tt_slab_role_blocks_x(slabs) : 0;
   const int g1 = grid_for(ctx, M * LG);
   const int g2 = grid_for(ctx, gl.max_chunks * LG);
   const int g3 = (int)(gl.max_long < (int64_t)ctx->num_cus * 8 ? gl.max_long : (int64_t)ctx->num_cus * 8);   // a workgroup per long row
@@ -2500,9 +2564,12 @@ int tt_embed_grad_bwd(tt_ctx* ctx, const tt_grad_src* srcs, int32_t n_srcs, int6
 #define TT_SEG_LAUNCH(V, D, G)                                                                                                  \
   do {                                                                                                                          \
     if (planned && slabs) {                                                                                                     \
-      seg_reduce_chunk_slab_kernel<V, D, G><<<nsx * slabs->n + g1 + g2, kThreads, 0, st>>>(                                     \
-          a, sorted_src, seg_offsets, unique_rows, n_unique, mode, out, gl.ws, LG, (uint32_t)g1, slabs->sb, (uint32_t)nsx,      \
-          (uint32_t)slabs->n);                                                                                                  \
+      const int sc = kSegThreads / kThreads;                                                                                  \
+      const int g1s = (int)tt_cdiv(g1, sc), g2s = (int)tt_cdiv(g2, sc), nsxs = (int)tt_cdiv(nsx, sc);                           \
+      const int nss = tt_slab_role_blocks(slabs, nsxs);                                                                         \
+      seg_reduce_chunk_slab_kernel<V, D, G><<<nss + g1s + g2s, kSegThreads, 0, st>>>(                                           \
+          a, sorted_src, seg_offsets, unique_rows, n_unique, mode, out, gl.ws, LG, (uint32_t)g1s, slabs->sb, (uint32_t)nsxs,    \
+          (uint32_t)slabs->n, (uint32_t)nss);                                                                                   \
       TT_LAUNCH_CHECK();                                                                                                        \
       slabs->n = 0;                                                                                                             \
       slabs->maxtotal = 1;                                                                                                      \

@@ -60,26 +60,69 @@ inline int tt_slab_blocks_x(const TnPending* p) {
   int64_t b = (p->maxtotal + 255) / 256;
   return (int)(b > 1024 ? 1024 : b);
 }
+// the slab reduction as a ROLE of another launch (tt_embed_grad_bwd's): a flat run of workgroups, `nbx` per ordinary item and ONE
+// per projection-bias item (a single workgroup's work).  One element per thread, as the stand-alone launch: a thread that owns four
+// lives 11 us (its 4 x 28 loads go out eight at a time), and the registers that would hold them all in flight (122 - 218) cost the row
+// role its occupancy (seg_reduce_chunk_slab anatomy, profiles/NOTES.md)
+#ifndef TT_SLAB_ROLE_PER_THREAD
+#define TT_SLAB_ROLE_PER_THREAD 1
+#endif
+inline int tt_slab_role_blocks_x(const TnPending* p) {
+  int64_t b = (p->maxtotal + 256 * TT_SLAB_ROLE_PER_THREAD - 1) / (256 * TT_SLAB_ROLE_PER_THREAD);
+  return (int)(b > 1024 ? 1024 : (b < 1 ? 1 : b));
+}
+inline int tt_slab_role_blocks(const TnPending* p, int nbx) {
+  int t = 0;
+  for (int i = 0; i < p->n; ++i) t += p->sb.a[i].proj_w ? 1 : nbx;
+  return t;
+}
 
 constexpr int kProjMaxH = 256;
 #ifdef __HIPCC__
-// colsum_out [proj_h0] = proj_w[:, 0:proj_h0]^T . (sum of the proj_colsum_splits slabs colsum_slab [.][M]): one workgroup
+// colsum_out [proj_h0] = proj_w[:, 0:proj_h0]^T . (sum of the proj_colsum_splits slabs colsum_slab [.][M]): one workgroup.
+// Every sum keeps its order (splits ascending, then h ascending); what changed in round 4 is how the loads are issued: 32 independent
+// loads per thread, THEN the 32 dependent adds -- the loop that alternated them made this one workgroup the longest of the launch it
+// rides in (10.4 us for a 64 x 128 matrix-vector product: profiles/NOTES.md, seg_reduce_chunk_slab anatomy).
 __device__ __forceinline__ void proj_bias_finish(const SlabArgs& a, int bx) {
   if (bx != 0) return;
   __shared__ float dbs[kProjMaxH];
   const int H = a.M, t = threadIdx.x, nt = blockDim.x;
+  constexpr int kAhead = 32;
   for (int h = t; h < H; h += nt) {
     float s = 0.f;
-#pragma unroll 8
-    for (int z = 0; z < a.proj_colsum_splits; ++z) s += a.colsum_slab[(int64_t)z * H + h];
+    for (int z0 = 0; z0 < a.proj_colsum_splits; z0 += kAhead) {
+      float v[kAhead];
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) v[k] = z0 + k < a.proj_colsum_splits ? a.colsum_slab[(int64_t)(z0 + k) * H + h] : 0.f;
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k)
+        if (z0 + k < a.proj_colsum_splits) s += v[k];
+    }
     dbs[h] = s;
   }
   __syncthreads();
   for (int i = t; i < a.proj_h0; i += nt) {
     float acc = 0.f;
-    for (int h = 0; h < H; ++h) acc = fmaf(a.proj_w[(int64_t)h * a.proj_ldw + i], dbs[h], acc);
+    for (int h0 = 0; h0 < H; h0 += kAhead) {
+      float w[kAhead];
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k) w[k] = h0 + k < H ? a.proj_w[(int64_t)(h0 + k) * a.proj_ldw + i] : 0.f;
+#pragma unroll
+      for (int k = 0; k < kAhead; ++k)
+        if (h0 + k < H) acc = fmaf(w[k], dbs[h0 + k], acc);
+    }
     a.colsum_out[i] = acc;
   }
+}
+
+// workgroup `blk` of the slab role (tt_slab_role_blocks) -> (item, block of the item); false past the end
+__device__ __forceinline__ bool slab_role_locate(const SlabBatch& batch, int n_items, int nbx, int blk, int& item, int& bx) {
+  for (item = 0; item < n_items; ++item) {
+    const int nb = batch.a[item].proj_w ? 1 : nbx;
+    if (blk < nb) { bx = blk; return true; }
+    blk -= nb;
+  }
+  return false;
 }
 
 // workgroup (bx of nbx, item by) of the slab reduction: the body of slab_reduce_kernel, also run by the first workgroups of
