@@ -1227,20 +1227,25 @@ __device__ unsigned long long g_seg_stamps[4096 * 4];
 // ... and, in front of both, the workgroups of a slab reduction tt_towers_mlp_bwd left queued in the context
 // (TT_OPT_DEFER_SLAB_REDUCE): the weight gradients' split-K slabs and this reduction do not depend on each other
 // Order of the roles in the flat grid (round 4, from per-workgroup stamps: tools/r04_seg_stamps.py).  The machine holds ~1800 of these
-// workgroups at a time and the dispatcher hands them out in index order, so what comes first starts at once and what comes last starts
-// when slots free up.  Longest first:
-//   [the first kChunkFirst chunk workgroups: the long rows' chunks, four dependent trips of gathers (9 us); they used to start last, 10 us in]
-//   [the first half of the row workgroups: the plan sorts a side's small-vocabulary keys first, whose 33-64-slot rows take 11 us]
-//   [the slab items: 2-4 us each; ONE workgroup per projection-bias item]
-//   [the second half of the rows: 3.5 us each]
+// workgroups at a time and hands them out in index order: what comes first starts at once, what comes last starts when slots free up.
+//   [the first kChunkFirst chunk workgroups: the long rows' chunks, four dependent trips of gathers (9 us) -- they used to be dispatched
+//    last, started 10 us in and ended the launch]
+//   [the slab items: 2-4 us each on the still empty machine; ONE workgroup per projection-bias item instead of a row of idle ones]
+//   [the rows: 3.5 us each, the plan's small-vocabulary keys (33-64-slot rows: 11 us) first]
 //   [the remaining chunk workgroups: idle unless the batch is skewed]
+// Rows (all, or half of them) in front of the slab items measured slower (profiles/NOTES.md: 20.3-20.9 against 18.5-19.4 us).
 constexpr uint32_t kChunkFirst = 8;
 #ifndef TT_SEG_THREADS
 #define TT_SEG_THREADS 256
 #endif
 constexpr int kSegThreads = TT_SEG_THREADS;          // (measurement builds: 512 / 1024 -- is the dispatch rate per workgroup or per wave?)
+#ifdef TT_SEG_WAVES                                  // (measurement builds: cap the waves per SIMD)
+#define TT_SEG_OCC __attribute__((amdgpu_waves_per_eu(1, TT_SEG_WAVES)))
+#else
+#define TT_SEG_OCC
+#endif
 template <int VEC, int DT, int LGT>
-__global__ __launch_bounds__(kSegThreads) void seg_reduce_chunk_slab_kernel(SideSet a, const int32_t* __restrict__ sorted_src,
+__global__ __launch_bounds__(kSegThreads) TT_SEG_OCC void seg_reduce_chunk_slab_kernel(SideSet a, const int32_t* __restrict__ sorted_src,
                                                                         const int32_t* __restrict__ seg, const int32_t* __restrict__ unique_rows,
                                                                         const int32_t* __restrict__ n_unique, int32_t mode,
                                                                         float* __restrict__ out, GradWs ws, uint32_t LG, uint32_t g1,
@@ -1248,9 +1253,9 @@ __global__ __launch_bounds__(kSegThreads) void seg_reduce_chunk_slab_kernel(Side
   const uint32_t g2 = gridDim.x - g1 - ns;
   const uint32_t gc = g2 < kChunkFirst ? g2 : kChunkFirst;
 #ifndef TT_SEG_LAYOUT
-#define TT_SEG_LAYOUT 2
+#define TT_SEG_LAYOUT 4
 #endif
-  // rows in front of the slab items: half of them (layout 2), all (3), none (4: measurement builds)
+  // rows in front of the slab items: none (layout 4, shipping); half of them (2), all (3): measurement builds
   const uint32_t r1 = TT_SEG_LAYOUT == 2 ? (g1 + 1) / 2 : (TT_SEG_LAYOUT == 3 ? g1 : 0u);
   uint32_t b = blockIdx.x;
   if (b < gc) {

@@ -87,7 +87,7 @@ __device__ __forceinline__ void proj_bias_finish(const SlabArgs& a, int bx) {
   if (bx != 0) return;
   __shared__ float dbs[kProjMaxH];
   const int H = a.M, t = threadIdx.x, nt = blockDim.x;
-  constexpr int kAhead = 32;
+  constexpr int kAhead = 16;
   for (int h = t; h < H; h += nt) {
     float s = 0.f;
     for (int z0 = 0; z0 < a.proj_colsum_splits; z0 += kAhead) {

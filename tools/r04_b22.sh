@@ -6,7 +6,7 @@ out=gpurun_out/r04_b22; mkdir -p $out
 A="--no-extra-legs --no-cpu-baseline --no-h2d"
 lib=jodalrob-twotower_amd/libtwotower_hip.so
 cp $lib /tmp/lib_l2.so
-for v in l2 layout3 layout4 prev l2 prev; do
+for v in ${VARIANTS:-l2 layout3 layout4 prev l2 prev}; do
   if [ $v = l2 ]; then cp /tmp/lib_l2.so $lib; else cp tools/probe/libtwotower_$v.so $lib; fi
   timeout -k 10 300 python bench.py $A > $out/${v}_$RANDOM.json 2> $out/$v.err || { echo "bench $v failed"; tail -3 $out/$v.err; exit 1; }
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$v -o k -- python bench.py $A --steps 50 > /dev/null 2> $out/prof_$v.err
