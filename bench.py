@@ -48,8 +48,11 @@ MFMA_FP8_PEAK_TFLOPS = 5000.0     # dense fp8 through the block-scaled f8f6f4 in
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=20)
+    # defaults: 2000 timed steps behind 200 warm-up steps = half a second of GPU time.  Round 4 measured what a short region costs: 100 steps
+    # behind 20 (23 ms) read 0.2308-0.2332 ms per step where 4000 behind 200 read 0.2263-0.2265 -- the first replays of a cold process are
+    # slower and the region's fixed ends (first enqueue, final synchronise: ~0.15 ms) weigh 0.6 % at 100 steps (profiles/NOTES.md)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=8192, help="pairs per step: per GPU at N = 1 and in the weak leg, GLOBAL in the strong leg")
     ap.add_argument("--rows-notice", type=int, default=None, help="table rows, notice tower (default 1 M at N = 1; 100 M over all GPUs at N > 1)")
     ap.add_argument("--rows-company", type=int, default=None, help="table rows, company tower (default 1 M at N = 1; 10 M over all GPUs at N > 1)")
