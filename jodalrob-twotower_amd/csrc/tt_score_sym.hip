@@ -319,9 +319,6 @@ __global__ __launch_bounds__(256) void score_sym_finish1_kernel(Fin1Args f) {
   const int Dp = f.KS * 16, stride = 4 + 2 * Dp;
   float* part = f.part + (int64_t)blockIdx.x * stride;
   __shared__ float red[4][4][kFinRows];                    // [quantity][wave][row]
-  // (the positives' raw products are needed behind the barrier below: asked for here, they arrive with the slab rows instead of costing
-  //  a memory round trip of their own at the end of this 7-us launch)
-  const float draw_early = (q == 0 && i < f.R) ? f.diag_raw[i] : 0.f;
   red[0][q][lane] = slab_sum4(f.rs, f.Rp, f.n_groups, q, i);
   red[1][q][lane] = slab_sum4(f.cs, f.Rp, f.n_chunks, q, i);
   if (f.want_rank) {
@@ -408,7 +405,7 @@ __global__ __launch_bounds__(256) void score_sym_finish1_kernel(Fin1Args f) {
     if (i < f.R) {
       const float rsum = (red[0][0][lane] + red[0][1][lane]) + (red[0][2][lane] + red[0][3][lane]);
       const float csum = (red[1][0][lane] + red[1][1][lane]) + (red[1][2][lane] + red[1][3][lane]);
-      const float draw = draw_early, d = draw * f.unscale;
+      const float draw = f.diag_raw[i], d = draw * f.unscale;
       f.inv_row[i] = 1.f / rsum;
       f.inv_col[i] = 1.f / csum;
       const float rs_shifted = f.unit ? rsum * f.kexp : rsum, cs_shifted = f.unit ? csum * f.kexp : csum;
