@@ -838,21 +838,33 @@ def hbm_resident_lookup_leg(args, ctx, rows_n: int = 100_000_000, rows_c: int = 
                     fn(b)
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize()
-            gr = torch.cuda.CUDAGraph()
             REP = 4
+            # (a) launch time: the kernels as the product launches them -- the stamp hook OFF (a stamped launch ends with a wait for its own
+            #     stores and two more stores per workgroup) --, HIP events around the replay; (b) body: a second capture with the hook on
+            prof.close()
+            gr = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gr, capture_error_mode=mode):
                 for _ in range(REP):
                     for b in pool:
                         fn(b)
             launch_us = []
-            prof.reset()
-            for rep in range(10):
+            for rep in range(12):
                 a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
                 gr.replay()
                 e.record()
                 torch.cuda.synchronize()
-                launch_us.append(a.elapsed_time(e) * 1e3 / (REP * len(pool)))
+                if rep >= 2:                                     # (the first replays of a graph are slower: warm-up)
+                    launch_us.append(a.elapsed_time(e) * 1e3 / (REP * len(pool)))
+            del gr
+            prof.reopen()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, capture_error_mode=mode):
+                for b in pool:
+                    fn(b)
+            prof.reset()
+            for rep in range(4):
+                gr.replay()
             body = prof.durations_us()
             phase = prof.durations_us(0, tiles) if name == "handover" else body
             del gr
@@ -880,8 +892,9 @@ def hbm_resident_lookup_leg(args, ctx, rows_n: int = 100_000_000, rows_c: int = 
             out[name] = rec
         out["frac"] = out["lookup_rows"]["frac"]                  # the headline of this leg: the captured step's lookup launch
         out["mean_launch_us"], out["mean_body_us"] = out["lookup_rows"]["mean_launch_us"], out["lookup_rows"]["mean_body_us"]
-        out["how"] = ("mean_launch_us: 32 launches over 8 id batches back to back in a captured graph, HIP events around the replay, median of 10 replays "
-                      "(kernel + boundary); mean_body_us: min start .. max end of the workgroups' s_memrealtime stamps in those launches; "
+        out["how"] = ("mean_launch_us: 32 launches over 8 id batches back to back in a captured graph, stamp hook off, HIP events around the replay, "
+                      "median of 10 replays behind 2 (kernel + boundary); mean_body_us: min start .. max end of the workgroups' s_memrealtime stamps in a "
+                      "second capture of the same launches with the hook on; "
                       "cold_cache_*: each launch behind a 256 MB streaming copy, HIP events around the single launch")
     finally:
         prof.close()
@@ -895,7 +908,8 @@ def configs4_leg(args, ctx):
     fused sparse Adam on the embedding rows; 1 M + 1 M-row tables; a few replayed steps + the score kernels' MFMA figure."""
     import copy
     a4 = copy.copy(args)
-    a4.batch, a4.final_dim, a4.score_dtype, a4.steps, a4.warmup, a4.pool, a4.no_lookup_profile = 65536, 256, "fp8", 5, 2, 2, True
+    # (40 steps behind 10: 0.35 s of GPU time; the five steps behind two of rounds 3-4 read a cold process, like configs[1]'s 100-step region)
+    a4.batch, a4.final_dim, a4.score_dtype, a4.steps, a4.warmup, a4.pool, a4.no_lookup_profile = 65536, 256, "fp8", 40, 10, 2, True
     a4.hidden, a4.optimizer, a4.mlp_dtype, a4.zipf = "128,64", "fused_sparse", "bf16", None
     leg = Leg(a4, ctx, a4.batch, 1_000_000, 1_000_000, False)
     try:
