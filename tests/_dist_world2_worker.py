@@ -101,6 +101,26 @@ def main():
             # gradient is not a rounding-level number (its sign is then the same in both runs)
             assert float((a - v).abs().max()) <= 2.1e-2, (k, float((a - v).abs().max()))
             assert float(((a - v).abs() > 1e-4).float().mean()) < 0.02 + 2.0 / a.numel(), (k, float(((a - v).abs() > 1e-4).float().mean()))
+    # the overflow path with real peers (untested on hardware): a capacity far below the need -> rows that do not fit go
+    # to the spare row, the sticky flag rises, check_overflow raises on every rank; after reset_capacity the next step is clean again
+    from jodalrob_twotower_amd.distributed import ExchangeOverflowError
+    mine = to_batch(slice(rank * Bl, (rank + 1) * Bl))
+    td.exchange.reset_capacity()
+    td.exchange.C = 16
+    od.zero_grad()
+    td(mine, return_metrics=True)["loss"].backward()
+    torch.cuda.synchronize()
+    try:
+        td.exchange.check_overflow()
+        raise AssertionError("a 16-row bucket cannot hold this batch's rows: the overflow flag did not rise")
+    except ExchangeOverflowError:
+        pass
+    td.exchange.reset_capacity()                             # (recalibrates on the next forward)
+    od.zero_grad()
+    r2 = td(mine, return_metrics=True)
+    r2["loss"].backward()
+    torch.cuda.synchronize()
+    assert not td.exchange.overflowed() and bool(torch.isfinite(r2["loss"]))
     del od, os_, td, ts
     torch.cuda.synchronize()
     dist.barrier()

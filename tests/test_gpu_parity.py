@@ -1866,7 +1866,8 @@ def test_two_processes_equal_single_process(tt):
     """SURVEY 8(e)'s parity definition on one GPU: a 2-rank job (two processes sharing the device, collectives through gloo
     with host staging) with row-wise sharded tables behind the fixed-capacity exchange, global in-batch negatives and SyncBN
     == the single-process task on the same global batch: loss, dense gradients, BN running statistics, parameters after one
-    Adam step (tests/_dist_world2_worker.py).  (Threads cannot stand in for ranks here: the backward passes of all
+    Adam step (tests/_dist_world2_worker.py); then the overflow path with real peers: a 16-row bucket capacity raises
+    ExchangeOverflowError on every rank, reset_capacity() recalibrates and the next step is clean.  (Threads cannot stand in for ranks here: the backward passes of all
     threads run on autograd's one device thread, so a collective inside backward deadlocks.)"""
     import os, socket, subprocess, sys
     from pathlib import Path
