@@ -1144,14 +1144,8 @@ __device__ __forceinline__ void seg_reduce_body(const SideSet& a, const int32_t*
   const uint32_t gthread = bid * blockDim.x + threadIdx.x;
   const uint32_t lig = gthread % LG;
   const uint32_t ngroups = nblocks * blockDim.x / LG;
-  // (a group that owns several rows asks for the next row's segment bounds before it walks this row's slots: adam_fused_kernel's note)
-  uint32_t u = gthread / LG;
-  int32_t s0n = u < U ? seg[u] : 0, s1n = u < U ? seg[u + 1] : 0;
-  for (; u < U; u += ngroups) {
-    const int32_t s0 = s0n, s1 = s1n;
-    const uint32_t un = u + ngroups;
-    s0n = un < U ? seg[un] : 0;
-    s1n = un < U ? seg[un + 1] : 0;
+  for (uint32_t u = gthread / LG; u < U; u += ngroups) {
+    const int32_t s0 = seg[u], s1 = seg[u + 1];
     if (planned && s1 - s0 > kLongSeg) continue;
     if (!all_short && s1 - s0 > kLongSeg) {
       const int32_t nch = (s1 - s0 + kLongSeg - 1) / kLongSeg;
@@ -1513,23 +1507,12 @@ __global__ __launch_bounds__(kThreads) void adam_fused_kernel(AdamFusedArgs a, f
   const uint32_t gthread = (blockIdx.x - first) * blockDim.x + threadIdx.x;
   const uint32_t lig = gthread % LG;
   const uint32_t ngroups = (gridDim.x - first) * blockDim.x / LG;
-  // a group that owns several rows (more distinct rows than groups: tables the caches cannot hold, 100 M rows: ~2.3 rows per group) asks
-  // for the NEXT row's index and segment bounds before it touches this row's data: one dependent memory trip per row instead of two
-  uint32_t u = gthread / LG;
-  int64_t row = u < U ? (int64_t)unique_rows[u] : 0;
-  int32_t slots = (LONG && u < U) ? seg[u + 1] - seg[u] : 0;
-  for (; u < U; u += ngroups) {
-    const uint32_t un = u + ngroups;
-    const int64_t row_next = un < U ? (int64_t)unique_rows[un] : 0;
-    const int32_t slots_next = (LONG && un < U) ? seg[un + 1] - seg[un] : 0;
-    const int64_t row_now = row;
-    const bool skip = row_now >= table_rows                // routing pad (multi-GPU fixed-capacity buckets)
-                      || (LONG && slots > kLongSeg);       // finished and applied by the long-row blocks
-    row = row_next;
-    slots = slots_next;
-    if (skip) continue;
+  for (uint32_t u = gthread / LG; u < U; u += ngroups) {
+    const int64_t row = unique_rows[u];
+    if (row >= table_rows) continue;                   // routing pad (multi-GPU fixed-capacity buckets)
+    if (LONG && seg[u + 1] - seg[u] > kLongSeg) continue;   // finished and applied by the long-row blocks
     for (uint32_t chunk = lig; chunk < C; chunk += LG) {
-      const int64_t o = row_now * E + chunk * VEC;
+      const int64_t o = row * E + chunk * VEC;
       const float* gp = grad_rows + (int64_t)u * E + chunk * VEC;
       if (VEC == 4) {
         float4 pp = *reinterpret_cast<float4*>(table + o), mm = *reinterpret_cast<float4*>(m + o),
