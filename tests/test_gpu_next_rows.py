@@ -462,3 +462,23 @@ def test_fast_evaluation_equals_batch_loop(tt, tmp_path):
     two = ev.evaluate_comprehensive(task, test_loader, verbose=False, max_batches=2)           # the cached graph again, two batches
     assert two["num_batches"] == 2 and two["loss"] == pytest.approx(sum(m["loss"] for m in per[:2]) / 2, rel=1e-6)
     ev.close()
+
+
+def test_bench_multi_gpu_path_with_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2` end to end with two REAL ranks sharing the one GPU (collectives staged through gloo, the sharded step captured in
+    segments): the weak leg incl. everything the bench does around a captured step -- bucket calibration over the batch pool, the lookup
+    stamps, the dispatch-overhead calibration that re-launches the step's lookup, the roofline object, teardown before the process group
+    goes.  Round 4 found that calibration indexing a rank's table SHARD with global key offsets (a GPU memory fault on every N > 1 run,
+    harmless at world 1); this is the regression test the suite lacked: rc 0, ONE JSON line with the N > 1 metric text, no fault."""
+    import os
+    root = ROOT
+    env = dict(os.environ, MASTER_PORT="29731")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--rows-notice", "400000", "--rows-company",
+                        "200000", "--no-cpu-baseline", "--dist-segmented", "--legs", "weak", "--pool", "3"], capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
+    assert "Memory access fault" not in r.stderr and "Memory access fault" not in r.stdout, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "PER GPU" in d["metric"]
+    assert d["config"]["launch"].startswith("segmented graph replay") and d["roofline"]["mean_launch_us"] > 0
