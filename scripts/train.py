@@ -220,6 +220,10 @@ def main():
             avg_train_acc = sum(train_accuracies) / max(len(train_accuracies), 1)
         torch.cuda.synchronize()
         t_e1 = time.time()
+        # the library's sticky device error word (a chained plan launch that gave up, a fused row outside its table): read where the host
+        # has synchronised anyway; a raised word invalidates the epoch's steps (include/twotower.h: tt_ctx_check_device_errors)
+        from jodalrob_twotower_amd import _lib as _tt_lib
+        _tt_lib.check_device_errors(torch.device(device))
         print(f"Train - Loss: {avg_train_loss:.4f}, Accuracy: {avg_train_acc:.3f}")
         # validation (:362-423): mean loss / accuracy over the test loader's batches, model in eval mode
         avg_val_loss = avg_train_loss
