@@ -471,8 +471,10 @@ def test_bench_multi_gpu_path_with_two_ranks_on_one_gpu():
     goes.  Round 4 found that calibration indexing a rank's table SHARD with global key offsets (a GPU memory fault on every N > 1 run,
     harmless at world 1); this is the regression test the suite lacked: rc 0, ONE JSON line with the N > 1 metric text, no fault."""
     import os
+    import socket
     root = ROOT
-    env = dict(os.environ, MASTER_PORT="29731")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()      # a free rendezvous port
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--rows-notice", "400000", "--rows-company",
                         "200000", "--no-cpu-baseline", "--dist-segmented", "--legs", "weak", "--pool", "3"], capture_output=True, text=True, timeout=600, env=env, cwd=str(root))
     assert "Memory access fault" not in r.stderr and "Memory access fault" not in r.stdout, r.stderr[-2000:]
